@@ -1,0 +1,98 @@
+"""Build the gfx950 shared objects in-tree with hipcc (no torch headers, no pybind, no hipify).
+
+  csrc/*.hip  --hipcc -c-->  build/*.o  --hipcc -shared-->  lib/libcln_amd.so
+  csrc/hgemm_vendor.hip  ------------------------------->  lib/libcln_amd_vendor.so (-lrocblas)
+
+Replaces the reference's JIT `torch.utils.cpp_extension.load(...)` at script import
+(kernels/hgemm/tools/utils.py:104-113, kernels/elementwise/elementwise.py:10-22).
+hipcc cross-compiles without a GPU, so this runs in the CPU-only container too.
+"""
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG_DIR, "csrc")
+BUILD = os.path.join(PKG_DIR, "build")
+LIBDIR = os.path.join(PKG_DIR, "lib")
+
+ARCH = "gfx950"
+KERNEL_SOURCES = [
+    "elementwise.hip", "reduce.hip", "softmax.hip", "norm.hip", "rope.hip",
+    "hgemm.hip", "hgemm_ring_nn.hip", "hgemm_ring_tn.hip", "flash_attn.hip",
+]
+VENDOR_SOURCES = ["hgemm_vendor.hip"]
+CFLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-ffp-contract=fast",
+          "-I" + CSRC]
+
+
+def hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (looked at $HIPCC, /opt/rocm/bin/hipcc, PATH)")
+
+
+def _deps_digest():
+    """Digest of every header/include file: any change rebuilds all objects."""
+    h = hashlib.sha256()
+    for fn in sorted(os.listdir(CSRC)):
+        if fn.endswith((".h", ".cuh", ".inc")):
+            with open(os.path.join(CSRC, fn), "rb") as f:
+                h.update(fn.encode())
+                h.update(f.read())
+    h.update(" ".join(CFLAGS).encode())
+    return h.hexdigest()
+
+
+def _compile_one(src, hdr_digest, verbose):
+    obj = os.path.join(BUILD, src.replace(".hip", ".o"))
+    stamp = obj + ".stamp"
+    with open(os.path.join(CSRC, src), "rb") as f:
+        digest = hashlib.sha256(f.read() + hdr_digest.encode()).hexdigest()
+    if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == digest:
+        return obj, False
+    cmd = [hipcc()] + CFLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-4000:]))
+    with open(stamp, "w") as f:
+        f.write(digest)
+    return obj, True
+
+
+def _link(objs, out, extra, verbose):
+    cmd = [hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC"] + objs + ["-o", out] + extra
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed for %s:\n%s" % (out, r.stderr[-4000:]))
+
+
+def build(verbose=False, force=False):
+    os.makedirs(BUILD, exist_ok=True)
+    os.makedirs(LIBDIR, exist_ok=True)
+    if force:
+        for fn in os.listdir(BUILD):
+            os.remove(os.path.join(BUILD, fn))
+    hd = _deps_digest()
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 4)) as ex:
+        res = list(ex.map(lambda s: _compile_one(s, hd, verbose), KERNEL_SOURCES + VENDOR_SOURCES))
+    objs = dict(zip(KERNEL_SOURCES + VENDOR_SOURCES, res))
+    main_so = os.path.join(LIBDIR, "libcln_amd.so")
+    vend_so = os.path.join(LIBDIR, "libcln_amd_vendor.so")
+    if force or not os.path.exists(main_so) or any(objs[s][1] for s in KERNEL_SOURCES):
+        _link([objs[s][0] for s in KERNEL_SOURCES], main_so, [], verbose)
+    if force or not os.path.exists(vend_so) or any(objs[s][1] for s in VENDOR_SOURCES):
+        _link([objs[s][0] for s in VENDOR_SOURCES], vend_so, ["-L/opt/rocm/lib", "-lrocblas"], verbose)
+    return main_so, vend_so
+
+
+if __name__ == "__main__":
+    print(build(verbose="-v" in sys.argv, force="-f" in sys.argv))

@@ -1,0 +1,157 @@
+// Shared device/host helpers for the gfx950 (MI355X, CDNA4) kernel library.
+//
+// One header instead of the reference's per-file macro blocks
+// (reference: kernels/*/**.cu top-of-file macro sections, e.g.
+// kernels/elementwise/elementwise.cu:12-18, kernels/reduce/block_all_reduce.cu:12-18).
+// Everything here assumes wave64 (gfx950) -- there is no 32-lane path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// ---------------------------------------------------------------- C-ABI status codes
+// Reference bindings throw std::runtime_error (e.g. kernels/hgemm/naive/hgemm.cu:772-782);
+// the C-ABI returns an int and the Python host maps it back to RuntimeError.
+#define CLN_OK 0
+#define CLN_ERR_BAD_ARG (-1)        // null pointer / non-positive dim / misaligned pointer
+#define CLN_ERR_UNSUPPORTED (-2)    // shape outside the supported set ("headdim not support!", K dispatch lists)
+#define CLN_ERR_LAUNCH (-3)         // hipGetLastError() != hipSuccess after the launch
+#define CLN_ERR_VENDOR (-4)         // rocBLAS row: handle missing / rocblas status != success
+
+#define CLN_API extern "C" __attribute__((visibility("default")))
+
+static inline int cln_check_launch() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? CLN_OK : CLN_ERR_LAUNCH;
+}
+
+static inline bool cln_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---------------------------------------------------------------- vector types
+typedef _Float16 half_t;
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef unsigned short us8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+
+#define CLN_WAVE 64
+
+// Grid sizing for HBM-bound streaming kernels: enough workgroups to cover all
+// 256 CUs several times over, grid-stride for the rest (cdna guide G11).
+static inline int cln_stream_grid(long long work_items, int block) {
+  long long g = (work_items + block - 1) / block;
+  const long long cap = 256LL * 16;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+#ifdef __HIPCC__
+// ---------------------------------------------------------------- wave64 reductions
+// xor-butterfly over all 64 lanes. (reference: warp_reduce_sum_f32 with WARP_SIZE 32,
+// kernels/reduce/block_all_reduce.cu:30-37 -- re-derived for 64 lanes, not translated.)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+  return v;
+}
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+// Block-wide sum for NT threads (NT multiple of 64, <= 1024). `scratch` must hold
+// 16 floats. Every thread gets the result. Two barriers.
+template <int NT>
+__device__ __forceinline__ float block_sum(float v, float* scratch) {
+  constexpr int NW = NT / 64;
+  v = wave_sum(v);
+  if constexpr (NW == 1) return v;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();  // protect scratch reuse across consecutive calls
+  if (lane == 0) scratch[w] = v;
+  __syncthreads();
+  float t = (lane < NW) ? scratch[lane] : 0.0f;
+#pragma unroll
+  for (int m = 8; m >= 1; m >>= 1) t += __shfl_xor(t, m, 64);  // NW <= 16
+  return __shfl(t, 0, 64);
+}
+template <int NT>
+__device__ __forceinline__ float block_max(float v, float* scratch) {
+  constexpr int NW = NT / 64;
+  v = wave_max(v);
+  if constexpr (NW == 1) return v;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) scratch[w] = v;
+  __syncthreads();
+  float t = (lane < NW) ? scratch[lane] : -3.402823466e+38f;
+#pragma unroll
+  for (int m = 8; m >= 1; m >>= 1) t = fmaxf(t, __shfl_xor(t, m, 64));
+  return __shfl(t, 0, 64);
+}
+
+// Runtime-block-size variants (blockDim.x multiple of 64, <= 1024).
+__device__ __forceinline__ float block_sum_rt(float v, float* scratch) {
+  const int nw = blockDim.x >> 6;
+  v = wave_sum(v);
+  if (nw == 1) return v;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) scratch[w] = v;
+  __syncthreads();
+  float t = (lane < nw) ? scratch[lane] : 0.0f;
+#pragma unroll
+  for (int m = 8; m >= 1; m >>= 1) t += __shfl_xor(t, m, 64);
+  return __shfl(t, 0, 64);
+}
+__device__ __forceinline__ float block_max_rt(float v, float* scratch) {
+  const int nw = blockDim.x >> 6;
+  v = wave_max(v);
+  if (nw == 1) return v;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) scratch[w] = v;
+  __syncthreads();
+  float t = (lane < nw) ? scratch[lane] : -3.402823466e+38f;
+#pragma unroll
+  for (int m = 8; m >= 1; m >>= 1) t = fmaxf(t, __shfl_xor(t, m, 64));
+  return __shfl(t, 0, 64);
+}
+
+// ---------------------------------------------------------------- LDS / global address-space casts
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_cvoid;
+
+// 16-byte async global->LDS copy (LDS-DMA). LDS destination is wave-uniform base +
+// lane*16 (cdna guide section 5 caveat) -- callers pass the wave-uniform base.
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((gbl_cvoid*)gsrc, (lds_void*)lds_wave_base, 16, 0, 0);
+}
+
+// LDS transpose read: within each 16-lane group the lanes supply the 8-byte pieces of a
+// [4][16] b16 block (lane i -> row i>>2, cols 4*(i&3)..+3) and lane i receives column i
+// (4 rows). (ds_read_b64_tr_b16, cdna guide section 2 / T10.)
+typedef __fp16 fp16x4_tr __attribute__((__vector_size__(4 * sizeof(__fp16))));
+__device__ __forceinline__ h4 lds_read_tr16(const void* lds_addr) {
+  fp16x4_tr t = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+      (__attribute__((address_space(3))) fp16x4_tr*)(lds_addr));
+  h4 r;
+  __builtin_memcpy(&r, &t, 8);
+  return r;
+}
+
+__device__ __forceinline__ h8 h8_cat(h4 lo, h4 hi) {
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+#endif  // __HIPCC__

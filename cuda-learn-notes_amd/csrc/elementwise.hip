@@ -1,0 +1,95 @@
+// c = a + b, six access-width rungs. HBM-bound: 3 streams, 3*sizeof(T) bytes per element.
+//
+// Replaces the kernels + bindings of reference kernels/elementwise/elementwise.cu:24-108
+// (kernels) and :122-177 (TORCH_BINDING_ELEM_ADD launch-shape macro + PYBIND11_MODULE).
+// Design for gfx950: every rung is a grid-stride loop over a capped grid (256 CUs x 16
+// workgroups of 256 threads = 4 waves), the rung name fixes only the per-lane access width
+// (4 B, 16 B, 2 B, 4 B, 4x4 B, 16 B), exactly what the reference ladder teaches.
+#include "common.h"
+
+namespace {
+
+template <typename VT>
+__global__ __launch_bounds__(256) void add_vec_kernel(const VT* __restrict__ a, const VT* __restrict__ b,
+                                                      VT* __restrict__ c, long long nvec) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (; i < nvec; i += stride) c[i] = a[i] + b[i];
+}
+
+// scalar tail (n not a multiple of the vector width)
+template <typename T>
+__global__ void add_tail_kernel(const T* a, const T* b, T* c, long long start, long long n) {
+  long long i = start + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) c[i] = a[i] + b[i];
+}
+
+// "f16x8" rung: eight halves per thread moved as four separate 4-byte half2 accesses
+// (reference elementwise.cu:62-86); the "_pack" rung below moves them as one 16-byte access.
+__global__ __launch_bounds__(256) void add_f16x8_unpacked_kernel(const h2* __restrict__ a, const h2* __restrict__ b,
+                                                                 h2* __restrict__ c, long long ngroups) {
+  long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (; g < ngroups; g += stride) {
+    const long long i = g * 4;
+    h2 a0 = a[i + 0], a1 = a[i + 1], a2 = a[i + 2], a3 = a[i + 3];
+    h2 b0 = b[i + 0], b1 = b[i + 1], b2 = b[i + 2], b3 = b[i + 3];
+    c[i + 0] = a0 + b0;
+    c[i + 1] = a1 + b1;
+    c[i + 2] = a2 + b2;
+    c[i + 3] = a3 + b3;
+  }
+}
+
+template <typename T, typename VT, int VEC>
+int launch_add(const void* a, const void* b, void* c, long long n, hipStream_t stream) {
+  if (!a || !b || !c || n < 0) return CLN_ERR_BAD_ARG;
+  if (n == 0) return CLN_OK;
+  if (VEC * sizeof(T) >= 16 && !(cln_aligned16(a) && cln_aligned16(b) && cln_aligned16(c))) return CLN_ERR_BAD_ARG;
+  const long long nvec = n / VEC;
+  if (nvec > 0) {
+    const int grid = cln_stream_grid(nvec, 256);
+    hipLaunchKernelGGL((add_vec_kernel<VT>), dim3(grid), dim3(256), 0, stream, (const VT*)a, (const VT*)b, (VT*)c,
+                       nvec);
+  }
+  const long long done = nvec * VEC;
+  if (done < n) {
+    hipLaunchKernelGGL((add_tail_kernel<T>), dim3(1), dim3(64), 0, stream, (const T*)a, (const T*)b, (T*)c, done, n);
+  }
+  return cln_check_launch();
+}
+
+}  // namespace
+
+// (a, b, c, n_elements, stream) -- replaces `void elementwise_add_*(torch::Tensor a, b, c)`
+// reference kernels/elementwise/elementwise.cu:163-168.
+CLN_API int elementwise_add_f32(const void* a, const void* b, void* c, long long n, void* stream) {
+  return launch_add<float, float, 1>(a, b, c, n, (hipStream_t)stream);
+}
+CLN_API int elementwise_add_f32x4(const void* a, const void* b, void* c, long long n, void* stream) {
+  return launch_add<float, f4, 4>(a, b, c, n, (hipStream_t)stream);
+}
+CLN_API int elementwise_add_f16(const void* a, const void* b, void* c, long long n, void* stream) {
+  return launch_add<half_t, half_t, 1>(a, b, c, n, (hipStream_t)stream);
+}
+CLN_API int elementwise_add_f16x2(const void* a, const void* b, void* c, long long n, void* stream) {
+  return launch_add<half_t, h2, 2>(a, b, c, n, (hipStream_t)stream);
+}
+CLN_API int elementwise_add_f16x8(const void* a, const void* b, void* c, long long n, void* stream) {
+  if (!a || !b || !c || n < 0) return CLN_ERR_BAD_ARG;
+  if (n == 0) return CLN_OK;
+  const long long ngroups = n / 8;
+  if (ngroups > 0) {
+    const int grid = cln_stream_grid(ngroups, 256);
+    hipLaunchKernelGGL(add_f16x8_unpacked_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const h2*)a,
+                       (const h2*)b, (h2*)c, ngroups);
+  }
+  if (ngroups * 8 < n) {
+    hipLaunchKernelGGL((add_tail_kernel<half_t>), dim3(1), dim3(64), 0, (hipStream_t)stream, (const half_t*)a,
+                       (const half_t*)b, (half_t*)c, ngroups * 8, n);
+  }
+  return cln_check_launch();
+}
+CLN_API int elementwise_add_f16x8_pack(const void* a, const void* b, void* c, long long n, void* stream) {
+  return launch_add<half_t, h8, 8>(a, b, c, n, (hipStream_t)stream);
+}

@@ -1,0 +1,23 @@
+// Head dims above 256 ("fine-grained tiling" rungs of the reference:
+// kernels/flash-attn/mma/basic/flash_attn_mma_tiling_qk.cu:72, flash_attn_mma_tiling_qkv.cu:70 --
+// config C5 is D = 512). Round-1 implementation: the same split-Q kernel with the whole K row in
+// LDS (160 KiB LDS makes the reference's 16-wide d-slicing of K unnecessary up to D = 1024) and
+// the OUTPUT head dim sliced across blockIdx.z (each workgroup recomputes S for its slice).
+#pragma once
+#include "flash_attn.cuh"
+
+namespace fa {
+inline int launch_fa2_large_d(const void* q, const void* k, const void* v, void* o, int B, int H, int N, int D,
+                              int stages, hipStream_t s) {
+  (void)stages;
+  switch (D) {
+    case 320: return launch_fa2<320, 160, 64, false, false>(q, k, v, o, B, H, N, s);
+    case 384: return launch_fa2<384, 192, 64, false, false>(q, k, v, o, B, H, N, s);
+    case 512: return launch_fa2<512, 256, 64, false, false>(q, k, v, o, B, H, N, s);
+    case 640: return launch_fa2<640, 320, 32, false, false>(q, k, v, o, B, H, N, s);
+    case 768: return launch_fa2<768, 192, 32, false, false>(q, k, v, o, B, H, N, s);
+    case 1024: return launch_fa2<1024, 256, 32, false, false>(q, k, v, o, B, H, N, s);
+    default: return CLN_ERR_UNSUPPORTED;
+  }
+}
+}  // namespace fa

@@ -1,0 +1,415 @@
+// MFMA HGEMM kernels for gfx950: C[M,N] = A[M,K] * B, fp16 in / fp32 accumulate / fp16 out.
+//
+// Replaces the tensor-core ladders of the reference:
+//   kernels/hgemm/mma/basic/hgemm_mma.cu:44,:135          (naive, 1-stage 128x128 tile)
+//   kernels/hgemm/mma/basic/hgemm_mma_stage.cu:68,:293,:603,:1044,:1460 (cp.async multi-stage rings)
+//   kernels/hgemm/mma/basic/hgemm_mma_stage_tn.cu:70, mma/swizzle/*.cu:121,:148 (TN, smem swizzle)
+//   kernels/hgemm/wmma/hgemm_wmma.cu:39-415, wmma/hgemm_wmma_stage.cu:56-721 (WMMA rungs)
+//   kernels/hgemm/cutlass/hgemm_mma_stage_tn_cute.cu:26   (CuTe 128x256 TN)
+//
+// MI355X design (not a translation):
+//  * one MFMA shape, v_mfma_f32_16x16x32_f16 (gfx950 2xK form), fp32 accumulators (MFMA has no
+//    fp16 accumulator; the reference accumulates in fp16 -- hgemm_mma.cu:37);
+//  * operands swapped in the MFMA call (a := B fragment, b := A fragment) so every lane ends up
+//    with 4 CONSECUTIVE n of one C row -> 8-byte packed stores without any cross-lane shuffle
+//    (the reference needs a 4-lane __shfl gather for that, hgemm_mma_stage.cu:991-1022);
+//  * LDS images are lane-linear so they can be filled by LDS-DMA (global_load_lds_dwordx4);
+//    the bank-conflict XOR swizzle is applied to the per-lane GLOBAL source address and, with
+//    the same involution, to the fragment read address (64-bank / 16-lane-group model of
+//    ds_read_b128 and ds_read_b64_tr_b16, MI355X_MICROARCH.md LDS table) -- no padding;
+//  * NN layout reads the B fragment with the hardware transpose read ds_read_b64_tr_b16 from a
+//    [k][n] image (no ldmatrix.trans on CDNA); TN reads it exactly like A;
+//  * multi-stage ring = `stages` LDS buffers, prefetch distance stages-1, ONE raw s_barrier per
+//    K tile, counted s_waitcnt vmcnt(N) so DMA stays in flight across the barrier;
+//  * block swizzle = XCD-aware remap (8 XCDs, private L2s) + N-band walk of `swizzle_stride`.
+#pragma once
+#include "common.h"
+
+namespace hgemm {
+
+enum Layout { NN = 0, TN = 1 };
+
+// ---- XOR swizzles (16-byte chunk index within a row of the LDS image) --------------------------
+// K-contiguous image ([rows][BK] halves). BK=64: 128-B rows, 8 chunks; BK=32: 64-B rows, 4 chunks.
+template <int BK>
+__device__ __forceinline__ int kswz(int row) {
+  if constexpr (BK == 64) {
+    return (row >> 1) & 7;
+  } else {
+    // BK == 32: table {0,2,3,1}[(row>>2)&3]  (derived for the 4x16-lane ds_read_b128 groups)
+    const int t = (row >> 2) & 3;
+    return (((t ^ (t >> 1)) & 1) << 1) | (t >> 1);
+  }
+}
+// N-contiguous image of B for the NN layout ([BK][BN] halves, BN in {128,256}).
+__device__ __forceinline__ int nswz(int krow) { return ((krow & 3) << 1) | (((krow >> 3) & 1) << 3); }
+
+// Counted wait: leaves N vector-memory ops (LDS-DMA pieces) in flight. vmcnt is a 6-bit field.
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N < 64, "vmcnt range");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// ---- block index -> (tile_m, tile_n) -----------------------------------------------------------
+// swizzle==0: plain row-major walk (the reference's un-swizzled grid).
+// swizzle!=0: (1) bijective XCD remap -- hardware places block b on XCD b%8, so give each XCD a
+// contiguous run of logical blocks (cdna guide T1); (2) walk N in bands of `band` tiles, M-major
+// inside a band (the reference's blockIdx.z N-band, hgemm_mma_stage.cu:608, re-expressed).
+__device__ __forceinline__ void tile_coords(int bid, int nblk, int tiles_m, int tiles_n, int swizzle, int band,
+                                            int& tm, int& tn) {
+  if (!swizzle) {
+    tm = bid / tiles_n;
+    tn = bid - tm * tiles_n;
+    return;
+  }
+  const int xcd = bid & 7, local = bid >> 3;
+  const int q = nblk >> 3, r = nblk & 7;
+  const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+  if (band <= 0 || band > tiles_n) band = tiles_n;
+  const int per_band = tiles_m * band;
+  const int b = wg / per_band;
+  const int rem = wg - b * per_band;
+  const int width = min(band, tiles_n - b * band);
+  tm = rem / width;
+  tn = b * band + (rem - tm * width);
+}
+
+// ---- tile configuration ------------------------------------------------------------------------
+template <int BM_, int BN_, int BK_, int WM_, int WN_, int STAGES_, int LAYOUT_>
+struct Cfg {
+  static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_, STAGES = STAGES_, LAYOUT = LAYOUT_;
+  static constexpr int NW = WM * WN, NT = NW * 64;
+  static constexpr int WTM = BM / WM, WTN = BN / WN;  // per-wave output tile
+  static constexpr int FM = WTM / 16, FN = WTN / 16;  // 16x16 fragments per wave
+  static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
+  static constexpr int A_LOADS = A_BYTES / 1024 / NW, B_LOADS = B_BYTES / 1024 / NW;  // glds per wave per tile
+  static constexpr int LOADS = A_LOADS + B_LOADS;
+  static constexpr int LDS_BYTES = STAGES * STAGE_BYTES;
+  static_assert(BK == 32 || BK == 64, "BK");
+  static_assert(A_BYTES % (1024 * NW) == 0 && B_BYTES % (1024 * NW) == 0, "tile must split evenly over waves");
+  static_assert(LAYOUT == TN || BN == 128 || BN == 256, "NN image swizzle derived for BN in {128,256}");
+  static_assert(WTM % 16 == 0 && WTN % 16 == 0, "wave tile");
+};
+
+// LDS-DMA issue hidden from hipcc's waitcnt bookkeeping (cdna guide 5.7): hipcc cannot prove that
+// an in-flight DMA does not alias the fragment reads of the OTHER stage buffer and would drain
+// vmcnt(0) before the first ds_read of every K tile. Issued from asm, the DMA is ordered only by
+// our counted s_waitcnt vmcnt(N) + s_barrier. Source = SGPR base + per-lane 32-bit byte offset,
+// LDS destination = M0 (wave-uniform) + lane*16. M0 is saved/restored inside the statement.
+__device__ __forceinline__ void glds16_asm(const void* sbase, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_dst)
+      : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+  return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) char*)p;
+}
+
+// Per-lane byte offsets for the DMA fill of one operand image (constant over the K loop; the
+// K advance is a scalar add on the base pointer).
+// K-contiguous image: element (row, kchunk) of the tile; `ld` = leading dimension in halves.
+template <typename C, int NLOADS>
+struct KFill {
+  unsigned voff[NLOADS];
+  __device__ __forceinline__ void init(int ld, int wave, int lane) {
+    constexpr int LPR = C::BK / 8;  // lanes (16-B chunks) per row
+    constexpr int RPI = 64 / LPR;   // rows per wave-instruction
+#pragma unroll
+    for (int i = 0; i < NLOADS; ++i) {
+      const int t = i * C::NW + wave;  // wave-instruction index within the image
+      const int row = t * RPI + lane / LPR;
+      const int c = lane % LPR;
+      voff[i] = ((unsigned)row * (unsigned)ld + ((c ^ kswz<C::BK>(row)) << 3)) * 2u;
+    }
+  }
+};
+// N-contiguous B image (NN): element (krow, nchunk).
+template <typename C, int NLOADS>
+struct NFill {
+  unsigned voff[NLOADS];
+  __device__ __forceinline__ void init(int N, int wave, int lane) {
+    constexpr int LPR = C::BN / 8;
+    constexpr int RPI = 64 / LPR;
+#pragma unroll
+    for (int i = 0; i < NLOADS; ++i) {
+      const int t = i * C::NW + wave;
+      const int krow = t * RPI + lane / LPR;
+      const int c = lane % LPR;
+      voff[i] = ((unsigned)krow * (unsigned)N + ((c ^ nswz(krow)) << 3)) * 2u;
+    }
+  }
+};
+// Issue one operand image: NLOADS pieces of 1 KiB per wave.
+template <int NW, int NLOADS>
+__device__ __forceinline__ void issue_image(const char* sbase, const unsigned (&voff)[NLOADS], unsigned lds_img,
+                                            int wave) {
+#pragma unroll
+  for (int i = 0; i < NLOADS; ++i) glds16_asm(sbase, voff[i], lds_img + (unsigned)(i * NW + wave) * 1024u);
+}
+
+// ---- fragment readers --------------------------------------------------------------------------
+// K-contiguous image, rows [row0 + 16*f + (lane&15)], k chunk (lane>>4) of k-step kk.
+template <int BK>
+__device__ __forceinline__ h8 read_kfrag(const char* img, int row, int lane, int kk) {
+  const int q = kk * 4 + (lane >> 4);
+  return *reinterpret_cast<const h8*>(img + row * (BK * 2) + ((q ^ kswz<BK>(row)) << 4));
+}
+// NN B image: 16 columns n0w..n0w+15 (tile-relative), k = kk*32 + 8*(lane>>4) .. +7, via two
+// transposing reads.
+template <int BN>
+__device__ __forceinline__ h8 read_nfrag(const char* img, int n0w, int lane, int kk) {
+  const int i = lane & 15, g = lane >> 4;
+  const int q = (n0w >> 3) + ((i & 3) >> 1);
+  const int k_lo = kk * 32 + 8 * g + (i >> 2);
+  const int k_hi = k_lo + 4;
+  const char* p_lo = img + k_lo * (BN * 2) + ((q ^ nswz(k_lo)) << 4) + ((i & 1) << 3);
+  const char* p_hi = img + k_hi * (BN * 2) + ((q ^ nswz(k_hi)) << 4) + ((i & 1) << 3);
+  return h8_cat(lds_read_tr16(p_lo), lds_read_tr16(p_hi));
+}
+
+__device__ __forceinline__ void store_c4(half_t* C, int N, int m, int n, const f4& v) {
+  h4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+  *reinterpret_cast<h4*>(C + (size_t)m * N + n) = o;
+}
+
+// ---- one K tile of MFMA work for a wave -------------------------------------------------------
+template <typename C>
+__device__ __forceinline__ void compute_tile(const char* a_img, const char* b_img, int wm, int wn, int lane,
+                                             f4 (&acc)[C::FM][C::FN]) {
+#pragma unroll
+  for (int kk = 0; kk < C::BK / 32; ++kk) {
+    h8 af[C::FM], bf[C::FN];
+#pragma unroll
+    for (int j = 0; j < C::FN; ++j) {
+      if constexpr (C::LAYOUT == TN) {
+        bf[j] = read_kfrag<C::BK>(b_img, wn * C::WTN + j * 16 + (lane & 15), lane, kk);
+      } else {
+        bf[j] = read_nfrag<C::BN>(b_img, wn * C::WTN + j * 16, lane, kk);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < C::FM; ++i) af[i] = read_kfrag<C::BK>(a_img, wm * C::WTM + i * 16 + (lane & 15), lane, kk);
+#pragma unroll
+    for (int i = 0; i < C::FM; ++i)
+#pragma unroll
+      for (int j = 0; j < C::FN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+  }
+}
+
+template <typename C>
+__device__ __forceinline__ void store_tile(half_t* Cmat, int N, int m0, int n0, int wm, int wn, int lane,
+                                           const f4 (&acc)[C::FM][C::FN]) {
+  // swapped-operand MFMA => lane holds C[m = .. + (lane&15)][n = .. + 4*(lane>>4) + r], r = 0..3
+#pragma unroll
+  for (int i = 0; i < C::FM; ++i)
+#pragma unroll
+    for (int j = 0; j < C::FN; ++j)
+      store_c4(Cmat, N, m0 + wm * C::WTM + i * 16 + (lane & 15), n0 + wn * C::WTN + j * 16 + 4 * (lane >> 4),
+               acc[i][j]);
+}
+
+// ---- multi-stage LDS-DMA ring kernel -----------------------------------------------------------
+template <typename C>
+__global__ __launch_bounds__(C::NT, (C::NT >= 512 ? 2 : 1)) void hgemm_ring_kernel(
+    const half_t* __restrict__ A, const half_t* __restrict__ B, half_t* __restrict__ Cmat, int M, int N, int K,
+    int tiles_m, int tiles_n, int swizzle, int band) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave / C::WN, wn = wave % C::WN;
+  int tm, tn;
+  tile_coords(blockIdx.x, gridDim.x, tiles_m, tiles_n, swizzle, band, tm, tn);
+  const int m0 = tm * C::BM, n0 = tn * C::BN;
+
+  KFill<C, C::A_LOADS> fa;
+  fa.init(K, wave, lane);
+  KFill<C, C::B_LOADS> fbt;  // TN
+  NFill<C, C::B_LOADS> fbn;  // NN
+  if constexpr (C::LAYOUT == TN) fbt.init(K, wave, lane);
+  else fbn.init(N, wave, lane);
+  // wave-uniform tile origins (bytes); advanced by one K tile per stage() call
+  const char* a_src = reinterpret_cast<const char*>(A + (size_t)m0 * K);
+  const char* b_src = (C::LAYOUT == TN) ? reinterpret_cast<const char*>(B + (size_t)n0 * K)
+                                        : reinterpret_cast<const char*>(B + n0);
+  const size_t a_step = (size_t)C::BK * 2;
+  const size_t b_step = (C::LAYOUT == TN) ? (size_t)C::BK * 2 : (size_t)C::BK * N * 2;
+  const unsigned lds0 = lds_addr_of(smem);
+
+  auto stage = [&](int buf) {
+    const unsigned a_img = lds0 + buf * C::STAGE_BYTES;
+    issue_image<C::NW, C::A_LOADS>(a_src, fa.voff, a_img, wave);
+    if constexpr (C::LAYOUT == TN) issue_image<C::NW, C::B_LOADS>(b_src, fbt.voff, a_img + C::A_BYTES, wave);
+    else issue_image<C::NW, C::B_LOADS>(b_src, fbn.voff, a_img + C::A_BYTES, wave);
+    a_src += a_step;
+    b_src += b_step;
+  };
+
+  f4 acc[C::FM][C::FN];
+#pragma unroll
+  for (int i = 0; i < C::FM; ++i)
+#pragma unroll
+    for (int j = 0; j < C::FN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+  const int nt = K / C::BK;
+  constexpr int S = C::STAGES;
+  // prologue: tiles 0 .. S-2 in flight
+#pragma unroll
+  for (int s = 0; s < S - 1; ++s)
+    if (s < nt) stage(s);
+
+  int buf = 0;
+  for (int t = 0; t < nt; ++t) {
+    // tile t must have landed; tiles t+1 .. t+S-2 may stay in flight
+    if (nt - 1 - t >= S - 2) wait_vmcnt<(S - 2) * C::LOADS>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();  // every wave's share of tile t is in LDS; all waves finished tile t-1
+    asm volatile("" ::: "memory");   // s_barrier is IntrNoMem: pin the fragment reads below it
+    if (t + S - 1 < nt) {
+      int pbuf = buf + (S - 1);
+      if (pbuf >= S) pbuf -= S;
+      stage(pbuf);  // overwrites the buffer read during iteration t-1
+    }
+    const char* a_img = smem + buf * C::STAGE_BYTES;
+    compute_tile<C>(a_img, a_img + C::A_BYTES, wm, wn, lane, acc);
+    buf = (buf + 1 == S) ? 0 : buf + 1;
+  }
+  store_tile<C>(Cmat, N, m0, n0, wm, wn, lane, acc);
+}
+
+// ---- single-stage, register-staged rung (the "1-stage MMA tile" of config C2) ------------------
+// Same LDS images and fragment readers; the fill goes global -> VGPR -> ds_write_b128 with two
+// barriers per K tile and no overlap, i.e. reference hgemm_mma_m16n8k16_mma2x4_warp4x4
+// (hgemm_mma.cu:135-266) re-thought for wave64/MFMA.
+template <typename C>
+__global__ __launch_bounds__(C::NT) void hgemm_1stage_kernel(const half_t* __restrict__ A,
+                                                              const half_t* __restrict__ B,
+                                                              half_t* __restrict__ Cmat, int M, int N, int K,
+                                                              int tiles_m, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int wm = wave / C::WN, wn = wave % C::WN;
+  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+  const int m0 = tm * C::BM, n0 = tn * C::BN;
+
+  KFill<C, C::A_LOADS> fa;
+  fa.init(K, wave, lane);
+  KFill<C, C::B_LOADS> fbt;
+  NFill<C, C::B_LOADS> fbn;
+  if constexpr (C::LAYOUT == TN) fbt.init(K, wave, lane);
+  else fbn.init(N, wave, lane);
+  const char* a_src = reinterpret_cast<const char*>(A + (size_t)m0 * K);
+  const char* b_src = (C::LAYOUT == TN) ? reinterpret_cast<const char*>(B + (size_t)n0 * K)
+                                        : reinterpret_cast<const char*>(B + n0);
+  const size_t a_step = (size_t)C::BK * 2;
+  const size_t b_step = (C::LAYOUT == TN) ? (size_t)C::BK * 2 : (size_t)C::BK * N * 2;
+
+  f4 acc[C::FM][C::FN];
+#pragma unroll
+  for (int i = 0; i < C::FM; ++i)
+#pragma unroll
+    for (int j = 0; j < C::FN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+  char* a_img = smem;
+  char* b_img = smem + C::A_BYTES;
+  const int nt = K / C::BK;
+  for (int t = 0; t < nt; ++t) {
+    u4 ra[C::A_LOADS], rb[C::B_LOADS];
+#pragma unroll
+    for (int i = 0; i < C::A_LOADS; ++i) ra[i] = *reinterpret_cast<const u4*>(a_src + fa.voff[i]);
+#pragma unroll
+    for (int i = 0; i < C::B_LOADS; ++i) {
+      if constexpr (C::LAYOUT == TN) rb[i] = *reinterpret_cast<const u4*>(b_src + fbt.voff[i]);
+      else rb[i] = *reinterpret_cast<const u4*>(b_src + fbn.voff[i]);
+    }
+    a_src += a_step;
+    b_src += b_step;
+    __syncthreads();  // previous tile's fragment reads are done
+#pragma unroll
+    for (int i = 0; i < C::A_LOADS; ++i)
+      *reinterpret_cast<u4*>(a_img + (i * C::NW + wave) * 1024 + lane * 16) = ra[i];
+#pragma unroll
+    for (int i = 0; i < C::B_LOADS; ++i)
+      *reinterpret_cast<u4*>(b_img + (i * C::NW + wave) * 1024 + lane * 16) = rb[i];
+    __syncthreads();
+    compute_tile<C>(a_img, b_img, wm, wn, lane, acc);
+  }
+  store_tile<C>(Cmat, N, m0, n0, wm, wn, lane, acc);
+}
+
+// ---- naive rung: one wave per 16x16 C tile, fragments straight from global memory --------------
+// (reference hgemm_mma_m16n8k16_naive hgemm_mma.cu:44-125 and hgemm_wmma_m16n16k16_naive
+// hgemm_wmma.cu:39-62: one warp per MMA tile, no reuse). v_mfma_f32_16x16x16_f16.
+template <int LAYOUT>
+__global__ __launch_bounds__(64) void hgemm_mfma_naive_kernel(const half_t* __restrict__ A,
+                                                               const half_t* __restrict__ B,
+                                                               half_t* __restrict__ Cmat, int M, int N, int K) {
+  const int lane = threadIdx.x;
+  const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
+  const int i = lane & 15, g = lane >> 4;
+  f4 acc = {0.f, 0.f, 0.f, 0.f};
+  const bool m_ok = (m0 + i) < M, n_ok = (n0 + i) < N;
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    const int k = k0 + 4 * g;
+    h4 af = {0, 0, 0, 0}, bf = {0, 0, 0, 0};
+    if (m_ok && k + 3 < K) af = *reinterpret_cast<const h4*>(A + (size_t)(m0 + i) * K + k);
+    if (n_ok && k + 3 < K) {
+      if constexpr (LAYOUT == TN) {
+        bf = *reinterpret_cast<const h4*>(B + (size_t)(n0 + i) * K + k);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bf[j] = B[(size_t)(k + j) * N + n0 + i];
+      }
+    }
+    acc = __builtin_amdgcn_mfma_f32_16x16x16f16(bf, af, acc, 0, 0, 0);
+  }
+  // lane holds C[m0 + i][n0 + 4g + r]
+  if (m_ok) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (n0 + 4 * g + r < N) Cmat[(size_t)(m0 + i) * N + n0 + 4 * g + r] = (half_t)acc[r];
+  }
+}
+
+// ---- host-side launchers -----------------------------------------------------------------------
+template <typename C>
+int launch_ring(const void* a, const void* b, void* c, int M, int N, int K, int swizzle, int swizzle_stride,
+                hipStream_t stream) {
+  if (M % C::BM || N % C::BN || K % C::BK) return CLN_ERR_UNSUPPORTED;
+  static bool attr_done = false;  // once per instantiation (reference re-issues it per call, hgemm_mma_stage.cu:2333)
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&hgemm_ring_kernel<C>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess)
+      return CLN_ERR_LAUNCH;
+    attr_done = true;
+  }
+  const int tiles_m = M / C::BM, tiles_n = N / C::BN;
+  int band = (swizzle && swizzle_stride >= C::BN) ? swizzle_stride / C::BN : tiles_n;
+  hipLaunchKernelGGL((hgemm_ring_kernel<C>), dim3(tiles_m * tiles_n), dim3(C::NT), C::LDS_BYTES, stream,
+                     (const half_t*)a, (const half_t*)b, (half_t*)c, M, N, K, tiles_m, tiles_n, swizzle ? 1 : 0, band);
+  return cln_check_launch();
+}
+
+template <typename C>
+int launch_1stage(const void* a, const void* b, void* c, int M, int N, int K, hipStream_t stream) {
+  if (M % C::BM || N % C::BN || K % C::BK) return CLN_ERR_UNSUPPORTED;
+  const int tiles_m = M / C::BM, tiles_n = N / C::BN;
+  hipLaunchKernelGGL((hgemm_1stage_kernel<C>), dim3(tiles_m * tiles_n), dim3(C::NT), C::STAGE_BYTES, stream,
+                     (const half_t*)a, (const half_t*)b, (half_t*)c, M, N, K, tiles_m, tiles_n);
+  return cln_check_launch();
+}
+
+template <int LAYOUT>
+int launch_naive(const void* a, const void* b, void* c, int M, int N, int K, hipStream_t stream) {
+  if (K % 4) return CLN_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL((hgemm_mfma_naive_kernel<LAYOUT>), dim3((N + 15) / 16, (M + 15) / 16), dim3(64), 0, stream,
+                     (const half_t*)a, (const half_t*)b, (half_t*)c, M, N, K);
+  return cln_check_launch();
+}
+
+}  // namespace hgemm

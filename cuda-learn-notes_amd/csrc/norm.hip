@@ -1,0 +1,120 @@
+// Row normalisations with scalar gain/bias: layer-norm (8 rungs) and rms-norm (9 rungs).
+//
+// Replaces reference kernels/layer-norm/layer_norm.cu:53-414 (kernels) / :732-814 (bindings) and
+// kernels/rms-norm/rms_norm.cu:54-370 / :457-813.
+// Arithmetic follows the reference KERNELS (these are their drop-ins):
+//   layer-norm: mean = sum(x)/K; rstd = rsqrt(sum((x-mean)^2) / (K + 1e-5)); y = (x-mean)*rstd*g + b
+//               (population variance, eps added to K -- layer_norm.cu:69, :103)
+//   rms-norm:   rstd = rsqrt(sum(x^2)/K + 1e-5); y = x*rstd*g            (rms_norm.cu:54-70)
+// Statistics are always fp32 here (the reference's *_f16 rungs keep them in fp16); both agree with
+// the script's torch oracles (layer_norm.py:25-29, rms_norm.py:26-31) within fp16 tolerance.
+// One workgroup per row, row register-resident: 1 read + 1 write of HBM per element.
+#include "rowwise.cuh"
+
+using namespace rowwise;
+
+namespace {
+
+template <typename T, int VEC, int MAXV>
+__global__ void layer_norm_kernel(const T* __restrict__ x, T* __restrict__ y, float g, float b, int K) {
+  __shared__ float scratch[16];
+  const size_t off = (size_t)blockIdx.x * K;
+  RowRegs<T, VEC, MAXV> r;
+  r.load(x + off, K, 0.f);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) s += r.x[i][e];
+  const float mean = block_sum_rt(s, scratch) / (float)K;
+  float v = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int col = (i * blockDim.x + threadIdx.x) * VEC;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float d = (col < K) ? (r.x[i][e] - mean) : 0.f;
+      r.x[i][e] = d;
+      v += d * d;
+    }
+  }
+  const float rstd = rsqrtf(block_sum_rt(v, scratch) / ((float)K + 1e-5f));
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) r.x[i][e] = r.x[i][e] * rstd * g + b;
+  r.store(y + off, K);
+}
+
+template <typename T, int VEC, int MAXV>
+__global__ void rms_norm_kernel(const T* __restrict__ x, T* __restrict__ y, float g, int K) {
+  __shared__ float scratch[16];
+  const size_t off = (size_t)blockIdx.x * K;
+  RowRegs<T, VEC, MAXV> r;
+  r.load(x + off, K, 0.f);
+  float v = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) v += r.x[i][e] * r.x[i][e];
+  const float rstd = rsqrtf(block_sum_rt(v, scratch) / (float)K + 1e-5f);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) r.x[i][e] = r.x[i][e] * rstd * g;
+  r.store(y + off, K);
+}
+
+template <typename T, int VEC>
+int launch_ln(const void* x, void* y, float g, float b, int N, int K, hipStream_t st) {
+  if (!x || !y || N <= 0 || K <= 0) return CLN_ERR_BAD_ARG;
+  if (K % VEC) return CLN_ERR_UNSUPPORTED;
+  const int nt = row_threads(K, VEC), vpt = vecs_per_thread(K, VEC, nt);
+#define CALL(MV)                                                                                              \
+  hipLaunchKernelGGL((layer_norm_kernel<T, VEC, MV>), dim3(N), dim3(nt), 0, st, (const T*)x, (T*)y, g, b, K)
+  ROWWISE_DISPATCH_MAXV(vpt, CALL);
+#undef CALL
+  return cln_check_launch();
+}
+template <typename T, int VEC>
+int launch_rms(const void* x, void* y, float g, int N, int K, hipStream_t st) {
+  if (!x || !y || N <= 0 || K <= 0) return CLN_ERR_BAD_ARG;
+  if (K % VEC) return CLN_ERR_UNSUPPORTED;
+  const int nt = row_threads(K, VEC), vpt = vecs_per_thread(K, VEC, nt);
+#define CALL(MV) \
+  hipLaunchKernelGGL((rms_norm_kernel<T, VEC, MV>), dim3(N), dim3(nt), 0, st, (const T*)x, (T*)y, g, K)
+  ROWWISE_DISPATCH_MAXV(vpt, CALL);
+#undef CALL
+  return cln_check_launch();
+}
+
+}  // namespace
+
+// (x, y, g, b, N rows, K cols, stream) -- reference `void layer_norm_*(Tensor x, Tensor y, float g, float b)`
+#define CLN_LN(name, T, VEC)                                                                       \
+  CLN_API int name(const void* x, void* y, float g, float b, int N, int K, void* stream) {         \
+    return launch_ln<T, VEC>(x, y, g, b, N, K, (hipStream_t)stream);                               \
+  }
+CLN_LN(layer_norm_f32, float, 1)
+CLN_LN(layer_norm_f32x4, float, 4)
+CLN_LN(layer_norm_f16_f16, half_t, 1)
+CLN_LN(layer_norm_f16x2_f16, half_t, 2)
+CLN_LN(layer_norm_f16x8_f16, half_t, 8)
+CLN_LN(layer_norm_f16x8_pack_f16, half_t, 8)
+CLN_LN(layer_norm_f16x8_pack_f32, half_t, 8)
+CLN_LN(layer_norm_f16_f32, half_t, 1)
+
+// (x, y, g, N rows, K cols, stream) -- reference `void rms_norm_*(Tensor x, Tensor y, float g)`
+#define CLN_RMS(name, T, VEC)                                                              \
+  CLN_API int name(const void* x, void* y, float g, int N, int K, void* stream) {          \
+    return launch_rms<T, VEC>(x, y, g, N, K, (hipStream_t)stream);                         \
+  }
+CLN_RMS(rms_norm_f32, float, 1)
+CLN_RMS(rms_norm_f32x4, float, 4)
+CLN_RMS(rms_norm_f16_f16, half_t, 1)
+CLN_RMS(rms_norm_f16x2_f16, half_t, 2)
+CLN_RMS(rms_norm_f16x8_f16, half_t, 8)
+CLN_RMS(rms_norm_f16x8_f32, half_t, 8)
+CLN_RMS(rms_norm_f16x8_pack_f16, half_t, 8)
+CLN_RMS(rms_norm_f16x8_pack_f32, half_t, 8)
+CLN_RMS(rms_norm_f16_f32, half_t, 1)

@@ -1,0 +1,198 @@
+// block_all_reduce_sum: scalar sum of a whole tensor, 20 rungs over dtype / access width / pack
+// accumulator. Replaces reference kernels/reduce/block_all_reduce.cu:42-687 (kernels) and
+// :734-813 (bindings). HBM-bound: sizeof(T) bytes read per element.
+//
+// gfx950 design: capped grid-stride streaming (256 CUs x 16 workgroups), per-lane access width
+// fixed by the rung name, wave64 xor-butterfly -> one LDS hop -> ONE atomic per workgroup
+// (the reference's structure, re-derived for 64 lanes: NUM_WARPS = NT/64).
+// "acc" in the rung name is the precision of the IN-PACK sum, as in the reference
+// (e.g. f16x8_pack_f16 adds the 8 halves of a pack in fp16, block_all_reduce.cu:252-262);
+// everything across packs / lanes / waves is fp32 (int32 for i8), result y is fp32 / int32.
+#include "common.h"
+
+namespace {
+
+struct F32 {};   struct F16 {};   struct BF16 {};   struct E4M3 {};   struct E5M2 {};   struct I8 {};
+
+__device__ __forceinline__ float bf16_to_f32(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
+__device__ __forceinline__ unsigned short f32_to_bf16_rn(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);  // quiet NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+
+// In-pack sum policies ---------------------------------------------------------------------------
+template <typename IN, typename ACC, int VEC>
+struct PackSum;
+
+template <int VEC>
+struct PackSum<F32, F32, VEC> {
+  using elem = float;
+  using out = float;
+  static __device__ __forceinline__ float sum(const float* p) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) s += p[i];
+    return s;
+  }
+};
+template <int VEC>
+struct PackSum<F16, F32, VEC> {
+  using elem = half_t;
+  using out = float;
+  static __device__ __forceinline__ float sum(const half_t* p) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) s += (float)p[i];
+    return s;
+  }
+};
+template <int VEC>
+struct PackSum<F16, F16, VEC> {
+  using elem = half_t;
+  using out = float;
+  static __device__ __forceinline__ float sum(const half_t* p) {
+    half_t s = p[0];
+#pragma unroll
+    for (int i = 1; i < VEC; ++i) s = s + p[i];  // fp16 adds (v_add_f16)
+    return (float)s;
+  }
+};
+template <int VEC>
+struct PackSum<BF16, F32, VEC> {
+  using elem = unsigned short;
+  using out = float;
+  static __device__ __forceinline__ float sum(const unsigned short* p) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) s += bf16_to_f32(p[i]);
+    return s;
+  }
+};
+template <int VEC>
+struct PackSum<BF16, BF16, VEC> {
+  using elem = unsigned short;
+  using out = float;
+  static __device__ __forceinline__ float sum(const unsigned short* p) {
+    float s = bf16_to_f32(p[0]);
+#pragma unroll
+    for (int i = 1; i < VEC; ++i) s = bf16_to_f32(f32_to_bf16_rn(s + bf16_to_f32(p[i])));  // bf16-rounded adds
+    return s;
+  }
+};
+// fp8 -> fp16 accumulate (reference fp8 rungs convert to half and add in half, block_all_reduce.cu:497-607).
+// gfx950 decodes OCP e4m3fn / e5m2 in hardware (v_cvt_f32_fp8 / v_cvt_f32_bf8).
+template <int VEC>
+struct PackSum<E4M3, F16, VEC> {
+  using elem = unsigned char;
+  using out = float;
+  static __device__ __forceinline__ float sum(const unsigned char* p) {
+    half_t s = (half_t)0.f;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) s = s + (half_t)__builtin_amdgcn_cvt_f32_fp8((int)p[i], 0);
+    return (float)s;
+  }
+};
+template <int VEC>
+struct PackSum<E5M2, F16, VEC> {
+  using elem = unsigned char;
+  using out = float;
+  static __device__ __forceinline__ float sum(const unsigned char* p) {
+    half_t s = (half_t)0.f;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) s = s + (half_t)__builtin_amdgcn_cvt_f32_bf8((int)p[i], 0);
+    return (float)s;
+  }
+};
+template <int VEC>
+struct PackSum<I8, I8, VEC> {
+  using elem = signed char;
+  using out = int;
+  static __device__ __forceinline__ int sum(const signed char* p) {
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) s += (int)p[i];
+    return s;
+  }
+};
+
+template <typename E, int VEC>
+struct alignas(sizeof(E) * VEC) Pack {
+  E v[VEC];
+};
+
+template <typename PS, int VEC>
+__global__ __launch_bounds__(256) void reduce_sum_kernel(const typename PS::elem* __restrict__ a,
+                                                         typename PS::out* __restrict__ y, long long n) {
+  using E = typename PS::elem;
+  using O = typename PS::out;
+  __shared__ O scratch[4];
+  O s = 0;
+  const long long nvec = n / VEC;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+       i += (long long)gridDim.x * blockDim.x) {
+    const Pack<E, VEC> p = *reinterpret_cast<const Pack<E, VEC>*>(a + i * VEC);
+    s += PS::sum(p.v);
+  }
+  if (blockIdx.x == 0) {  // ragged tail, element-wise
+    for (long long i = nvec * VEC + threadIdx.x; i < n; i += blockDim.x) {
+      E one[VEC] = {};
+      one[0] = a[i];
+      // sum of a pack whose other slots are zero == decode of the single element
+      s += PS::sum(one);
+    }
+  }
+  // wave64 butterfly
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) scratch[w] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    O t = scratch[0] + scratch[1] + scratch[2] + scratch[3];
+    atomicAdd(y, t);
+  }
+}
+
+template <typename IN, typename ACC, int VEC>
+int launch_reduce(const void* a, void* y, long long n, hipStream_t st) {
+  using PS = PackSum<IN, ACC, VEC>;
+  using E = typename PS::elem;
+  if (!a || !y || n < 0) return CLN_ERR_BAD_ARG;
+  if (n == 0) return CLN_OK;
+  if (sizeof(E) * VEC >= 16 && !cln_aligned16(a)) return CLN_ERR_BAD_ARG;
+  const int grid = cln_stream_grid(n / VEC + 1, 256);
+  hipLaunchKernelGGL((reduce_sum_kernel<PS, VEC>), dim3(grid), dim3(256), 0, st, (const E*)a,
+                     (typename PS::out*)y, n);
+  return cln_check_launch();
+}
+
+}  // namespace
+
+// (a, y, n_elements, stream): y is a 1-element fp32 (int32 for i8) buffer the caller zeroed --
+// the reference binding allocates it with torch::zeros on cuda:0 (block_all_reduce.cu:737-738).
+#define CLN_RED(name, IN, ACC, VEC)                                            \
+  CLN_API int name(const void* a, void* y, long long n, void* stream) {        \
+    return launch_reduce<IN, ACC, VEC>(a, y, n, (hipStream_t)stream);          \
+  }
+CLN_RED(block_all_reduce_sum_f32_f32, F32, F32, 1)
+CLN_RED(block_all_reduce_sum_f32x4_f32, F32, F32, 4)
+CLN_RED(block_all_reduce_sum_f16_f16, F16, F16, 1)
+CLN_RED(block_all_reduce_sum_f16_f32, F16, F32, 1)
+CLN_RED(block_all_reduce_sum_f16x2_f16, F16, F16, 2)
+CLN_RED(block_all_reduce_sum_f16x2_f32, F16, F32, 2)
+CLN_RED(block_all_reduce_sum_f16x8_pack_f16, F16, F16, 8)
+CLN_RED(block_all_reduce_sum_f16x8_pack_f32, F16, F32, 8)
+CLN_RED(block_all_reduce_sum_bf16_bf16, BF16, BF16, 1)
+CLN_RED(block_all_reduce_sum_bf16_f32, BF16, F32, 1)
+CLN_RED(block_all_reduce_sum_bf16x2_bf16, BF16, BF16, 2)
+CLN_RED(block_all_reduce_sum_bf16x2_f32, BF16, F32, 2)
+CLN_RED(block_all_reduce_sum_bf16x8_pack_bf16, BF16, BF16, 8)
+CLN_RED(block_all_reduce_sum_bf16x8_pack_f32, BF16, F32, 8)
+CLN_RED(block_all_reduce_sum_fp8_e4m3_f16, E4M3, F16, 1)
+CLN_RED(block_all_reduce_sum_fp8_e4m3x16_pack_f16, E4M3, F16, 16)
+CLN_RED(block_all_reduce_sum_fp8_e5m2_f16, E5M2, F16, 1)
+CLN_RED(block_all_reduce_sum_fp8_e5m2x16_pack_f16, E5M2, F16, 16)
+CLN_RED(block_all_reduce_sum_i8_i32, I8, I8, 1)
+CLN_RED(block_all_reduce_sum_i8x16_pack_i32, I8, I8, 16)

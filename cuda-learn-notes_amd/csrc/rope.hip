@@ -1,0 +1,83 @@
+// Rotary position embedding on x[seq_len, hidden] fp32, interleaved pairs (x[2i], x[2i+1]),
+// theta = 10000. Replaces reference kernels/rope/rope.cu:20-67 (kernels) / :80-120 (bindings).
+//
+// Semantics: the TORCH ORACLE the reference script prints beside its kernels (naive_rope,
+// kernels/rope/rope.py:68-88): pair i of token t is rotated by t * theta^(-2i/hidden).
+// The reference CUDA kernels compute the exponent with an INTEGER division
+// (`token_idx / (N * 2)`, rope.cu:26, :41, :55-56) which is always 0, so every pair is rotated by
+// t radians; `ref_quirk != 0` reproduces that behaviour bit-for-bit in structure for users who
+// depend on it. HBM-bound (1 read + 1 write); sincos is computed in-kernel because the API passes
+// no table (two v_sin/v_cos per pair hide under the 8 B/pair of traffic at ~6 TB/s).
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ void rotate(float x1, float x2, float ang, float& o1, float& o2) {
+  // angles reach seq_len radians: two-constant Cody-Waite reduction to [-pi, pi] (exact to ~1e-7
+  // for |ang| < 2^15), then the hardware sin/cos, whose argument is in revolutions.
+  const float k = rintf(ang * 0.15915494309189535f);
+  float r = fmaf(-k, 6.28318548202514648f, ang);   // 2*pi rounded to fp32
+  r = fmaf(-k, -1.74845553e-07f, r);                // 2*pi - fp32(2*pi)
+  const float rev = r * 0.15915494309189535f;
+  const float s = __builtin_amdgcn_sinf(rev), c = __builtin_amdgcn_cosf(rev);
+  o1 = x1 * c - x2 * s;
+  o2 = x1 * s + x2 * c;
+}
+
+// PAIRS pairs per thread: 1 -> 8-byte accesses (f32 / f32_v2 rungs), 2 -> 16-byte (f32x4_pack)
+template <int PAIRS>
+__global__ __launch_bounds__(256) void rope_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                   int seq_len, int half_hidden, int ref_quirk,
+                                                   float neg_log2_theta_over_half) {
+  const long long units = (long long)seq_len * half_hidden / PAIRS;
+  for (long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x; u < units;
+       u += (long long)gridDim.x * blockDim.x) {
+    const long long pair0 = u * PAIRS;
+    const int t = (int)(pair0 / half_hidden);
+    const int i0 = (int)(pair0 - (long long)t * half_hidden);
+    float v[2 * PAIRS], o[2 * PAIRS];
+    if constexpr (PAIRS == 2) {
+      *reinterpret_cast<f4*>(v) = *reinterpret_cast<const f4*>(x + pair0 * 2);
+    } else {
+      *reinterpret_cast<f2*>(v) = *reinterpret_cast<const f2*>(x + pair0 * 2);
+    }
+#pragma unroll
+    for (int p = 0; p < PAIRS; ++p) {
+      // freq = theta^(-(i/half_hidden)) = exp2(i * (-log2(theta)/half_hidden))
+      const float freq = ref_quirk ? 1.0f : exp2f((float)(i0 + p) * neg_log2_theta_over_half);
+      rotate(v[2 * p], v[2 * p + 1], (float)t * freq, o[2 * p], o[2 * p + 1]);
+    }
+    if constexpr (PAIRS == 2) {
+      *reinterpret_cast<f4*>(out + pair0 * 2) = *reinterpret_cast<const f4*>(o);
+    } else {
+      *reinterpret_cast<f2*>(out + pair0 * 2) = *reinterpret_cast<const f2*>(o);
+    }
+  }
+}
+
+template <int PAIRS>
+int launch_rope(const void* x, void* out, int seq_len, int hidden, int ref_quirk, hipStream_t st) {
+  if (!x || !out || seq_len <= 0 || hidden <= 0) return CLN_ERR_BAD_ARG;
+  if (hidden % (2 * PAIRS)) return CLN_ERR_UNSUPPORTED;
+  if (PAIRS == 2 && !(cln_aligned16(x) && cln_aligned16(out))) return CLN_ERR_BAD_ARG;
+  const int half_hidden = hidden / 2;
+  const long long units = (long long)seq_len * half_hidden / PAIRS;
+  const int grid = cln_stream_grid(units, 256);
+  const float k = -13.287712379549449f / (float)half_hidden;  // -log2(10000) / (hidden/2)
+  hipLaunchKernelGGL((rope_kernel<PAIRS>), dim3(grid), dim3(256), 0, st, (const float*)x, (float*)out, seq_len,
+                     half_hidden, ref_quirk, k);
+  return cln_check_launch();
+}
+
+}  // namespace
+
+// (x, out, seq_len, hidden, ref_quirk, stream) -- reference `void rope_*(Tensor x, Tensor out)`
+CLN_API int rope_f32(const void* x, void* out, int seq_len, int hidden, int ref_quirk, void* stream) {
+  return launch_rope<1>(x, out, seq_len, hidden, ref_quirk, (hipStream_t)stream);
+}
+CLN_API int rope_f32_v2(const void* x, void* out, int seq_len, int hidden, int ref_quirk, void* stream) {
+  return launch_rope<1>(x, out, seq_len, hidden, ref_quirk, (hipStream_t)stream);
+}
+CLN_API int rope_f32x4_pack(const void* x, void* out, int seq_len, int hidden, int ref_quirk, void* stream) {
+  return launch_rope<2>(x, out, seq_len, hidden, ref_quirk, (hipStream_t)stream);
+}

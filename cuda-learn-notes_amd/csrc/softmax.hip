@@ -1,0 +1,158 @@
+// Softmax, 11 rungs. Replaces reference kernels/softmax/softmax.cu:102-390 (kernels) and
+// :776-885 (bindings).
+//   softmax_f32 / softmax_f32x4         : ONE distribution over the whole 1-D tensor, no max
+//                                         subtraction (softmax.cu:102-148). The reference sums
+//                                         block partials with atomicAdd + __threadfence and divides
+//                                         in the same launch (racy by construction); here it is two
+//                                         stream-ordered launches: sum(exp) -> *total, then divide.
+//   *_per_token                          : one row per workgroup; "safe" subtracts the row max,
+//                                         "online" merges (m, d) pairs (softmax.cu:22-41, :314-390).
+// Row kernels keep the row in registers: 1 HBM read + 1 HBM write per element.
+#include "rowwise.cuh"
+
+using namespace rowwise;
+
+namespace {
+
+enum Mode { UNSAFE = 0, SAFE = 1, ONLINE = 2 };
+
+template <int VEC>
+__global__ __launch_bounds__(256) void exp_sum_kernel(const float* __restrict__ x, float* __restrict__ total,
+                                                      long long n) {
+  __shared__ float scratch[16];
+  float s = 0.f;
+  const long long nvec = n / VEC;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+       i += (long long)gridDim.x * blockDim.x) {
+    const Pack<float, VEC> p = *reinterpret_cast<const Pack<float, VEC>*>(x + i * VEC);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) s += __expf(p.v[e]);
+  }
+  if (blockIdx.x == 0)
+    for (long long i = nvec * VEC + threadIdx.x; i < n; i += blockDim.x) s += __expf(x[i]);
+  s = block_sum<256>(s, scratch);
+  if (threadIdx.x == 0) atomicAdd(total, s);
+}
+template <int VEC>
+__global__ __launch_bounds__(256) void exp_div_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                      const float* __restrict__ total, long long n) {
+  const float inv = 1.0f / *total;
+  const long long nvec = n / VEC;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+       i += (long long)gridDim.x * blockDim.x) {
+    Pack<float, VEC> p = *reinterpret_cast<const Pack<float, VEC>*>(x + i * VEC);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) p.v[e] = __expf(p.v[e]) * inv;
+    *reinterpret_cast<Pack<float, VEC>*>(y + i * VEC) = p;
+  }
+  if (blockIdx.x == 0)
+    for (long long i = nvec * VEC + threadIdx.x; i < n; i += blockDim.x) y[i] = __expf(x[i]) * inv;
+}
+
+template <int VEC>
+int launch_global(const void* x, void* y, void* total, long long n, hipStream_t st) {
+  if (!x || !y || !total || n <= 0) return CLN_ERR_BAD_ARG;
+  const int grid = cln_stream_grid(n / VEC + 1, 256);
+  hipLaunchKernelGGL((exp_sum_kernel<VEC>), dim3(grid), dim3(256), 0, st, (const float*)x, (float*)total, n);
+  hipLaunchKernelGGL((exp_div_kernel<VEC>), dim3(grid), dim3(256), 0, st, (const float*)x, (float*)y,
+                     (const float*)total, n);
+  return cln_check_launch();
+}
+
+template <typename T, int VEC, int MAXV, int MODE>
+__global__ void softmax_row_kernel(const T* __restrict__ x, T* __restrict__ y, int H) {
+  __shared__ float scratch[16];
+  const size_t off = (size_t)blockIdx.x * H;
+  RowRegs<T, VEC, MAXV> r;
+  r.load(x + off, H, -INFINITY);
+  float m = 0.f, d = 0.f;
+  if constexpr (MODE == UNSAFE) {
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        r.x[i][e] = __expf(r.x[i][e]);
+        d += r.x[i][e];
+      }
+    d = block_sum_rt(d, scratch);
+  } else if constexpr (MODE == SAFE) {
+    m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) m = fmaxf(m, r.x[i][e]);
+    m = block_max_rt(m, scratch);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        r.x[i][e] = __expf(r.x[i][e] - m);
+        d += r.x[i][e];
+      }
+    d = block_sum_rt(d, scratch);
+  } else {
+    // online normaliser: per-thread (m, d), then one max-reduction and one rescaled sum-reduction
+    m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const float v = r.x[i][e];
+        const float mn = fmaxf(m, v);
+        d = d * __expf(m - mn) + __expf(v - mn);  // m == mn == -inf only for all-padding lanes
+        m = mn;
+      }
+    if (m == -INFINITY) d = 0.f;
+    const float mg = block_max_rt(m, scratch);
+    d = block_sum_rt((m == -INFINITY) ? 0.f : d * __expf(m - mg), scratch);
+    m = mg;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) r.x[i][e] = __expf(r.x[i][e] - m);
+  }
+  const float inv = 1.0f / d;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) r.x[i][e] *= inv;
+  r.store(y + off, H);
+}
+
+template <typename T, int VEC, int MODE>
+int launch_rows(const void* x, void* y, int S, int H, hipStream_t st) {
+  if (!x || !y || S <= 0 || H <= 0) return CLN_ERR_BAD_ARG;
+  if (H % VEC) return CLN_ERR_UNSUPPORTED;
+  const int nt = row_threads(H, VEC), vpt = vecs_per_thread(H, VEC, nt);
+#define CALL(MV) \
+  hipLaunchKernelGGL((softmax_row_kernel<T, VEC, MV, MODE>), dim3(S), dim3(nt), 0, st, (const T*)x, (T*)y, H)
+  ROWWISE_DISPATCH_MAXV(vpt, CALL);
+#undef CALL
+  return cln_check_launch();
+}
+
+}  // namespace
+
+// (x, y, total_workspace[1] (zeroed by the caller), n, stream) -- reference softmax_f32[x4](x, y)
+CLN_API int softmax_f32(const void* x, void* y, void* total, long long n, void* stream) {
+  return launch_global<1>(x, y, total, n, (hipStream_t)stream);
+}
+CLN_API int softmax_f32x4(const void* x, void* y, void* total, long long n, void* stream) {
+  if (!cln_aligned16(x) || !cln_aligned16(y)) return CLN_ERR_BAD_ARG;
+  return launch_global<4>(x, y, total, n, (hipStream_t)stream);
+}
+
+// (x, y, S rows, H cols, stream)
+#define CLN_SM(name, T, VEC, MODE)                                                  \
+  CLN_API int name(const void* x, void* y, int S, int H, void* stream) {            \
+    return launch_rows<T, VEC, MODE>(x, y, S, H, (hipStream_t)stream);              \
+  }
+CLN_SM(softmax_f32_per_token, float, 1, UNSAFE)
+CLN_SM(softmax_f32x4_per_token, float, 4, UNSAFE)
+CLN_SM(safe_softmax_f32_per_token, float, 1, SAFE)
+CLN_SM(safe_softmax_f32x4_per_token, float, 4, SAFE)
+CLN_SM(safe_softmax_f16_f32_per_token, half_t, 1, SAFE)
+CLN_SM(safe_softmax_f16x2_f32_per_token, half_t, 2, SAFE)
+CLN_SM(safe_softmax_f16x8_pack_f32_per_token, half_t, 8, SAFE)
+CLN_SM(online_safe_softmax_f32_per_token, float, 1, ONLINE)
+CLN_SM(online_safe_softmax_f32x4_pack_per_token, float, 4, ONLINE)

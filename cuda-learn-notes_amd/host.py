@@ -1,0 +1,268 @@
+"""Host-side mirror of the reference's per-kernel PyTorch-extension API.
+
+Every reference `lib.<name>(tensors..., knobs...)` exists here with the same name, argument order
+and error behaviour, implemented as: dtype/shape checks -> `extern "C" int <name>(ptrs, dims, knobs,
+stream)` through ctypes -> status code mapped back to RuntimeError. PyTorch is only plumbing
+(device memory + current HIP stream). Tensors must live on the GPU: there is no CPU path.
+
+Reference bindings mirrored (checks and messages):
+  CHECK_TORCH_TENSOR_DTYPE -> RuntimeError("values must be torch::kHalf")   kernels/hgemm/naive/hgemm.cu:772-777
+  CHECK_TORCH_TENSOR_SHAPE -> RuntimeError("Tensor size mismatch!")          kernels/hgemm/naive/hgemm.cu:778-782
+  head-dim switch default  -> RuntimeError("headdim not support!")           flash_attn_mma_share_qkv.cu:860,:882
+"""
+import os
+import types
+
+import torch
+
+from . import _loader, manifest
+
+_TH_NAME = {
+    torch.float16: "torch::kHalf", torch.float32: "torch::kFloat32", torch.bfloat16: "torch::kBFloat16",
+    torch.int8: "torch::kInt8", torch.int32: "torch::kInt32",
+}
+if hasattr(torch, "float8_e4m3fn"):
+    _TH_NAME[torch.float8_e4m3fn] = "torch::kFloat8_e4m3fn"
+    _TH_NAME[torch.float8_e5m2] = "torch::kFloat8_e5m2"
+
+_STATUS_TEXT = {
+    -1: "bad argument (null/misaligned pointer or non-positive size)",
+    -2: "unsupported shape",
+    -3: "HIP launch failed (hipGetLastError)",
+    -4: "rocBLAS row failed (call init_cublas_handle() first?)",
+}
+
+
+def _check_dtype(t, dtype):
+    if t.dtype != dtype:
+        print("Tensor Info:", t.dtype, t.device, tuple(t.shape))
+        raise RuntimeError("values must be %s" % _TH_NAME.get(dtype, str(dtype)))
+
+
+def _check_dev(*ts):
+    for t in ts:
+        if not t.is_cuda:
+            raise RuntimeError("expected a GPU (HIP) tensor, got device=%s: the kernel library has no CPU path"
+                               % t.device)
+        if not t.is_contiguous():
+            raise RuntimeError("tensor must be contiguous (the kernels take raw data_ptr())")
+
+
+def _check_shape(t, *shape):
+    if tuple(t.shape) != tuple(shape):
+        raise RuntimeError("Tensor size mismatch!")
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _raise(name, rc, unsupported_msg=None):
+    if rc == 0:
+        return
+    if rc == -2 and unsupported_msg:
+        raise RuntimeError(unsupported_msg)
+    raise RuntimeError("%s: %s (status %d)" % (name, _STATUS_TEXT.get(rc, "error"), rc))
+
+
+# ------------------------------------------------------------------------------------------------
+def _make_g3(name):
+    fn = _loader.symbol(name)
+
+    def f(a, b, c):
+        for t in (a, b, c):
+            _check_dtype(t, torch.float16)
+        _check_dev(a, b, c)
+        M, K = a.size(0), a.size(1)
+        N = b.size(1)  # TN operands keep the [K,N] shape (reference as_col_major)
+        _check_shape(a, M, K)
+        _check_shape(b, K, N)
+        _check_shape(c, M, N)
+        _raise(name, fn(a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, _stream()),
+               "%s: M/N/K must be multiples of the block tile" % name)
+    f.__name__ = name
+    return f
+
+
+def _make_g6(name):
+    fn = _loader.symbol(name)
+
+    def f(a, b, c, stages, swizzle, swizzle_stride):
+        for t in (a, b, c):
+            _check_dtype(t, torch.float16)
+        _check_dev(a, b, c)
+        M, K = a.size(0), a.size(1)
+        N = b.size(1)
+        _check_shape(a, M, K)
+        _check_shape(b, K, N)
+        _check_shape(c, M, N)
+        _raise(name, fn(a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, int(stages), int(bool(swizzle)),
+                        int(swizzle_stride), _stream()),
+               "%s: M/N/K must be multiples of the block tile" % name)
+    f.__name__ = name
+    return f
+
+
+def _make_h0(name):
+    fn = _loader.symbol(name)
+
+    def f():
+        _raise(name, fn())
+    f.__name__ = name
+    return f
+
+
+def _make_fa(name):
+    fn = _loader.symbol(name)
+    vt = name in manifest.FA_V_TRANSPOSED
+
+    def f(Q, K, V, O, stages):
+        for t in (Q, K, V, O):
+            _check_dtype(t, torch.float16)
+        _check_dev(Q, K, V, O)
+        B, H, N, D = Q.shape
+        _check_shape(K, B, H, N, D)
+        _check_shape(O, B, H, N, D)
+        if vt:
+            _check_shape(V, B, H, D, N)
+        else:
+            _check_shape(V, B, H, N, D)
+        rc = fn(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), B, H, N, D, int(stages), _stream())
+        if rc == -2:
+            if N % 128 != 0:
+                raise RuntimeError("%s: seqlen must be a multiple of 128 (Br)" % name)
+            raise RuntimeError("headdim not support!")
+        _raise(name, rc)
+    f.__name__ = name
+    return f
+
+
+def _make_p3(name):
+    fn = _loader.symbol(name)
+    dtype = torch.float32 if "_f32" in name else torch.float16
+
+    def f(a, b, c):
+        for t in (a, b, c):
+            _check_dtype(t, dtype)
+        _check_dev(a, b, c)
+        _check_shape(b, *a.shape)
+        _check_shape(c, *a.shape)
+        _raise(name, fn(a.data_ptr(), b.data_ptr(), c.data_ptr(), a.numel(), _stream()))
+    f.__name__ = name
+    return f
+
+
+def _make_r1(name):
+    fn = _loader.symbol(name)
+    in_dt, out_dt = (getattr(torch, n) for n in manifest.REDUCE_DTYPES[name])
+
+    def f(x):
+        _check_dtype(x, in_dt)
+        _check_dev(x)
+        y = torch.zeros(1, dtype=out_dt, device=x.device)  # reference allocates it in the binding
+        _raise(name, fn(x.data_ptr(), y.data_ptr(), x.numel(), _stream()))
+        return y
+    f.__name__ = name
+    return f
+
+
+def _make_sg(name):
+    fn = _loader.symbol(name)
+
+    def f(x, y):
+        _check_dtype(x, torch.float32)
+        _check_dtype(y, torch.float32)
+        _check_dev(x, y)
+        _check_shape(y, *x.shape)
+        total = torch.zeros(1, dtype=torch.float32, device=x.device)  # reference softmax.cu:419
+        _raise(name, fn(x.data_ptr(), y.data_ptr(), total.data_ptr(), x.numel(), _stream()))
+    f.__name__ = name
+    return f
+
+
+def _make_xy(name):
+    fn = _loader.symbol(name)
+    dtype = torch.float16 if "_f16" in name else torch.float32
+
+    def f(x, y):
+        _check_dtype(x, dtype)
+        _check_dtype(y, dtype)
+        _check_dev(x, y)
+        _check_shape(y, *x.shape)
+        S, H = x.size(0), x.size(1)
+        _raise(name, fn(x.data_ptr(), y.data_ptr(), S, H, _stream()),
+               "%s: unsupported H=%d (must be a multiple of the pack width and fit 8 packs x 1024 lanes)"
+               % (name, H))
+    f.__name__ = name
+    return f
+
+
+def _make_ln(name):
+    fn = _loader.symbol(name)
+    dtype = torch.float32 if name.startswith("layer_norm_f32") else torch.float16
+
+    def f(x, y, g, b):
+        _check_dtype(x, dtype)
+        _check_dtype(y, dtype)
+        _check_dev(x, y)
+        _check_shape(y, *x.shape)
+        N, K = x.size(0), x.size(1)
+        _raise(name, fn(x.data_ptr(), y.data_ptr(), float(g), float(b), N, K, _stream()),
+               "%s: unsupported K=%d" % (name, K))
+    f.__name__ = name
+    return f
+
+
+def _make_rn(name):
+    fn = _loader.symbol(name)
+    dtype = torch.float32 if name.startswith("rms_norm_f32") else torch.float16
+
+    def f(x, y, g):
+        _check_dtype(x, dtype)
+        _check_dtype(y, dtype)
+        _check_dev(x, y)
+        _check_shape(y, *x.shape)
+        N, K = x.size(0), x.size(1)
+        _raise(name, fn(x.data_ptr(), y.data_ptr(), float(g), N, K, _stream()), "%s: unsupported K=%d" % (name, K))
+    f.__name__ = name
+    return f
+
+
+def _make_rp(name):
+    fn = _loader.symbol(name)
+
+    def f(x, out):
+        _check_dtype(x, torch.float32)
+        _check_dtype(out, torch.float32)
+        _check_dev(x, out)
+        _check_shape(out, *x.shape)
+        quirk = 1 if os.environ.get("CLN_AMD_ROPE_REF_QUIRK", "0") == "1" else 0
+        _raise(name, fn(x.data_ptr(), out.data_ptr(), x.size(0), x.size(1), quirk, _stream()),
+               "%s: hidden size must be a multiple of the pack width" % name)
+    f.__name__ = name
+    return f
+
+
+_MAKERS = {"G3": _make_g3, "G6": _make_g6, "H0": _make_h0, "FA": _make_fa, "P3": _make_p3, "R1": _make_r1,
+           "SG": _make_sg, "XY": _make_xy, "LN": _make_ln, "RN": _make_rn, "RP": _make_rp}
+
+
+def load_lib(*groups):
+    """Return a module-like object whose attributes are the exported functions of the given lib
+    groups ('hgemm' also pulls in the vendor row, as the reference's single hgemm module does)."""
+    ns = types.SimpleNamespace()
+    for e in manifest.ENTRIES:
+        if e.lib in groups:
+            setattr(ns, e.name, _MAKERS[e.sig](e.name))
+    return ns
+
+
+def hgemm_variant(kind, layout, tile, bk, stages, a, b, c, swizzle=0, swizzle_stride=1):
+    """Tuning hook (not part of the reference surface): run an explicit tile/BK/stage variant."""
+    _check_dev(a, b, c)
+    M, K = a.size(0), a.size(1)
+    N = b.size(1)
+    fn = _loader.load_so("libcln_amd.so").cln_hgemm_variant
+    rc = fn(kind, layout, tile, bk, stages, a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, int(swizzle),
+            int(swizzle_stride), _stream())
+    _raise("cln_hgemm_variant", rc, "variant not available for this shape/LDS budget")

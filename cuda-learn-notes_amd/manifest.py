@@ -1,0 +1,192 @@
+"""Exported-name manifest: every function the reference's extension modules export, the C-ABI
+signature class it has here, and the gfx950 kernel that implements it.
+
+Generated from / checked against the reference PYBIND11_MODULE blocks:
+  kernels/hgemm/pybind/hgemm.cc:58-107, kernels/flash-attn/pybind/flash_attn.cc:182-215,
+  kernels/elementwise/elementwise.cu:170-177, kernels/reduce/block_all_reduce.cu:792-813,
+  kernels/softmax/softmax.cu:873-885, kernels/layer-norm/layer_norm.cu:804-814,
+  kernels/rms-norm/rms_norm.cu:803-813, kernels/rope/rope.cu:116-120.
+
+`impl` names the distinct HIP kernel (template + parameters); entries sharing an `impl` are aliases:
+reference variants that differ only by an NVIDIA mechanism (ldmatrix.x2 vs .x4, register trimming,
+stmatrix, WMMA-vs-MMA API, CuTe, smem swizzle-vs-pad) map onto the same CDNA4 kernel.
+"""
+from collections import namedtuple
+
+Entry = namedtuple("Entry", "name sig lib impl")
+
+# signature classes (C side):
+#   G3   int f(a, b, c, M, N, K, stream)
+#   G6   int f(a, b, c, M, N, K, stages, swizzle, swizzle_stride, stream)
+#   H0   int f(void)
+#   FA   int f(q, k, v, o, B, H, N, D, stages, stream)
+#   P3   int f(a, b, c, n, stream)
+#   R1   int f(a, y, n, stream)                 (python: Tensor f(x))
+#   SG   int f(x, y, total_ws, n, stream)       (python: f(x, y))
+#   XY   int f(x, y, S, H, stream)
+#   LN   int f(x, y, g, b, N, K, stream)
+#   RN   int f(x, y, g, N, K, stream)
+#   RP   int f(x, out, seq_len, hidden, ref_quirk, stream)
+
+_E = []
+
+
+def _add(lib, sig, impl, *names):
+    for n in names:
+        _E.append(Entry(n, sig, lib, impl))
+
+
+# ---------------------------------------------------------------- hgemm (38)
+_add("hgemm", "G3", "valu_naive(1 elem/thread)", "hgemm_naive_f16")
+_add("hgemm", "G3", "valu_sliced_k(32x32x32 LDS)", "hgemm_sliced_k_f16")
+_add("hgemm", "G3", "valu_tile<BK=8,TM=8,single-buffer> v_dot2_f32_f16",
+     "hgemm_t_8x8_sliced_k_f16x4", "hgemm_t_8x8_sliced_k_f16x4_pack", "hgemm_t_8x8_sliced_k_f16x4_bcf",
+     "hgemm_t_8x8_sliced_k_f16x4_pack_bcf", "hgemm_t_8x8_sliced_k_f16x8_pack_bcf")
+_add("hgemm", "G3", "valu_tile<BK=8,TM=8,dbuf>", "hgemm_t_8x8_sliced_k_f16x8_pack_bcf_dbuf")
+_add("hgemm", "G3", "valu_tile<BK=16,TM=8,dbuf>", "hgemm_t_8x8_sliced_k16_f16x8_pack_dbuf")
+_add("hgemm", "G3", "valu_tile<BK=16,TM=8,dbuf,issue-early/write-late>",
+     "hgemm_t_8x8_sliced_k16_f16x8_pack_dbuf_async")
+_add("hgemm", "G3", "valu_tile<BK=32,TM=8,dbuf>", "hgemm_t_8x8_sliced_k32_f16x8_pack_dbuf")
+_add("hgemm", "G3", "valu_tile<BK=32,TM=8,dbuf,issue-early/write-late>",
+     "hgemm_t_8x8_sliced_k32_f16x8_pack_dbuf_async")
+_add("hgemm", "G3", "valu_tile<BK=32,TM=16,dbuf>", "hgemm_t_16x8_sliced_k32_f16x8_pack_dbuf")
+_add("hgemm", "G3", "valu_tile<BK=32,TM=16,dbuf,issue-early/write-late>",
+     "hgemm_t_16x8_sliced_k32_f16x8_pack_dbuf_async")
+_add("hgemm_vendor", "H0", "rocblas_create_handle", "init_cublas_handle")
+_add("hgemm_vendor", "H0", "rocblas_destroy_handle", "destroy_cublas_handle")
+_add("hgemm_vendor", "G3", "rocblas_gemm_ex f16/f32-acc NN", "hgemm_cublas_tensor_op_nn")
+_add("hgemm_vendor", "G3", "rocblas_gemm_ex f16/f32-acc TN", "hgemm_cublas_tensor_op_tn")
+_add("hgemm", "G3", "mfma_naive<NN> 1 wave/16x16 tile, mfma_16x16x16",
+     "hgemm_wmma_m16n16k16_naive", "hgemm_mma_m16n8k16_naive")
+_add("hgemm", "G3", "mfma_1stage<64x128x32,2 waves,NN>", "hgemm_wmma_m16n16k16_mma4x2")
+_add("hgemm", "G3", "mfma_1stage<128x128x32,4 waves,NN>",
+     "hgemm_wmma_m16n16k16_mma4x2_warp2x4", "hgemm_mma_m16n8k16_mma2x4_warp4x4")
+_add("hgemm", "G3", "mfma_ring<128x128,BK=64|32,stages=2,NN>", "hgemm_wmma_m16n16k16_mma4x2_warp2x4_dbuf_async")
+_add("hgemm", "G3", "mfma_ring<128x128,BK=32,stages=2,NN>", "hgemm_wmma_m32n8k16_mma2x4_warp2x4_dbuf_async")
+_add("hgemm", "G6", "mfma_ring<128x128,BK by stages,NN>",
+     "hgemm_wmma_m16n16k16_mma4x2_warp2x4_stages", "hgemm_wmma_m16n16k16_mma4x2_warp2x4_stages_dsmem",
+     "hgemm_mma_m16n8k16_mma2x4_warp4x4_stages", "hgemm_mma_m16n8k16_mma2x4_warp4x4_stages_dsmem")
+_add("hgemm", "G6", "mfma_ring<256x128,8 waves,NN>", "hgemm_wmma_m16n16k16_mma4x2_warp4x4_stages_dsmem")
+_add("hgemm", "G6", "mfma_ring<256x256,8 waves,NN>", "hgemm_wmma_m16n16k16_mma4x4_warp4x4_stages_dsmem")
+_add("hgemm", "G6", "mfma_ring<best tile: 256x256 if >=200 tiles else 128x128,NN>",
+     "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem", "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_x4",
+     "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_rr",
+     "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_swizzle")
+_add("hgemm", "G6", "mfma_ring<128x128,TN>", "hgemm_mma_m16n8k16_mma2x4_warp4x4_stages_dsmem_tn")
+_add("hgemm", "G6", "mfma_ring<best tile,TN>", "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_tn_swizzle_x4")
+_add("hgemm", "G6", "mfma_ring<128x256,8 waves,TN>", "hgemm_mma_stages_block_swizzle_tn_cute")
+
+# ---------------------------------------------------------------- flash-attn (28 + 3)
+_FA_PLAIN = [
+    "flash_attn_mma_stages_split_kv", "flash_attn_mma_stages_split_q",
+    "flash_attn_mma_stages_split_q_shared_kv", "flash_attn_mma_stages_split_q_shared_qkv",
+    "flash_attn_mma_stages_split_q_tiling_qk", "flash_attn_mma_stages_split_q_tiling_qkv",
+    "flash_attn_mma_stages_split_q_shared_kv_acc_f32", "flash_attn_mma_stages_split_q_shared_qkv_acc_f32",
+    "flash_attn_mma_stages_split_q_tiling_qk_acc_f32", "flash_attn_mma_stages_split_q_tiling_qkv_acc_f32",
+    "flash_attn_mma_stages_split_q_shared_kv_swizzle_q", "flash_attn_mma_stages_split_q_shared_kv_swizzle_qk",
+    "flash_attn_mma_stages_split_q_shared_qkv_swizzle_q", "flash_attn_mma_stages_split_q_shared_qkv_swizzle_qk",
+    "flash_attn_mma_stages_split_q_tiling_qk_swizzle_q", "flash_attn_mma_stages_split_q_tiling_qk_swizzle_qk",
+    "flash_attn_mma_stages_split_q_tiling_qkv_swizzle_q", "flash_attn_mma_stages_split_q_tiling_qkv_swizzle_qk",
+    "flash_attn_mma_stages_split_q_tiling_qkv_swizzle_qkv",
+    "flash_attn_mma_stages_split_q_tiling_qkv_acc_f32_swizzle_q",
+    "flash_attn_mma_stages_split_q_tiling_qkv_acc_f32_swizzle_qk",
+    "flash_attn_mma_stages_split_q_tiling_qkv_acc_f32_swizzle_qkv",
+    "flash_attn_mma_stages_split_q_shared_qkv_Os2g", "flash_attn_mma_stages_split_q_shared_kv_acc_f32_rr",
+    "flash_attn_mma_stages_split_q_shared_qkv_acc_f32_rr",
+]
+_FA_VT = [
+    "flash_attn_mma_stages_split_q_shared_kv_swizzle_qkv", "flash_attn_mma_stages_split_q_shared_qkv_swizzle_qkv",
+    "flash_attn_mma_stages_split_q_tiling_qk_swizzle_qkv",
+]
+_add("flash_attn", "FA", "fa2_fwd<D,DV,BC,V row-major> split-Q 4 waves x 32 rows, mfma_32x32x16, f32 acc",
+     *_FA_PLAIN)
+_add("flash_attn", "FA", "fa2_fwd<D,D,64,V transposed [B,H,D,N]>", *_FA_VT)
+
+# max head dim per function (reference flash_attn_mma.py:436-506; C side enforces the same)
+FA_MAX_HEADDIM = {n: 256 for n in _FA_PLAIN + _FA_VT}
+for _n in _FA_PLAIN:
+    if "tiling" in _n:
+        FA_MAX_HEADDIM[_n] = 1024
+FA_MAX_HEADDIM["flash_attn_mma_stages_split_kv"] = 128
+FA_MAX_HEADDIM["flash_attn_mma_stages_split_q"] = 128
+FA_V_TRANSPOSED = set(_FA_VT)
+
+# ---------------------------------------------------------------- bandwidth kernels
+_add("elementwise", "P3", "add_vec<float,4B>", "elementwise_add_f32")
+_add("elementwise", "P3", "add_vec<float4,16B>", "elementwise_add_f32x4")
+_add("elementwise", "P3", "add_vec<half,2B>", "elementwise_add_f16")
+_add("elementwise", "P3", "add_vec<half2,4B>", "elementwise_add_f16x2")
+_add("elementwise", "P3", "add_f16x8_unpacked(4x4B)", "elementwise_add_f16x8")
+_add("elementwise", "P3", "add_vec<half8,16B>", "elementwise_add_f16x8_pack")
+
+for _n, _impl in [
+    ("f32_f32", "f32,1"), ("f32x4_f32", "f32,4"), ("f16_f16", "f16 acc f16,1"), ("f16_f32", "f16 acc f32,1"),
+    ("f16x2_f16", "f16 acc f16,2"), ("f16x2_f32", "f16 acc f32,2"), ("f16x8_pack_f16", "f16 acc f16,8"),
+    ("f16x8_pack_f32", "f16 acc f32,8"), ("bf16_bf16", "bf16 acc bf16,1"), ("bf16_f32", "bf16 acc f32,1"),
+    ("bf16x2_bf16", "bf16 acc bf16,2"), ("bf16x2_f32", "bf16 acc f32,2"), ("bf16x8_pack_bf16", "bf16 acc bf16,8"),
+    ("bf16x8_pack_f32", "bf16 acc f32,8"), ("fp8_e4m3_f16", "e4m3 acc f16,1"),
+    ("fp8_e4m3x16_pack_f16", "e4m3 acc f16,16"), ("fp8_e5m2_f16", "e5m2 acc f16,1"),
+    ("fp8_e5m2x16_pack_f16", "e5m2 acc f16,16"), ("i8_i32", "i8 acc i32,1"), ("i8x16_pack_i32", "i8 acc i32,16"),
+]:
+    _add("reduce", "R1", "reduce_sum<%s>" % _impl, "block_all_reduce_sum_" + _n)
+
+_add("softmax", "SG", "exp_sum<1> + exp_div<1>", "softmax_f32")
+_add("softmax", "SG", "exp_sum<4> + exp_div<4>", "softmax_f32x4")
+for _n, _impl in [
+    ("softmax_f32_per_token", "float,1,unsafe"), ("softmax_f32x4_per_token", "float,4,unsafe"),
+    ("safe_softmax_f32_per_token", "float,1,safe"), ("safe_softmax_f32x4_per_token", "float,4,safe"),
+    ("safe_softmax_f16_f32_per_token", "half,1,safe"), ("safe_softmax_f16x2_f32_per_token", "half,2,safe"),
+    ("safe_softmax_f16x8_pack_f32_per_token", "half,8,safe"),
+    ("online_safe_softmax_f32_per_token", "float,1,online"),
+    ("online_safe_softmax_f32x4_pack_per_token", "float,4,online"),
+]:
+    _add("softmax", "XY", "softmax_row<%s>" % _impl, _n)
+
+for _n, _impl in [
+    ("layer_norm_f32", "float,1"), ("layer_norm_f32x4", "float,4"), ("layer_norm_f16_f16", "half,1"),
+    ("layer_norm_f16_f32", "half,1"), ("layer_norm_f16x2_f16", "half,2"), ("layer_norm_f16x8_f16", "half,8"),
+    ("layer_norm_f16x8_pack_f16", "half,8"), ("layer_norm_f16x8_pack_f32", "half,8"),
+]:
+    _add("layer_norm", "LN", "layer_norm_row<%s> fp32 stats" % _impl, _n)
+for _n, _impl in [
+    ("rms_norm_f32", "float,1"), ("rms_norm_f32x4", "float,4"), ("rms_norm_f16_f16", "half,1"),
+    ("rms_norm_f16x2_f16", "half,2"), ("rms_norm_f16x8_f16", "half,8"), ("rms_norm_f16x8_pack_f16", "half,8"),
+    ("rms_norm_f16x8_f32", "half,8"), ("rms_norm_f16x8_pack_f32", "half,8"), ("rms_norm_f16_f32", "half,1"),
+]:
+    _add("rms_norm", "RN", "rms_norm_row<%s> fp32 stats" % _impl, _n)
+
+_add("rope", "RP", "rope<1 pair/thread, 8B>", "rope_f32", "rope_f32_v2")
+_add("rope", "RP", "rope<2 pairs/thread, 16B>", "rope_f32x4_pack")
+
+ENTRIES = tuple(_E)
+BY_NAME = {e.name: e for e in ENTRIES}
+assert len(BY_NAME) == len(ENTRIES), "duplicate exported name"
+
+# which shared object holds which lib group
+SO_OF_LIB = {
+    "hgemm": "libcln_amd.so", "flash_attn": "libcln_amd.so", "elementwise": "libcln_amd.so",
+    "reduce": "libcln_amd.so", "softmax": "libcln_amd.so", "layer_norm": "libcln_amd.so",
+    "rms_norm": "libcln_amd.so", "rope": "libcln_amd.so", "hgemm_vendor": "libcln_amd_vendor.so",
+}
+
+# element dtype (torch name) each reduce rung takes, and the result dtype
+REDUCE_DTYPES = {}
+for e in ENTRIES:
+    if e.sig == "R1":
+        n = e.name[len("block_all_reduce_sum_"):]
+        if n.startswith("f32"):
+            REDUCE_DTYPES[e.name] = ("float32", "float32")
+        elif n.startswith("f16"):
+            REDUCE_DTYPES[e.name] = ("float16", "float32")
+        elif n.startswith("bf16"):
+            REDUCE_DTYPES[e.name] = ("bfloat16", "float32")
+        elif n.startswith("fp8_e4m3"):
+            REDUCE_DTYPES[e.name] = ("float8_e4m3fn", "float32")
+        elif n.startswith("fp8_e5m2"):
+            REDUCE_DTYPES[e.name] = ("float8_e5m2", "float32")
+        else:
+            REDUCE_DTYPES[e.name] = ("int8", "int32")
+
+
+def entries_of(lib):
+    return [e for e in ENTRIES if e.lib == lib]

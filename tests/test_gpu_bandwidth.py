@@ -1,0 +1,228 @@
+"""GPU parity: elementwise / reduce / softmax / layer-norm / rms-norm / rope through the C-ABI vs the
+CPU oracle on the same seeded inputs. Tolerances are stated per test."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def seeded(seed, *shape, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g).to(dtype)
+
+
+@pytest.fixture(scope="module")
+def lib(built, dev):
+    return built.load("elementwise", "reduce", "softmax", "layer_norm", "rms_norm", "rope")
+
+
+# ------------------------------------------------------------------ elementwise: bit-exact
+@pytest.mark.parametrize("shape", [(2048, 2048), (1024, 1024), (7, 33), (1, 1), (3, 8), (4096, 1000)])
+def test_elementwise_add_bit_exact(lib, dev, oracle, shape):
+    a, b = seeded(1, *shape), seeded(2, *shape)
+    ref32 = oracle.elementwise_add(a, b)
+    for name in ("elementwise_add_f32", "elementwise_add_f32x4"):
+        c = torch.zeros(shape, device=dev)
+        getattr(lib, name)(a.to(dev), b.to(dev), c)
+        assert torch.equal(c.cpu(), ref32), name
+    ah, bh = a.half(), b.half()
+    ref16 = oracle.elementwise_add(ah, bh)  # one rounding of the exact sum: identical on both sides
+    for name in ("elementwise_add_f16", "elementwise_add_f16x2", "elementwise_add_f16x8",
+                 "elementwise_add_f16x8_pack"):
+        c = torch.zeros(shape, device=dev, dtype=torch.half)
+        getattr(lib, name)(ah.to(dev), bh.to(dev), c)
+        assert torch.equal(c.cpu(), ref16), name
+
+
+def test_elementwise_linearity_full_size(lib, dev):
+    """size-independent property at the C1 size and beyond: add(a,b) == add(b,a); add(a,0) == a."""
+    a = torch.randn(4096, 4096, device=dev)
+    b = torch.randn(4096, 4096, device=dev)
+    c1, c2 = torch.empty_like(a), torch.empty_like(a)
+    lib.elementwise_add_f32x4(a, b, c1)
+    lib.elementwise_add_f32(b, a, c2)
+    assert torch.equal(c1, c2)
+    lib.elementwise_add_f32x4(a, torch.zeros_like(a), c1)
+    assert torch.equal(c1, a)
+
+
+# ------------------------------------------------------------------ reduce
+REDUCE_F = ["f32_f32", "f32x4_f32", "f16_f16", "f16_f32", "f16x2_f16", "f16x2_f32", "f16x8_pack_f16",
+            "f16x8_pack_f32", "bf16_bf16", "bf16_f32", "bf16x2_bf16", "bf16x2_f32", "bf16x8_pack_bf16",
+            "bf16x8_pack_f32", "fp8_e4m3_f16", "fp8_e4m3x16_pack_f16", "fp8_e5m2_f16", "fp8_e5m2x16_pack_f16"]
+
+
+@pytest.mark.parametrize("shape", [(1024, 1024), (257, 33), (5,), (4096, 2048)])
+@pytest.mark.parametrize("variant", REDUCE_F)
+def test_reduce_float(lib, dev, oracle, built, variant, shape):
+    name = "block_all_reduce_sum_" + variant
+    in_dt = getattr(torch, built.manifest.REDUCE_DTYPES[name][0])
+    x = seeded(11, *shape).to(in_dt)
+    exact = oracle.reduce_sum(x)  # fp64 sum of the stored values
+    y = getattr(lib, name)(x.to(dev))
+    assert y.dtype == torch.float32 and y.numel() == 1
+    n = x.numel()
+    # error model: fp32 accumulation of n values with |x|~1: random-walk rounding ~ sqrt(n)*eps32*|partial|
+    # plus, for *_f16/_bf16 in-pack accumulation, one half-precision rounding per pack (<= 2^-11 / 2^-8 relative
+    # of the pack sum). Atomic order is non-deterministic, hence a tolerance even for f32.
+    sum_abs = float(x.to(torch.float64).abs().sum())
+    tol = 1e-6 * sum_abs + 1e-3
+    if variant.endswith(("_f16",)) and ("x" in variant.split("_")[0] or "pack" in variant):
+        tol += 2 ** -10 * sum_abs
+    if variant.endswith("_bf16") and ("x" in variant):
+        tol += 2 ** -7 * sum_abs
+    assert abs(y.item() - exact) <= tol, (y.item(), exact, tol)
+
+
+@pytest.mark.parametrize("shape", [(1024, 1024), (4096, 4096), (3, 5, 7), (1,)])
+def test_reduce_i8_bit_exact(lib, dev, oracle, shape):
+    g = torch.Generator().manual_seed(3)
+    x = torch.randint(-128, 128, shape, generator=g, dtype=torch.int8)
+    exact = oracle.reduce_sum(x)
+    for name in ("block_all_reduce_sum_i8_i32", "block_all_reduce_sum_i8x16_pack_i32"):
+        y = getattr(lib, name)(x.to(dev))
+        assert y.dtype == torch.int32
+        assert y.item() == exact, name
+
+
+# ------------------------------------------------------------------ softmax
+@pytest.mark.parametrize("H", [64, 256, 1024, 4096, 8192, 1000])
+def test_softmax_per_token(lib, dev, oracle, H):
+    S = 128
+    x = seeded(21, S, H) * 3.0
+    ref = oracle.softmax_per_token(x)  # fp64 math rounded to fp32
+    for name in ("softmax_f32_per_token", "softmax_f32x4_per_token", "safe_softmax_f32_per_token",
+                 "safe_softmax_f32x4_per_token", "online_safe_softmax_f32_per_token",
+                 "online_safe_softmax_f32x4_pack_per_token"):
+        y = torch.zeros(S, H, device=dev)
+        getattr(lib, name)(x.to(dev), y)
+        # fast-math exp (reference builds with --use_fast_math): 2e-6 abs on probabilities <= 1
+        assert torch.allclose(y.cpu(), ref, atol=2e-6, rtol=2e-5), name
+        assert torch.allclose(y.sum(dim=1).cpu(), torch.ones(S), atol=1e-5)
+    if H % 8 == 0:
+        xh = x.half()
+        refh = oracle.softmax_per_token(xh)
+        for name in ("safe_softmax_f16_f32_per_token", "safe_softmax_f16x2_f32_per_token",
+                     "safe_softmax_f16x8_pack_f32_per_token"):
+            y = torch.zeros(S, H, device=dev, dtype=torch.half)
+            getattr(lib, name)(xh.to(dev), y)
+            assert torch.allclose(y.cpu().float(), refh.float(), atol=1e-6, rtol=2e-3), name  # 1 fp16 ulp
+
+
+def test_softmax_safe_handles_large_logits(lib, dev, oracle):
+    x = seeded(22, 16, 512) * 50.0 + 200.0  # exp overflows fp32 without max subtraction
+    ref = oracle.softmax_per_token(x)
+    for name in ("safe_softmax_f32_per_token", "online_safe_softmax_f32x4_pack_per_token"):
+        y = torch.zeros(16, 512, device=dev)
+        getattr(lib, name)(x.to(dev), y)
+        assert torch.isfinite(y).all()
+        assert torch.allclose(y.cpu(), ref, atol=1e-5, rtol=1e-4), name
+
+
+@pytest.mark.parametrize("n", [16384, 4096 * 256, 1000])
+def test_softmax_global(lib, dev, oracle, n):
+    x = seeded(23, n)
+    ref = oracle.softmax_global(x)
+    for name in ("softmax_f32", "softmax_f32x4"):
+        if name.endswith("x4") and n % 4:
+            continue
+        y = torch.zeros(n, device=dev)
+        getattr(lib, name)(x.to(dev), y)
+        assert torch.allclose(y.cpu(), ref, rtol=2e-5, atol=1e-12), name
+        assert abs(y.sum().item() - 1.0) < 1e-4
+
+
+# ------------------------------------------------------------------ norms
+LN_F32 = ["layer_norm_f32", "layer_norm_f32x4"]
+LN_F16 = ["layer_norm_f16_f16", "layer_norm_f16_f32", "layer_norm_f16x2_f16", "layer_norm_f16x8_f16",
+          "layer_norm_f16x8_pack_f16", "layer_norm_f16x8_pack_f32"]
+RMS_F32 = ["rms_norm_f32", "rms_norm_f32x4"]
+RMS_F16 = ["rms_norm_f16_f16", "rms_norm_f16x2_f16", "rms_norm_f16x8_f16", "rms_norm_f16x8_pack_f16",
+           "rms_norm_f16x8_f32", "rms_norm_f16x8_pack_f32", "rms_norm_f16_f32"]
+
+
+@pytest.mark.parametrize("K", [64, 512, 1024, 4096, 8192, 1000])
+def test_layer_norm(lib, dev, oracle, K):
+    N, g, b = 96, 1.5, -0.25
+    x = seeded(31, N, K) * 2.0 + 0.5
+    ref_k = oracle.layer_norm_kernel(x, g, b)  # the reference KERNEL's arithmetic (population var, eps on K)
+    ref_t = oracle.layer_norm_torch(x, g, b)   # the script's torch column (unbiased std)
+    for name in LN_F32:
+        y = torch.zeros(N, K, device=dev)
+        getattr(lib, name)(x.to(dev), y, g, b)
+        assert torch.allclose(y.cpu(), ref_k, atol=2e-5, rtol=1e-5), name
+        assert torch.allclose(y.cpu(), ref_t, atol=6.0 / K + 1e-4), name  # sqrt((K-1)/K) factor on |y| <~ 6
+    if K % 8 == 0:
+        xh = x.half()
+        ref_kh = oracle.layer_norm_kernel(xh, g, b)
+        for name in LN_F16:
+            y = torch.zeros(N, K, device=dev, dtype=torch.half)
+            getattr(lib, name)(xh.to(dev), y, g, b)
+            assert torch.allclose(y.cpu().float(), ref_kh.float(), atol=1e-3, rtol=2e-3), name  # 1 fp16 ulp
+
+
+@pytest.mark.parametrize("K", [64, 512, 1024, 4096, 8192, 1000])
+def test_rms_norm(lib, dev, oracle, K):
+    N, g = 96, 0.75
+    x = seeded(32, N, K) * 2.0
+    ref_k = oracle.rms_norm_kernel(x, g)
+    ref_t = oracle.rms_norm_torch(x, g)
+    for name in RMS_F32:
+        y = torch.zeros(N, K, device=dev)
+        getattr(lib, name)(x.to(dev), y, g)
+        assert torch.allclose(y.cpu(), ref_k, atol=2e-5, rtol=1e-5), name
+        assert torch.allclose(y.cpu(), ref_t, atol=1e-4), name  # eps 1e-5 on mean(x^2) ~ 4
+    if K % 8 == 0:
+        xh = x.half()
+        ref_kh = oracle.rms_norm_kernel(xh, g)
+        for name in RMS_F16:
+            y = torch.zeros(N, K, device=dev, dtype=torch.half)
+            getattr(lib, name)(xh.to(dev), y, g)
+            assert torch.allclose(y.cpu().float(), ref_kh.float(), atol=1e-3, rtol=2e-3), name
+
+
+def test_norm_full_size_properties(lib, dev):
+    """[4096,4096] / [8192,8192] fp16: rows of layer-norm have mean ~0 / var ~1, rms-norm rows have unit rms."""
+    x = torch.randn(4096, 4096, device=dev) * 3 + 1
+    y = torch.empty_like(x)
+    lib.layer_norm_f32x4(x, y, 1.0, 0.0)
+    assert y.mean(dim=1).abs().max() < 1e-4
+    assert (y.var(dim=1, unbiased=False) - 1).abs().max() < 1e-3
+    xh = torch.randn(8192, 8192, device=dev, dtype=torch.half)
+    yh = torch.empty_like(xh)
+    lib.rms_norm_f16x8_pack_f32(xh, yh, 1.0)
+    rms = yh.float().pow(2).mean(dim=1).sqrt()
+    assert (rms - 1).abs().max() < 2e-3
+
+
+# ------------------------------------------------------------------ rope
+@pytest.mark.parametrize("shape", [(64, 128), (4096, 512), (8192, 1024), (17, 64)])
+def test_rope_matches_torch_oracle(lib, dev, oracle, shape, monkeypatch):
+    monkeypatch.delenv("CLN_AMD_ROPE_REF_QUIRK", raising=False)
+    x = seeded(41, *shape)
+    ref = oracle.rope_torch(x)
+    for name in ("rope_f32", "rope_f32_v2", "rope_f32x4_pack"):
+        out = torch.zeros(shape, device=dev)
+        getattr(lib, name)(x.to(dev), out)
+        d = (out.cpu() - ref).abs()
+        # angle = t*freq is formed in fp32 on both sides; freq differs by ~2 ulp (exp2 vs pow), so the angle
+        # error grows like t * 2.4e-7 rad and the output error like |x| * that: 1e-2 covers t = 8192, |x| < 5
+        assert d.max() < 1e-2, (name, d.max())
+        small_t = min(64, shape[0])
+        assert d[:small_t].max() < 2e-4, (name, d[:small_t].max())
+        # rotation preserves each pair's norm
+        n_in = x.view(shape[0], -1, 2).norm(dim=-1)
+        n_out = out.cpu().view(shape[0], -1, 2).norm(dim=-1)
+        assert torch.allclose(n_in, n_out, atol=1e-4, rtol=1e-4)
+
+
+def test_rope_reference_kernel_quirk_mode(lib, dev, oracle, monkeypatch):
+    monkeypatch.setenv("CLN_AMD_ROPE_REF_QUIRK", "1")
+    x = seeded(42, 512, 256)
+    ref = oracle.rope_kernel(x)
+    for name in ("rope_f32", "rope_f32x4_pack"):
+        out = torch.zeros(512, 256, device=dev)
+        getattr(lib, name)(x.to(dev), out)
+        assert (out.cpu() - ref).abs().max() < 5e-4, name

@@ -1,0 +1,178 @@
+"""GPU parity: every HGEMM entry point through the C-ABI vs the CPU oracle (fp32-accumulate product of
+the same fp16 inputs). Tolerance: the kernels accumulate in fp32 and round once to fp16, so the result
+must be within one fp16 ulp of the fp32 truth: rtol 2^-10 (plus atol 2e-3 for near-cancelled sums)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 2 ** -10, 2e-3
+
+
+def seeded(seed, *shape):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g).half()
+
+
+@pytest.fixture(scope="module")
+def hg(built, dev):
+    lib = built.hgemm_lib()
+    lib.init_cublas_handle()
+    yield lib
+    lib.destroy_cublas_handle()
+
+
+def check(c, a, b):
+    truth = a.float() @ b.float()
+    got = c.cpu().float()
+    err = (got - truth).abs()
+    bound = ATOL + RTOL * truth.abs()
+    bad = (err > bound).sum().item()
+    assert bad == 0, "mismatches=%d max_err=%g" % (bad, err.max().item())
+
+
+G3_NN = [e for e in [
+    "hgemm_naive_f16", "hgemm_sliced_k_f16", "hgemm_t_8x8_sliced_k_f16x4", "hgemm_t_8x8_sliced_k_f16x4_pack",
+    "hgemm_t_8x8_sliced_k_f16x4_bcf", "hgemm_t_8x8_sliced_k_f16x4_pack_bcf", "hgemm_t_8x8_sliced_k_f16x8_pack_bcf",
+    "hgemm_t_8x8_sliced_k_f16x8_pack_bcf_dbuf", "hgemm_t_8x8_sliced_k16_f16x8_pack_dbuf",
+    "hgemm_t_8x8_sliced_k16_f16x8_pack_dbuf_async", "hgemm_t_8x8_sliced_k32_f16x8_pack_dbuf",
+    "hgemm_t_8x8_sliced_k32_f16x8_pack_dbuf_async", "hgemm_t_16x8_sliced_k32_f16x8_pack_dbuf",
+    "hgemm_t_16x8_sliced_k32_f16x8_pack_dbuf_async", "hgemm_cublas_tensor_op_nn", "hgemm_wmma_m16n16k16_naive",
+    "hgemm_wmma_m16n16k16_mma4x2", "hgemm_wmma_m16n16k16_mma4x2_warp2x4",
+    "hgemm_wmma_m16n16k16_mma4x2_warp2x4_dbuf_async", "hgemm_wmma_m32n8k16_mma2x4_warp2x4_dbuf_async",
+    "hgemm_mma_m16n8k16_naive", "hgemm_mma_m16n8k16_mma2x4_warp4x4"]]
+G6_NN = ["hgemm_wmma_m16n16k16_mma4x2_warp2x4_stages", "hgemm_wmma_m16n16k16_mma4x2_warp2x4_stages_dsmem",
+         "hgemm_wmma_m16n16k16_mma4x2_warp4x4_stages_dsmem", "hgemm_wmma_m16n16k16_mma4x4_warp4x4_stages_dsmem",
+         "hgemm_mma_m16n8k16_mma2x4_warp4x4_stages", "hgemm_mma_m16n8k16_mma2x4_warp4x4_stages_dsmem",
+         "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem", "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_x4",
+         "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_rr",
+         "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_swizzle"]
+G6_TN = ["hgemm_mma_m16n8k16_mma2x4_warp4x4_stages_dsmem_tn",
+         "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_tn_swizzle_x4", "hgemm_mma_stages_block_swizzle_tn_cute"]
+
+
+@pytest.mark.parametrize("name", G3_NN)
+def test_g3_functions(hg, dev, name):
+    M, N, K = 256, 384, 512  # asymmetric on purpose
+    a, b = seeded(1, M, K), seeded(2, K, N)
+    c = torch.zeros(M, N, dtype=torch.half, device=dev)
+    getattr(hg, name)(a.to(dev), b.to(dev), c)
+    check(c, a, b)
+
+
+@pytest.mark.parametrize("stages", [2, 3, 4, 5])
+@pytest.mark.parametrize("swizzle", [False, True])
+@pytest.mark.parametrize("name", G6_NN)
+def test_g6_nn_functions(hg, dev, name, stages, swizzle):
+    M, N, K = 512, 768, 320  # K % 64 == 0; 5 K-tiles of 64
+    a, b = seeded(3, M, K), seeded(4, K, N)
+    c = torch.zeros(M, N, dtype=torch.half, device=dev)
+    getattr(hg, name)(a.to(dev), b.to(dev), c, stages, swizzle, 256)
+    check(c, a, b)
+
+
+@pytest.mark.parametrize("stages", [2, 3, 4])
+@pytest.mark.parametrize("swizzle", [False, True])
+@pytest.mark.parametrize("name", G6_TN + ["hgemm_cublas_tensor_op_tn"])
+def test_tn_functions(hg, dev, built, name, stages, swizzle):
+    from cuda_learn_notes_amd.bench_utils import as_col_major
+    M, N, K = 512, 768, 320
+    a, b = seeded(5, M, K), seeded(6, K, N)
+    bt = as_col_major(b)  # [K,N] shape, [N,K] storage
+    c = torch.zeros(M, N, dtype=torch.half, device=dev)
+    if name.startswith("hgemm_cublas"):
+        getattr(hg, name)(a.to(dev), bt.to(dev), c)
+    else:
+        getattr(hg, name)(a.to(dev), bt.to(dev), c, stages, swizzle, 256)
+    check(c, a, b)
+
+
+@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+@pytest.mark.parametrize("bk,stages", [(64, 2), (64, 3), (64, 5), (32, 2), (32, 3), (32, 4), (32, 5)])
+def test_every_ring_instantiation(built, dev, layout, tile, bk, stages):
+    """Each (tile, BK, stages, layout) template instantiation, incl. K tiles fewer than stages."""
+    from cuda_learn_notes_amd import host
+    from cuda_learn_notes_amd.bench_utils import as_col_major
+    lds = stages * {0: 256, 1: 512, 2: 384, 3: 384}[tile] * bk * 2
+    if lds > 160 * 1024:
+        pytest.skip("does not fit LDS")
+    for K in (bk, 3 * bk, 9 * bk):
+        M, N = 512, 512
+        a, b = seeded(7 + K, M, K), seeded(8 + K, K, N)
+        c = torch.zeros(M, N, dtype=torch.half, device=dev)
+        bb = as_col_major(b) if layout else b
+        host.hgemm_variant(0, layout, tile, bk, stages, a.to(dev), bb.to(dev), c, swizzle=1, swizzle_stride=256)
+        check(c, a, b)
+
+
+def test_identity_times_asymmetric_b_is_exact(hg, dev):
+    """A = I catches any row/column transposition in fragment or C layouts (cdna guide G9)."""
+    n = 512
+    a = torch.eye(n).half()
+    b = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 2039 - 1000).half() / 8  # asymmetric, exact in fp16
+    for name in ("hgemm_mma_m16n8k16_naive", "hgemm_mma_m16n8k16_mma2x4_warp4x4"):
+        c = torch.zeros(n, n, dtype=torch.half, device=dev)
+        getattr(hg, name)(a.to(dev), b.to(dev), c)
+        assert torch.equal(c.cpu(), b), name
+    for name in G6_NN:
+        c = torch.zeros(n, n, dtype=torch.half, device=dev)
+        getattr(hg, name)(a.to(dev), b.to(dev), c, 2, True, 256)
+        assert torch.equal(c.cpu(), b), name
+    # and B = I: C must equal A
+    a2 = b.t().contiguous()
+    c = torch.zeros(n, n, dtype=torch.half, device=dev)
+    hg.hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem(a2.to(dev), torch.eye(n).half().to(dev), c, 3, False, 1)
+    assert torch.equal(c.cpu(), a2)
+
+
+def test_block_swizzle_is_a_pure_schedule_change(hg, dev):
+    M = N = K = 1024
+    a, b = seeded(9, M, K).to(dev), seeded(10, K, N).to(dev)
+    outs = []
+    for swizzle, stride in ((False, 1), (True, 256), (True, 512), (True, 2048)):
+        c = torch.zeros(M, N, dtype=torch.half, device=dev)
+        hg.hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem(a, b, c, 2, swizzle, stride)
+        outs.append(c)
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+
+
+def test_k_not_multiple_of_64_uses_bk32(hg, dev):
+    M, N, K = 256, 256, 96
+    a, b = seeded(11, M, K), seeded(12, K, N)
+    c = torch.zeros(M, N, dtype=torch.half, device=dev)
+    hg.hgemm_mma_m16n8k16_mma2x4_warp4x4_stages_dsmem(a.to(dev), b.to(dev), c, 3, False, 1)
+    check(c, a, b)
+
+
+def test_unsupported_shape_raises(hg, dev):
+    a = torch.zeros(100, 64, dtype=torch.half, device=dev)
+    b = torch.zeros(64, 100, dtype=torch.half, device=dev)
+    c = torch.zeros(100, 100, dtype=torch.half, device=dev)
+    with pytest.raises(RuntimeError, match="multiples of the block tile"):
+        hg.hgemm_mma_m16n8k16_mma2x4_warp4x4_stages_dsmem(a, b, c, 2, False, 1)
+    hg.hgemm_naive_f16(a, b, c)  # the naive rungs take any shape
+    hg.hgemm_mma_m16n8k16_naive(a, b, c)
+
+
+@pytest.mark.parametrize("size", [1024, 4096, 8192])
+def test_baseline_configs_sampled_rows(hg, dev, size):
+    """C2 / C3 sizes: rows sampled across the matrix vs the fp32 oracle computed on CPU."""
+    from cuda_learn_notes_amd.bench_utils import make_block_swizzle_stride
+    M = N = K = size
+    torch.manual_seed(size)
+    a = torch.randn(M, K, dtype=torch.half, device=dev)
+    b = torch.randn(K, N, dtype=torch.half, device=dev)
+    rows = torch.arange(0, M, max(1, M // 64))[:64]
+    truth = a[rows].cpu().float() @ b.cpu().float()
+    stride = make_block_swizzle_stride(N, K)
+    for name, args in (("hgemm_mma_m16n8k16_mma2x4_warp4x4", ()),
+                       ("hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem", (2, True, stride)),
+                       ("hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem", (3, False, 1)),
+                       ("hgemm_cublas_tensor_op_nn", ())):
+        c = torch.zeros(M, N, dtype=torch.half, device=dev)
+        getattr(hg, name)(a, b, c, *args)
+        got = c[rows].cpu().float()
+        err = (got - truth).abs()
+        assert (err <= ATOL + RTOL * truth.abs()).all(), (name, err.max().item())

@@ -1,0 +1,78 @@
+"""CPU: the oracle restatement agrees with the outputs of the REFERENCE's own Python functions
+(fixtures written by tests/golden/make_golden.py, which executes the reference code)."""
+import json
+import os
+
+import numpy as np
+import torch
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def seeded(seed, *shape, dtype=torch.float32):
+    g = torch.Generator().manual_seed(int(seed))
+    return torch.randn(*shape, generator=g).to(dtype)
+
+
+def test_attention_matches_reference_function(oracle):
+    z = np.load(os.path.join(GOLD, "attn_b2h2n128d64.npz"))
+    B, H, N, D = z["shape"]
+    q, k, v = (seeded(s, B, H, N, D, dtype=torch.float16) for s in z["seeds"])
+    ref = torch.from_numpy(z["out"])
+    got = oracle.unfused_standard_attn(q.float(), k.float(), v.float())
+    assert torch.allclose(got, ref, atol=1e-6, rtol=1e-6)
+    # the fp64 oracle used by the GPU tests is the same function at higher precision
+    assert (oracle.attention_fp64(q, k, v).float() - ref).abs().max() < 1e-5
+    assert (oracle.sdpa(q.float(), k.float(), v.float()) - ref).abs().max() < 1e-5
+
+
+def test_hgemm_matches_script_column(oracle):
+    z = np.load(os.path.join(GOLD, "hgemm_128x192x256.npz"))
+    M, N, K = z["shape"]
+    a, b = seeded(z["seeds"][0], M, K, dtype=torch.float16), seeded(z["seeds"][1], K, N, dtype=torch.float16)
+    ref = torch.from_numpy(z["out"])  # torch.matmul on fp16 (hgemm.py:420-421)
+    assert torch.equal(oracle.hgemm_fp16_path(a, b), ref)
+    # fp32-accumulate oracle differs from the fp16 script column by at most fp16 rounding of |C|~16
+    assert (oracle.hgemm(a, b).float() - ref.float()).abs().max() <= 0.0625
+    assert torch.equal(oracle.as_col_major(b), torch.from_numpy(z["b_col_major"]))
+    # as_col_major keeps the [K,N] shape with [N,K] storage
+    assert torch.equal(oracle.as_col_major(b).reshape(N, K).t().contiguous(), b)
+
+
+def test_scalars(oracle):
+    sc = json.load(open(os.path.join(GOLD, "scalars.json")))
+    for key, val in sc["block_swizzle_stride"].items():
+        n, k = map(int, key.split("_"))
+        assert oracle.make_block_swizzle_stride(n, k) == val
+    assert abs(oracle.get_mha_tflops(4, 8, 2048, 64, 1.0) - sc["mha_tflops_at_1s"]["C4"]) < 1e-12
+    assert abs(oracle.get_mha_tflops(1, 32, 4096, 512, 1.0) - sc["mha_tflops_at_1s"]["C5"]) < 1e-12
+    assert abs(oracle.get_mha_tflops(4, 8, 2048, 64, 1.0, True) - sc["mha_tflops_at_1s"]["C4_mm"]) < 1e-12
+
+
+def test_row_ops_match_reference_functions(oracle):
+    z = np.load(os.path.join(GOLD, "rows_64x512.npz"))
+    x = seeded(z["seed"], 64, 512)
+    t = lambda k: torch.from_numpy(z[k])
+    assert torch.allclose(oracle.layer_norm_torch(x, 1.0, 0.0), t("layer_norm"), atol=2e-6)
+    assert torch.allclose(oracle.layer_norm_torch(x, 1.5, -0.25), t("layer_norm_gb"), atol=2e-6)
+    assert torch.allclose(oracle.rms_norm_torch(x, 1.0), t("rms_norm"), atol=2e-6)
+    assert torch.allclose(oracle.rms_norm_torch(x, 0.5), t("rms_norm_g"), atol=2e-6)
+    assert torch.allclose(oracle.rope_torch(x), t("rope"), atol=1e-6)
+    assert torch.allclose(oracle.softmax_per_token(x), t("softmax"), atol=1e-7)
+    assert torch.allclose(oracle.softmax_global(x).flatten(), t("softmax_global"), atol=1e-9)
+    assert torch.equal(oracle.elementwise_add(x, seeded(301, 64, 512)), t("add"))
+    assert abs(oracle.reduce_sum(x) - float(z["sum"])) < 1e-9
+
+
+def test_kernel_semantics_vs_torch_oracle(oracle):
+    """The documented quirks: kernel-semantics restatements stay within fp16 tolerance of the torch
+    oracle for the norms, and rope's kernel quirk equals the torch oracle only at position 0."""
+    x = seeded(7, 32, 1024)
+    d = (oracle.layer_norm_kernel(x, 1.0, 0.0) - oracle.layer_norm_torch(x, 1.0, 0.0)).abs().max()
+    assert d < 3e-3  # sqrt(1023/1024) factor on |y| <~ 4
+    d = (oracle.rms_norm_kernel(x, 1.0) - oracle.rms_norm_torch(x, 1.0)).abs().max()
+    assert d < 1e-4
+    rk, rt = oracle.rope_kernel(x), oracle.rope_torch(x)
+    assert torch.allclose(rk[0], rt[0], atol=1e-6)
+    assert torch.allclose(rk[:, :2], rt[:, :2], atol=1e-4)  # pair 0 has frequency 1 in both
+    assert (rk[5] - rt[5]).abs().max() > 0.1
