@@ -146,16 +146,17 @@ def cpu_baseline(a, b, M, N, K):
     """The reference's own torch path (`torch.matmul` on fp16 tensors, hgemm.py:420-421) on the host cores,
     on a bounded sample of the same workload: the first `rows` rows of A against the full B."""
     orc = entry.load_oracle()
-    rows = 512
-    a_s, b_c = a[:rows].cpu(), b.cpu()
+    b_c = b.cpu()
+    rows = 16  # probe run (~1-2 s: fp16 matmul on CPU has no fast path), then one sample sized for ~10 s
     t0 = time.perf_counter()
-    orc.hgemm_fp16_path(a_s, b_c)
+    orc.hgemm_fp16_path(a[:rows].cpu(), b_c)
     dt = time.perf_counter() - t0
-    if dt < 2.0 and rows * 4 <= M:  # grow the sample towards ~10 s of CPU work
-        rows *= 4
-        a_s = a[:rows].cpu()
+    target = int(rows * 10.0 / max(dt, 1e-3))
+    target = max(16, min(M, (target // 16) * 16))
+    if target > rows:
+        rows = target
         t0 = time.perf_counter()
-        orc.hgemm_fp16_path(a_s, b_c)
+        orc.hgemm_fp16_path(a[:rows].cpu(), b_c)
         dt = time.perf_counter() - t0
     return {"value": round(2.0 * rows * N * K / dt * 1e-12, 5), "unit": "TFLOPS", "cores": torch.get_num_threads(),
             "kind": "port", "sample": "torch.matmul fp16 on CPU, first %d of %d rows of A x full B, 1 iteration "
