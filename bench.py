@@ -93,7 +93,7 @@ def main():
     achieved = flops / (ev_ms * 1e-3) * 1e-12
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": bu.PEAK_FP16_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(achieved / bu.PEAK_FP16_MFMA_TFLOPS, 4), "traffic": None,
-                "kernel": "hgemm_ring_kernel<256x256x64,2 stages,NN>", "avg_launch_ms": round(ev_ms, 5),
+                "kernel": "hgemm_pp_kernel<NN,256x256x64,4 slots,split DMA,LDS epilogue>", "avg_launch_ms": round(ev_ms, 5),
                 "min_launch_ms": round(ev_min, 5), "algorithmic_flops_per_launch": flops,
                 "algorithmic_bytes_per_launch": bu.hgemm_bytes(M, N, K)}
 

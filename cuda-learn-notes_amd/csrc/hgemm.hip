@@ -30,6 +30,22 @@ int best_tile(int M, int N) {
   return T128;
 }
 
+// Top rungs (reference warp4x4x2 family): for 256x256-tileable problems the `stages` knob selects a
+// distinct pipeline structure: 2 -> quadrant ping-pong over a 2 x 64-deep ring with split DMA,
+// 4 -> k-half ping-pong over a 4 x 32-deep ring, 3/5 -> plain multi-stage ring.
+template <int LAYOUT>
+int best_dispatch(const void* a, const void* b, void* c, int M, int N, int K, int stages, int swizzle, int stride,
+                  hipStream_t st) {
+  const int tile = best_tile(M, N);
+  if (tile == T256) {
+    if ((stages == 2 || stages < 2 || stages > 5) && K % 64 == 0)
+      return launch_pp<LAYOUT, 2, 4, 0, 1>(a, b, c, M, N, K, swizzle, stride, st);
+    if (stages == 4 && K % 32 == 0) return launch_pp32<LAYOUT, 2>(a, b, c, M, N, K, swizzle, stride, st);
+  }
+  return LAYOUT == TN ? ring_dispatch_tn(tile, a, b, c, M, N, K, stages, swizzle, stride, st)
+                      : ring_dispatch_nn(tile, a, b, c, M, N, K, stages, swizzle, stride, st);
+}
+
 using C1S_128_NN = Cfg<128, 128, 32, 2, 2, 1, NN>;
 using C1S_64x128_NN = Cfg<64, 128, 32, 1, 2, 1, NN>;
 
@@ -98,19 +114,19 @@ CLN_G6(hgemm_mma_m16n8k16_mma2x4_warp4x4_stages,
 CLN_G6(hgemm_mma_m16n8k16_mma2x4_warp4x4_stages_dsmem,
        ring_dispatch_nn(T128, a, b, c, M, N, K, stages, swizzle, swizzle_stride, stream))
 CLN_G6(hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem,
-       ring_dispatch_nn(best_tile(M, N), a, b, c, M, N, K, stages, swizzle, swizzle_stride, stream))
+       best_dispatch<NN>(a, b, c, M, N, K, stages, swizzle, swizzle_stride, stream))
 CLN_G6(hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_x4,
-       ring_dispatch_nn(best_tile(M, N), a, b, c, M, N, K, stages, swizzle, swizzle_stride, stream))
+       best_dispatch<NN>(a, b, c, M, N, K, stages, swizzle, swizzle_stride, stream))
 CLN_G6(hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_rr,
-       ring_dispatch_nn(best_tile(M, N), a, b, c, M, N, K, stages, swizzle, swizzle_stride, stream))
+       best_dispatch<NN>(a, b, c, M, N, K, stages, swizzle, swizzle_stride, stream))
 CLN_G6(hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_swizzle,
-       ring_dispatch_nn(best_tile(M, N), a, b, c, M, N, K, stages, swizzle, swizzle_stride, stream))
+       best_dispatch<NN>(a, b, c, M, N, K, stages, swizzle, swizzle_stride, stream))
 // TN family: reference hgemm_mma_stage_tn.cu:517, hgemm_mma_stage_tn_swizzle_x4.cu:860,
 // cutlass/hgemm_mma_stage_tn_cute.cu:521 (128x256 tile)
 CLN_G6(hgemm_mma_m16n8k16_mma2x4_warp4x4_stages_dsmem_tn,
        ring_dispatch_tn(T128, a, b, c, M, N, K, stages, swizzle, swizzle_stride, stream))
 CLN_G6(hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_tn_swizzle_x4,
-       ring_dispatch_tn(best_tile(M, N), a, b, c, M, N, K, stages, swizzle, swizzle_stride, stream))
+       best_dispatch<TN>(a, b, c, M, N, K, stages, swizzle, swizzle_stride, stream))
 CLN_G6(hgemm_mma_stages_block_swizzle_tn_cute,
        ring_dispatch_tn((N % 256 == 0) ? T128x256 : T128, a, b, c, M, N, K, stages, swizzle, swizzle_stride,
                         stream))
@@ -129,6 +145,40 @@ CLN_API int cln_hgemm_variant(int kind, int layout, int tile, int bk, int stages
   if (kind == 1) {
     return layout == TN ? launch_1stage<Cfg<128, 128, 32, 2, 2, 1, TN>>(a, b, c, M, N, K, stream)
                         : launch_1stage<C1S_128_NN>(a, b, c, M, N, K, stream);
+  }
+  if (kind == 3) {  // ping-pong 256x256x64
+    return layout == TN ? launch_pp<TN>(a, b, c, M, N, K, swizzle, swizzle_stride, stream)
+                        : launch_pp<NN>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+  }
+  if (kind == 4) return launch_pp<NN, 1>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);  // no-store probe
+  if (kind == 5) {  // ping-pong + LDS-staged epilogue; `stages` selects 8 or 4 slots per K tile
+    if (stages == 4)
+      return layout == TN ? launch_pp<TN, 2, 4>(a, b, c, M, N, K, swizzle, swizzle_stride, stream)
+                          : launch_pp<NN, 2, 4>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+    return layout == TN ? launch_pp<TN, 2, 8>(a, b, c, M, N, K, swizzle, swizzle_stride, stream)
+                        : launch_pp<NN, 2, 8>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+  }
+  if (kind == 8) {  // 4-slot ping-pong, split DMA, LDS epilogue (stages==1: no-store probe)
+    if (stages == 1) return launch_pp<NN, 1, 4, 0, 1>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+    return layout == TN ? launch_pp<TN, 2, 4, 0, 1>(a, b, c, M, N, K, swizzle, swizzle_stride, stream)
+                        : launch_pp<NN, 2, 4, 0, 1>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+  }
+  if (kind == 9) {  // k-half ping-pong (BK=32 sub-tiles, 4-deep ring); stages==1: no-store probe
+    if (stages == 1) return launch_pp32<NN, 1>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+    return layout == TN ? launch_pp32<TN, 2>(a, b, c, M, N, K, swizzle, swizzle_stride, stream)
+                        : launch_pp32<NN, 2>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+  }
+  if (kind == 6) return launch_pp<NN, 1, 4>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);  // 4-slot no-store probe
+  if (kind == 7) {  // ablations of the 4-slot no-store probe; `stages` = ABL bits (results are garbage by design)
+    switch (stages) {
+      case 1: return launch_pp<NN, 1, 4, 1>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+      case 2: return launch_pp<NN, 1, 4, 2>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+      case 3: return launch_pp<NN, 1, 4, 3>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+      case 7: return launch_pp<NN, 1, 4, 7>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+      case 8: return launch_pp<NN, 1, 4, 8>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+      case 4: return launch_pp<NN, 1, 4, 4>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+      default: return CLN_ERR_BAD_ARG;
+    }
   }
   if (kind == 2) return layout == TN ? launch_naive<TN>(a, b, c, M, N, K, stream) : launch_naive<NN>(a, b, c, M, N, K, stream);
   return CLN_ERR_BAD_ARG;

@@ -151,6 +151,15 @@ __device__ __forceinline__ void issue_image(const char* sbase, const unsigned (&
   for (int i = 0; i < NLOADS; ++i) glds16_asm(sbase, voff[i], lds_img + (unsigned)(i * NW + wave) * 1024u);
 }
 
+// Same, but only the pieces whose index bit is set in MASK (compile-time).
+template <int NW, int NLOADS, unsigned MASK>
+__device__ __forceinline__ void issue_image_masked(const char* sbase, const unsigned (&voff)[NLOADS], unsigned lds_img,
+                                                   int wave) {
+#pragma unroll
+  for (int i = 0; i < NLOADS; ++i)
+    if ((MASK >> i) & 1u) glds16_asm(sbase, voff[i], lds_img + (unsigned)(i * NW + wave) * 1024u);
+}
+
 // ---- fragment readers --------------------------------------------------------------------------
 // K-contiguous image, rows [row0 + 16*f + (lane&15)], k chunk (lane>>4) of k-step kk.
 template <int BK>
@@ -211,6 +220,36 @@ __device__ __forceinline__ void store_tile(half_t* Cmat, int N, int m0, int n0, 
     for (int j = 0; j < C::FN; ++j)
       store_c4(Cmat, N, m0 + wm * C::WTM + i * 16 + (lane & 15), n0 + wn * C::WTN + j * 16 + 4 * (lane >> 4),
                acc[i][j]);
+}
+
+// ---- epilogue through LDS: full-line 16-byte stores ---------------------------------------------
+// After the K loop the operand ring is dead, so each wave parks its 128x64 fp16 result in a PRIVATE
+// LDS region ([64 rows][144 B], two passes of 64 rows) and streams it out as 16 bytes per lane:
+// one store instruction = 8 rows x 128 contiguous bytes instead of 16 rows x 4 x 8-byte pieces
+// (store tail is issue- and partial-line-bound, cdna guide T21). No barrier: the region is
+// wave-private and LDS ops of one wave complete in order.
+template <int FM, int FN>
+__device__ __forceinline__ void store_tile_via_lds(half_t* Cmat, int N, int row0, int col0, int lane, char* wave_lds,
+                                                   const f4 (&acc)[FM][FN]) {
+  static_assert(FN == 4 && FM % 4 == 0, "wave tile N must be 64");
+  constexpr int RS = 144;  // row stride: 128 B of data + 16 B pad (keeps 16-B alignment, 2-way write conflict)
+#pragma unroll
+  for (int h = 0; h < FM / 4; ++h) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const f4 v = acc[h * 4 + i][j];
+        h4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+        *reinterpret_cast<h4*>(wave_lds + (i * 16 + (lane & 15)) * RS + (j * 16 + 4 * (lane >> 4)) * 2) = o;
+      }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int r = it * 8 + (lane >> 3);
+      const u4 v = *reinterpret_cast<const u4*>(wave_lds + r * RS + (lane & 7) * 16);
+      *reinterpret_cast<u4*>(Cmat + (size_t)(row0 + h * 64 + r) * N + col0 + (lane & 7) * 8) = v;
+    }
+  }
 }
 
 // ---- multi-stage LDS-DMA ring kernel -----------------------------------------------------------
@@ -278,7 +317,376 @@ __global__ __launch_bounds__(C::NT, (C::NT >= 512 ? 2 : 1)) void hgemm_ring_kern
     compute_tile<C>(a_img, a_img + C::A_BYTES, wm, wn, lane, acc);
     buf = (buf + 1 == S) ? 0 : buf + 1;
   }
-  store_tile<C>(Cmat, N, m0, n0, wm, wn, lane, acc);
+  if constexpr (C::FN == 4 && C::FM % 4 == 0 && C::NW * 64 * 144 <= C::LDS_BYTES) {
+    __syncthreads();  // other waves may still be reading fragments of the last K tile
+    store_tile_via_lds<C::FM, C::FN>(Cmat, N, m0 + wm * C::WTM, n0 + wn * C::WTN, lane, smem + wave * (64 * 144), acc);
+  } else {
+    store_tile<C>(Cmat, N, m0, n0, wm, wn, lane, acc);
+  }
+}
+
+// ---- ping-pong kernel: 256x256x64, 8 waves, the two waves of every SIMD alternate roles -----------
+// Waves 0-3 (group 0, M rows 0-127) and waves 4-7 (group 1, rows 128-255) are the two residents of
+// SIMD 0-3. Each K tile is cut into 4 quadrant phases of the wave's 128x64 output (64x32 each =
+// 16 MFMAs over both k-steps); a phase is  [LDS fragment reads] s_barrier [16 MFMA] s_barrier.
+// Group 1 runs ONE barrier behind group 0, so in every barrier-to-barrier slot one wave of a SIMD
+// is in its MFMA segment while its partner is in its read (+DMA issue) segment: matrix pipe and
+// LDS pipe overlap without any intra-wave software pipelining (cdna guide T3/T5 mechanism, built
+// here on a 2-buffer K-tile ring). s_setprio(1) around the MFMA segment lets the scheduler favour
+// the computing wave.
+//   slot:    0        1        2        3        4        5        6        7      (per K tile)
+//   G0:  DMA+L(q0)  M(q0)    L(q1)    M(q1)    L(q2)    M(q2)   wait DMA  M(q3)
+//   G1:   M(q3')   DMA+L(q0) M(q0)    L(q1)    M(q1)    L(q2)    M(q2)   wait DMA
+// quadrants: q0=(A0,B0) loads A0+B0 (12 frag reads), q1=(A0,B1) loads B1 (4), q2=(A1,B1) loads A1
+// (8), q3=(A1,B0) loads nothing (B0 still live).
+// Ordering of the LDS-DMA ring (2 K-tile buffers): tile t+1 is issued in slot 0 of tile t into the
+// buffer tile t-1 was read from (its last reads, L(q2), ended >= 2 barriers earlier for both
+// groups); every wave drains its own DMA with vmcnt(0) BEFORE the barrier that ends slot 6, which
+// for group 1 is one rendezvous earlier than group 0's first read of tile t+1.
+template <int LAYOUT, int EPI = 0, int SLOTS = 8, int ABL = 0, int SPLIT = 0>
+__global__ __launch_bounds__(512, 2) void hgemm_pp_kernel(const half_t* __restrict__ A, const half_t* __restrict__ B,
+                                                          half_t* __restrict__ Cmat, int M, int N, int K,
+                                                          int tiles_m, int tiles_n, int swizzle, int band) {
+  using C = Cfg<256, 256, 64, 2, 4, 2, LAYOUT>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 2, wn = wave & 3;  // wm == group
+  int tm, tn;
+  tile_coords(blockIdx.x, gridDim.x, tiles_m, tiles_n, swizzle, band, tm, tn);
+  const int m0 = tm * C::BM, n0 = tn * C::BN;
+
+  KFill<C, C::A_LOADS> fa;
+  fa.init(K, wave, lane);
+  KFill<C, C::B_LOADS> fbt;
+  NFill<C, C::B_LOADS> fbn;
+  if constexpr (LAYOUT == TN) fbt.init(K, wave, lane);
+  else fbn.init(N, wave, lane);
+  const char* a_src = reinterpret_cast<const char*>(A + (size_t)m0 * K);
+  const char* b_src = (LAYOUT == TN) ? reinterpret_cast<const char*>(B + (size_t)n0 * K)
+                                     : reinterpret_cast<const char*>(B + n0);
+  const size_t a_step = (size_t)C::BK * 2;
+  const size_t b_step = (LAYOUT == TN) ? (size_t)C::BK * 2 : (size_t)C::BK * N * 2;
+  const unsigned lds0 = lds_addr_of(smem);
+  auto stage = [&](int buf) {
+    const unsigned a_img = lds0 + buf * C::STAGE_BYTES;
+    issue_image<C::NW, C::A_LOADS>(a_src, fa.voff, a_img, wave);
+    if constexpr (LAYOUT == TN) issue_image<C::NW, C::B_LOADS>(b_src, fbt.voff, a_img + C::A_BYTES, wave);
+    else issue_image<C::NW, C::B_LOADS>(b_src, fbn.voff, a_img + C::A_BYTES, wave);
+    a_src += a_step;
+    b_src += b_step;
+  };
+
+  f4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+  h8 af[2][4];     // A half (4 row-fragments) x 2 k-steps, re-used for A0 then A1
+  h8 bf[2][2][2];  // [B half][k-step][2 col-fragments], both halves stay live
+
+  bool first_tile = true;  // ablation builds only
+  auto load_a = [&](const char* a_img, int half) {
+    if constexpr ((ABL & 1) != 0) { if (!first_tile) return; }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        af[kk][i] = read_kfrag<64>(a_img, wm * 128 + half * 64 + i * 16 + (lane & 15), lane, kk);
+  };
+  auto load_b = [&](const char* b_img, int half) {
+    if constexpr ((ABL & 1) != 0) { if (!first_tile) return; }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if constexpr (LAYOUT == TN)
+          bf[half][kk][j] = read_kfrag<64>(b_img, wn * 64 + half * 32 + j * 16 + (lane & 15), lane, kk);
+        else
+          bf[half][kk][j] = read_nfrag<256>(b_img, wn * 64 + half * 32 + j * 16, lane, kk);
+      }
+  };
+  auto mma = [&](int ah, int bh) {
+    if constexpr ((ABL & 8) == 0) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[ah * 4 + i][bh * 2 + j] =
+              __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[bh][kk][j], af[kk][i], acc[ah * 4 + i][bh * 2 + j], 0, 0, 0);
+    if constexpr ((ABL & 8) == 0) __builtin_amdgcn_s_setprio(0);
+  };
+#define PP_BARRIER()                          \
+  do {                                        \
+    __builtin_amdgcn_sched_barrier(0);        \
+    if constexpr ((ABL & 4) == 0) __builtin_amdgcn_s_barrier(); \
+    asm volatile("" ::: "memory");            \
+    __builtin_amdgcn_sched_barrier(0);        \
+  } while (0)
+
+  const int nt = K / 64;
+  stage(0);
+  wait_vmcnt<0>();
+  PP_BARRIER();                  // tile 0 visible to everyone
+  if (wm == 1) PP_BARRIER();     // group 1 runs one slot behind
+
+  for (int t = 0; t < nt; ++t) {
+    const char* a_img = smem + (t & 1) * C::STAGE_BYTES;
+    const char* b_img = a_img + C::A_BYTES;
+    if constexpr ((ABL & 2) == 0 && SPLIT == 0) { if (t + 1 < nt) stage((t + 1) & 1); }
+    if constexpr (SLOTS == 8) {
+      load_a(a_img, 0);
+      load_b(b_img, 0);
+      PP_BARRIER();
+      mma(0, 0);
+      PP_BARRIER();
+      load_b(b_img, 1);
+      PP_BARRIER();
+      mma(0, 1);
+      PP_BARRIER();
+      load_a(a_img, 1);
+      PP_BARRIER();
+      mma(1, 1);
+      PP_BARRIER();
+      wait_vmcnt<0>();             // own pieces of tile t+1 have landed
+      PP_BARRIER();
+      mma(1, 0);
+      PP_BARRIER();
+    } else if constexpr (SPLIT == 0) {
+      // 4 slots per tile, 32 MFMAs per compute slot: half the barriers per tile.
+      //   G0:  DMA+L(A0,B0,B1)   M(q0,q1)   L(A1)+wait DMA   M(q2,q3)
+      // Reads are drained (lgkmcnt(0)) BEFORE the barrier that ends a read slot: the partner group
+      // issues the next tile's DMA into this tile's ring buffer right after that rendezvous.
+      load_a(a_img, 0);
+      load_b(b_img, 0);
+      load_b(b_img, 1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      PP_BARRIER();
+      mma(0, 0);
+      mma(0, 1);
+      PP_BARRIER();
+      load_a(a_img, 1);
+      wait_vmcnt<0>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      PP_BARRIER();
+      mma(1, 1);
+      mma(1, 0);
+      PP_BARRIER();
+    }
+    if constexpr (SLOTS == 4 && SPLIT == 1) {
+      // Same 4 slots, but the next tile's DMA is split over BOTH read slots so neither is bound by the
+      // texture-address path (32 pieces of 1 KiB per group per slot were): slot 0 issues H0(t+1) = the
+      // A rows every wave reads first (A0 halves: pieces 0,2) + all of B (6 pieces); slot 2 issues
+      // H1(t+1) = the A1 halves (pieces 1,3). Counted waits keep the younger group in flight:
+      //   end of slot 2 (t):   vmcnt(2) -> H0(t+1) landed (needed by slot 0 of t+1), H1(t+1) still flying
+      //   end of slot 0 (t+1): vmcnt(6) -> H1(t+1) landed (needed by slot 2 of t+1), H0(t+2) still flying
+      const bool more = (t + 1 < nt);
+      if (more) {
+        const unsigned nimg = lds0 + ((t + 1) & 1) * C::STAGE_BYTES;
+        issue_image_masked<C::NW, C::A_LOADS, 0x5u>(a_src, fa.voff, nimg, wave);
+        if constexpr (LAYOUT == TN) issue_image<C::NW, C::B_LOADS>(b_src, fbt.voff, nimg + C::A_BYTES, wave);
+        else issue_image<C::NW, C::B_LOADS>(b_src, fbn.voff, nimg + C::A_BYTES, wave);
+        b_src += b_step;
+      }
+      load_a(a_img, 0);
+      load_b(b_img, 0);
+      load_b(b_img, 1);
+      if (more) wait_vmcnt<6>();
+      else wait_vmcnt<0>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      PP_BARRIER();
+      mma(0, 0);
+      mma(0, 1);
+      PP_BARRIER();
+      if (more) {
+        const unsigned nimg = lds0 + ((t + 1) & 1) * C::STAGE_BYTES;
+        issue_image_masked<C::NW, C::A_LOADS, 0xAu>(a_src, fa.voff, nimg, wave);
+        a_src += a_step;
+      }
+      load_a(a_img, 1);
+      if (more) wait_vmcnt<2>();
+      else wait_vmcnt<0>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      PP_BARRIER();
+      mma(1, 1);
+      mma(1, 0);
+      PP_BARRIER();
+    }
+    first_tile = false;
+  }
+  if (wm == 0) PP_BARRIER();     // balance the stagger
+#undef PP_BARRIER
+  if constexpr (EPI == 0) {
+    store_tile<C>(Cmat, N, m0, n0, wm, wn, lane, acc);
+  } else if constexpr (EPI == 2) {
+    // every wave is past its last fragment read of the final K tile (see the slot table above)
+    store_tile_via_lds<8, 4>(Cmat, N, m0 + wm * 128, n0 + wn * 64, lane, smem + wave * (64 * 144), acc);
+  } else {  // measurement-only variant: keep the accumulators live, store (almost) nothing
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (s == 123.456f) Cmat[(size_t)m0 * N + n0] = (half_t)s;
+  }
+}
+
+template <int LAYOUT, int EPI = 0, int SLOTS = 8, int ABL = 0, int SPLIT = 0>
+int launch_pp(const void* a, const void* b, void* c, int M, int N, int K, int swizzle, int swizzle_stride,
+              hipStream_t stream) {
+  using C = Cfg<256, 256, 64, 2, 4, 2, LAYOUT>;
+  if (M % 256 || N % 256 || K % 64) return CLN_ERR_UNSUPPORTED;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&hgemm_pp_kernel<LAYOUT, EPI, SLOTS, ABL, SPLIT>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess)
+      return CLN_ERR_LAUNCH;
+    attr_done = true;
+  }
+  const int tiles_m = M / 256, tiles_n = N / 256;
+  int band = (swizzle && swizzle_stride >= 256) ? swizzle_stride / 256 : tiles_n;
+  hipLaunchKernelGGL((hgemm_pp_kernel<LAYOUT, EPI, SLOTS, ABL, SPLIT>), dim3(tiles_m * tiles_n), dim3(512), C::LDS_BYTES, stream,
+                     (const half_t*)a, (const half_t*)b, (half_t*)c, M, N, K, tiles_m, tiles_n, swizzle ? 1 : 0, band);
+  return cln_check_launch();
+}
+
+// ---- ping-pong over k-halves: 256x256 tile, BK = 32 sub-tiles, 4-deep LDS-DMA ring ---------------
+// Every barrier-to-barrier slot is identical: a wave in its READ slot issues the DMA of sub-tile
+// s+3 (4 pieces of 1 KiB), reads the 12 fragments of sub-tile s (8 A + 4 B for one 32-deep k-step)
+// and drains them; in its COMPUTE slot it issues the 32 MFMAs of that k-step over all 8x4
+// accumulators. Group 1 (waves 4-7 = the second resident of each SIMD) runs one barrier behind
+// group 0, so a SIMD always has one wave computing and one reading. Versus the quadrant schedule
+// above: balanced read slots (the quadrant slots carried 24/8 reads and 8/0 DMA pieces), prefetch
+// distance 3 sub-tiles instead of 1 tile, 48 instead of 64 fragment registers.
+//   ring invariants (4 buffers of 32 KiB):  DMA(s+3) overwrites buffer (s-1)&3 whose reads were
+//   drained (lgkmcnt(0)) before the barrier that ended READ(s-1) of BOTH groups; every wave drains
+//   its own DMA(s+1) pieces (counted vmcnt) before the barrier that ends READ(s), which precedes
+//   the first read of sub-tile s+1 by either group.
+template <int LAYOUT, int EPI = 2>
+__global__ __launch_bounds__(512, 2) void hgemm_pp32_kernel(const half_t* __restrict__ A,
+                                                            const half_t* __restrict__ B,
+                                                            half_t* __restrict__ Cmat, int M, int N, int K,
+                                                            int tiles_m, int tiles_n, int swizzle, int band) {
+  using C = Cfg<256, 256, 32, 2, 4, 4, LAYOUT>;
+  static_assert(C::LOADS == 4, "4 DMA pieces per wave per sub-tile");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  int tm, tn;
+  tile_coords(blockIdx.x, gridDim.x, tiles_m, tiles_n, swizzle, band, tm, tn);
+  const int m0 = tm * 256, n0 = tn * 256;
+
+  KFill<C, C::A_LOADS> fa;
+  fa.init(K, wave, lane);
+  KFill<C, C::B_LOADS> fbt;
+  NFill<C, C::B_LOADS> fbn;
+  if constexpr (LAYOUT == TN) fbt.init(K, wave, lane);
+  else fbn.init(N, wave, lane);
+  const char* a_src = reinterpret_cast<const char*>(A + (size_t)m0 * K);
+  const char* b_src = (LAYOUT == TN) ? reinterpret_cast<const char*>(B + (size_t)n0 * K)
+                                     : reinterpret_cast<const char*>(B + n0);
+  const size_t a_step = 64;  // 32 halves
+  const size_t b_step = (LAYOUT == TN) ? (size_t)64 : (size_t)32 * N * 2;
+  const unsigned lds0 = lds_addr_of(smem);
+  auto stage = [&](int buf) {
+    const unsigned a_img = lds0 + buf * C::STAGE_BYTES;
+    issue_image<C::NW, C::A_LOADS>(a_src, fa.voff, a_img, wave);
+    if constexpr (LAYOUT == TN) issue_image<C::NW, C::B_LOADS>(b_src, fbt.voff, a_img + C::A_BYTES, wave);
+    else issue_image<C::NW, C::B_LOADS>(b_src, fbn.voff, a_img + C::A_BYTES, wave);
+    a_src += a_step;
+    b_src += b_step;
+  };
+
+  f4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+#define PP_BARRIER()                          \
+  do {                                        \
+    __builtin_amdgcn_sched_barrier(0);        \
+    __builtin_amdgcn_s_barrier();             \
+    asm volatile("" ::: "memory");            \
+    __builtin_amdgcn_sched_barrier(0);        \
+  } while (0)
+
+  const int ns = K / 32;
+  // prologue: sub-tiles 0..2 in flight, sub-tile 0 landed and visible
+  stage(0);
+  if (ns > 1) stage(1);
+  if (ns > 2) stage(2);
+  if (ns > 2) wait_vmcnt<8>();
+  else if (ns > 1) wait_vmcnt<4>();
+  else wait_vmcnt<0>();
+  PP_BARRIER();
+  if (wm == 1) PP_BARRIER();  // group 1 runs one slot behind
+
+  for (int s = 0; s < ns; ++s) {
+    // ---------------- READ slot
+    if (s + 3 < ns) stage((s + 3) & 3);
+    const char* a_img = smem + (s & 3) * C::STAGE_BYTES;
+    const char* b_img = a_img + C::A_BYTES;
+    h8 af[8], bf[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if constexpr (LAYOUT == TN) bf[j] = read_kfrag<32>(b_img, wn * 64 + j * 16 + (lane & 15), lane, 0);
+      else bf[j] = read_nfrag<256>(b_img, wn * 64 + j * 16, lane, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) af[i] = read_kfrag<32>(a_img, wm * 128 + i * 16 + (lane & 15), lane, 0);
+    // own pieces of sub-tile s+1 must have landed; s+2, s+3 may stay in flight
+    if (s + 3 < ns) wait_vmcnt<8>();
+    else if (s + 2 < ns) wait_vmcnt<4>();
+    else wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    PP_BARRIER();
+    // ---------------- COMPUTE slot
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    PP_BARRIER();
+  }
+  if (wm == 0) PP_BARRIER();  // balance the stagger
+#undef PP_BARRIER
+  if constexpr (EPI == 2) {
+    store_tile_via_lds<8, 4>(Cmat, N, m0 + wm * 128, n0 + wn * 64, lane, smem + wave * (64 * 144), acc);
+  } else if constexpr (EPI == 0) {
+    store_tile<C>(Cmat, N, m0, n0, wm, wn, lane, acc);
+  } else {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (t == 123.456f) Cmat[(size_t)m0 * N + n0] = (half_t)t;
+  }
+}
+
+template <int LAYOUT, int EPI = 2>
+int launch_pp32(const void* a, const void* b, void* c, int M, int N, int K, int swizzle, int swizzle_stride,
+                hipStream_t stream) {
+  using C = Cfg<256, 256, 32, 2, 4, 4, LAYOUT>;
+  if (M % 256 || N % 256 || K % 32) return CLN_ERR_UNSUPPORTED;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&hgemm_pp32_kernel<LAYOUT, EPI>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess)
+      return CLN_ERR_LAUNCH;
+    attr_done = true;
+  }
+  const int tiles_m = M / 256, tiles_n = N / 256;
+  int band = (swizzle && swizzle_stride >= 256) ? swizzle_stride / 256 : tiles_n;
+  hipLaunchKernelGGL((hgemm_pp32_kernel<LAYOUT, EPI>), dim3(tiles_m * tiles_n), dim3(512), C::LDS_BYTES, stream,
+                     (const half_t*)a, (const half_t*)b, (half_t*)c, M, N, K, tiles_m, tiles_n, swizzle ? 1 : 0, band);
+  return cln_check_launch();
 }
 
 // ---- single-stage, register-staged rung (the "1-stage MMA tile" of config C2) ------------------

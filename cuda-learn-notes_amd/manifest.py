@@ -68,12 +68,12 @@ _add("hgemm", "G6", "mfma_ring<128x128,BK by stages,NN>",
      "hgemm_mma_m16n8k16_mma2x4_warp4x4_stages", "hgemm_mma_m16n8k16_mma2x4_warp4x4_stages_dsmem")
 _add("hgemm", "G6", "mfma_ring<256x128,8 waves,NN>", "hgemm_wmma_m16n16k16_mma4x2_warp4x4_stages_dsmem")
 _add("hgemm", "G6", "mfma_ring<256x256,8 waves,NN>", "hgemm_wmma_m16n16k16_mma4x4_warp4x4_stages_dsmem")
-_add("hgemm", "G6", "mfma_ring<best tile: 256x256 if >=200 tiles else 128x128,NN>",
+_add("hgemm", "G6", "best<NN>: >=200 256x256 tiles -> pingpong<256x256x64,4 slots,split DMA> (stages 2) | pingpong_khalf<4x32 ring> (stages 4) | mfma_ring; else mfma_ring<128x128>",
      "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem", "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_x4",
      "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_rr",
      "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_swizzle")
 _add("hgemm", "G6", "mfma_ring<128x128,TN>", "hgemm_mma_m16n8k16_mma2x4_warp4x4_stages_dsmem_tn")
-_add("hgemm", "G6", "mfma_ring<best tile,TN>", "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_tn_swizzle_x4")
+_add("hgemm", "G6", "best<TN>: pingpong / pingpong_khalf / mfma_ring as for NN", "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_tn_swizzle_x4")
 _add("hgemm", "G6", "mfma_ring<128x256,8 waves,TN>", "hgemm_mma_stages_block_swizzle_tn_cute")
 
 # ---------------------------------------------------------------- flash-attn (28 + 3)

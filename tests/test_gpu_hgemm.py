@@ -106,6 +106,28 @@ def test_every_ring_instantiation(built, dev, layout, tile, bk, stages):
         check(c, a, b)
 
 
+@pytest.mark.parametrize("layout", [0, 1])
+def test_pingpong_kernel(built, dev, layout):
+    """256x256x64 phase-staggered kernel (kind 3): several K depths incl. a single K tile, many launches
+    (a barrier/DMA ordering slip shows up as rare wrong tiles, so repeat and compare bit-exactly)."""
+    from cuda_learn_notes_amd import host
+    from cuda_learn_notes_amd.bench_utils import as_col_major
+    for (M, N, K) in ((256, 256, 64), (512, 768, 320), (512, 512, 128), (1024, 1024, 1024), (2048, 2048, 512)):
+        a, b = seeded(70 + K, M, K), seeded(71 + K, K, N)
+        bb = (as_col_major(b) if layout else b).to(dev)
+        ad = a.to(dev)
+        first = None
+        for rep in range(10):
+            c = torch.zeros(M, N, dtype=torch.half, device=dev)
+            kind, st = ((3, 2), (5, 8), (5, 4), (8, 4), (9, 4))[rep % 5]  # plain / LDS-epilogue 8 slots / 4 slots / split DMA / k-half ring
+            host.hgemm_variant(kind, layout, 1, 64, st, ad, bb, c, swizzle=rep & 1, swizzle_stride=512)
+            if first is None:
+                check(c, a, b)
+                first = c
+            else:
+                assert torch.equal(c, first)
+
+
 def test_identity_times_asymmetric_b_is_exact(hg, dev):
     """A = I catches any row/column transposition in fragment or C layouts (cdna guide G9)."""
     n = 512
