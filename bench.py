@@ -79,10 +79,7 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = bu.max_over_ranks(elapsed, dist, dev)
 
     flops = bu.hgemm_flops(M, N, K)
     ms_per_step = elapsed / args.steps * 1e3
@@ -91,9 +88,11 @@ def main():
     # ---- roofline of the dominant kernel: HIP events on the launch stream, per launch
     ev_ms, ev_min, _ = bu.time_call_events(step, 3, max(10, min(args.steps, 50)))
     achieved = flops / (ev_ms * 1e-3) * 1e-12
+    traffic, traffic_src = bu.pmc_traffic(os.path.join(ROOT, "profiles"), "hgemm", M)
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": bu.PEAK_FP16_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / bu.PEAK_FP16_MFMA_TFLOPS, 4), "traffic": None,
-                "kernel": "hgemm_pp_kernel<NN,256x256x64,4 slots,split DMA,LDS epilogue>", "avg_launch_ms": round(ev_ms, 5),
+                "unit": "TFLOP/s", "frac": round(achieved / bu.PEAK_FP16_MFMA_TFLOPS, 4), "traffic": traffic,
+                "traffic_source": traffic_src,
+                "kernel": bu.HEADLINE_HGEMM_KERNEL, "avg_launch_ms": round(ev_ms, 5),
                 "min_launch_ms": round(ev_min, 5), "algorithmic_flops_per_launch": flops,
                 "algorithmic_bytes_per_launch": bu.hgemm_bytes(M, N, K)}
 
@@ -116,6 +115,13 @@ def main():
             ms, _, _ = bu.time_call_events(lambda: hg.hgemm_cublas_tensor_op_nn(a, b, c), 5, 20)
             extras["rocblas_tflops"] = round(flops / (ms * 1e-3) * 1e-12, 2)
             extras["pct_of_rocblas"] = round(100.0 * achieved / extras["rocblas_tflops"], 2)
+            bt = bu.as_col_major(b)
+            ms, _, _ = bu.time_call_events(lambda: hg.hgemm_cublas_tensor_op_tn(a, bt, c), 5, 20)
+            extras["rocblas_tn_tflops"] = round(flops / (ms * 1e-3) * 1e-12, 2)
+            tn = hg.hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_tn_swizzle_x4
+            ms, _, _ = bu.time_call_events(lambda: tn(a, bt, c, args.stages, True, stride), 5, 20)
+            extras["hgemm_tn_tflops"] = round(flops / (ms * 1e-3) * 1e-12, 2)
+            del bt
             hg.destroy_cublas_handle()
         except Exception as e:  # the vendor row is a comparison, never the product
             extras["rocblas_error"] = str(e)[:200]
@@ -127,10 +133,18 @@ def main():
                 o = torch.zeros_like(q)
                 fn = lambda: fa.flash_attn_mma_stages_split_q_shared_qkv(q, k, v, o, 2)
                 ms, _, _ = bu.time_call_events(fn, 5, 30)
-                extras["fa2_fwd_d%d" % D] = {
-                    "shape": [B_, H_, N_, D], "ms": round(ms, 5),
-                    "tflops_ref_model": round(bu.get_mha_tflops(B_, H_, N_, D, ms * 1e-3), 2),
-                    "tflops_4bhn2d": round(bu.mha_flops_conventional(B_, H_, N_, D) / (ms * 1e-3) * 1e-12, 2)}
+                row = {"shape": [B_, H_, N_, D], "ms": round(ms, 5),
+                       "tflops_ref_model": round(bu.get_mha_tflops(B_, H_, N_, D, ms * 1e-3), 2),
+                       "tflops_4bhn2d": round(bu.mha_flops_conventional(B_, H_, N_, D) / (ms * 1e-3) * 1e-12, 2)}
+                try:  # the FlashAttention-2-ROCm row available on the box: torch SDPA (reference prints it too,
+                    # flash_attn_mma.py:391-398)
+                    import torch.nn.functional as F
+                    ms2, _, _ = bu.time_call_events(lambda: F.scaled_dot_product_attention(q, k, v), 5, 30)
+                    row["torch_sdpa_tflops_4bhn2d"] = round(
+                        bu.mha_flops_conventional(B_, H_, N_, D) / (ms2 * 1e-3) * 1e-12, 2)
+                except Exception as e:
+                    row["torch_sdpa_error"] = str(e)[:120]
+                extras["fa2_fwd_d%d" % D] = row
         except Exception as e:
             extras["fa2_error"] = str(e)[:200]
         out["extras"] = extras

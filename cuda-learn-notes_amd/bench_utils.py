@@ -12,6 +12,7 @@ import torch
 
 PEAK_FP16_MFMA_TFLOPS = 2500.0  # dense fp16/bf16 MFMA, MI355X
 PEAK_HBM_GBPS = 8000.0          # HBM3E spec (6290 measured float4 copy)
+HEADLINE_HGEMM_KERNEL = "hgemm_pp_kernel<NN,256x256x64,4 slots,split DMA,LDS epilogue>"
 
 
 def get_device_name():
@@ -94,3 +95,69 @@ def time_call_events(fn, warmup: int, iters: int, stream=None):
     torch.cuda.synchronize()
     ts = [s.elapsed_time(e) for s, e in zip(start, end)]
     return sum(ts) / len(ts), min(ts), ts
+
+
+def time_call_graph(fn, iters: int = 20, replays: int = 5):
+    """Per-launch device time (ms) for kernels shorter than the host launch path: capture `iters` calls in a
+    hipGraph on a side stream, replay it, divide. Includes the ~1.5 us dependent-kernel boundary."""
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            fn()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(iters):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
+    best, tot = 1e30, 0.0
+    for _ in range(replays):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) / iters
+        best, tot = min(best, t), tot + t
+    return tot / replays, best
+
+
+def max_over_ranks(seconds: float, dist=None, device=None) -> float:
+    """bench.py timing contract: the step time of the job is the MAX over ranks (replicas run independently;
+    no data-path collective). `dist` is torch.distributed or None for a single process."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(seconds)
+    t = torch.tensor([seconds], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def aggregate_value(per_rank_units: float, world: int, seconds: float) -> float:
+    """Whole-job throughput of N independent replicas: units all ranks processed / max-over-ranks time."""
+    return world * per_rank_units / seconds
+
+
+def pmc_traffic(profiles_dir: str, kernel_sub: str, size: int):
+    """HBM bytes per launch of the headline kernel from the committed rocprofv3 PMC summary
+    (profiles/rNN_pmc_<kernel>.json, written by tools/pmc_summary.py on the GPU box; PMC counters cannot be
+    collected from inside the timed process). Only valid for the size the pass was taken at (4096)."""
+    import glob
+    import json
+    import os
+    if size != 4096:
+        return None, None
+    files = sorted(glob.glob(os.path.join(profiles_dir, "r*_pmc_%s.json" % kernel_sub)))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+        best = None
+        for k, e in d.items():
+            if "hbm_traffic_bytes_per_launch" in e:
+                best = e["hbm_traffic_bytes_per_launch"]
+        return (round(best) if best else None), os.path.basename(files[-1])
+    except Exception:
+        return None, None

@@ -62,3 +62,27 @@ def hbm_row(tag, shape, ms, nbytes):
     gbps = nbytes / ms * 1e-6
     return {"kernel": tag, "shape": list(shape), "ms": ms, "gbps": gbps,
             "roofline": {"bound": "hbm", "peak": PEAK_HBM_GBPS, "achieved": gbps, "frac": gbps / PEAK_HBM_GBPS}}
+
+
+def run_table(title_width, sections, out_width=20, json_rows=None, bytes_per_elem=None):
+    """Walk a list of (header, [(tag, callable | None, out_tensor | None)]) sections and print the reference
+    scripts' row format `out_<tag>: [v0, v1, v2], time:<ms>ms`. A row whose callable is None is a kernel row
+    without a GPU: it is reported as skipped (no CPU fallback)."""
+    for header, rows, warmup, iters in sections:
+        print("-" * title_width)
+        print(" " * (title_width // 2 - 5) + header)
+        print("-" * title_width)
+        for tag, call, out, shape, nbytes in rows:
+            info = "out_" + tag
+            if call is None:
+                print(f"{info:>{out_width}}: skipped (no GPU: the HIP kernel path has no CPU fallback)")
+                continue
+            if out is not None:
+                out.fill_(0)
+            res, ms = timed(call, warmup, iters)
+            val = out if out is not None else res
+            vals = [f"{round(v, 8):<12}" for v in val.flatten()[:3].float().cpu().tolist()]
+            print(f"{info:>{out_width}}: {vals}, time:{ms:.8f}ms")
+            if json_rows is not None and nbytes:
+                json_rows.append(hbm_row(tag, shape, ms, nbytes))
+    print("-" * title_width)
