@@ -60,6 +60,10 @@ def load_so(so_name):
         fn = lib.cln_hgemm_variant
         fn.argtypes = [c_int] * 5 + [c_void_p] * 3 + [c_int] * 5 + [c_void_p]
         fn.restype = c_int
+        if hasattr(lib, "cln_fa2_variant"):
+            fn = lib.cln_fa2_variant
+            fn.argtypes = [c_int] * 5 + [c_void_p] * 4 + [c_int] * 3 + [c_void_p]
+            fn.restype = c_int
     _cache[so_name] = lib
     return lib
 

@@ -7,6 +7,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 // ---------------------------------------------------------------- C-ABI status codes
 // Reference bindings throw std::runtime_error (e.g. kernels/hgemm/naive/hgemm.cu:772-782);
@@ -19,9 +20,29 @@
 
 #define CLN_API extern "C" __attribute__((visibility("default")))
 
+// Launch with a clean per-thread error slot: hipGetLastError() is sticky across unrelated runtime calls of
+// the host process (e.g. torch's allocator polls events -> hipErrorNotReady), which must not be reported as
+// a failure of OUR launch.
+#define CLN_LAUNCH(...)            \
+  do {                             \
+    (void)hipGetLastError();       \
+    hipLaunchKernelGGL(__VA_ARGS__); \
+  } while (0)
+
 static inline int cln_check_launch() {
   hipError_t e = hipGetLastError();
+  if (e != hipSuccess) fprintf(stderr, "[cln_amd] launch failed: %s\n", hipGetErrorString(e));
   return e == hipSuccess ? CLN_OK : CLN_ERR_LAUNCH;
+}
+// hipFuncSetAttribute wrapper with the same diagnostics
+static inline int cln_set_lds(const void* fn, int bytes) {
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) {
+    fprintf(stderr, "[cln_amd] hipFuncSetAttribute(%d B LDS) failed: %s\n", bytes, hipGetErrorString(e));
+    (void)hipGetLastError();
+    return CLN_ERR_LAUNCH;
+  }
+  return CLN_OK;
 }
 
 static inline bool cln_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -49,12 +49,12 @@ int launch_add(const void* a, const void* b, void* c, long long n, hipStream_t s
   const long long nvec = n / VEC;
   if (nvec > 0) {
     const int grid = cln_stream_grid(nvec, 256);
-    hipLaunchKernelGGL((add_vec_kernel<VT>), dim3(grid), dim3(256), 0, stream, (const VT*)a, (const VT*)b, (VT*)c,
+    CLN_LAUNCH((add_vec_kernel<VT>), dim3(grid), dim3(256), 0, stream, (const VT*)a, (const VT*)b, (VT*)c,
                        nvec);
   }
   const long long done = nvec * VEC;
   if (done < n) {
-    hipLaunchKernelGGL((add_tail_kernel<T>), dim3(1), dim3(64), 0, stream, (const T*)a, (const T*)b, (T*)c, done, n);
+    CLN_LAUNCH((add_tail_kernel<T>), dim3(1), dim3(64), 0, stream, (const T*)a, (const T*)b, (T*)c, done, n);
   }
   return cln_check_launch();
 }
@@ -81,11 +81,11 @@ CLN_API int elementwise_add_f16x8(const void* a, const void* b, void* c, long lo
   const long long ngroups = n / 8;
   if (ngroups > 0) {
     const int grid = cln_stream_grid(ngroups, 256);
-    hipLaunchKernelGGL(add_f16x8_unpacked_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const h2*)a,
+    CLN_LAUNCH(add_f16x8_unpacked_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const h2*)a,
                        (const h2*)b, (h2*)c, ngroups);
   }
   if (ngroups * 8 < n) {
-    hipLaunchKernelGGL((add_tail_kernel<half_t>), dim3(1), dim3(64), 0, (hipStream_t)stream, (const half_t*)a,
+    CLN_LAUNCH((add_tail_kernel<half_t>), dim3(1), dim3(64), 0, (hipStream_t)stream, (const half_t*)a,
                        (const half_t*)b, (half_t*)c, ngroups * 8, n);
   }
   return cln_check_launch();

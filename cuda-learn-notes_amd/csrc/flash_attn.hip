@@ -9,6 +9,7 @@
 // (reference kStage template parameter, flash_attn_mma_share_qkv.cu:843-884).
 #include "flash_attn.cuh"
 #include "flash_attn_large_d.cuh"
+#include "flash_attn_v2.cuh"
 
 namespace {
 
@@ -18,21 +19,27 @@ int fa2_dispatch(const void* q, const void* k, const void* v, void* o, int B, in
   if (!q || !k || !v || !o || B <= 0 || H <= 0 || N <= 0) return CLN_ERR_BAD_ARG;
   if (!cln_aligned16(q) || !cln_aligned16(k) || !cln_aligned16(v) || !cln_aligned16(o)) return CLN_ERR_BAD_ARG;
   if (D > max_d) return CLN_ERR_UNSUPPORTED;  // "headdim not support!"
-  const bool pf = stages >= 2;
-#define FA_CASE(DD)                                                                  \
-  case DD:                                                                           \
-    return pf ? fa::launch_fa2<DD, DD, 64, VT, true>(q, k, v, o, B, H, N, s)         \
-              : fa::launch_fa2<DD, DD, 64, VT, false>(q, k, v, o, B, H, N, s);
+  (void)stages;  // v2 always runs the double-buffered prefetch pipeline; `stages` 1 and 2 are the same kernel
+  // Head dims 32..256: v2 kernel. Workgroup = 8 / 4 / 2 waves x 32 query rows by the divisibility of N
+  // (reference: N % max(Br,Bc) == 0 with Br = 128 or 64, flash_attn_mma_share_qkv.cu:769, split_q.cu:754).
+#define FA_V2(DD, OPTT)                                                                            \
+  case DD:                                                                                         \
+    if (N % 256 == 0) return fa2::launch_v2<DD, 8, VT, OPTT>(q, k, v, o, B, H, N, s);              \
+    if (N % 128 == 0) return fa2::launch_v2<DD, 4, VT, OPTT>(q, k, v, o, B, H, N, s);              \
+    if (N % 64 == 0) return fa2::launch_v2<DD, 2, VT, OPTT>(q, k, v, o, B, H, N, s);               \
+    return CLN_ERR_UNSUPPORTED;
   switch (D) {
-    FA_CASE(32)
-    FA_CASE(64)
-    FA_CASE(96)
-    FA_CASE(128)
-    FA_CASE(256)
+    FA_V2(32, 13)
+    FA_V2(64, 13)
+    FA_V2(96, 15)
+    FA_V2(128, 15)
+    case 256:  // needs the whole register file (one wave per SIMD): 4 waves x 32 rows only
+      if (N % 128 == 0) return fa2::launch_v2<256, 4, VT, 15>(q, k, v, o, B, H, N, s);
+      return CLN_ERR_UNSUPPORTED;
     default:
       break;
   }
-#undef FA_CASE
+#undef FA_V2
   if constexpr (!VT) {
     if (D == 512 || D == 1024 || D == 768 || D == 320 || D == 384 || D == 640)
       return fa::launch_fa2_large_d(q, k, v, o, B, H, N, D, stages, s);

@@ -1,0 +1,14 @@
+// Tuning / ablation hook for the v2 FlashAttention kernel (not part of the reference surface).
+//   int cln_fa2_variant(D, nw, vt, opt, abl, q, k, v, o, B, H, N, stream)
+#include "flash_attn_v2.cuh"
+
+#define V2(DD, NWW, OPTT, ABLL) \
+  if (D == DD && nw == NWW && opt == OPTT && abl == ABLL && !vt) \
+    return fa2::launch_v2<DD, NWW, false, OPTT, ABLL>(q, k, v, o, B, H, N, (hipStream_t)stream);
+
+CLN_API int cln_fa2_variant(int D, int nw, int vt, int opt, int abl, const void* q, const void* k, const void* v,
+                            void* o, int B, int H, int N, void* stream) {
+  V2(64, 8, 13, 0) V2(64, 4, 13, 0) V2(64, 4, 77, 0) V2(128, 8, 15, 0) V2(128, 4, 15, 0) V2(128, 4, 79, 0)
+  V2(64, 8, 13, 1) V2(64, 8, 13, 2) V2(64, 8, 13, 7) V2(128, 8, 15, 1) V2(128, 8, 15, 7)
+  return CLN_ERR_UNSUPPORTED;
+}

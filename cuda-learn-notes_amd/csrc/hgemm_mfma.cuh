@@ -541,14 +541,12 @@ int launch_pp(const void* a, const void* b, void* c, int M, int N, int K, int sw
   if (M % 256 || N % 256 || K % 64) return CLN_ERR_UNSUPPORTED;
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&hgemm_pp_kernel<LAYOUT, EPI, SLOTS, ABL, SPLIT>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess)
-      return CLN_ERR_LAUNCH;
+    if (cln_set_lds(reinterpret_cast<const void*>(&hgemm_pp_kernel<LAYOUT, EPI, SLOTS, ABL, SPLIT>), C::LDS_BYTES) != CLN_OK) return CLN_ERR_LAUNCH;
     attr_done = true;
   }
   const int tiles_m = M / 256, tiles_n = N / 256;
   int band = (swizzle && swizzle_stride >= 256) ? swizzle_stride / 256 : tiles_n;
-  hipLaunchKernelGGL((hgemm_pp_kernel<LAYOUT, EPI, SLOTS, ABL, SPLIT>), dim3(tiles_m * tiles_n), dim3(512), C::LDS_BYTES, stream,
+  CLN_LAUNCH((hgemm_pp_kernel<LAYOUT, EPI, SLOTS, ABL, SPLIT>), dim3(tiles_m * tiles_n), dim3(512), C::LDS_BYTES, stream,
                      (const half_t*)a, (const half_t*)b, (half_t*)c, M, N, K, tiles_m, tiles_n, swizzle ? 1 : 0, band);
   return cln_check_launch();
 }
@@ -677,14 +675,12 @@ int launch_pp32(const void* a, const void* b, void* c, int M, int N, int K, int 
   if (M % 256 || N % 256 || K % 32) return CLN_ERR_UNSUPPORTED;
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&hgemm_pp32_kernel<LAYOUT, EPI>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess)
-      return CLN_ERR_LAUNCH;
+    if (cln_set_lds(reinterpret_cast<const void*>(&hgemm_pp32_kernel<LAYOUT, EPI>), C::LDS_BYTES) != CLN_OK) return CLN_ERR_LAUNCH;
     attr_done = true;
   }
   const int tiles_m = M / 256, tiles_n = N / 256;
   int band = (swizzle && swizzle_stride >= 256) ? swizzle_stride / 256 : tiles_n;
-  hipLaunchKernelGGL((hgemm_pp32_kernel<LAYOUT, EPI>), dim3(tiles_m * tiles_n), dim3(512), C::LDS_BYTES, stream,
+  CLN_LAUNCH((hgemm_pp32_kernel<LAYOUT, EPI>), dim3(tiles_m * tiles_n), dim3(512), C::LDS_BYTES, stream,
                      (const half_t*)a, (const half_t*)b, (half_t*)c, M, N, K, tiles_m, tiles_n, swizzle ? 1 : 0, band);
   return cln_check_launch();
 }
@@ -791,14 +787,12 @@ int launch_ring(const void* a, const void* b, void* c, int M, int N, int K, int 
   if (M % C::BM || N % C::BN || K % C::BK) return CLN_ERR_UNSUPPORTED;
   static bool attr_done = false;  // once per instantiation (reference re-issues it per call, hgemm_mma_stage.cu:2333)
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&hgemm_ring_kernel<C>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess)
-      return CLN_ERR_LAUNCH;
+    if (cln_set_lds(reinterpret_cast<const void*>(&hgemm_ring_kernel<C>), C::LDS_BYTES) != CLN_OK) return CLN_ERR_LAUNCH;
     attr_done = true;
   }
   const int tiles_m = M / C::BM, tiles_n = N / C::BN;
   int band = (swizzle && swizzle_stride >= C::BN) ? swizzle_stride / C::BN : tiles_n;
-  hipLaunchKernelGGL((hgemm_ring_kernel<C>), dim3(tiles_m * tiles_n), dim3(C::NT), C::LDS_BYTES, stream,
+  CLN_LAUNCH((hgemm_ring_kernel<C>), dim3(tiles_m * tiles_n), dim3(C::NT), C::LDS_BYTES, stream,
                      (const half_t*)a, (const half_t*)b, (half_t*)c, M, N, K, tiles_m, tiles_n, swizzle ? 1 : 0, band);
   return cln_check_launch();
 }
@@ -807,7 +801,7 @@ template <typename C>
 int launch_1stage(const void* a, const void* b, void* c, int M, int N, int K, hipStream_t stream) {
   if (M % C::BM || N % C::BN || K % C::BK) return CLN_ERR_UNSUPPORTED;
   const int tiles_m = M / C::BM, tiles_n = N / C::BN;
-  hipLaunchKernelGGL((hgemm_1stage_kernel<C>), dim3(tiles_m * tiles_n), dim3(C::NT), C::STAGE_BYTES, stream,
+  CLN_LAUNCH((hgemm_1stage_kernel<C>), dim3(tiles_m * tiles_n), dim3(C::NT), C::STAGE_BYTES, stream,
                      (const half_t*)a, (const half_t*)b, (half_t*)c, M, N, K, tiles_m, tiles_n);
   return cln_check_launch();
 }
@@ -815,7 +809,7 @@ int launch_1stage(const void* a, const void* b, void* c, int M, int N, int K, hi
 template <int LAYOUT>
 int launch_naive(const void* a, const void* b, void* c, int M, int N, int K, hipStream_t stream) {
   if (K % 4) return CLN_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL((hgemm_mfma_naive_kernel<LAYOUT>), dim3((N + 15) / 16, (M + 15) / 16), dim3(64), 0, stream,
+  CLN_LAUNCH((hgemm_mfma_naive_kernel<LAYOUT>), dim3((N + 15) / 16, (M + 15) / 16), dim3(64), 0, stream,
                      (const half_t*)a, (const half_t*)b, (half_t*)c, M, N, K);
   return cln_check_launch();
 }

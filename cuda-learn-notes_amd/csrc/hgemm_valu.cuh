@@ -171,12 +171,12 @@ __global__ __launch_bounds__(128 * 8 / TM * 2) void hgemm_valu_tile_kernel(const
 }
 
 inline int launch_valu_naive(const void* a, const void* b, void* c, int M, int N, int K, hipStream_t s) {
-  hipLaunchKernelGGL(hgemm_naive_f16_kernel, dim3((N + 15) / 16, (M + 15) / 16), dim3(256), 0, s, (const half_t*)a,
+  CLN_LAUNCH(hgemm_naive_f16_kernel, dim3((N + 15) / 16, (M + 15) / 16), dim3(256), 0, s, (const half_t*)a,
                      (const half_t*)b, (half_t*)c, M, N, K);
   return cln_check_launch();
 }
 inline int launch_valu_sliced_k(const void* a, const void* b, void* c, int M, int N, int K, hipStream_t s) {
-  hipLaunchKernelGGL(hgemm_sliced_k_f16_kernel, dim3((N + 31) / 32, (M + 31) / 32), dim3(1024), 0, s,
+  CLN_LAUNCH(hgemm_sliced_k_f16_kernel, dim3((N + 31) / 32, (M + 31) / 32), dim3(1024), 0, s,
                      (const half_t*)a, (const half_t*)b, (half_t*)c, M, N, K);
   return cln_check_launch();
 }
@@ -184,7 +184,7 @@ template <int BK, int TM, bool DBUF, bool ASYNC>
 int launch_valu_tile(const void* a, const void* b, void* c, int M, int N, int K, hipStream_t s) {
   if (M % 128 || N % 128 || K % BK) return CLN_ERR_UNSUPPORTED;
   constexpr int NT = (128 / TM) * 16;
-  hipLaunchKernelGGL((hgemm_valu_tile_kernel<BK, TM, DBUF, ASYNC>), dim3(N / 128, M / 128), dim3(NT), 0, s,
+  CLN_LAUNCH((hgemm_valu_tile_kernel<BK, TM, DBUF, ASYNC>), dim3(N / 128, M / 128), dim3(NT), 0, s,
                      (const half_t*)a, (const half_t*)b, (half_t*)c, M, N, K);
   return cln_check_launch();
 }

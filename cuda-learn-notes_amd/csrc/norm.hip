@@ -71,7 +71,7 @@ int launch_ln(const void* x, void* y, float g, float b, int N, int K, hipStream_
   if (K % VEC) return CLN_ERR_UNSUPPORTED;
   const int nt = row_threads(K, VEC), vpt = vecs_per_thread(K, VEC, nt);
 #define CALL(MV)                                                                                              \
-  hipLaunchKernelGGL((layer_norm_kernel<T, VEC, MV>), dim3(N), dim3(nt), 0, st, (const T*)x, (T*)y, g, b, K)
+  CLN_LAUNCH((layer_norm_kernel<T, VEC, MV>), dim3(N), dim3(nt), 0, st, (const T*)x, (T*)y, g, b, K)
   ROWWISE_DISPATCH_MAXV(vpt, CALL);
 #undef CALL
   return cln_check_launch();
@@ -82,7 +82,7 @@ int launch_rms(const void* x, void* y, float g, int N, int K, hipStream_t st) {
   if (K % VEC) return CLN_ERR_UNSUPPORTED;
   const int nt = row_threads(K, VEC), vpt = vecs_per_thread(K, VEC, nt);
 #define CALL(MV) \
-  hipLaunchKernelGGL((rms_norm_kernel<T, VEC, MV>), dim3(N), dim3(nt), 0, st, (const T*)x, (T*)y, g, K)
+  CLN_LAUNCH((rms_norm_kernel<T, VEC, MV>), dim3(N), dim3(nt), 0, st, (const T*)x, (T*)y, g, K)
   ROWWISE_DISPATCH_MAXV(vpt, CALL);
 #undef CALL
   return cln_check_launch();

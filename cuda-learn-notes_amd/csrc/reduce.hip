@@ -163,7 +163,7 @@ int launch_reduce(const void* a, void* y, long long n, hipStream_t st) {
   if (n == 0) return CLN_OK;
   if (sizeof(E) * VEC >= 16 && !cln_aligned16(a)) return CLN_ERR_BAD_ARG;
   const int grid = cln_stream_grid(n / VEC + 1, 256);
-  hipLaunchKernelGGL((reduce_sum_kernel<PS, VEC>), dim3(grid), dim3(256), 0, st, (const E*)a,
+  CLN_LAUNCH((reduce_sum_kernel<PS, VEC>), dim3(grid), dim3(256), 0, st, (const E*)a,
                      (typename PS::out*)y, n);
   return cln_check_launch();
 }

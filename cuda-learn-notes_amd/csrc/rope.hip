@@ -64,7 +64,7 @@ int launch_rope(const void* x, void* out, int seq_len, int hidden, int ref_quirk
   const long long units = (long long)seq_len * half_hidden / PAIRS;
   const int grid = cln_stream_grid(units, 256);
   const float k = -13.287712379549449f / (float)half_hidden;  // -log2(10000) / (hidden/2)
-  hipLaunchKernelGGL((rope_kernel<PAIRS>), dim3(grid), dim3(256), 0, st, (const float*)x, (float*)out, seq_len,
+  CLN_LAUNCH((rope_kernel<PAIRS>), dim3(grid), dim3(256), 0, st, (const float*)x, (float*)out, seq_len,
                      half_hidden, ref_quirk, k);
   return cln_check_launch();
 }

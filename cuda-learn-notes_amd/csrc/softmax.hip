@@ -53,8 +53,8 @@ template <int VEC>
 int launch_global(const void* x, void* y, void* total, long long n, hipStream_t st) {
   if (!x || !y || !total || n <= 0) return CLN_ERR_BAD_ARG;
   const int grid = cln_stream_grid(n / VEC + 1, 256);
-  hipLaunchKernelGGL((exp_sum_kernel<VEC>), dim3(grid), dim3(256), 0, st, (const float*)x, (float*)total, n);
-  hipLaunchKernelGGL((exp_div_kernel<VEC>), dim3(grid), dim3(256), 0, st, (const float*)x, (float*)y,
+  CLN_LAUNCH((exp_sum_kernel<VEC>), dim3(grid), dim3(256), 0, st, (const float*)x, (float*)total, n);
+  CLN_LAUNCH((exp_div_kernel<VEC>), dim3(grid), dim3(256), 0, st, (const float*)x, (float*)y,
                      (const float*)total, n);
   return cln_check_launch();
 }
@@ -125,7 +125,7 @@ int launch_rows(const void* x, void* y, int S, int H, hipStream_t st) {
   if (H % VEC) return CLN_ERR_UNSUPPORTED;
   const int nt = row_threads(H, VEC), vpt = vecs_per_thread(H, VEC, nt);
 #define CALL(MV) \
-  hipLaunchKernelGGL((softmax_row_kernel<T, VEC, MV, MODE>), dim3(S), dim3(nt), 0, st, (const T*)x, (T*)y, H)
+  CLN_LAUNCH((softmax_row_kernel<T, VEC, MV, MODE>), dim3(S), dim3(nt), 0, st, (const T*)x, (T*)y, H)
   ROWWISE_DISPATCH_MAXV(vpt, CALL);
 #undef CALL
   return cln_check_launch();

@@ -129,8 +129,8 @@ def _make_fa(name):
             _check_shape(V, B, H, N, D)
         rc = fn(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), B, H, N, D, int(stages), _stream())
         if rc == -2:
-            if N % 128 != 0:
-                raise RuntimeError("%s: seqlen must be a multiple of 128 (Br)" % name)
+            if N % 64 != 0 or (D == 256 and N % 128 != 0) or (D > 256 and N % 128 != 0):
+                raise RuntimeError("%s: seqlen must be a multiple of 64 (128 for headdim >= 256)" % name)
             raise RuntimeError("headdim not support!")
         _raise(name, rc)
     f.__name__ = name
@@ -266,3 +266,13 @@ def hgemm_variant(kind, layout, tile, bk, stages, a, b, c, swizzle=0, swizzle_st
     rc = fn(kind, layout, tile, bk, stages, a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, int(swizzle),
             int(swizzle_stride), _stream())
     _raise("cln_hgemm_variant", rc, "variant not available for this shape/LDS budget")
+
+
+def fa2_variant(D_nw_vt_opt_abl, Q, K, V, O):
+    """Tuning hook (not part of the reference surface): run an explicit v2 FlashAttention variant."""
+    _check_dev(Q, K, V, O)
+    nw, vt, opt, abl = D_nw_vt_opt_abl
+    B, H, N, D = Q.shape
+    fn = _loader.load_so("libcln_amd.so").cln_fa2_variant
+    rc = fn(D, nw, vt, opt, abl, Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), B, H, N, _stream())
+    _raise("cln_fa2_variant", rc, "variant not instantiated / shape not supported")

@@ -98,9 +98,9 @@ _FA_VT = [
     "flash_attn_mma_stages_split_q_shared_kv_swizzle_qkv", "flash_attn_mma_stages_split_q_shared_qkv_swizzle_qkv",
     "flash_attn_mma_stages_split_q_tiling_qk_swizzle_qkv",
 ]
-_add("flash_attn", "FA", "fa2_fwd<D,DV,BC,V row-major> split-Q 4 waves x 32 rows, mfma_32x32x16, f32 acc",
-     *_FA_PLAIN)
-_add("flash_attn", "FA", "fa2_fwd<D,D,64,V transposed [B,H,D,N]>", *_FA_VT)
+_add("flash_attn", "FA", "fa2_fwd_v2<D<=256, 8|4|2 waves x 32 rows, dbuf K/V, deferred max> | fa2_fwd<D>256, DV-sliced> "
+     "mfma_32x32x16, f32 acc", *_FA_PLAIN)
+_add("flash_attn", "FA", "fa2_fwd_v2<D<=256, V transposed [B,H,D,N]>", *_FA_VT)
 
 # max head dim per function (reference flash_attn_mma.py:436-506; C side enforces the same)
 FA_MAX_HEADDIM = {n: 256 for n in _FA_PLAIN + _FA_VT}

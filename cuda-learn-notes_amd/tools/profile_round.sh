@@ -8,7 +8,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out
 T=$REPO/cuda-learn-notes_amd/tools
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $OUT/prof_bench -o $TAG -- python $REPO/bench.py --steps 20 --warmup 5 --no-extras > $OUT/prof_bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -o $TAG -- python $REPO/bench.py --steps 20 --warmup 5 --no-extras > $OUT/prof_bench.log 2>&1
 python - <<PY
 import csv
 rows = list(csv.DictReader(open("$OUT/prof_bench/${TAG}_kernel_stats.csv")))
@@ -18,7 +18,7 @@ with open("$OUT/${TAG}_bench_kernel_stats.csv", "w") as f:
 PY
 pmc() {  # name, counters..., then "--", then target args
   local name=$1; shift; local ctrs=(); while [ "$1" != "--" ]; do ctrs+=("$1"); shift; done; shift
-  rocprofv3 --kernel-trace --pmc "${ctrs[@]}" -d $OUT/pmc_$name -o pmc -- python $T/prof_target.py "$@" > $OUT/pmc_$name.log 2>&1
+  rocprofv3 --kernel-trace --output-format csv --pmc "${ctrs[@]}" -d $OUT/pmc_$name -o pmc -- python $T/prof_target.py "$@" > $OUT/pmc_$name.log 2>&1
 }
 HG="hgemm 8 0 1 64 2 4096 12"
 pmc hg_fetch FETCH_SIZE -- $HG

@@ -87,8 +87,38 @@ def test_max_headdim_table_and_unsupported_dims(fa, dev):
     with pytest.raises(RuntimeError, match="headdim not support!"):
         fa.flash_attn_mma_stages_split_q(q, q, q, q.clone(), 1)  # max 128 (flash_attn_mma.py:436-506)
     q = torch.zeros(1, 1, 100, 64, dtype=torch.half, device=dev)
-    with pytest.raises(RuntimeError, match="multiple of 128"):
+    with pytest.raises(RuntimeError, match="multiple of 64"):
         fa.flash_attn_mma_stages_split_q_shared_qkv(q, q, q, q.clone(), 1)
+
+
+@pytest.mark.parametrize("N", [64, 192, 320, 128, 640, 256, 768])
+@pytest.mark.parametrize("D", [32, 64, 128])
+def test_workgroup_shapes_by_seqlen(fa, built, dev, oracle, N, D):
+    """N % 256 == 0 -> 8 waves x 32 rows, N % 128 == 0 -> 4 waves, N % 64 == 0 -> 2 waves (ragged vs Br)."""
+    B, H = 1, 3
+    q, k, v = seeded(20 + N, B, H, N, D), seeded(21 + N, B, H, N, D), seeded(22 + N, B, H, N, D)
+    ref = oracle.attention_fp64(q, k, v)
+    for name in ("flash_attn_mma_stages_split_q", "flash_attn_mma_stages_split_q_shared_kv_swizzle_qkv"):
+        o = run(fa, built, name, q, k, v, 2, dev)
+        assert (o.double() - ref).abs().max().item() <= TOL, (name, N, D)
+
+
+def test_deferred_max_paths(fa, built, dev, oracle):
+    """The v2 kernel rescales O only when some row's running max grew by more than 2^8 (scaled log2 domain).
+    Three regimes in one tensor (cdna guide rule 26): (a) key norms growing slowly along N so the true max creeps
+    up every tile but stays below the threshold (stale-max path, P up to 2^8), (b) one huge jump late (forced
+    rescale with a non-trivial alpha), (c) a row whose scores are all very negative after an early spike."""
+    B, H, N, D = 1, 2, 1024, 64
+    q, k, v = seeded(31, B, H, N, D), seeded(32, B, H, N, D), seeded(33, B, H, N, D)
+    ramp = torch.linspace(0.2, 1.6, N).view(1, 1, N, 1)
+    k = (k.float() * ramp).half()                      # (a) slowly growing logits
+    k[0, 0, 900] = q[0, 0, 5] * 3.0                    # (b) late spike for row 5: jump >> 8
+    k[0, 1, 10] = q[0, 1, 300] * 5.0                   # (c) early spike for row 300: everything later is ~ -inf
+    ref = oracle.attention_fp64(q, k, v)
+    for name in ("flash_attn_mma_stages_split_q_shared_qkv", "flash_attn_mma_stages_split_q_shared_qkv_swizzle_qkv"):
+        o = run(fa, built, name, q, k, v, 2, dev)
+        assert torch.isfinite(o).all()
+        assert (o.double() - ref).abs().max().item() <= TOL, name
 
 
 def test_all_ones_qk_gives_column_mean_of_v(fa, built, dev):
