@@ -28,8 +28,8 @@ import __graft_entry__ as entry  # noqa: E402
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=50)
-    p.add_argument("--warmup", type=int, default=10)
+    p.add_argument("--steps", type=int, default=500)
+    p.add_argument("--warmup", type=int, default=100)
     p.add_argument("--mnk", type=int, default=4096)
     p.add_argument("--stages", type=int, default=2)
     p.add_argument("--no-extras", action="store_true", help="skip FA2 / rocBLAS / CPU baseline side measurements")

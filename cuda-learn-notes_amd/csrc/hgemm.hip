@@ -168,6 +168,21 @@ CLN_API int cln_hgemm_variant(int kind, int layout, int tile, int bk, int stages
     return layout == TN ? launch_pp32<TN, 2>(a, b, c, M, N, K, swizzle, swizzle_stride, stream)
                         : launch_pp32<NN, 2>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
   }
+  if (kind == 10) {  // ping-pong on mfma_32x32x16; stages==1: no-store probe; stages>=16: ablation bits = stages-16
+    if (stages == 1) return launch_m32<NN, 1>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+    if (stages >= 16) {
+      switch (stages - 16) {
+        case 1: return launch_m32<NN, 1, 1>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+        case 2: return launch_m32<NN, 1, 2>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+        case 3: return launch_m32<NN, 1, 3>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+        case 7: return launch_m32<NN, 1, 7>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+        case 8: return launch_m32<NN, 2, 8>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+        default: return CLN_ERR_BAD_ARG;
+      }
+    }
+    return layout == TN ? launch_m32<TN>(a, b, c, M, N, K, swizzle, swizzle_stride, stream)
+                        : launch_m32<NN>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+  }
   if (kind == 6) return launch_pp<NN, 1, 4>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);  // 4-slot no-store probe
   if (kind == 7) {  // ablations of the 4-slot no-store probe; `stages` = ABL bits (results are garbage by design)
     switch (stages) {

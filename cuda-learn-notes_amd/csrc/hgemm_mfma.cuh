@@ -685,6 +685,238 @@ int launch_pp32(const void* a, const void* b, void* c, int M, int N, int K, int 
   return cln_check_launch();
 }
 
+// ---- ping-pong kernel on the 32x32x16 matrix instruction -------------------------------------------
+// Same 256x256x64 tile, 2-buffer ring, split LDS-DMA and two-group stagger as hgemm_pp_kernel<SLOTS=4,
+// SPLIT=1>, but the wave's 128x64 result is held as 4x2 tiles of v_mfma_f32_32x32x16_f16: half the MFMA
+// instructions per K tile (32 instead of 64, each 8 passes), half the operand-register reads per flop, and
+// the 32x32 shape's higher sustained rate (cdna guide section 3 ubench: 2178 vs 1955 TF for f16).
+// Fragment maps (operands swapped so a lane owns 4 consecutive n of one C row):
+//   "A" slot  <- B fragment: MFMA row  = n (lane&31), k = 8*(lane>>5) .. +7
+//   "B" slot  <- A fragment: MFMA col  = m (lane&31), k = 8*(lane>>5) .. +7
+//   result reg r: m = lane&31, n = (r&3) + 8*(r>>2) + 4*(lane>>5)
+// K-contiguous images keep kswz<64> (conflict-free for the 32-row / 4x16-lane-group b128 pattern as well:
+// the 8 even and the 8 odd rows of every lane group get distinct (row>>1)&7). The NN B image gets its own
+// chunk swizzle: a 32-lane half reads rows r..r+3 of TWO adjacent 16-column blocks, so rows are spread by
+// 4 chunks (64 B) instead of 2.
+__device__ __forceinline__ int nswz32(int krow) { return (krow & 3) << 2; }
+
+template <typename C, int NLOADS>
+struct NFill32 {
+  unsigned voff[NLOADS];
+  __device__ __forceinline__ void init(int N, int wave, int lane) {
+    constexpr int LPR = C::BN / 8;
+    constexpr int RPI = 64 / LPR;
+#pragma unroll
+    for (int i = 0; i < NLOADS; ++i) {
+      const int t = i * C::NW + wave;
+      const int krow = t * RPI + lane / LPR;
+      const int c = lane % LPR;
+      voff[i] = ((unsigned)krow * (unsigned)N + ((c ^ nswz32(krow)) << 3)) * 2u;
+    }
+  }
+};
+
+__device__ __forceinline__ h8 read_kfrag32(const char* img, int row, int lane, int kk) {
+  const int q = kk * 2 + (lane >> 5);
+  return *reinterpret_cast<const h8*>(img + row * 128 + ((q ^ kswz<64>(row)) << 4));
+}
+// NN B image [64 k][BN n]: 32 columns n0w..n0w+31 (tile-relative), k = kk*16 + 8*(lane>>5) .. +7.
+template <int BN>
+__device__ __forceinline__ h8 read_nfrag32(const char* img, int n0w, int lane, int kk) {
+  const int i = lane & 15, gp = lane >> 4;
+  const int c = ((n0w + 16 * (gp & 1)) >> 3) + ((i & 3) >> 1);
+  const int k_lo = kk * 16 + 8 * (gp >> 1) + (i >> 2);
+  const int k_hi = k_lo + 4;
+  const char* p_lo = img + k_lo * (BN * 2) + ((c ^ nswz32(k_lo)) << 4) + ((i & 1) << 3);
+  const char* p_hi = img + k_hi * (BN * 2) + ((c ^ nswz32(k_hi)) << 4) + ((i & 1) << 3);
+  return h8_cat(lds_read_tr16(p_lo), lds_read_tr16(p_hi));
+}
+
+// LDS-staged epilogue for the 4x2 grid of 32x32 result tiles of one wave (128 rows x 64 columns).
+__device__ __forceinline__ void store_tile32_via_lds(half_t* Cmat, int N, int row0, int col0, int lane,
+                                                     char* wave_lds, const f16v (&acc)[4][2]) {
+  constexpr int RS = 144;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          const f16v& v = acc[h * 2 + i][j];
+          h4 o = {(half_t)v[rq * 4], (half_t)v[rq * 4 + 1], (half_t)v[rq * 4 + 2], (half_t)v[rq * 4 + 3]};
+          *reinterpret_cast<h4*>(wave_lds + (i * 32 + (lane & 31)) * RS + (j * 32 + 8 * rq + 4 * (lane >> 5)) * 2) = o;
+        }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int r = it * 8 + (lane >> 3);
+      const u4 v = *reinterpret_cast<const u4*>(wave_lds + r * RS + (lane & 7) * 16);
+      *reinterpret_cast<u4*>(Cmat + (size_t)(row0 + h * 64 + r) * N + col0 + (lane & 7) * 8) = v;
+    }
+  }
+}
+
+// ABL bits (measurement builds): 1 no fragment reads after tile 0, 2 no DMA after tile 0, 4 no barriers,
+// 8 no setprio.  EPI: 2 LDS-staged store, 1 no store (probe).
+template <int LAYOUT, int EPI = 2, int ABL = 0>
+__global__ __launch_bounds__(512, 2) void hgemm_m32_kernel(const half_t* __restrict__ A, const half_t* __restrict__ B,
+                                                           half_t* __restrict__ Cmat, int M, int N, int K,
+                                                           int tiles_m, int tiles_n, int swizzle, int band) {
+  using C = Cfg<256, 256, 64, 2, 4, 2, LAYOUT>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 2, wn = wave & 3;  // wm == group
+  int tm, tn;
+  tile_coords(blockIdx.x, gridDim.x, tiles_m, tiles_n, swizzle, band, tm, tn);
+  const int m0 = tm * 256, n0 = tn * 256;
+
+  KFill<C, C::A_LOADS> fa;
+  fa.init(K, wave, lane);
+  KFill<C, C::B_LOADS> fbt;
+  NFill32<C, C::B_LOADS> fbn;
+  if constexpr (LAYOUT == TN) fbt.init(K, wave, lane);
+  else fbn.init(N, wave, lane);
+  const char* a_src = reinterpret_cast<const char*>(A + (size_t)m0 * K);
+  const char* b_src = (LAYOUT == TN) ? reinterpret_cast<const char*>(B + (size_t)n0 * K)
+                                     : reinterpret_cast<const char*>(B + n0);
+  const size_t a_step = 128;
+  const size_t b_step = (LAYOUT == TN) ? (size_t)128 : (size_t)64 * N * 2;
+  const unsigned lds0 = lds_addr_of(smem);
+  auto issue_b = [&](unsigned img) {
+    if constexpr (LAYOUT == TN) issue_image<C::NW, C::B_LOADS>(b_src, fbt.voff, img + C::A_BYTES, wave);
+    else issue_image<C::NW, C::B_LOADS>(b_src, fbn.voff, img + C::A_BYTES, wave);
+  };
+
+  f16v acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  h8 af[4][2];  // [k-step][m-tile of the current 64-row half]
+  h8 bf[2][4];  // [n-tile][k-step]
+
+  bool first_tile = true;
+  auto load_a = [&](const char* a_img, int half) {
+    if constexpr ((ABL & 1) != 0) { if (!first_tile) return; }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        af[kk][i] = read_kfrag32(a_img, wm * 128 + half * 64 + i * 32 + (lane & 31), lane, kk);
+  };
+  auto load_b = [&](const char* b_img) {
+    if constexpr ((ABL & 1) != 0) { if (!first_tile) return; }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        if constexpr (LAYOUT == TN) bf[j][kk] = read_kfrag32(b_img, wn * 64 + j * 32 + (lane & 31), lane, kk);
+        else bf[j][kk] = read_nfrag32<256>(b_img, wn * 64 + j * 32, lane, kk);
+      }
+  };
+  auto mma = [&](int half) {
+    if constexpr ((ABL & 8) == 0) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[half * 2 + i][j] =
+              __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j][kk], af[kk][i], acc[half * 2 + i][j], 0, 0, 0);
+    if constexpr ((ABL & 8) == 0) __builtin_amdgcn_s_setprio(0);
+  };
+#define M32_BARRIER()                                            \
+  do {                                                           \
+    __builtin_amdgcn_sched_barrier(0);                           \
+    if constexpr ((ABL & 4) == 0) __builtin_amdgcn_s_barrier();  \
+    asm volatile("" ::: "memory");                               \
+    __builtin_amdgcn_sched_barrier(0);                           \
+  } while (0)
+
+  const int nt = K / 64;
+  {  // tile 0: everything
+    issue_image<C::NW, C::A_LOADS>(a_src, fa.voff, lds0, wave);
+    issue_b(lds0);
+    a_src += a_step;
+    b_src += b_step;
+  }
+  wait_vmcnt<0>();
+  M32_BARRIER();
+  if (wm == 1) M32_BARRIER();  // group 1 runs one slot behind
+
+  for (int t = 0; t < nt; ++t) {
+    const char* a_img = smem + (t & 1) * C::STAGE_BYTES;
+    const char* b_img = a_img + C::A_BYTES;
+    bool more = (t + 1 < nt);
+    if constexpr ((ABL & 2) != 0) more = false;
+    const unsigned nimg = lds0 + ((t + 1) & 1) * C::STAGE_BYTES;
+    // ---- read slot 0: H0(t+1) = A rows every group reads first + all of B
+    if (more) {
+      issue_image_masked<C::NW, C::A_LOADS, 0x5u>(a_src, fa.voff, nimg, wave);
+      issue_b(nimg);
+      b_src += b_step;
+    }
+    load_a(a_img, 0);
+    load_b(b_img);
+    if (more) wait_vmcnt<6>();  // H1(t) landed (needed by read slot 1), H0(t+1) may fly
+    else wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    M32_BARRIER();
+    mma(0);
+    M32_BARRIER();
+    // ---- read slot 1: H1(t+1) = the second 64-row halves of A
+    if (more) {
+      issue_image_masked<C::NW, C::A_LOADS, 0xAu>(a_src, fa.voff, nimg, wave);
+      a_src += a_step;
+    }
+    load_a(a_img, 1);
+    if (more) wait_vmcnt<2>();  // H0(t+1) landed (needed by read slot 0 of t+1), H1(t+1) may fly
+    else wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    M32_BARRIER();
+    mma(1);
+    M32_BARRIER();
+    first_tile = false;
+  }
+  if (wm == 0) M32_BARRIER();  // balance the stagger
+#undef M32_BARRIER
+  if constexpr (EPI == 2) {
+    store_tile32_via_lds(Cmat, N, m0 + wm * 128, n0 + wn * 64, lane, smem + wave * (64 * 144), acc);
+  } else {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+    if (s == 123.456f) Cmat[(size_t)m0 * N + n0] = (half_t)s;
+  }
+}
+
+template <int LAYOUT, int EPI = 2, int ABL = 0>
+int launch_m32(const void* a, const void* b, void* c, int M, int N, int K, int swizzle, int swizzle_stride,
+               hipStream_t stream) {
+  using C = Cfg<256, 256, 64, 2, 4, 2, LAYOUT>;
+  if (M % 256 || N % 256 || K % 64) return CLN_ERR_UNSUPPORTED;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (cln_set_lds(reinterpret_cast<const void*>(&hgemm_m32_kernel<LAYOUT, EPI, ABL>), C::LDS_BYTES) != CLN_OK)
+      return CLN_ERR_LAUNCH;
+    attr_done = true;
+  }
+  const int tiles_m = M / 256, tiles_n = N / 256;
+  int band = (swizzle && swizzle_stride >= 256) ? swizzle_stride / 256 : tiles_n;
+  CLN_LAUNCH((hgemm_m32_kernel<LAYOUT, EPI, ABL>), dim3(tiles_m * tiles_n), dim3(512), C::LDS_BYTES, stream,
+             (const half_t*)a, (const half_t*)b, (half_t*)c, M, N, K, tiles_m, tiles_n, swizzle ? 1 : 0, band);
+  return cln_check_launch();
+}
+
 // ---- single-stage, register-staged rung (the "1-stage MMA tile" of config C2) ------------------
 // Same LDS images and fragment readers; the fill goes global -> VGPR -> ds_write_b128 with two
 // barriers per K tile and no overlap, i.e. reference hgemm_mma_m16n8k16_mma2x4_warp4x4
