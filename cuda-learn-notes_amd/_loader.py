@@ -27,6 +27,8 @@ ARGTYPES = {
     "LN": [c_void_p, c_void_p, c_float, c_float, c_int, c_int, c_void_p],
     "RN": [c_void_p, c_void_p, c_float, c_int, c_int, c_void_p],
     "RP": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "HI": [c_void_p, c_void_p, c_longlong, c_int, c_void_p],
+    "EM": [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p],
 }
 
 _cache = {}

@@ -1,0 +1,159 @@
+// Bit-exact indexing kernels named by north_star's tolerance clause:
+//   histogram_i32 / histogram_i32x4     reference kernels/histogram/histogram.cu:19-37, bindings :56-80
+//   embedding_{f32,f32x4,f32x4_pack,f16,f16x8,f16x8_pack}   reference kernels/embedding/embedding.cu:16-79,
+//                                                           bindings :99-133
+// gfx950 design (integer / byte work: HBM + atomic bound, nothing here goes near the matrix cores):
+//  * histogram: the reference issues one global atomic per element. Here each workgroup counts into an LDS
+//    histogram (ds_add_u32, no return) when the bin count fits 32 KiB, streams its grid-stride share of the
+//    input with the access width the rung name states (4 B or 16 B per lane), and flushes only its non-zero
+//    bins with global atomics -- device-scope atomics drop from N to <= grid x bins. Bin counts above the
+//    LDS budget fall back to the reference's direct global atomics. Values outside [0, nbins) are ignored
+//    (the reference reads/writes out of bounds for them).
+//  * embedding: out[i, :] = weight[idx[i], :]. A row is a contiguous run, so the copy is flattened over
+//    (row, pack) pairs: lane-consecutive packs of one row coalesce into full lines; the index word is
+//    read once per pack (L1 broadcast). Pack width per the rung name: 4 B, 4 x 4 B, 16 B (f32), 2 B,
+//    8 x 2 B, 16 B (f16). Rows whose index is outside [0, vocab) are written as zeros.
+#include "common.h"
+
+namespace {
+
+constexpr int HIST_LDS_BINS = 8192;  // 32 KiB of LDS counters
+
+template <int VEC>
+__global__ __launch_bounds__(256) void histogram_lds_kernel(const int* __restrict__ a, int* __restrict__ y,
+                                                            long long n, int nbins) {
+  __shared__ int h[HIST_LDS_BINS];
+  for (int i = threadIdx.x; i < nbins; i += 256) h[i] = 0;
+  __syncthreads();
+  const long long nvec = n / VEC;
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride) {
+    if constexpr (VEC == 4) {
+      const int4 v = *reinterpret_cast<const int4*>(a + i * 4);
+      if ((unsigned)v.x < (unsigned)nbins) atomicAdd(&h[v.x], 1);
+      if ((unsigned)v.y < (unsigned)nbins) atomicAdd(&h[v.y], 1);
+      if ((unsigned)v.z < (unsigned)nbins) atomicAdd(&h[v.z], 1);
+      if ((unsigned)v.w < (unsigned)nbins) atomicAdd(&h[v.w], 1);
+    } else {
+      const int v = a[i];
+      if ((unsigned)v < (unsigned)nbins) atomicAdd(&h[v], 1);
+    }
+  }
+  if (VEC > 1 && blockIdx.x == 0) {  // ragged tail
+    for (long long i = nvec * VEC + threadIdx.x; i < n; i += 256) {
+      const int v = a[i];
+      if ((unsigned)v < (unsigned)nbins) atomicAdd(&h[v], 1);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nbins; i += 256) {
+    const int c = h[i];
+    if (c) atomicAdd(&y[i], c);
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void histogram_global_kernel(const int* __restrict__ a, int* __restrict__ y,
+                                                               long long n, int nbins) {
+  const long long nvec = n / VEC;
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride) {
+    if constexpr (VEC == 4) {
+      const int4 v = *reinterpret_cast<const int4*>(a + i * 4);
+      if ((unsigned)v.x < (unsigned)nbins) atomicAdd(&y[v.x], 1);
+      if ((unsigned)v.y < (unsigned)nbins) atomicAdd(&y[v.y], 1);
+      if ((unsigned)v.z < (unsigned)nbins) atomicAdd(&y[v.z], 1);
+      if ((unsigned)v.w < (unsigned)nbins) atomicAdd(&y[v.w], 1);
+    } else {
+      const int v = a[i];
+      if ((unsigned)v < (unsigned)nbins) atomicAdd(&y[v], 1);
+    }
+  }
+  if (VEC > 1 && blockIdx.x == 0) {
+    for (long long i = nvec * VEC + threadIdx.x; i < n; i += 256) {
+      const int v = a[i];
+      if ((unsigned)v < (unsigned)nbins) atomicAdd(&y[v], 1);
+    }
+  }
+}
+
+template <int VEC>
+int launch_hist(const void* a, void* y, long long n, int nbins, hipStream_t st) {
+  if (!a || !y || n < 0 || nbins <= 0) return CLN_ERR_BAD_ARG;
+  if (n == 0) return CLN_OK;
+  if (VEC == 4 && !cln_aligned16(a)) return CLN_ERR_BAD_ARG;
+  long long g = (n / VEC + 255) / 256;
+  if (nbins <= HIST_LDS_BINS) {
+    // enough workgroups to fill the chip, few enough that the flush (grid x bins atomics) stays small
+    const int cap = nbins <= 1024 ? 1024 : 256;
+    const int grid = (int)(g < 1 ? 1 : (g > cap ? cap : g));
+    CLN_LAUNCH((histogram_lds_kernel<VEC>), dim3(grid), dim3(256), 0, st, (const int*)a, (int*)y, n, nbins);
+  } else {
+    const int grid = (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+    CLN_LAUNCH((histogram_global_kernel<VEC>), dim3(grid), dim3(256), 0, st, (const int*)a, (int*)y, n, nbins);
+  }
+  return cln_check_launch();
+}
+
+// ---- embedding -----------------------------------------------------------------------------------
+// T: element type, VEC: elements per lane, PACKED: one 16-byte (VEC*sizeof(T)) access vs VEC scalar accesses
+template <typename T, int VEC, bool PACKED>
+__global__ __launch_bounds__(256) void embedding_kernel(const int* __restrict__ idx, const T* __restrict__ weight,
+                                                        T* __restrict__ out, long long n, int emb, int vocab) {
+  const int ppr = emb / VEC;  // packs per row
+  const long long total = n * ppr;
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += stride) {
+    const long long row = t / ppr;
+    const int col = (int)(t - row * ppr) * VEC;
+    const int id = idx[row];
+    const bool ok = (unsigned)id < (unsigned)vocab;
+    const T* src = weight + (size_t)(ok ? id : 0) * emb + col;
+    T* dst = out + (size_t)row * emb + col;
+    if constexpr (PACKED) {
+      typedef T vec_t __attribute__((ext_vector_type(VEC)));
+      vec_t v = *reinterpret_cast<const vec_t*>(src);
+      if (!ok) v = vec_t(0);
+      *reinterpret_cast<vec_t*>(dst) = v;
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) dst[e] = ok ? src[e] : (T)0;
+    }
+  }
+}
+
+template <typename T, int VEC, bool PACKED>
+int launch_emb(const void* idx, const void* weight, void* out, long long n, int emb, int vocab, hipStream_t st) {
+  if (!idx || !weight || !out || n < 0 || emb <= 0 || vocab <= 0) return CLN_ERR_BAD_ARG;
+  if (emb % VEC != 0) return CLN_ERR_UNSUPPORTED;
+  if (PACKED && (!cln_aligned16(weight) || !cln_aligned16(out))) return CLN_ERR_BAD_ARG;
+  if (n == 0) return CLN_OK;
+  const long long total = n * (emb / VEC);
+  const int grid = cln_stream_grid(total, 256);
+  CLN_LAUNCH((embedding_kernel<T, VEC, PACKED>), dim3(grid), dim3(256), 0, st, (const int*)idx, (const T*)weight,
+             (T*)out, n, emb, vocab);
+  return cln_check_launch();
+}
+
+}  // namespace
+
+// (a int32[n], y int32[nbins] zeroed by the caller, n, nbins, stream)
+CLN_API int histogram_i32(const void* a, void* y, long long n, int nbins, void* stream) {
+  return launch_hist<1>(a, y, n, nbins, (hipStream_t)stream);
+}
+CLN_API int histogram_i32x4(const void* a, void* y, long long n, int nbins, void* stream) {
+  return launch_hist<4>(a, y, n, nbins, (hipStream_t)stream);
+}
+
+// (idx int32[n], weight T[vocab, emb], out T[n, emb], n, emb, vocab, stream)
+#define CLN_EMB(name, T, VEC, PACKED)                                                                   \
+  CLN_API int name(const void* idx, const void* weight, void* out, long long n, int emb, int vocab,    \
+                   void* stream) {                                                                      \
+    return launch_emb<T, VEC, PACKED>(idx, weight, out, n, emb, vocab, (hipStream_t)stream);            \
+  }
+CLN_EMB(embedding_f32, float, 1, false)
+CLN_EMB(embedding_f32x4, float, 4, false)
+CLN_EMB(embedding_f32x4_pack, float, 4, true)
+CLN_EMB(embedding_f16, half_t, 1, false)
+CLN_EMB(embedding_f16x8, half_t, 8, false)
+CLN_EMB(embedding_f16x8_pack, half_t, 8, true)

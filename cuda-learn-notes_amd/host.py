@@ -243,7 +243,39 @@ def _make_rp(name):
     return f
 
 
-_MAKERS = {"G3": _make_g3, "G6": _make_g6, "H0": _make_h0, "FA": _make_fa, "P3": _make_p3, "R1": _make_r1,
+def _make_hi(name):
+    fn = _loader.symbol(name)
+
+    def f(a):
+        _check_dtype(a, torch.int32)
+        _check_dev(a)
+        # reference binding: M = max(a) on the host, y = zeros(M + 1) (histogram.cu:60-66)
+        nbins = int(a.max().item()) + 1 if a.numel() else 1
+        y = torch.zeros(max(nbins, 1), dtype=torch.int32, device=a.device)
+        _raise(name, fn(a.data_ptr(), y.data_ptr(), a.numel(), max(nbins, 1), _stream()))
+        return y
+    f.__name__ = name
+    return f
+
+
+def _make_em(name):
+    fn = _loader.symbol(name)
+    dtype = torch.float32 if "_f32" in name else torch.float16
+
+    def f(a, weight, o):
+        _check_dtype(a, torch.int32)
+        _check_dtype(weight, dtype)
+        _check_dtype(o, dtype)
+        _check_dev(a, weight, o)
+        n, emb = a.size(0), weight.size(1)
+        _check_shape(o, n, emb)
+        _raise(name, fn(a.data_ptr(), weight.data_ptr(), o.data_ptr(), n, emb, weight.size(0), _stream()),
+               "%s: embedding size must be a multiple of the pack width" % name)
+    f.__name__ = name
+    return f
+
+
+_MAKERS = {"HI": _make_hi, "EM": _make_em, "G3": _make_g3, "G6": _make_g6, "H0": _make_h0, "FA": _make_fa, "P3": _make_p3, "R1": _make_r1,
            "SG": _make_sg, "XY": _make_xy, "LN": _make_ln, "RN": _make_rn, "RP": _make_rp}
 
 

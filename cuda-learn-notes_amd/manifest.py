@@ -158,6 +158,18 @@ for _n, _impl in [
 _add("rope", "RP", "rope<1 pair/thread, 8B>", "rope_f32", "rope_f32_v2")
 _add("rope", "RP", "rope<2 pairs/thread, 16B>", "rope_f32x4_pack")
 
+# ---------------------------------------------------------------- bit-exact indexing kernels
+#   HI   int f(a, y, n, nbins, stream)                     (python: Tensor f(a))
+#   EM   int f(idx, weight, out, n, emb_size, vocab, stream)  (python: f(a, weight, o))
+_add("histogram", "HI", "histogram<4 B/lane> LDS-privatised counters, flush non-zero bins", "histogram_i32")
+_add("histogram", "HI", "histogram<16 B/lane> LDS-privatised counters, flush non-zero bins", "histogram_i32x4")
+_add("embedding", "EM", "row gather<float,1>", "embedding_f32")
+_add("embedding", "EM", "row gather<float,4 scalar accesses>", "embedding_f32x4")
+_add("embedding", "EM", "row gather<float,16 B pack>", "embedding_f32x4_pack")
+_add("embedding", "EM", "row gather<half,1>", "embedding_f16")
+_add("embedding", "EM", "row gather<half,8 scalar accesses>", "embedding_f16x8")
+_add("embedding", "EM", "row gather<half,16 B pack>", "embedding_f16x8_pack")
+
 ENTRIES = tuple(_E)
 BY_NAME = {e.name: e for e in ENTRIES}
 assert len(BY_NAME) == len(ENTRIES), "duplicate exported name"
@@ -167,6 +179,7 @@ SO_OF_LIB = {
     "hgemm": "libcln_amd.so", "flash_attn": "libcln_amd.so", "elementwise": "libcln_amd.so",
     "reduce": "libcln_amd.so", "softmax": "libcln_amd.so", "layer_norm": "libcln_amd.so",
     "rms_norm": "libcln_amd.so", "rope": "libcln_amd.so", "hgemm_vendor": "libcln_amd_vendor.so",
+    "histogram": "libcln_amd.so", "embedding": "libcln_amd.so",
 }
 
 # element dtype (torch name) each reduce rung takes, and the result dtype

@@ -23,7 +23,7 @@ __all__ = [
     "hgemm", "hgemm_fp16_path", "as_col_major", "make_block_swizzle_stride", "unfused_standard_attn",
     "attention_fp64", "sdpa", "get_mha_tflops", "elementwise_add", "reduce_sum", "softmax_global",
     "softmax_per_token", "layer_norm_torch", "layer_norm_kernel", "rms_norm_torch", "rms_norm_kernel",
-    "rope_torch", "rope_kernel", "fp8_to_float",
+    "rope_torch", "rope_kernel", "fp8_to_float", "histogram", "embedding",
 ]
 
 
@@ -168,3 +168,18 @@ def rope_kernel(x: torch.Tensor) -> torch.Tensor:
     out[:, 0::2] = x1 * c - x2 * s
     out[:, 1::2] = x1 * s + x2 * c
     return out.to(x.dtype)
+
+
+# ---------------------------------------------------------------- indexing (bit-exact)
+def histogram(a: torch.Tensor) -> torch.Tensor:
+    """Reference kernels/histogram/histogram.cu:19-22 + binding :56-70: y = zeros(max(a)+1, int32);
+    y[a[i]] += 1 for every element. Pinned by the reference's own README transcript
+    (kernels/histogram/README.md:24-44: list(range(10))*1000 -> ten bins of 1000)."""
+    a64 = a.to(torch.int64)
+    return torch.bincount(a64, minlength=int(a64.max().item()) + 1).to(torch.int32)
+
+
+def embedding(idx: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    """Reference check column: torch.nn.functional.embedding (kernels/embedding/embedding.py:6, :82, :91);
+    kernel: output[i, :] = weight[idx[i], :] (embedding.cu:16-24). Pure copy -> bit-exact."""
+    return F.embedding(idx.to(torch.int64), weight)

@@ -10,7 +10,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # hand-kept copy of the reference surface counts as an independent check
 EXPECTED_COUNTS = {"hgemm": 34, "hgemm_vendor": 4, "flash_attn": 28, "elementwise": 6, "reduce": 20,
-                   "softmax": 11, "layer_norm": 8, "rms_norm": 9, "rope": 3}
+                   "softmax": 11, "layer_norm": 8, "rms_norm": 9, "rope": 3,
+                   "histogram": 2, "embedding": 6}  # last two: SURVEY 8(f) rank 1 (bit-exact indexing kernels)
 SPOT_NAMES = [
     "hgemm_naive_f16", "hgemm_t_16x8_sliced_k32_f16x8_pack_dbuf_async", "init_cublas_handle",
     "hgemm_cublas_tensor_op_tn", "hgemm_wmma_m16n16k16_mma4x4_warp4x4_stages_dsmem",
@@ -27,7 +28,7 @@ def test_manifest_counts(pkg):
     from collections import Counter
     c = Counter(e.lib for e in pkg.manifest.ENTRIES)
     assert dict(c) == EXPECTED_COUNTS
-    assert len(pkg.manifest.ENTRIES) == 123
+    assert len(pkg.manifest.ENTRIES) == 131
     for n in SPOT_NAMES:
         assert n in pkg.manifest.BY_NAME
 
@@ -54,6 +55,9 @@ def test_python_surface_has_every_reference_name(built):
     assert len(vars(fa)) == 28
     rest = built.load("elementwise", "reduce", "softmax", "layer_norm", "rms_norm", "rope")
     assert len(vars(rest)) == 57
+    idx = built.load("histogram", "embedding")
+    assert sorted(vars(idx)) == ["embedding_f16", "embedding_f16x8", "embedding_f16x8_pack", "embedding_f32",
+                                 "embedding_f32x4", "embedding_f32x4_pack", "histogram_i32", "histogram_i32x4"]
     for n in SPOT_NAMES:
         assert any(hasattr(ns, n) for ns in (hg, fa, rest))
 

@@ -76,3 +76,20 @@ def test_kernel_semantics_vs_torch_oracle(oracle):
     assert torch.allclose(rk[0], rt[0], atol=1e-6)
     assert torch.allclose(rk[:, :2], rt[:, :2], atol=1e-4)  # pair 0 has frequency 1 in both
     assert (rk[5] - rt[5]).abs().max() > 0.1
+
+
+def test_histogram_known_answer_from_reference_readme(oracle):
+    """kernels/histogram/histogram.py:22 feeds list(range(10))*1000; the README transcript of the reference
+    kernels (kernels/histogram/README.md:24-44) prints 1000 for each of the ten bins."""
+    a = torch.tensor(list(range(10)) * 1000, dtype=torch.int32)
+    h = oracle.histogram(a)
+    assert h.dtype == torch.int32 and h.tolist() == [1000] * 10
+
+
+def test_embedding_is_a_row_gather(oracle):
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn(37, 24, generator=g)
+    idx = torch.tensor([0, 36, 5, 5, 17], dtype=torch.int32)
+    out = oracle.embedding(idx, w)
+    for r, i in enumerate(idx.tolist()):
+        assert torch.equal(out[r], w[i])
