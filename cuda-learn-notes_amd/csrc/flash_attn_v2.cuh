@@ -24,7 +24,7 @@
 
 namespace fa2 {
 
-enum : int { OPT_DEFER = 1, OPT_PRIO = 2, OPT_LDS_EPI = 4, OPT_XCD = 8, OPT_STAGGER = 16, OPT_ONES = 32, OPT_SOLO = 64, OPT_DEFAULT = 15 };
+enum : int { OPT_DEFER = 1, OPT_PRIO = 2, OPT_LDS_EPI = 4, OPT_XCD = 8, OPT_STAGGER = 16, OPT_ONES = 32, OPT_SOLO = 64, OPT_PK = 512, OPT_DEFAULT = 15 };
 enum : int { ABL_NO_SOFTMAX = 1, ABL_NO_STAGE = 2, ABL_NO_FRAG_READS = 4, ABL_NO_BARRIER = 8 };
 
 template <int D, int NW, bool VT>
@@ -221,6 +221,26 @@ __global__ __launch_bounds__(NW * 64, (D > 128 ? 1 : 2)) void fa2_fwd_v2_kernel(
       }
       const float nm = -m_run;
       float psum = 0.f;
+      if constexpr ((OPT & OPT_PK) != 0) {
+        // packed-f32 VALU: one v_pk_fma_f32 / v_pk_add_f32 does two lanes-values per 4-cycle issue slot
+        // (PMC: a plain VALU op and a packed one both hold the VALU for one quad-cycle; v_exp_f32 two)
+        const f2 c2 = {scale_log2e, scale_log2e}, nm2 = {nm, nm};
+        f2 ps = {0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const f2 ea = __builtin_elementwise_fma(f2{s0[r], s0[r + 1]}, c2, nm2);
+          const f2 eb = __builtin_elementwise_fma(f2{s1[r], s1[r + 1]}, c2, nm2);
+          const f2 pa = {__builtin_amdgcn_exp2f(ea[0]), __builtin_amdgcn_exp2f(ea[1])};
+          const f2 pb = {__builtin_amdgcn_exp2f(eb[0]), __builtin_amdgcn_exp2f(eb[1])};
+          ps += pa;
+          ps += pb;
+          const h2 a = __builtin_convertvector(pa, h2);
+          const h2 b = __builtin_convertvector(pb, h2);
+          pf[r >> 3][r & 7] = a[0], pf[r >> 3][(r & 7) + 1] = a[1];
+          pf[2 + (r >> 3)][r & 7] = b[0], pf[2 + (r >> 3)][(r & 7) + 1] = b[1];
+        }
+        psum = ps[0] + ps[1];
+      } else {
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
         const float a0 = __builtin_amdgcn_exp2f(fmaf(s0[r], scale_log2e, nm));
@@ -232,6 +252,7 @@ __global__ __launch_bounds__(NW * 64, (D > 128 ? 1 : 2)) void fa2_fwd_v2_kernel(
         const h2 b = __builtin_convertvector(f2{b0, b1}, h2);
         pf[r >> 3][r & 7] = a[0], pf[r >> 3][(r & 7) + 1] = a[1];
         pf[2 + (r >> 3)][r & 7] = b[0], pf[2 + (r >> 3)][(r & 7) + 1] = b[1];
+      }
       }
       l_run += psum;
     }

@@ -1,7 +1,11 @@
 // Tuning / ablation hook for the v2 FlashAttention kernel (not part of the reference surface).
 //   int cln_fa2_variant(D, nw, vt, opt, abl, q, k, v, o, B, H, N, stream)
-#include "flash_attn_v2.cuh"
+#include "flash_attn_v3.cuh"
+#include <type_traits>
 
+#define V3(DD, NWW, OPTT) \
+  if (D == DD && nw == NWW && opt == OPTT && abl == 100 && !vt) \
+    return fa2::launch_v3<DD, NWW, false, OPTT>(q, k, v, o, B, H, N, (hipStream_t)stream);
 #define V2(DD, NWW, OPTT, ABLL) \
   if (D == DD && nw == NWW && opt == OPTT && abl == ABLL && !vt) \
     return fa2::launch_v2<DD, NWW, false, OPTT, ABLL>(q, k, v, o, B, H, N, (hipStream_t)stream);
@@ -10,5 +14,7 @@ CLN_API int cln_fa2_variant(int D, int nw, int vt, int opt, int abl, const void*
                             void* o, int B, int H, int N, void* stream) {
   V2(64, 8, 13, 0) V2(64, 4, 13, 0) V2(64, 4, 77, 0) V2(128, 8, 15, 0) V2(128, 4, 15, 0) V2(128, 4, 79, 0)
   V2(64, 8, 13, 1) V2(64, 8, 13, 2) V2(64, 8, 13, 7) V2(128, 8, 15, 1) V2(128, 8, 15, 7)
+  V2(64, 8, 525, 0) V2(128, 8, 527, 0) V2(64, 8, 524, 0)
+  V3(64, 8, 13) V3(64, 8, 269) V3(64, 8, 15) V3(64, 4, 13) V3(128, 8, 15) V3(128, 8, 13) V3(128, 8, 271) V3(128, 4, 15)
   return CLN_ERR_UNSUPPORTED;
 }

@@ -37,6 +37,13 @@ def main():
         fn = fa.flash_attn_mma_stages_split_q_shared_qkv if D <= 256 else fa.flash_attn_mma_stages_split_q_tiling_qkv
         for _ in range(iters):
             fn(q, k, v, o, stages)
+    elif what == "fa2":  # fa2 <D> <nw> <opt> <abl> <B> <H> <N> [iters]
+        D, nw, opt, abl, B, H, N = map(int, sys.argv[2:9])
+        iters = int(sys.argv[9]) if len(sys.argv) > 9 else 10
+        q, k, v = (torch.randn(B, H, N, D, dtype=torch.half, device=dev) for _ in range(3))
+        o = torch.zeros_like(q)
+        for _ in range(iters):
+            host.fa2_variant((nw, 0, opt, abl), q, k, v, o)
     torch.cuda.synchronize()
 
 
