@@ -73,21 +73,45 @@ static inline int cln_stream_grid(long long work_items, int block) {
 
 #ifdef __HIPCC__
 // ---------------------------------------------------------------- wave64 reductions
-// xor-butterfly over all 64 lanes. (reference: warp_reduce_sum_f32 with WARP_SIZE 32,
-// kernels/reduce/block_all_reduce.cu:30-37 -- re-derived for 64 lanes, not translated.)
+// All-lanes reductions on the VALU only (no LDS round trips): four DPP steps inside a 16-lane row
+// (quad_perm xor 1, xor 2, row_half_mirror, row_mirror), then v_permlane16_swap / v_permlane32_swap (gfx950)
+// for the cross-row steps. ~12 VALU instructions instead of six dependent ds_bpermute (~100+ cycles each):
+// the row kernels (softmax / norms, one workgroup per row) are latency-bound on exactly this chain.
+// (reference: warp_reduce_sum_f32 with WARP_SIZE 32, kernels/reduce/block_all_reduce.cu:30-37 -- re-derived for
+// 64 lanes, not translated.)
+template <int CTRL>
+__device__ __forceinline__ float cln_dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int cln_dpp_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+#define CLN_WAVE_REDUCE(v, OP, DPPF, TOBITS, FROMBITS)                                              \
+  v = OP(v, DPPF<0xB1>(v));  /* quad_perm [1,0,3,2] */                                               \
+  v = OP(v, DPPF<0x4E>(v));  /* quad_perm [2,3,0,1] */                                               \
+  v = OP(v, DPPF<0x141>(v)); /* row_half_mirror */                                                   \
+  v = OP(v, DPPF<0x140>(v)); /* row_mirror */                                                        \
+  {                                                                                                  \
+    const auto s16 = __builtin_amdgcn_permlane16_swap(TOBITS(v), TOBITS(v), false, false);           \
+    v = OP(FROMBITS(s16[0]), FROMBITS(s16[1]));                                                      \
+    const auto s32 = __builtin_amdgcn_permlane32_swap(TOBITS(v), TOBITS(v), false, false);           \
+    v = OP(FROMBITS(s32[0]), FROMBITS(s32[1]));                                                      \
+  }
+__device__ __forceinline__ float cln_addf(float a, float b) { return a + b; }
+__device__ __forceinline__ int cln_addi(int a, int b) { return a + b; }
+__device__ __forceinline__ unsigned cln_i2u(int a) { return (unsigned)a; }
+__device__ __forceinline__ int cln_u2i(unsigned a) { return (int)a; }
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  CLN_WAVE_REDUCE(v, cln_addf, cln_dpp, __float_as_uint, __uint_as_float)
   return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+  CLN_WAVE_REDUCE(v, fmaxf, cln_dpp, __float_as_uint, __uint_as_float)
   return v;
 }
 __device__ __forceinline__ int wave_sum_i32(int v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  CLN_WAVE_REDUCE(v, cln_addi, cln_dpp_i, cln_i2u, cln_u2i)
   return v;
 }
 

@@ -1,0 +1,257 @@
+// FlashAttention-2 forward for head dims 384 / 512 (BASELINE config C5 = [1,32,4096,512]): the reference's
+// "fine-grained QKV tiling" rungs (kernels/flash-attn/mma/basic/flash_attn_mma_tiling_qkv.cu:70, :732;
+// tiling_qk.cu:72) keep O(1) shared memory by streaming Q, K and V in 16-wide d slices and re-reading Q for
+// every KV tile. On MI355X the register file is the big resource, so the roles are inverted:
+//   * a workgroup = 4 waves, ONE wave per SIMD, each wave owns 32 query rows and the WHOLE 512-register
+//     file: the full-width O^T accumulator (D/32 x 16 = 256 registers at D = 512) and the Q fragments
+//     (D/16 x 4 = 128 registers) stay in registers for the whole kernel -- Q is read from HBM exactly
+//     once, S is computed once (the previous large-D path recomputed S per output slice: 1.5x the MFMA work);
+//   * KV tile = 32 keys; K and V tiles ([32][D] fp16 = 32 KiB each at D = 512) are double-buffered in LDS
+//     (128 KiB) and filled by LDS-DMA (global_load_lds_dwordx4, no staging registers -- there are none to
+//     spare), one barrier per tile, tile j+1 in flight while tile j is consumed;
+//   * LDS images are lane-linear (DMA constraint); bank conflicts of the 1-KiB-strided rows are removed by
+//     XOR-swizzling the 16-byte chunk index on the DMA *source* address and on the fragment read:
+//     K (ds_read_b128, 32 rows at one chunk column):   chunk ^= row & 15
+//     V (ds_read_b64_tr_b16, 4 rows x 2 column blocks): chunk ^= (row & 3) << 2
+//   * softmax / P handling as in flash_attn_v2.cuh (lane-local rows, deferred max, packed RNE conversion).
+#pragma once
+#include "flash_attn_v2.cuh"
+#include "hgemm_mfma.cuh"  // glds16_asm, lds_addr_of, wait_vmcnt
+
+namespace fa2 {
+
+template <int D>
+struct GeoBig {
+  static constexpr int BC = 32, NW = 4, BR = 128, NT = 256;
+  static constexpr int ROW = D * 2;               // bytes per K/V row
+  static constexpr int TILE = BC * ROW;           // one K (or V) tile
+  static constexpr int STAGE = 2 * TILE;          // K + V
+  static constexpr int RING = 2 * STAGE;
+  static constexpr int OS = D * 2 + 16;
+  static constexpr int EPI = NW * 32 * OS;
+  static constexpr int LDS_BYTES = RING > EPI ? RING : EPI;
+  static constexpr int PIECES = TILE / 1024;      // 1-KiB DMA pieces per tile image
+  static constexpr int PPW = PIECES / NW;         // per wave per image
+  static_assert(D % 128 == 0 && D >= 256 && D <= 512, "big-D kernel: D in {256,384,512}");
+  static_assert(PIECES % NW == 0, "pieces split over the waves");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+};
+
+template <int D, int OPT>
+__global__ __launch_bounds__(256, 1) void fa2_fwd_bigd_kernel(const half_t* __restrict__ Q,
+                                                              const half_t* __restrict__ K,
+                                                              const half_t* __restrict__ V, half_t* __restrict__ O,
+                                                              int N, int n_qblk, int n_heads, float scale_log2e) {
+  using G = GeoBig<D>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+
+  int head_i, qb;
+  {
+    const int bid = blockIdx.x;
+    if ((OPT & OPT_XCD) && (n_heads & 7) == 0) {
+      const int xcd = bid & 7, k = bid >> 3;
+      head_i = (k / n_qblk) * 8 + xcd;
+      qb = k - (k / n_qblk) * n_qblk;
+    } else {
+      head_i = bid / n_qblk;
+      qb = bid - head_i * n_qblk;
+    }
+  }
+  const size_t head = (size_t)head_i * N * D;
+  const int q_row0 = qb * G::BR + wave * 32;
+  const char* Kh = reinterpret_cast<const char*>(K + head);
+  const char* Vh = reinterpret_cast<const char*>(V + head);
+
+  // ---- DMA source offsets (bytes, relative to the tile origin), constant over the KV loop
+  unsigned k_voff[G::PPW], v_voff[G::PPW];
+#pragma unroll
+  for (int i = 0; i < G::PPW; ++i) {
+    const int piece = i * G::NW + wave;
+    const int byte = piece * 1024 + lane * 16;  // position in the linear LDS image
+    const int row = byte / G::ROW, c = (byte % G::ROW) >> 4;
+    k_voff[i] = (unsigned)(row * G::ROW + ((c ^ (row & 15)) << 4));
+    v_voff[i] = (unsigned)(row * G::ROW + ((c ^ ((row & 3) << 2)) << 4));
+  }
+  const unsigned lds0 = hgemm::lds_addr_of(smem);
+  auto dma_tile = [&](int j, int buf) {
+    const char* ks = Kh + (size_t)j * G::TILE;
+    const char* vs = Vh + (size_t)j * G::TILE;
+    const unsigned kimg = lds0 + buf * G::STAGE, vimg = kimg + G::TILE;
+#pragma unroll
+    for (int i = 0; i < G::PPW; ++i) hgemm::glds16_asm(ks, k_voff[i], kimg + (unsigned)(i * G::NW + wave) * 1024u);
+#pragma unroll
+    for (int i = 0; i < G::PPW; ++i) hgemm::glds16_asm(vs, v_voff[i], vimg + (unsigned)(i * G::NW + wave) * 1024u);
+  };
+
+  // ---- Q fragments: the whole head dim lives in registers
+  h8 qf[D / 16];
+  {
+    const half_t* qp = Q + head + (size_t)(q_row0 + l31) * D + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < D / 16; ++ks) qf[ks] = *reinterpret_cast<const h8*>(qp + ks * 16);
+  }
+
+  f16v ot[D / 32];
+#pragma unroll
+  for (int b = 0; b < D / 32; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ot[b][r] = 0.f;
+  float m_run = -1.0e30f, l_run = 0.f;
+
+  const int T = N / G::BC;
+  dma_tile(0, 0);
+  hgemm::wait_vmcnt<0>();  // also covers the Q loads
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  // Lane-constant LDS offsets. The swizzles only touch the low 4 bits of the 16-byte chunk index, so a read
+  // address is (one of a few lane-constant registers) + (compile-time immediate): 8 registers for K, 4 for V.
+  // (Computing the full XOR per fragment makes LICM hoist D/16 + D/32 address registers out of the KV loop
+  // and the kernel spills -- the register file is full by design.)
+  int koff[8];  // k-step ks reads chunk (2*ks + hi) ^ (row & 15):   low 4 bits from ks & 7, rest immediate
+#pragma unroll
+  for (int i = 0; i < 8; ++i) koff[i] = l31 * G::ROW + (((2 * i + hi) ^ (l31 & 15)) << 4);
+  const int i16 = lane & 15;
+  const int v_row = 4 * hi + (i16 >> 2);  // + 16*st (+ 8 for the second read): (row & 3) is the same for all
+  int voff[4];  // output block b reads chunk (4*b + cc) ^ ((row & 3) << 2) = 4*(b ^ (row&3)) + cc
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    voff[i] = v_row * G::ROW + ((((i ^ (v_row & 3)) << 2) + (((lane >> 4) & 1) * 2) + ((i16 & 3) >> 1)) << 4) +
+              ((i16 & 1) << 3);
+
+  for (int j = 0; j < T; ++j) {
+    const char* kb = smem + (j & 1) * G::STAGE;
+    const char* vb = kb + G::TILE;
+    if (j + 1 < T) dma_tile(j + 1, (j + 1) & 1);  // its readers (tile j-1) finished before the last barrier
+
+    // ---- S^T = K Q^T (32 keys x 32 queries), one accumulator chain over D/16 k-steps
+    f16v s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    if constexpr ((OPT & OPT_PRIO) != 0) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < D / 16; ++ks) {
+      const h8 kf = *reinterpret_cast<const h8*>(kb + koff[ks & 7] + (ks >> 3) * 256);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s, 0, 0, 0);
+      // fence the scheduler every 4 k-steps: without it all D/16 fragment reads are hoisted ahead of the MFMA
+      // chain and the kernel spills (the register file is full by design)
+      if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr ((OPT & OPT_PRIO) != 0) __builtin_amdgcn_s_setprio(0);
+
+    // ---- online softmax
+    float mx = s[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+    {
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+      mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
+    const float mxs = mx * scale_log2e;
+    bool grow;
+    if constexpr ((OPT & OPT_DEFER) != 0) grow = (mxs - m_run) > 8.0f;
+    else grow = mxs > m_run;
+    if (__builtin_amdgcn_ballot_w64(grow) != 0) {
+      const float m_new = fmaxf(m_run, mxs);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      l_run *= alpha;
+      // The accumulators live in AGPRs and VALU ops cannot read those: every element makes a round trip through a
+      // VGPR. Left alone, the compiler batches all D/2 reads (256 VGPR temporaries at D = 512 -> spills in the
+      // hot loop); the empty volatile asm statements serialise the round trips to 4 live temporaries.
+#pragma unroll
+      for (int b = 0; b < D / 32; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; r += 4) {
+          float t0 = ot[b][r], t1 = ot[b][r + 1], t2 = ot[b][r + 2], t3 = ot[b][r + 3];
+          asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
+          ot[b][r] = t0 * alpha, ot[b][r + 1] = t1 * alpha, ot[b][r + 2] = t2 * alpha, ot[b][r + 3] = t3 * alpha;
+        }
+    }
+    h8 pf[2];
+    {
+      const float nm = -m_run;
+      float psum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const float a0 = __builtin_amdgcn_exp2f(fmaf(s[r], scale_log2e, nm));
+        const float a1 = __builtin_amdgcn_exp2f(fmaf(s[r + 1], scale_log2e, nm));
+        psum += a0 + a1;
+        const h2 a = __builtin_convertvector(f2{a0, a1}, h2);
+        pf[r >> 3][r & 7] = a[0], pf[r >> 3][(r & 7) + 1] = a[1];
+      }
+      l_run += psum;
+    }
+
+    // ---- O^T += V^T P^T : 2 k-steps x D/32 output blocks
+    if constexpr ((OPT & OPT_PRIO) != 0) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+#pragma unroll
+      for (int b = 0; b < D / 32; ++b) {
+        // rows 16*st + v_row and + 8 ((row + 8) & 3 == row & 3: same swizzle); 4 output blocks = 256 bytes
+        const char* vp = vb + voff[b & 3] + (16 * st) * G::ROW + (b >> 2) * 256;
+        const h8 vf = h8_cat(lds_read_tr16(vp), lds_read_tr16(vp + 8 * G::ROW));
+        ot[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[st], ot[b], 0, 0, 0);
+        if ((b & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if constexpr ((OPT & OPT_PRIO) != 0) __builtin_amdgcn_s_setprio(0);
+
+    // tile j+1 landed (own pieces) + everyone is done reading buffer j&1
+    hgemm::wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+
+  // ---- epilogue: O = O^T / l, staged through LDS (wave-private rows)
+  float l_tot;
+  {
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
+    l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+  }
+  const float inv = 1.0f / l_tot;
+  char* ob = smem + wave * (32 * G::OS);
+#pragma unroll
+  for (int b = 0; b < D / 32; ++b) {
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      h4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (half_t)(ot[b][rq * 4 + e] * inv);
+      *reinterpret_cast<h4*>(ob + l31 * G::OS + (b * 32 + rq * 8 + hi * 4) * 2) = o;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  constexpr int LPR = D / 8;
+  half_t* og = O + head + (size_t)q_row0 * D;
+#pragma unroll 4
+  for (int it = 0; it < (32 * LPR) / 64; ++it) {
+    const int idx = it * 64 + lane;
+    const int row = idx / LPR, c = idx % LPR;
+    const u4 v = *reinterpret_cast<const u4*>(ob + row * G::OS + c * 16);
+    *reinterpret_cast<u4*>(og + (size_t)row * D + c * 8) = v;
+  }
+}
+
+template <int D, int OPT>
+int launch_bigd(const void* q, const void* k, const void* v, void* o, int B, int H, int N, hipStream_t stream) {
+  using G = GeoBig<D>;
+  if (N % G::BR != 0) return CLN_ERR_UNSUPPORTED;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (cln_set_lds(reinterpret_cast<const void*>(&fa2_fwd_bigd_kernel<D, OPT>), G::LDS_BYTES) != CLN_OK)
+      return CLN_ERR_LAUNCH;
+    attr_done = true;
+  }
+  const float scale_log2e = 1.4426950408889634f / sqrtf((float)D);
+  const int n_qblk = N / G::BR;
+  CLN_LAUNCH((fa2_fwd_bigd_kernel<D, OPT>), dim3(n_qblk * B * H), dim3(G::NT), G::LDS_BYTES, stream,
+             (const half_t*)q, (const half_t*)k, (const half_t*)v, (half_t*)o, N, n_qblk, B * H, scale_log2e);
+  return cln_check_launch();
+}
+
+}  // namespace fa2

@@ -15,9 +15,27 @@ using namespace rowwise;
 
 namespace {
 
+// Row statistics: lanes reduce their own elements, wave64 DPP/permlane all-reduce, lane 0 of every wave parks
+// its partial in LDS, and after ONE barrier every thread folds the <= 16 wave partials itself (same order
+// everywhere -> identical result, no broadcast hop). Each scratch array is written once per kernel, so no
+// protecting barrier is needed; layer-norm keeps the reference kernels' two-pass mean / variance
+// (layer_norm.cu:53-110) and therefore uses two scratch arrays and two barriers.
+__device__ __forceinline__ float row_sum(float v, float* scratch) {
+  v = wave_sum(v);
+  const int nw = blockDim.x >> 6;
+  if (nw > 1) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) scratch[w] = v;
+    __syncthreads();
+    v = scratch[0];
+    for (int i = 1; i < nw; ++i) v += scratch[i];
+  }
+  return v;
+}
+
 template <typename T, int VEC, int MAXV>
 __global__ void layer_norm_kernel(const T* __restrict__ x, T* __restrict__ y, float g, float b, int K) {
-  __shared__ float scratch[16];
+  __shared__ float scratch[2][16];
   const size_t off = (size_t)blockIdx.x * K;
   RowRegs<T, VEC, MAXV> r;
   r.load(x + off, K, 0.f);
@@ -26,7 +44,7 @@ __global__ void layer_norm_kernel(const T* __restrict__ x, T* __restrict__ y, fl
   for (int i = 0; i < MAXV; ++i)
 #pragma unroll
     for (int e = 0; e < VEC; ++e) s += r.x[i][e];
-  const float mean = block_sum_rt(s, scratch) / (float)K;
+  const float mean = row_sum(s, scratch[0]) / (float)K;
   float v = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
@@ -38,11 +56,11 @@ __global__ void layer_norm_kernel(const T* __restrict__ x, T* __restrict__ y, fl
       v += d * d;
     }
   }
-  const float rstd = rsqrtf(block_sum_rt(v, scratch) / ((float)K + 1e-5f));
+  const float a = rsqrtf(row_sum(v, scratch[1]) / ((float)K + 1e-5f)) * g;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i)
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) r.x[i][e] = r.x[i][e] * rstd * g + b;
+    for (int e = 0; e < VEC; ++e) r.x[i][e] = fmaf(r.x[i][e], a, b);
   r.store(y + off, K);
 }
 
@@ -57,11 +75,11 @@ __global__ void rms_norm_kernel(const T* __restrict__ x, T* __restrict__ y, floa
   for (int i = 0; i < MAXV; ++i)
 #pragma unroll
     for (int e = 0; e < VEC; ++e) v += r.x[i][e] * r.x[i][e];
-  const float rstd = rsqrtf(block_sum_rt(v, scratch) / (float)K + 1e-5f);
+  const float a = rsqrtf(row_sum(v, scratch) / (float)K + 1e-5f) * g;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i)
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) r.x[i][e] = r.x[i][e] * rstd * g;
+    for (int e = 0; e < VEC; ++e) r.x[i][e] = r.x[i][e] * a;
   r.store(y + off, K);
 }
 

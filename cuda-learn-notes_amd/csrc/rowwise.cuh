@@ -20,10 +20,12 @@ __device__ __forceinline__ float from_f32<float>(float x) { return x; }
 template <>
 __device__ __forceinline__ half_t from_f32<half_t>(float x) { return (half_t)x; }
 
-// Threads per row: enough lanes to cover the row once, rounded to whole waves, capped at 1024.
+// Threads per row: about four packs per lane (independent loads in flight per lane, several rows resident
+// per CU, and the cross-wave reduction stays small or disappears: <= 256 packs -> a single wave, no barrier),
+// rounded to whole waves, capped at 1024.
 inline int row_threads(int K, int VEC) {
-  int nvec = K / VEC;
-  int nt = ((nvec + 63) / 64) * 64;
+  const int nvec = K / VEC;
+  int nt = (((nvec + 3) / 4 + 63) / 64) * 64;
   if (nt > 1024) nt = 1024;
   if (nt < 64) nt = 64;
   return nt;

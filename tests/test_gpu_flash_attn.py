@@ -174,3 +174,18 @@ def test_config_c5_shape_sampled_heads(fa, built, dev, oracle):
     for h in (0, 31):
         ref = oracle.attention_fp64(q[0, h].cpu(), k[0, h].cpu(), v[0, h].cpu())
         assert (o[0, h].cpu().double() - ref).abs().max().item() <= TOL
+
+
+def test_probe_variants_match_production(fa, built, dev, oracle):
+    """v3 (software-pipelined) and the big-D register-resident probe kernels are kept as measured alternatives;
+    they must agree with the oracle like the shipped v2 kernel does."""
+    from cuda_learn_notes_amd import host
+    for (B, H, N, D, variants) in ((1, 2, 512, 64, [(8, 0, 13, 100), (4, 0, 13, 100), (8, 0, 269, 100)]),
+                                   (1, 2, 512, 128, [(8, 0, 15, 100), (8, 0, 13, 100)]),
+                                   (1, 1, 256, 256, [(4, 0, 15, 200)]), (1, 1, 256, 512, [(4, 0, 15, 200)])):
+        q, k, v = seeded(41, B, H, N, D), seeded(42, B, H, N, D), seeded(43, B, H, N, D)
+        ref = oracle.attention_fp64(q, k, v)
+        for var in variants:
+            o = torch.zeros(B, H, N, D, dtype=torch.half, device=dev)
+            host.fa2_variant(var, q.to(dev), k.to(dev), v.to(dev), o)
+            assert (o.cpu().double() - ref).abs().max().item() <= TOL, (D, var)

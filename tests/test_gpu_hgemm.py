@@ -198,3 +198,22 @@ def test_baseline_configs_sampled_rows(hg, dev, size):
         got = c[rows].cpu().float()
         err = (got - truth).abs()
         assert (err <= ATOL + RTOL * truth.abs()).all(), (name, err.max().item())
+
+
+@pytest.mark.parametrize("layout", [0, 1])
+def test_probe_kernels_stay_correct(built, dev, layout):
+    """Tuning hooks kept in the library as measured (slower) alternatives must stay bit-identical to the shipped
+    kernel: kind 10 = ping-pong on mfma_32x32x16, ring tile 4 = 256x256 tile with 4 waves x 128x128."""
+    from cuda_learn_notes_amd import host
+    from cuda_learn_notes_amd.bench_utils import as_col_major
+    for (M, N, K) in ((256, 256, 64), (512, 768, 320), (1024, 1024, 1024)):
+        a, b = seeded(90 + K, M, K), seeded(91 + K, K, N)
+        bb = (as_col_major(b) if layout else b).to(dev)
+        ad = a.to(dev)
+        base = torch.zeros(M, N, dtype=torch.half, device=dev)
+        host.hgemm_variant(8, layout, 1, 64, 4, ad, bb, base, swizzle=1, swizzle_stride=512)
+        check(base, a, b)
+        for kind, tile, bk, st in ((10, 1, 64, 2), (0, 4, 64, 2), (0, 4, 32, 4)):
+            c = torch.zeros(M, N, dtype=torch.half, device=dev)
+            host.hgemm_variant(kind, layout, tile, bk, st, ad, bb, c, swizzle=1, swizzle_stride=512)
+            assert torch.equal(c, base), (kind, tile, bk, st)
