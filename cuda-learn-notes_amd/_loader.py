@@ -28,6 +28,7 @@ ARGTYPES = {
     "RN": [c_void_p, c_void_p, c_float, c_int, c_int, c_void_p],
     "RP": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "HI": [c_void_p, c_void_p, c_longlong, c_int, c_void_p],
+    "UN": [c_void_p, c_void_p, c_longlong, c_void_p],
     "EM": [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p],
 }
 

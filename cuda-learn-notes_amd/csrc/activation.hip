@@ -1,0 +1,100 @@
+// Activation family: relu / sigmoid / gelu / swish / elu / hardswish / hardshrink, six rungs
+// each (f32, f32x4, f16, f16x2, f16x8, f16x8_pack) = 42 exported functions `void f(Tensor x, Tensor y)`.
+// Reference: kernels/relu/relu.cu:20-150, sigmoid/sigmoid.cu:19-180, gelu/gelu.cu:19-230, swish/swish.cu:18-160,
+// elu/elu.cu:19-170, hardswish/hardswish.cu:12-190, hardshrink/hardshrink.cu:18-180 (same binding macro in each).
+//
+// gfx950 design: ONE streaming template (HBM-bound, 1R + 1W per element) parameterised by the op and by the
+// per-lane access the rung name states (4 B, 16 B; 2 B, 4 B, 8 x 2 B, 16 B); capped grid-stride grid.
+// Arithmetic is fp32 for every rung (the reference's f16 rungs use half intrinsics: hexp, __hdiv ...): the
+// result is rounded to fp16 once, which is at least as close to the script's torch column as the reference's own
+// half arithmetic. Constants follow the reference kernels: sigmoid / gelu clamp their argument to
+// +-88.3762626647949 (sigmoid.cu:19-20, gelu.cu:19-20), gelu is the tanh approximation (gelu.cu:46-48), elu alpha
+// = 1 (elu.cu:19), hardswish thresholds +-3 (hardswish.cu:12-13), hardshrink lambda = 0.5 (hardshrink.cu:19).
+#include "common.h"
+
+namespace {
+
+struct Relu { static __device__ __forceinline__ float f(float x) { return fmaxf(0.f, x); } };
+struct Sigmoid {
+  static __device__ __forceinline__ float f(float x) {
+    x = fminf(fmaxf(x, -88.3762626647949f), 88.3762626647949f);
+    return 1.0f / (1.0f + __expf(-x));
+  }
+};
+struct Gelu {
+  static __device__ __forceinline__ float f(float x) {
+    x = fminf(fmaxf(x, -88.3762626647949f), 88.3762626647949f);
+    return 0.5f * x * (1.0f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));
+  }
+};
+struct Swish { static __device__ __forceinline__ float f(float x) { return x / (1.0f + __expf(-x)); } };
+struct Elu { static __device__ __forceinline__ float f(float x) { return x > 0.f ? x : (__expf(x) - 1.f); } };
+struct HardSwish {
+  static __device__ __forceinline__ float f(float x) {
+    return x >= 3.f ? x : (x <= -3.f ? 0.f : x * (x + 3.f) / 6.f);
+  }
+};
+struct HardShrink {
+  static __device__ __forceinline__ float f(float x) { return (x > 0.5f || x < -0.5f) ? x : 0.f; }
+};
+
+__device__ __forceinline__ float ld(float v) { return v; }
+__device__ __forceinline__ float ld(half_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T st(float v);
+template <> __device__ __forceinline__ float st<float>(float v) { return v; }
+template <> __device__ __forceinline__ half_t st<half_t>(float v) { return (half_t)v; }
+
+// VEC elements per lane; PACKED: one VEC*sizeof(T)-byte access, else VEC accesses of CHUNK elements
+// (f16x8 = four half2 accesses in the reference, f32x4 = one float4).
+template <typename Op, typename T, int VEC, int CHUNK>
+__global__ __launch_bounds__(256) void unary_kernel(const T* __restrict__ x, T* __restrict__ y, long long n) {
+  typedef T chunk_t __attribute__((ext_vector_type(CHUNK)));
+  const long long nvec = n / VEC;
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride) {
+    if constexpr (VEC == 1) {
+      y[i] = st<T>(Op::f(ld(x[i])));
+    } else {
+      chunk_t v[VEC / CHUNK];
+#pragma unroll
+      for (int c = 0; c < VEC / CHUNK; ++c) v[c] = *reinterpret_cast<const chunk_t*>(x + i * VEC + c * CHUNK);
+#pragma unroll
+      for (int c = 0; c < VEC / CHUNK; ++c) {
+#pragma unroll
+        for (int e = 0; e < CHUNK; ++e) v[c][e] = st<T>(Op::f(ld(v[c][e])));
+        *reinterpret_cast<chunk_t*>(y + i * VEC + c * CHUNK) = v[c];
+      }
+    }
+  }
+  if (VEC > 1 && blockIdx.x == 0) {  // ragged tail (the reference requires N % VEC == 0)
+    for (long long i = nvec * VEC + threadIdx.x; i < n; i += 256) y[i] = st<T>(Op::f(ld(x[i])));
+  }
+}
+
+template <typename Op, typename T, int VEC, int CHUNK>
+int launch_unary(const void* x, void* y, long long n, hipStream_t st_) {
+  if (!x || !y || n < 0) return CLN_ERR_BAD_ARG;
+  if (n == 0) return CLN_OK;
+  if (sizeof(T) * CHUNK >= 16 && (!cln_aligned16(x) || !cln_aligned16(y))) return CLN_ERR_BAD_ARG;
+  const int grid = cln_stream_grid(n / VEC + 1, 256);
+  CLN_LAUNCH((unary_kernel<Op, T, VEC, CHUNK>), dim3(grid), dim3(256), 0, st_, (const T*)x, (T*)y, n);
+  return cln_check_launch();
+}
+
+}  // namespace
+
+// (x, y, n_elements, stream) -- reference `void <op>_<rung>(torch::Tensor x, torch::Tensor y)`
+#define CLN_UN(op, Op)                                                                                             \
+  CLN_API int op##_f32(const void* x, void* y, long long n, void* s) { return launch_unary<Op, float, 1, 1>(x, y, n, (hipStream_t)s); }        \
+  CLN_API int op##_f32x4(const void* x, void* y, long long n, void* s) { return launch_unary<Op, float, 4, 4>(x, y, n, (hipStream_t)s); }      \
+  CLN_API int op##_f16(const void* x, void* y, long long n, void* s) { return launch_unary<Op, half_t, 1, 1>(x, y, n, (hipStream_t)s); }       \
+  CLN_API int op##_f16x2(const void* x, void* y, long long n, void* s) { return launch_unary<Op, half_t, 2, 2>(x, y, n, (hipStream_t)s); }     \
+  CLN_API int op##_f16x8(const void* x, void* y, long long n, void* s) { return launch_unary<Op, half_t, 8, 2>(x, y, n, (hipStream_t)s); }     \
+  CLN_API int op##_f16x8_pack(const void* x, void* y, long long n, void* s) { return launch_unary<Op, half_t, 8, 8>(x, y, n, (hipStream_t)s); }
+CLN_UN(relu, Relu)
+CLN_UN(sigmoid, Sigmoid)
+CLN_UN(gelu, Gelu)
+CLN_UN(swish, Swish)
+CLN_UN(elu, Elu)
+CLN_UN(hardswish, HardSwish)
+CLN_UN(hardshrink, HardShrink)

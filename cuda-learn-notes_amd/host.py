@@ -275,7 +275,21 @@ def _make_em(name):
     return f
 
 
-_MAKERS = {"HI": _make_hi, "EM": _make_em, "G3": _make_g3, "G6": _make_g6, "H0": _make_h0, "FA": _make_fa, "P3": _make_p3, "R1": _make_r1,
+def _make_un(name):
+    fn = _loader.symbol(name)
+    dtype = torch.float32 if "_f32" in name else torch.float16
+
+    def f(x, y):
+        _check_dtype(x, dtype)
+        _check_dtype(y, dtype)
+        _check_dev(x, y)
+        _check_shape(y, *x.shape)
+        _raise(name, fn(x.data_ptr(), y.data_ptr(), x.numel(), _stream()))
+    f.__name__ = name
+    return f
+
+
+_MAKERS = {"UN": _make_un, "HI": _make_hi, "EM": _make_em, "G3": _make_g3, "G6": _make_g6, "H0": _make_h0, "FA": _make_fa, "P3": _make_p3, "R1": _make_r1,
            "SG": _make_sg, "XY": _make_xy, "LN": _make_ln, "RN": _make_rn, "RP": _make_rp}
 
 

@@ -170,6 +170,14 @@ _add("embedding", "EM", "row gather<half,1>", "embedding_f16")
 _add("embedding", "EM", "row gather<half,8 scalar accesses>", "embedding_f16x8")
 _add("embedding", "EM", "row gather<half,16 B pack>", "embedding_f16x8_pack")
 
+# ---------------------------------------------------------------- activation family (7 x 6)
+#   UN   int f(x, y, n, stream)                            (python: f(x, y))
+ACTIVATIONS = ("relu", "sigmoid", "gelu", "swish", "elu", "hardswish", "hardshrink")
+for _op in ACTIVATIONS:
+    for _r, _impl in (("f32", "float,4 B"), ("f32x4", "float,16 B"), ("f16", "half,2 B"), ("f16x2", "half,4 B"),
+                      ("f16x8", "half,4 x 4 B"), ("f16x8_pack", "half,16 B")):
+        _add("activation", "UN", "unary<%s,%s> fp32 math" % (_op, _impl), "%s_%s" % (_op, _r))
+
 ENTRIES = tuple(_E)
 BY_NAME = {e.name: e for e in ENTRIES}
 assert len(BY_NAME) == len(ENTRIES), "duplicate exported name"
@@ -179,7 +187,7 @@ SO_OF_LIB = {
     "hgemm": "libcln_amd.so", "flash_attn": "libcln_amd.so", "elementwise": "libcln_amd.so",
     "reduce": "libcln_amd.so", "softmax": "libcln_amd.so", "layer_norm": "libcln_amd.so",
     "rms_norm": "libcln_amd.so", "rope": "libcln_amd.so", "hgemm_vendor": "libcln_amd_vendor.so",
-    "histogram": "libcln_amd.so", "embedding": "libcln_amd.so",
+    "histogram": "libcln_amd.so", "embedding": "libcln_amd.so", "activation": "libcln_amd.so",
 }
 
 # element dtype (torch name) each reduce rung takes, and the result dtype

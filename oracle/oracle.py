@@ -23,7 +23,7 @@ __all__ = [
     "hgemm", "hgemm_fp16_path", "as_col_major", "make_block_swizzle_stride", "unfused_standard_attn",
     "attention_fp64", "sdpa", "get_mha_tflops", "elementwise_add", "reduce_sum", "softmax_global",
     "softmax_per_token", "layer_norm_torch", "layer_norm_kernel", "rms_norm_torch", "rms_norm_kernel",
-    "rope_torch", "rope_kernel", "fp8_to_float", "histogram", "embedding",
+    "rope_torch", "rope_kernel", "fp8_to_float", "histogram", "embedding", "activation",
 ]
 
 
@@ -183,3 +183,27 @@ def embedding(idx: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
     """Reference check column: torch.nn.functional.embedding (kernels/embedding/embedding.py:6, :82, :91);
     kernel: output[i, :] = weight[idx[i], :] (embedding.cu:16-24). Pure copy -> bit-exact."""
     return F.embedding(idx.to(torch.int64), weight)
+
+
+# ---------------------------------------------------------------- activations (SURVEY 8(f) rank 2)
+def activation(op: str, x: torch.Tensor) -> torch.Tensor:
+    """The torch column each reference script prints: torch.relu (relu.py:71), torch.sigmoid (sigmoid.py:70),
+    torch.nn.GELU("tanh") (gelu.py:62), x*sigmoid(x) (swish.py:57-61), F.elu (elu.py:48-52),
+    F.hardswish (hardswish.py:49-53), F.hardshrink(lambd=0.5) (hardshrink.py:49-53). Evaluated in fp64 on the
+    fp16/fp32 input values (the parity target; dtype rounding is the test's tolerance)."""
+    xd = x.double()
+    if op == "relu":
+        return torch.relu(xd)
+    if op == "sigmoid":
+        return torch.sigmoid(xd)
+    if op == "gelu":
+        return F.gelu(xd, approximate="tanh")
+    if op == "swish":
+        return xd * torch.sigmoid(xd)
+    if op == "elu":
+        return F.elu(xd)
+    if op == "hardswish":
+        return F.hardswish(xd)
+    if op == "hardshrink":
+        return F.hardshrink(xd, lambd=0.5)
+    raise KeyError(op)
