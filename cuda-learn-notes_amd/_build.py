@@ -21,7 +21,7 @@ LIBDIR = os.path.join(PKG_DIR, "lib")
 
 ARCH = "gfx950"
 KERNEL_SOURCES = [
-    "elementwise.hip", "activation.hip", "indexing.hip", "reduce.hip", "softmax.hip", "norm.hip", "rope.hip",
+    "elementwise.hip", "activation.hip", "blas1.hip", "indexing.hip", "reduce.hip", "softmax.hip", "norm.hip", "rope.hip",
     "hgemm.hip", "hgemm_ring_nn.hip", "hgemm_ring_tn.hip", "flash_attn.hip", "flash_attn_v2_probe.hip",
 ]
 VENDOR_SOURCES = ["hgemm_vendor.hip"]

@@ -29,6 +29,9 @@ ARGTYPES = {
     "RP": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "HI": [c_void_p, c_void_p, c_longlong, c_int, c_void_p],
     "UN": [c_void_p, c_void_p, c_longlong, c_void_p],
+    "D2": [c_void_p, c_void_p, c_void_p, c_longlong, c_void_p],
+    "GV": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
+    "TR": [c_void_p, c_void_p, c_int, c_int, c_void_p],
     "EM": [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p],
 }
 

@@ -1,0 +1,246 @@
+// dot-product (5), sgemv (3), hgemv (3), mat-transpose (13).
+//   reference kernels/dot-product/dot_product.cu:35-276, kernels/sgemv/sgemv.cu:29-190,
+//   kernels/hgemv/hgemv.cu:34-196, kernels/mat-transpose/mat_transpose.cu:29-360.
+// gfx950 design (all HBM/latency bound, nothing for the matrix cores):
+//  * dot_prod: the block_all_reduce structure with two input streams: one 1024-thread workgroup per CU,
+//    4 independent pack pairs in flight per lane, fp32 accumulate, DPP wave reduce, one atomic per workgroup.
+//  * gemv: y[m] = sum_k a[m,k] x[k]; G lanes per row (G = 16 / 32 / 64 by K), 64/G rows per wave, the rung's
+//    access width per lane, fp32 accumulate (the reference's hgemv adds in half), reduction inside the G-lane
+//    group on the VALU (DPP row ops; v_permlane16_swap / 32_swap across rows), 4 waves per workgroup.
+//  * transpose: y[n,m] = x[m,n], bit-exact. The reference's 13 rungs differ in which side is coalesced, 4-wide
+//    packing, 1-D vs 2-D grids, diagonal block order and a padded / unpadded shared tile; here:
+//      *_col2row*  -> read-coalesced streaming kernel (scattered 4-byte writes), 1 or 4 elements per lane
+//      *_row2col*  -> write-coalesced streaming kernel (scattered reads)
+//      diagonal2d  -> write-coalesced kernel with the reference's diagonal block order
+//      *_shared_*  -> 64x64 tile through LDS, 16-byte accesses on BOTH sides; `bcf` pads the tile rows (+1)
+#include "common.h"
+
+namespace {
+
+template <typename T, int VEC>
+struct alignas(sizeof(T) * VEC) Pk {
+  T v[VEC];
+};
+__device__ __forceinline__ float tof(float x) { return x; }
+__device__ __forceinline__ float tof(half_t x) { return (float)x; }
+
+// ---- dot product ---------------------------------------------------------------------------------
+template <typename T, int VEC>
+__global__ __launch_bounds__(1024) void dot_kernel(const T* __restrict__ a, const T* __restrict__ b,
+                                                   float* __restrict__ y, long long n) {
+  __shared__ float scratch[16];
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  const long long nvec = n / VEC, stride = (long long)gridDim.x * 1024;
+  long long i = (long long)blockIdx.x * 1024 + threadIdx.x;
+  auto fma_pack = [&](long long j, float& acc) {
+    const Pk<T, VEC> pa = *reinterpret_cast<const Pk<T, VEC>*>(a + j * VEC);
+    const Pk<T, VEC> pb = *reinterpret_cast<const Pk<T, VEC>*>(b + j * VEC);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc = fmaf(tof(pa.v[e]), tof(pb.v[e]), acc);
+  };
+  for (; i + 3 * stride < nvec; i += 4 * stride) {
+    fma_pack(i, s0);
+    fma_pack(i + stride, s1);
+    fma_pack(i + 2 * stride, s2);
+    fma_pack(i + 3 * stride, s3);
+  }
+  for (; i < nvec; i += stride) fma_pack(i, s0);
+  float s = (s0 + s1) + (s2 + s3);
+  if (blockIdx.x == 0)
+    for (long long t = nvec * VEC + threadIdx.x; t < n; t += 1024) s = fmaf(tof(a[t]), tof(b[t]), s);
+  s = wave_sum(s);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) scratch[w] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int k = 0; k < 16; ++k) t += scratch[k];
+    atomicAdd(y, t);
+  }
+}
+template <typename T, int VEC>
+int launch_dot(const void* a, const void* b, void* y, long long n, hipStream_t st) {
+  if (!a || !b || !y || n < 0) return CLN_ERR_BAD_ARG;
+  if (n == 0) return CLN_OK;
+  if (sizeof(T) * VEC >= 16 && (!cln_aligned16(a) || !cln_aligned16(b))) return CLN_ERR_BAD_ARG;
+  long long g = (n / VEC + 1023) / 1024;
+  const int grid = (int)(g < 1 ? 1 : (g > 256 ? 256 : g));
+  CLN_LAUNCH((dot_kernel<T, VEC>), dim3(grid), dim3(1024), 0, st, (const T*)a, (const T*)b, (float*)y, n);
+  return cln_check_launch();
+}
+
+// ---- gemv ----------------------------------------------------------------------------------------
+// G lanes cooperate on one row; a wave holds 64/G rows. Reduction inside the G-lane group.
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+  v += cln_dpp<0xB1>(v);
+  v += cln_dpp<0x4E>(v);
+  v += cln_dpp<0x141>(v);
+  v += cln_dpp<0x140>(v);  // 16-lane row total in every lane
+  if constexpr (G >= 32) {
+    const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(s16[0]) + __uint_as_float(s16[1]);
+  }
+  if constexpr (G >= 64) {
+    const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(s32[0]) + __uint_as_float(s32[1]);
+  }
+  return v;
+}
+template <typename T, int VEC, int G>
+__global__ __launch_bounds__(256) void gemv_kernel(const T* __restrict__ a, const T* __restrict__ x,
+                                                   T* __restrict__ y, int M, int K) {
+  constexpr int RPW = 64 / G;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane % G, sub = lane / G;
+  const int m = (blockIdx.x * 4 + wave) * RPW + sub;
+  float s = 0.f;
+  if (m < M) {
+    const T* row = a + (size_t)m * K;
+    for (int k = g * VEC; k < K; k += G * VEC) {
+      const Pk<T, VEC> pa = *reinterpret_cast<const Pk<T, VEC>*>(row + k);
+      const Pk<T, VEC> px = *reinterpret_cast<const Pk<T, VEC>*>(x + k);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) s = fmaf(tof(pa.v[e]), tof(px.v[e]), s);
+    }
+  }
+  s = group_sum<G>(s);
+  if (m < M && g == 0) y[m] = (T)s;
+}
+template <typename T, int VEC, int G>
+int launch_gemv(const void* a, const void* x, void* y, int M, int K, hipStream_t st) {
+  if (!a || !x || !y || M <= 0 || K <= 0) return CLN_ERR_BAD_ARG;
+  if (K % VEC) return CLN_ERR_UNSUPPORTED;
+  constexpr int RPB = 4 * (64 / G);
+  CLN_LAUNCH((gemv_kernel<T, VEC, G>), dim3((M + RPB - 1) / RPB), dim3(256), 0, st, (const T*)a, (const T*)x,
+             (T*)y, M, K);
+  return cln_check_launch();
+}
+
+// ---- transpose -----------------------------------------------------------------------------------
+// x: [row, col] -> y: [col, row]
+template <int VEC>
+__global__ __launch_bounds__(256) void tr_read_coalesced(const float* __restrict__ x, float* __restrict__ y, int row,
+                                                         int col) {
+  const long long total = (long long)row * col / VEC, stride = (long long)gridDim.x * 256;
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += stride) {
+    const long long e = t * VEC;
+    const int r = (int)(e / col), c = (int)(e - (long long)r * col);
+    const Pk<float, VEC> p = *reinterpret_cast<const Pk<float, VEC>*>(x + e);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) y[(size_t)(c + k) * row + r] = p.v[k];
+  }
+}
+template <int VEC, bool DIAG>
+__global__ __launch_bounds__(256) void tr_write_coalesced(const float* __restrict__ x, float* __restrict__ y, int row,
+                                                          int col) {
+  const long long total = (long long)row * col / VEC, stride = (long long)gridDim.x * 256;
+  for (long long t0 = (long long)blockIdx.x * 256 + threadIdx.x; t0 < total; t0 += stride) {
+    long long t = t0;
+    if constexpr (DIAG) {  // walk the output in a diagonal block order (reference mat_transpose.cu:81-90)
+      const long long nb = total / 256;
+      if (nb > 1 && t < nb * 256) {
+        const long long b = t / 256, side = (long long)sqrtf((float)nb);
+        if (side * side == nb) t = ((b % side) * side + (b / side + b % side) % side) * 256 + (t % 256);
+      }
+    }
+    const long long e = t * VEC;  // output element index: y[c, r..r+VEC)
+    const int c = (int)(e / row), r = (int)(e - (long long)c * row);
+    Pk<float, VEC> p;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) p.v[k] = x[(size_t)(r + k) * col + c];
+    *reinterpret_cast<Pk<float, VEC>*>(y + e) = p;
+  }
+}
+// 64 x 64 tile through LDS, float4 on both sides. PAD = 1 makes the transposed (column) reads conflict-free.
+template <int PAD>
+__global__ __launch_bounds__(256) void tr_lds_tile(const float* __restrict__ x, float* __restrict__ y, int row,
+                                                   int col) {
+  __shared__ float tile[64][64 + PAD];
+  const int tiles_c = col / 64;
+  const int tr = blockIdx.x / tiles_c, tc = blockIdx.x - tr * tiles_c;
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int r = it * 16 + (t >> 4), c4 = (t & 15) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(x + (size_t)(tr * 64 + r) * col + tc * 64 + c4);
+    tile[r][c4] = v.x, tile[r][c4 + 1] = v.y, tile[r][c4 + 2] = v.z, tile[r][c4 + 3] = v.w;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int c = it * 16 + (t >> 4), r4 = (t & 15) * 4;  // output row = input column c, 4 consecutive input rows
+    float4 v = {tile[r4][c], tile[r4 + 1][c], tile[r4 + 2][c], tile[r4 + 3][c]};
+    *reinterpret_cast<float4*>(y + (size_t)(tc * 64 + c) * row + tr * 64 + r4) = v;
+  }
+}
+
+enum TrKind { TR_READ1, TR_READ4, TR_WRITE1, TR_WRITE4, TR_DIAG, TR_LDS, TR_LDS_BCF };
+int launch_tr(int kind, const void* x, void* y, int row, int col, hipStream_t st) {
+  if (!x || !y || row <= 0 || col <= 0) return CLN_ERR_BAD_ARG;
+  const long long n = (long long)row * col;
+  const float* xp = (const float*)x;
+  float* yp = (float*)y;
+  const bool v4 = (kind == TR_READ4 || kind == TR_WRITE4);
+  if (v4 && ((kind == TR_READ4 ? col : row) % 4 || !cln_aligned16(x) || !cln_aligned16(y))) return CLN_ERR_UNSUPPORTED;
+  if ((kind == TR_LDS || kind == TR_LDS_BCF) && (row % 64 || col % 64 || !cln_aligned16(x) || !cln_aligned16(y)))
+    return CLN_ERR_UNSUPPORTED;
+  const int grid = cln_stream_grid(n / (v4 ? 4 : 1), 256);
+  switch (kind) {
+    case TR_READ1: CLN_LAUNCH((tr_read_coalesced<1>), dim3(grid), dim3(256), 0, st, xp, yp, row, col); break;
+    case TR_READ4: CLN_LAUNCH((tr_read_coalesced<4>), dim3(grid), dim3(256), 0, st, xp, yp, row, col); break;
+    case TR_WRITE1: CLN_LAUNCH((tr_write_coalesced<1, false>), dim3(grid), dim3(256), 0, st, xp, yp, row, col); break;
+    case TR_WRITE4: CLN_LAUNCH((tr_write_coalesced<4, false>), dim3(grid), dim3(256), 0, st, xp, yp, row, col); break;
+    case TR_DIAG: CLN_LAUNCH((tr_write_coalesced<1, true>), dim3((int)((n + 255) / 256)), dim3(256), 0, st, xp, yp, row, col); break;
+    case TR_LDS: CLN_LAUNCH((tr_lds_tile<0>), dim3((row / 64) * (col / 64)), dim3(256), 0, st, xp, yp, row, col); break;
+    case TR_LDS_BCF: CLN_LAUNCH((tr_lds_tile<1>), dim3((row / 64) * (col / 64)), dim3(256), 0, st, xp, yp, row, col); break;
+    default: return CLN_ERR_BAD_ARG;
+  }
+  return cln_check_launch();
+}
+
+}  // namespace
+
+// (a, b, y fp32[1] zeroed, n, stream) -- reference `torch::Tensor dot_prod_*(Tensor a, Tensor b)`
+#define CLN_DOT(name, T, VEC)                                                              \
+  CLN_API int name(const void* a, const void* b, void* y, long long n, void* stream) {     \
+    return launch_dot<T, VEC>(a, b, y, n, (hipStream_t)stream);                            \
+  }
+CLN_DOT(dot_prod_f32_f32, float, 1)
+CLN_DOT(dot_prod_f32x4_f32, float, 4)
+CLN_DOT(dot_prod_f16_f32, half_t, 1)
+CLN_DOT(dot_prod_f16x2_f32, half_t, 2)
+CLN_DOT(dot_prod_f16x8_pack_f32, half_t, 8)
+
+// (a [M,K], x [K], y [M], M, K, stream) -- reference `void sgemv_*(Tensor a, Tensor x, Tensor y)`; K constraints
+// as in the reference bindings (sgemv.cu:138-190: K % 32, K % 128, K == 16).
+#define CLN_GEMV(name, T, VEC, G, COND)                                                              \
+  CLN_API int name(const void* a, const void* x, void* y, int M, int K, void* stream) {              \
+    if (!(COND)) return CLN_ERR_UNSUPPORTED;                                                          \
+    return launch_gemv<T, VEC, G>(a, x, y, M, K, (hipStream_t)stream);                                \
+  }
+CLN_GEMV(sgemv_k32_f32, float, 1, 32, K % 32 == 0)
+CLN_GEMV(sgemv_k128_f32x4, float, 4, 32, K % 128 == 0)
+CLN_GEMV(sgemv_k16_f32, float, 1, 16, K == 16)
+CLN_GEMV(hgemv_k32_f16, half_t, 1, 32, K % 32 == 0)
+CLN_GEMV(hgemv_k128_f16x4, half_t, 4, 32, K % 128 == 0)
+CLN_GEMV(hgemv_k16_f16, half_t, 1, 16, K == 16)
+
+// (x [row,col], y [col,row], row, col, stream) -- reference `void mat_transpose_*(Tensor x, Tensor y)`
+#define CLN_TR(name, KIND)                                                          \
+  CLN_API int name(const void* x, void* y, int row, int col, void* stream) {        \
+    return launch_tr(KIND, x, y, row, col, (hipStream_t)stream);                    \
+  }
+CLN_TR(mat_transpose_f32_col2row, TR_READ1)
+CLN_TR(mat_transpose_f32x4_col2row, TR_READ4)
+CLN_TR(mat_transpose_f32_row2col, TR_WRITE1)
+CLN_TR(mat_transpose_f32x4_row2col, TR_WRITE4)
+CLN_TR(mat_transpose_f32_col2row2d, TR_READ1)
+CLN_TR(mat_transpose_f32x4_col2row2d, TR_READ4)
+CLN_TR(mat_transpose_f32_row2col2d, TR_WRITE1)
+CLN_TR(mat_transpose_f32x4_row2col2d, TR_WRITE4)
+CLN_TR(mat_transpose_f32_diagonal2d, TR_DIAG)
+CLN_TR(mat_transpose_f32x4_shared_col2row2d, TR_LDS)
+CLN_TR(mat_transpose_f32x4_shared_row2col2d, TR_LDS)
+CLN_TR(mat_transpose_f32x4_shared_bcf_col2row2d, TR_LDS_BCF)
+CLN_TR(mat_transpose_f32x4_shared_bcf_row2col2d, TR_LDS_BCF)

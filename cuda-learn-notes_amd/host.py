@@ -289,7 +289,55 @@ def _make_un(name):
     return f
 
 
-_MAKERS = {"UN": _make_un, "HI": _make_hi, "EM": _make_em, "G3": _make_g3, "G6": _make_g6, "H0": _make_h0, "FA": _make_fa, "P3": _make_p3, "R1": _make_r1,
+def _make_d2(name):
+    fn = _loader.symbol(name)
+    dtype = torch.float32 if name.startswith("dot_prod_f32") else torch.float16
+
+    def f(a, b):
+        _check_dtype(a, dtype)
+        _check_dtype(b, dtype)
+        _check_dev(a, b)
+        _check_shape(b, *a.shape)
+        prod = torch.zeros(1, dtype=torch.float32, device=a.device)  # reference dot_product.cu:236-238
+        _raise(name, fn(a.data_ptr(), b.data_ptr(), prod.data_ptr(), a.numel(), _stream()))
+        return prod
+    f.__name__ = name
+    return f
+
+
+def _make_gv(name):
+    fn = _loader.symbol(name)
+    dtype = torch.float32 if name.startswith("sgemv") else torch.float16
+    kmsg = {"k32": "K must be multiple of 32", "k128": "K must be multiple of 128", "k16": "K must be 16"}[name.split("_")[1]]
+
+    def f(a, x, y):
+        for t in (a, x, y):
+            _check_dtype(t, dtype)
+        _check_dev(a, x, y)
+        M, K = a.size(0), a.size(1)
+        _check_shape(x, K, 1)
+        _check_shape(y, M, 1)
+        _raise(name, fn(a.data_ptr(), x.data_ptr(), y.data_ptr(), M, K, _stream()), kmsg)  # sgemv.cu:134-137
+    f.__name__ = name
+    return f
+
+
+def _make_tr(name):
+    fn = _loader.symbol(name)
+
+    def f(x, y):
+        _check_dtype(x, torch.float32)
+        _check_dtype(y, torch.float32)
+        _check_dev(x, y)
+        M, N = x.size(0), x.size(1)
+        _check_shape(y, N, M)
+        _raise(name, fn(x.data_ptr(), y.data_ptr(), M, N, _stream()),
+               "%s: rows/cols must be multiples of 4 (x4 rungs) / 64 (shared rungs)" % name)
+    f.__name__ = name
+    return f
+
+
+_MAKERS = {"D2": _make_d2, "GV": _make_gv, "TR": _make_tr, "UN": _make_un, "HI": _make_hi, "EM": _make_em, "G3": _make_g3, "G6": _make_g6, "H0": _make_h0, "FA": _make_fa, "P3": _make_p3, "R1": _make_r1,
            "SG": _make_sg, "XY": _make_xy, "LN": _make_ln, "RN": _make_rn, "RP": _make_rp}
 
 

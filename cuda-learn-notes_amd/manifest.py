@@ -178,6 +178,29 @@ for _op in ACTIVATIONS:
                       ("f16x8", "half,4 x 4 B"), ("f16x8_pack", "half,16 B")):
         _add("activation", "UN", "unary<%s,%s> fp32 math" % (_op, _impl), "%s_%s" % (_op, _r))
 
+# ---------------------------------------------------------------- dot / gemv / transpose
+#   D2   int f(a, b, y, n, stream)              (python: Tensor f(a, b))
+#   GV   int f(a, x, y, M, K, stream)           (python: f(a, x, y))
+#   TR   int f(x, y, row, col, stream)          (python: f(x, y))
+for _n, _impl in (("dot_prod_f32_f32", "float,4 B"), ("dot_prod_f32x4_f32", "float,16 B"), ("dot_prod_f16_f32", "half,2 B"),
+                  ("dot_prod_f16x2_f32", "half,4 B"), ("dot_prod_f16x8_pack_f32", "half,16 B")):
+    _add("dot_product", "D2", "dot<%s> fp32 acc, 1 workgroup/CU" % _impl, _n)
+for _n, _impl in (("sgemv_k32_f32", "float,1,32 lanes/row"), ("sgemv_k128_f32x4", "float,4,32 lanes/row"),
+                  ("sgemv_k16_f32", "float,1,16 lanes/row")):
+    _add("sgemv", "GV", "gemv<%s> fp32 acc" % _impl, _n)
+for _n, _impl in (("hgemv_k32_f16", "half,1,32 lanes/row"), ("hgemv_k128_f16x4", "half,4,32 lanes/row"),
+                  ("hgemv_k16_f16", "half,1,16 lanes/row")):
+    _add("hgemv", "GV", "gemv<%s> fp32 acc" % _impl, _n)
+_add("mat_transpose", "TR", "transpose read-coalesced<1>", "mat_transpose_f32_col2row", "mat_transpose_f32_col2row2d")
+_add("mat_transpose", "TR", "transpose read-coalesced<4>", "mat_transpose_f32x4_col2row", "mat_transpose_f32x4_col2row2d")
+_add("mat_transpose", "TR", "transpose write-coalesced<1>", "mat_transpose_f32_row2col", "mat_transpose_f32_row2col2d")
+_add("mat_transpose", "TR", "transpose write-coalesced<4>", "mat_transpose_f32x4_row2col", "mat_transpose_f32x4_row2col2d")
+_add("mat_transpose", "TR", "transpose write-coalesced<1>, diagonal block order", "mat_transpose_f32_diagonal2d")
+_add("mat_transpose", "TR", "transpose 64x64 LDS tile, 16 B both sides", "mat_transpose_f32x4_shared_col2row2d",
+     "mat_transpose_f32x4_shared_row2col2d")
+_add("mat_transpose", "TR", "transpose 64x64 LDS tile padded (+1), 16 B both sides",
+     "mat_transpose_f32x4_shared_bcf_col2row2d", "mat_transpose_f32x4_shared_bcf_row2col2d")
+
 ENTRIES = tuple(_E)
 BY_NAME = {e.name: e for e in ENTRIES}
 assert len(BY_NAME) == len(ENTRIES), "duplicate exported name"
@@ -188,6 +211,7 @@ SO_OF_LIB = {
     "reduce": "libcln_amd.so", "softmax": "libcln_amd.so", "layer_norm": "libcln_amd.so",
     "rms_norm": "libcln_amd.so", "rope": "libcln_amd.so", "hgemm_vendor": "libcln_amd_vendor.so",
     "histogram": "libcln_amd.so", "embedding": "libcln_amd.so", "activation": "libcln_amd.so",
+    "dot_product": "libcln_amd.so", "sgemv": "libcln_amd.so", "hgemv": "libcln_amd.so", "mat_transpose": "libcln_amd.so",
 }
 
 # element dtype (torch name) each reduce rung takes, and the result dtype

@@ -27,6 +27,9 @@ PROTO = {
     "RP": "int {n}(const void* x, void* out, int seq_len, int hidden, int ref_quirk, void* stream);",
     "HI": "int {n}(const void* a, void* y, long long n, int nbins, void* stream);",
     "UN": "int {n}(const void* x, void* y, long long n, void* stream);",
+    "D2": "int {n}(const void* a, const void* b, void* y, long long n, void* stream);",
+    "GV": "int {n}(const void* a, const void* x, void* y, int M, int K, void* stream);",
+    "TR": "int {n}(const void* x, void* y, int row, int col, void* stream);",
     "EM": "int {n}(const void* idx, const void* weight, void* out, long long n, int emb_size, int vocab, void* stream);",
 }
 
@@ -52,6 +55,10 @@ GROUPS = [
                   " * Replaces reference kernels/histogram/histogram.cu:56-80 (`torch::Tensor f(torch::Tensor a)`, nbins = max(a)+1)."),
     ("activation", "y = act(x), elementwise, n elements; relu / sigmoid / gelu(tanh) / swish / elu(alpha=1) / hardswish / hardshrink(0.5).\n"
                    " * Replaces the `void f(Tensor x, Tensor y)` bindings of reference kernels/{relu,sigmoid,gelu,swish,elu,hardswish,hardshrink}/*.cu."),
+    ("dot_product", "y[0] += sum(a*b), y fp32[1] zeroed by the caller. Replaces reference kernels/dot-product/dot_product.cu:232-276."),
+    ("sgemv", "y[M] = a[M,K] * x[K], fp32. Replaces reference kernels/sgemv/sgemv.cu:138-190 (K % 32, K % 128, K == 16)."),
+    ("hgemv", "y[M] = a[M,K] * x[K], fp16 in/out, fp32 accumulate. Replaces reference kernels/hgemv/hgemv.cu:140-196."),
+    ("mat_transpose", "y[col,row] = x[row,col]^T, fp32, bit-exact. Replaces reference kernels/mat-transpose/mat_transpose.cu:270-360."),
     ("embedding", "out[i,:] = weight[idx[i],:]; idx int32[n], weight [vocab, emb_size]; out-of-range rows are zero-filled.\n"
                   " * Replaces reference kernels/embedding/embedding.cu:99-133 (`void f(Tensor a, Tensor weight, Tensor o)`)."),
 ]

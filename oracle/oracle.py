@@ -23,7 +23,7 @@ __all__ = [
     "hgemm", "hgemm_fp16_path", "as_col_major", "make_block_swizzle_stride", "unfused_standard_attn",
     "attention_fp64", "sdpa", "get_mha_tflops", "elementwise_add", "reduce_sum", "softmax_global",
     "softmax_per_token", "layer_norm_torch", "layer_norm_kernel", "rms_norm_torch", "rms_norm_kernel",
-    "rope_torch", "rope_kernel", "fp8_to_float", "histogram", "embedding", "activation",
+    "rope_torch", "rope_kernel", "fp8_to_float", "histogram", "embedding", "activation", "dot_prod", "gemv", "mat_transpose",
 ]
 
 
@@ -207,3 +207,19 @@ def activation(op: str, x: torch.Tensor) -> torch.Tensor:
     if op == "hardshrink":
         return F.hardshrink(xd, lambd=0.5)
     raise KeyError(op)
+
+
+# ---------------------------------------------------------------- dot / gemv / transpose
+def dot_prod(a: torch.Tensor, b: torch.Tensor) -> float:
+    """torch.dot on the flattened operands (kernels/dot-product/dot_product.py:54-70), evaluated in fp64."""
+    return float(torch.dot(a.double().flatten(), b.double().flatten()).item())
+
+
+def gemv(a: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """torch.matmul(a, x) (kernels/sgemv/sgemv.py:67, kernels/hgemv/hgemv.py:67), evaluated in fp64."""
+    return a.double() @ x.double()
+
+
+def mat_transpose(x: torch.Tensor) -> torch.Tensor:
+    """torch.transpose_copy / `out.T.equal(x)` (kernels/mat-transpose/mat_transpose.py:60, :94): bit-exact."""
+    return x.t().contiguous()
