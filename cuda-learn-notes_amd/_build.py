@@ -22,7 +22,7 @@ LIBDIR = os.path.join(PKG_DIR, "lib")
 ARCH = "gfx950"
 KERNEL_SOURCES = [
     "elementwise.hip", "activation.hip", "blas1.hip", "indexing.hip", "reduce.hip", "softmax.hip", "norm.hip", "rope.hip",
-    "hgemm.hip", "hgemm_ring_nn.hip", "hgemm_ring_tn.hip", "flash_attn.hip", "flash_attn_v2_probe.hip",
+    "sgemm.hip", "hgemm.hip", "hgemm_ring_nn.hip", "hgemm_ring_tn.hip", "flash_attn.hip", "flash_attn_v2_probe.hip",
 ]
 VENDOR_SOURCES = ["hgemm_vendor.hip"]
 CFLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-ffp-contract=fast",

@@ -19,6 +19,8 @@ ARGTYPES = {
     "G3": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "G6": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "H0": [],
+    "S3": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "S6": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "FA": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "P3": [c_void_p, c_void_p, c_void_p, c_longlong, c_void_p],
     "R1": [c_void_p, c_void_p, c_longlong, c_void_p],

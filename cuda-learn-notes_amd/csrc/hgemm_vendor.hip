@@ -41,3 +41,23 @@ CLN_API int hgemm_cublas_tensor_op_nn(const void* a, const void* b, void* c, int
 CLN_API int hgemm_cublas_tensor_op_tn(const void* a, const void* b, void* c, int M, int N, int K, void* stream) {
   return gemm_ex(rocblas_operation_transpose, a, b, c, M, N, K, K, stream);
 }
+
+// ---- SGEMM vendor rows (reference kernels/sgemm/sgemm_cublas.cu:15-120). The reference creates and destroys a
+// cuBLAS handle inside every call; here a lazily created process-global handle serves both (and the HGEMM rows).
+// sgemm_cublas_tf32 asks cuBLAS for TF32 tensor-op math; gfx950 has no TF32, so both names run the exact-f32
+// rocBLAS SGEMM (which itself uses the f32 matrix instruction).
+static int sgemm_vendor(const void* a, const void* b, void* c, int M, int N, int K, void* stream) {
+  if (!g_handle && init_cublas_handle() != CLN_OK) return CLN_ERR_VENDOR;
+  if (!a || !b || !c || M <= 0 || N <= 0 || K <= 0) return CLN_ERR_BAD_ARG;
+  if (rocblas_set_stream(g_handle, (hipStream_t)stream) != rocblas_status_success) return CLN_ERR_VENDOR;
+  const float alpha = 1.0f, beta = 0.0f;
+  rocblas_status s = rocblas_sgemm(g_handle, rocblas_operation_none, rocblas_operation_none, N, M, K, &alpha,
+                                   (const float*)b, N, (const float*)a, K, &beta, (float*)c, N);
+  return s == rocblas_status_success ? CLN_OK : CLN_ERR_VENDOR;
+}
+CLN_API int sgemm_cublas(const void* a, const void* b, void* c, int M, int N, int K, void* stream) {
+  return sgemm_vendor(a, b, c, M, N, K, stream);
+}
+CLN_API int sgemm_cublas_tf32(const void* a, const void* b, void* c, int M, int N, int K, void* stream) {
+  return sgemm_vendor(a, b, c, M, N, K, stream);
+}

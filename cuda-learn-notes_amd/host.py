@@ -66,12 +66,12 @@ def _raise(name, rc, unsupported_msg=None):
 
 
 # ------------------------------------------------------------------------------------------------
-def _make_g3(name):
+def _make_g3(name, dtype=torch.float16):
     fn = _loader.symbol(name)
 
     def f(a, b, c):
         for t in (a, b, c):
-            _check_dtype(t, torch.float16)
+            _check_dtype(t, dtype)
         _check_dev(a, b, c)
         M, K = a.size(0), a.size(1)
         N = b.size(1)  # TN operands keep the [K,N] shape (reference as_col_major)
@@ -84,12 +84,12 @@ def _make_g3(name):
     return f
 
 
-def _make_g6(name):
+def _make_g6(name, dtype=torch.float16):
     fn = _loader.symbol(name)
 
-    def f(a, b, c, stages, swizzle, swizzle_stride):
+    def f(a, b, c, stages, swizzle=False, swizzle_stride=1):
         for t in (a, b, c):
-            _check_dtype(t, torch.float16)
+            _check_dtype(t, dtype)
         _check_dev(a, b, c)
         M, K = a.size(0), a.size(1)
         N = b.size(1)
@@ -337,7 +337,15 @@ def _make_tr(name):
     return f
 
 
-_MAKERS = {"D2": _make_d2, "GV": _make_gv, "TR": _make_tr, "UN": _make_un, "HI": _make_hi, "EM": _make_em, "G3": _make_g3, "G6": _make_g6, "H0": _make_h0, "FA": _make_fa, "P3": _make_p3, "R1": _make_r1,
+def _make_s3(name):
+    return _make_g3(name, torch.float32)
+
+
+def _make_s6(name):
+    return _make_g6(name, torch.float32)
+
+
+_MAKERS = {"S3": _make_s3, "S6": _make_s6, "D2": _make_d2, "GV": _make_gv, "TR": _make_tr, "UN": _make_un, "HI": _make_hi, "EM": _make_em, "G3": _make_g3, "G6": _make_g6, "H0": _make_h0, "FA": _make_fa, "P3": _make_p3, "R1": _make_r1,
            "SG": _make_sg, "XY": _make_xy, "LN": _make_ln, "RN": _make_rn, "RP": _make_rp}
 
 

@@ -201,6 +201,22 @@ _add("mat_transpose", "TR", "transpose 64x64 LDS tile, 16 B both sides", "mat_tr
 _add("mat_transpose", "TR", "transpose 64x64 LDS tile padded (+1), 16 B both sides",
      "mat_transpose_f32x4_shared_bcf_col2row2d", "mat_transpose_f32x4_shared_bcf_row2col2d")
 
+# ---------------------------------------------------------------- SGEMM (fp32)
+#   S3 = G3 with fp32 tensors, S6 = G6 with fp32 tensors
+_add("sgemm", "S3", "sgemm_naive(1 elem/thread)", "sgemm_naive_f32")
+_add("sgemm", "S3", "sgemm_sliced_k(32x32x32 LDS)", "sgemm_sliced_k_f32")
+_add("sgemm", "S3", "sgemm_valu_tile<BK=8,8x8,single buffer>", "sgemm_t_8x8_sliced_k_f32x4",
+     "sgemm_t_8x8_sliced_k_f32x4_bcf", "sgemm_t_8x8_sliced_k_f32x4_bcf_offset")
+_add("sgemm", "S3", "sgemm_valu_tile<BK=8,8x8,dbuf>", "sgemm_t_8x8_sliced_k_f32x4_bcf_dbuf",
+     "sgemm_t_8x8_sliced_k_f32x4_bcf_dbuf_offset")
+for _tn in (4, 8, 16):
+    _add("sgemm", "S3", "sgemm_valu_tile<BK=16,8x%d,dbuf>" % _tn, "sgemm_t_8x%d_sliced_k16_f32x4_bcf_dbuf" % _tn)
+    _add("sgemm", "S3", "sgemm_valu_tile<BK=16,8x%d,dbuf,issue-early/write-late>" % _tn,
+         "sgemm_t_8x%d_sliced_k16_f32x4_bcf_dbuf_async" % _tn)
+_add("sgemm", "S6", "sgemm_mfma<128x128x16, v_mfma_f32_32x32x2_f32 (exact f32; no TF32 on gfx950), stages 2|3>",
+     "sgemm_wmma_m16n16k8_mma4x2_warp2x4_stages", "sgemm_wmma_m16n16k8_mma4x2_warp2x4_stages_dsmem")
+_add("sgemm_vendor", "S3", "rocblas_sgemm (exact f32)", "sgemm_cublas", "sgemm_cublas_tf32")
+
 ENTRIES = tuple(_E)
 BY_NAME = {e.name: e for e in ENTRIES}
 assert len(BY_NAME) == len(ENTRIES), "duplicate exported name"
@@ -211,6 +227,7 @@ SO_OF_LIB = {
     "reduce": "libcln_amd.so", "softmax": "libcln_amd.so", "layer_norm": "libcln_amd.so",
     "rms_norm": "libcln_amd.so", "rope": "libcln_amd.so", "hgemm_vendor": "libcln_amd_vendor.so",
     "histogram": "libcln_amd.so", "embedding": "libcln_amd.so", "activation": "libcln_amd.so",
+    "sgemm": "libcln_amd.so", "sgemm_vendor": "libcln_amd_vendor.so",
     "dot_product": "libcln_amd.so", "sgemv": "libcln_amd.so", "hgemv": "libcln_amd.so", "mat_transpose": "libcln_amd.so",
 }
 

@@ -16,6 +16,9 @@ PROTO = {
     "G6": "int {n}(const void* a, const void* b, void* c, int M, int N, int K, int stages, int swizzle, "
           "int swizzle_stride, void* stream);",
     "H0": "int {n}(void);",
+    "S3": "int {n}(const void* a, const void* b, void* c, int M, int N, int K, void* stream);",
+    "S6": "int {n}(const void* a, const void* b, void* c, int M, int N, int K, int stages, int swizzle, "
+          "int swizzle_stride, void* stream);",
     "FA": "int {n}(const void* q, const void* k, const void* v, void* o, int B, int H, int N, int D, int stages, "
           "void* stream);",
     "P3": "int {n}(const void* a, const void* b, void* c, long long n, void* stream);",
@@ -55,6 +58,9 @@ GROUPS = [
                   " * Replaces reference kernels/histogram/histogram.cu:56-80 (`torch::Tensor f(torch::Tensor a)`, nbins = max(a)+1)."),
     ("activation", "y = act(x), elementwise, n elements; relu / sigmoid / gelu(tanh) / swish / elu(alpha=1) / hardswish / hardshrink(0.5).\n"
                    " * Replaces the `void f(Tensor x, Tensor y)` bindings of reference kernels/{relu,sigmoid,gelu,swish,elu,hardswish,hardshrink}/*.cu."),
+    ("sgemm", "SGEMM: C[M,N] = A[M,K] * B[K,N], fp32 row-major. Replaces reference kernels/sgemm/sgemm.cu:495-640,\n"
+              " * sgemm_async.cu bindings, sgemm_wmma_tf32_stage.cu:575-700 (TF32 rungs -> exact-f32 MFMA)."),
+    ("sgemm_vendor", "Vendor SGEMM rows (libcln_amd_vendor.so): reference kernels/sgemm/sgemm_cublas.cu:80-120."),
     ("dot_product", "y[0] += sum(a*b), y fp32[1] zeroed by the caller. Replaces reference kernels/dot-product/dot_product.cu:232-276."),
     ("sgemv", "y[M] = a[M,K] * x[K], fp32. Replaces reference kernels/sgemv/sgemv.cu:138-190 (K % 32, K % 128, K == 16)."),
     ("hgemv", "y[M] = a[M,K] * x[K], fp16 in/out, fp32 accumulate. Replaces reference kernels/hgemv/hgemv.cu:140-196."),

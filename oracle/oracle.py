@@ -23,7 +23,7 @@ __all__ = [
     "hgemm", "hgemm_fp16_path", "as_col_major", "make_block_swizzle_stride", "unfused_standard_attn",
     "attention_fp64", "sdpa", "get_mha_tflops", "elementwise_add", "reduce_sum", "softmax_global",
     "softmax_per_token", "layer_norm_torch", "layer_norm_kernel", "rms_norm_torch", "rms_norm_kernel",
-    "rope_torch", "rope_kernel", "fp8_to_float", "histogram", "embedding", "activation", "dot_prod", "gemv", "mat_transpose",
+    "rope_torch", "rope_kernel", "fp8_to_float", "histogram", "embedding", "activation", "dot_prod", "gemv", "mat_transpose", "sgemm",
 ]
 
 
@@ -223,3 +223,9 @@ def gemv(a: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
 def mat_transpose(x: torch.Tensor) -> torch.Tensor:
     """torch.transpose_copy / `out.T.equal(x)` (kernels/mat-transpose/mat_transpose.py:60, :94): bit-exact."""
     return x.t().contiguous()
+
+
+def sgemm(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """torch.matmul(a, b) on fp32 (kernels/sgemm/sgemm.py:135), evaluated in fp64 (the parity target: every rung
+    here accumulates in exact fp32, so the error is the fp32 summation error only)."""
+    return a.double() @ b.double()

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXPECTED_COUNTS = {"hgemm": 34, "hgemm_vendor": 4, "flash_attn": 28, "elementwise": 6, "reduce": 20,
                    "softmax": 11, "layer_norm": 8, "rms_norm": 9, "rope": 3,
                    "histogram": 2, "embedding": 6, "activation": 42,
-                   "dot_product": 5, "sgemv": 3, "hgemv": 3, "mat_transpose": 13}  # last two: SURVEY 8(f) rank 1 (bit-exact indexing kernels)
+                   "sgemm": 15, "sgemm_vendor": 2, "dot_product": 5, "sgemv": 3, "hgemv": 3, "mat_transpose": 13}  # last two: SURVEY 8(f) rank 1 (bit-exact indexing kernels)
 SPOT_NAMES = [
     "hgemm_naive_f16", "hgemm_t_16x8_sliced_k32_f16x8_pack_dbuf_async", "init_cublas_handle",
     "hgemm_cublas_tensor_op_tn", "hgemm_wmma_m16n16k16_mma4x4_warp4x4_stages_dsmem",
@@ -29,7 +29,7 @@ def test_manifest_counts(pkg):
     from collections import Counter
     c = Counter(e.lib for e in pkg.manifest.ENTRIES)
     assert dict(c) == EXPECTED_COUNTS
-    assert len(pkg.manifest.ENTRIES) == 197
+    assert len(pkg.manifest.ENTRIES) == 214
     for n in SPOT_NAMES:
         assert n in pkg.manifest.BY_NAME
 
