@@ -8,6 +8,11 @@ Reference boundary being replaced: `lib = load(name=..., sources=[...])` returni
 import ctypes
 import os
 
+# torch FIRST: the PyTorch-ROCm wheel bundles its own HIP runtime (torch/lib/libamdhip64.so). If libcln_amd.so is
+# dlopen'ed before torch, the system runtime (/opt/rocm/lib/libamdhip64.so.7) is mapped first and the process ends
+# up with two HIP runtimes; the second one reports "no ROCm-capable device is detected" on the first launch.
+import torch  # noqa: F401
+
 from . import manifest
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
