@@ -23,10 +23,13 @@ int check_args(const void* a, const void* b, const void* c, int M, int N, int K)
   return CLN_OK;
 }
 
-// "best" policy shared by the reference's top rungs (warp4x4x2 family): 256x256 tiles when they
-// fill most of the 256 CUs, else 128x128.
+// "best" policy shared by the reference's top rungs (warp4x4x2 family), from the size sweep in
+// profiles/r01_hgemm_midsize_probe.log: 256x256 ping-pong tiles once they cover about half of the 256 CUs
+// (3072^3: 144 tiles -> 969 TF vs 783 with 128x128); below that, 64x128 tiles while 128x128 tiles would leave
+// CUs with fewer than two workgroups (2048^3: 712 vs 647 TF; 1024^3: 182 vs 155), else 128x128.
 int best_tile(int M, int N) {
-  if (M % 256 == 0 && N % 256 == 0 && (M / 256) * (N / 256) >= 200) return T256;
+  if (M % 256 == 0 && N % 256 == 0 && (M / 256) * (N / 256) >= 120) return T256;
+  if (M % 64 == 0 && N % 128 == 0 && (long long)((M + 127) / 128) * (N / 128) < 512) return T64x128;
   return T128;
 }
 

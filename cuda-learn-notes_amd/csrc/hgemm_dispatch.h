@@ -2,7 +2,7 @@
 #pragma once
 #include "common.h"
 namespace hgemm {
-enum TileId { T128 = 0, T256 = 1, T256x128 = 2, T128x256 = 3, T256W4 = 4 };  // T256W4: 256x256 tile, 4 waves x 128x128
+enum TileId { T128 = 0, T256 = 1, T256x128 = 2, T128x256 = 3, T256W4 = 4, T128W8 = 5, T64x128 = 6 };  // T256W4: 256x256 tile, 4 waves x 128x128
 // stages in [2,5]; BK (64 or 32) is chosen so that stages * stage_bytes fits the 160 KiB LDS and
 // K % BK == 0. Returns CLN_ERR_UNSUPPORTED when M/N/K do not divide the tile.
 int ring_dispatch_nn(int tile, const void* a, const void* b, void* c, int M, int N, int K, int stages, int swizzle,

@@ -16,11 +16,11 @@ dev = torch.device("cuda:0")
 hg = pkg.hgemm_lib()
 hg.init_cublas_handle()
 sizes = [int(x) for x in sys.argv[1:]] or [4096, 8192]
-VARS = [("pp16 split NN", 8, 0, 1, 64, 4), ("pp16 split TN", 8, 1, 1, 64, 4),
-        ("w4 ring NN bk64 s2", 0, 0, 4, 64, 2), ("w4 ring TN bk64 s2", 0, 1, 4, 64, 2),
-        ("w4 ring NN bk32 s4", 0, 0, 4, 32, 4), ("w4 ring TN bk32 s4", 0, 1, 4, 32, 4),
-        ("w4 ring NN bk32 s2", 0, 0, 4, 32, 2),
-        ("pp16 nostore", 8, 0, 1, 64, 1), ("pp16 abl7 mfma-only", 7, 0, 1, 64, 7)]
+VARS = [("T128 bk64 s2 NN", 0, 0, 0, 64, 2), ("T128 bk64 s2 TN", 0, 1, 0, 64, 2), ("T128 bk32 s3 NN", 0, 0, 0, 32, 3),
+        ("T128W8 bk64 s2 NN", 0, 0, 5, 64, 2), ("T128W8 bk64 s2 TN", 0, 1, 5, 64, 2), ("T128W8 bk32 s4 NN", 0, 0, 5, 32, 4),
+        ("T128W8 bk64 s3 NN", 0, 0, 5, 64, 3),
+        ("T64x128 bk64 s2 NN", 0, 0, 6, 64, 2), ("T64x128 bk64 s3 NN", 0, 0, 6, 64, 3), ("T64x128 bk64 s3 TN", 0, 1, 6, 64, 3),
+        ("T256x128 bk64 s2 NN", 0, 0, 2, 64, 2), ("pp16 split NN", 8, 0, 1, 64, 4)]
 for S in sizes:
     torch.manual_seed(S)
     a = torch.randn(S, S, dtype=torch.half, device=dev)
