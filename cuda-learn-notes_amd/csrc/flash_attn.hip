@@ -22,12 +22,22 @@ int fa2_dispatch(const void* q, const void* k, const void* v, void* o, int B, in
   (void)stages;  // v2 always runs the double-buffered prefetch pipeline; `stages` 1 and 2 are the same kernel
   // Head dims 32..256: v2 kernel. Workgroup = 8 / 4 / 2 waves x 32 query rows by the divisibility of N
   // (reference: N % max(Br,Bc) == 0 with Br = 128 or 64, flash_attn_mma_share_qkv.cu:769, split_q.cu:754).
+  // waves per workgroup: the largest of 8 / 4 / 2 (x 32 query rows) that N allows AND that still gives every one of
+  // the 256 CUs a workgroup; small problems take the smaller workgroup (measured [2,8,2048,64]: 534 TF with
+  // 4 waves x 256 workgroups vs 413 TF with 8 waves x 128 workgroups).
+  const long long bh = (long long)B * H;
+  int nw = 0;
+  for (int cand : {8, 4, 2}) {
+    if (N % (cand * 32) != 0) continue;
+    nw = cand;
+    if (bh * (N / (cand * 32)) >= 256) break;
+  }
+  if (nw == 0) return CLN_ERR_UNSUPPORTED;
 #define FA_V2(DD, OPTT)                                                                            \
   case DD:                                                                                         \
-    if (N % 256 == 0) return fa2::launch_v2<DD, 8, VT, OPTT>(q, k, v, o, B, H, N, s);              \
-    if (N % 128 == 0) return fa2::launch_v2<DD, 4, VT, OPTT>(q, k, v, o, B, H, N, s);              \
-    if (N % 64 == 0) return fa2::launch_v2<DD, 2, VT, OPTT>(q, k, v, o, B, H, N, s);               \
-    return CLN_ERR_UNSUPPORTED;
+    if (nw == 8) return fa2::launch_v2<DD, 8, VT, OPTT>(q, k, v, o, B, H, N, s);                   \
+    if (nw == 4) return fa2::launch_v2<DD, 4, VT, OPTT>(q, k, v, o, B, H, N, s);                   \
+    return fa2::launch_v2<DD, 2, VT, OPTT>(q, k, v, o, B, H, N, s);
   switch (D) {
     FA_V2(32, 13)
     FA_V2(64, 13)

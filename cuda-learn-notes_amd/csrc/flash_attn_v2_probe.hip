@@ -20,6 +20,7 @@ CLN_API int cln_fa2_variant(int D, int nw, int vt, int opt, int abl, const void*
   if (D == 512 && abl == 200 && opt == 13) return fa2::launch_bigd<512, 13>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 384 && abl == 200) return fa2::launch_bigd<384, 15>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 256 && abl == 200) return fa2::launch_bigd<256, 15>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  V2(64, 8, 77, 0) V2(128, 8, 79, 0)
   V3(64, 8, 13) V3(64, 8, 269) V3(64, 8, 15) V3(64, 4, 13) V3(128, 8, 15) V3(128, 8, 13) V3(128, 8, 271) V3(128, 4, 15)
   return CLN_ERR_UNSUPPORTED;
 }

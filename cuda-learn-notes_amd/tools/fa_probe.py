@@ -18,10 +18,10 @@ fa = pkg.flash_attn_lib()
 quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
 
 VARIANTS = {
-    64: [(8, 0, 13, 0), (8, 0, 525, 0), (8, 0, 13, 100)],
-    128: [(8, 0, 15, 0), (8, 0, 527, 0), (8, 0, 13, 100)],
+    64: [(8, 0, 13, 0), (8, 0, 77, 0), (4, 0, 13, 0)],
+    128: [(8, 0, 15, 0), (8, 0, 79, 0), (4, 0, 15, 0)],
 }
-SHAPES = [(4, 8, 2048, 64), (4, 8, 2048, 128), (1, 48, 8192, 64), (2, 32, 4096, 128)]
+SHAPES = [(4, 8, 2048, 64), (4, 8, 2048, 128), (2, 8, 2048, 64), (8, 8, 2048, 64)]
 if quick:
     SHAPES = SHAPES[:2]
 

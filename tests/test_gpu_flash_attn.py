@@ -103,6 +103,24 @@ def test_workgroup_shapes_by_seqlen(fa, built, dev, oracle, N, D):
         assert (o.double() - ref).abs().max().item() <= TOL, (name, N, D)
 
 
+@pytest.mark.parametrize("B,H,N,D", [(4, 8, 2048, 128), (2, 8, 2048, 64), (1, 8, 2048, 32), (2, 16, 1024, 96),
+                                     (2, 64, 512, 64), (1, 128, 256, 128)])
+def test_workgroup_size_heuristic_covers_8_4_2_waves(fa, built, dev, oracle, B, H, N, D):
+    """The dispatcher picks 8 / 4 / 2 waves per workgroup so that every CU gets a workgroup (flash_attn.hip):
+    these shapes land on each of the three workgroup sizes at several head dims; sampled heads vs the fp64 oracle."""
+    torch.manual_seed(N + D)
+    q = torch.randn(B, H, N, D, dtype=torch.half, device=dev)
+    k = torch.randn(B, H, N, D, dtype=torch.half, device=dev)
+    v = torch.randn(B, H, N, D, dtype=torch.half, device=dev)
+    for name in ("flash_attn_mma_stages_split_q_shared_qkv", "flash_attn_mma_stages_split_q_shared_qkv_swizzle_qkv"):
+        o = torch.zeros_like(q)
+        vv = v.transpose(-2, -1).contiguous() if name in built.manifest.FA_V_TRANSPOSED else v
+        getattr(fa, name)(q, k, vv, o, 2)
+        for (b, h) in ((0, 0), (B - 1, H - 1), (B // 2, H // 2)):
+            ref = oracle.attention_fp64(q[b, h].cpu(), k[b, h].cpu(), v[b, h].cpu())
+            assert (o[b, h].cpu().double() - ref).abs().max().item() <= TOL, (name, b, h)
+
+
 def test_deferred_max_paths(fa, built, dev, oracle):
     """The v2 kernel rescales O only when some row's running max grew by more than 2^8 (scaled log2 domain).
     Three regimes in one tensor (cdna guide rule 26): (a) key norms growing slowly along N so the true max creeps
