@@ -20,70 +20,86 @@
 
 namespace fa2 {
 
-template <int D>
+// DV: width of the output / V column slice one workgroup produces (DV == D: everything in one workgroup; DV < D:
+// the grid carries D/DV slices and every slice recomputes S -- the price for fitting O^T + Q in the register file).
+template <int D, int DV>
 struct GeoBig {
   static constexpr int BC = 32, NW = 4, BR = 128, NT = 256;
-  static constexpr int ROW = D * 2;               // bytes per K/V row
-  static constexpr int TILE = BC * ROW;           // one K (or V) tile
-  static constexpr int STAGE = 2 * TILE;          // K + V
+  static constexpr int ROW = D * 2;               // bytes per K row
+  static constexpr int VROW = DV * 2;             // bytes per V-slice row
+  static constexpr int KTILE = BC * ROW, VTILE = BC * VROW;
+  static constexpr int STAGE = KTILE + VTILE;     // K + V
   static constexpr int RING = 2 * STAGE;
-  static constexpr int OS = D * 2 + 16;
+  static constexpr int OS = DV * 2 + 16;
   static constexpr int EPI = NW * 32 * OS;
   static constexpr int LDS_BYTES = RING > EPI ? RING : EPI;
-  static constexpr int PIECES = TILE / 1024;      // 1-KiB DMA pieces per tile image
-  static constexpr int PPW = PIECES / NW;         // per wave per image
-  static_assert(D % 128 == 0 && D >= 256 && D <= 512, "big-D kernel: D in {256,384,512}");
-  static_assert(PIECES % NW == 0, "pieces split over the waves");
+  static constexpr int KPPW = KTILE / 1024 / NW;  // 1-KiB DMA pieces per wave per K image
+  static constexpr int VPPW = VTILE / 1024 / NW;
+  static constexpr int NS = D / DV;
+  static_assert(D % 128 == 0 && D >= 256 && D <= 1024, "big-D kernel: D multiple of 128");
+  static_assert(DV % 128 == 0 && D % DV == 0 && DV <= 512, "slice width");
+  static_assert((KTILE / 1024) % NW == 0 && (VTILE / 1024) % NW == 0, "pieces split over the waves");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
-template <int D, int OPT>
+template <int D, int DV, int OPT>
 __global__ __launch_bounds__(256, 1) void fa2_fwd_bigd_kernel(const half_t* __restrict__ Q,
                                                               const half_t* __restrict__ K,
                                                               const half_t* __restrict__ V, half_t* __restrict__ O,
                                                               int N, int n_qblk, int n_heads, float scale_log2e) {
-  using G = GeoBig<D>;
+  using G = GeoBig<D, DV>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hi = lane >> 5;
 
-  int head_i, qb;
+  int head_i, qb, slice;
   {
     const int bid = blockIdx.x;
+    int k;
     if ((OPT & OPT_XCD) && (n_heads & 7) == 0) {
-      const int xcd = bid & 7, k = bid >> 3;
+      const int xcd = bid & 7;
+      k = bid >> 3;
+      slice = k % G::NS;
+      k /= G::NS;
       head_i = (k / n_qblk) * 8 + xcd;
       qb = k - (k / n_qblk) * n_qblk;
     } else {
-      head_i = bid / n_qblk;
-      qb = bid - head_i * n_qblk;
+      slice = bid % G::NS;
+      k = bid / G::NS;
+      head_i = k / n_qblk;
+      qb = k - head_i * n_qblk;
     }
   }
   const size_t head = (size_t)head_i * N * D;
   const int q_row0 = qb * G::BR + wave * 32;
+  const int dv0 = slice * DV;
   const char* Kh = reinterpret_cast<const char*>(K + head);
-  const char* Vh = reinterpret_cast<const char*>(V + head);
+  const char* Vh = reinterpret_cast<const char*>(V + head + dv0);
 
   // ---- DMA source offsets (bytes, relative to the tile origin), constant over the KV loop
-  unsigned k_voff[G::PPW], v_voff[G::PPW];
+  unsigned k_voff[G::KPPW], v_voff[G::VPPW];
 #pragma unroll
-  for (int i = 0; i < G::PPW; ++i) {
-    const int piece = i * G::NW + wave;
-    const int byte = piece * 1024 + lane * 16;  // position in the linear LDS image
+  for (int i = 0; i < G::KPPW; ++i) {
+    const int byte = (i * G::NW + wave) * 1024 + lane * 16;  // position in the linear LDS image
     const int row = byte / G::ROW, c = (byte % G::ROW) >> 4;
     k_voff[i] = (unsigned)(row * G::ROW + ((c ^ (row & 15)) << 4));
-    v_voff[i] = (unsigned)(row * G::ROW + ((c ^ ((row & 3) << 2)) << 4));
+  }
+#pragma unroll
+  for (int i = 0; i < G::VPPW; ++i) {
+    const int byte = (i * G::NW + wave) * 1024 + lane * 16;
+    const int row = byte / G::VROW, c = (byte % G::VROW) >> 4;
+    v_voff[i] = (unsigned)(row * G::ROW + ((c ^ ((row & 3) << 2)) << 4));  // source rows are D wide
   }
   const unsigned lds0 = hgemm::lds_addr_of(smem);
   auto dma_tile = [&](int j, int buf) {
-    const char* ks = Kh + (size_t)j * G::TILE;
-    const char* vs = Vh + (size_t)j * G::TILE;
-    const unsigned kimg = lds0 + buf * G::STAGE, vimg = kimg + G::TILE;
+    const char* ks = Kh + (size_t)j * G::KTILE;
+    const char* vs = Vh + (size_t)j * G::KTILE;  // 32 source rows of D halves
+    const unsigned kimg = lds0 + buf * G::STAGE, vimg = kimg + G::KTILE;
 #pragma unroll
-    for (int i = 0; i < G::PPW; ++i) hgemm::glds16_asm(ks, k_voff[i], kimg + (unsigned)(i * G::NW + wave) * 1024u);
+    for (int i = 0; i < G::KPPW; ++i) hgemm::glds16_asm(ks, k_voff[i], kimg + (unsigned)(i * G::NW + wave) * 1024u);
 #pragma unroll
-    for (int i = 0; i < G::PPW; ++i) hgemm::glds16_asm(vs, v_voff[i], vimg + (unsigned)(i * G::NW + wave) * 1024u);
+    for (int i = 0; i < G::VPPW; ++i) hgemm::glds16_asm(vs, v_voff[i], vimg + (unsigned)(i * G::NW + wave) * 1024u);
   };
 
   // ---- Q fragments: the whole head dim lives in registers
@@ -94,9 +110,9 @@ __global__ __launch_bounds__(256, 1) void fa2_fwd_bigd_kernel(const half_t* __re
     for (int ks = 0; ks < D / 16; ++ks) qf[ks] = *reinterpret_cast<const h8*>(qp + ks * 16);
   }
 
-  f16v ot[D / 32];
+  f16v ot[DV / 32];
 #pragma unroll
-  for (int b = 0; b < D / 32; ++b)
+  for (int b = 0; b < DV / 32; ++b)
 #pragma unroll
     for (int r = 0; r < 16; ++r) ot[b][r] = 0.f;
   float m_run = -1.0e30f, l_run = 0.f;
@@ -119,12 +135,12 @@ __global__ __launch_bounds__(256, 1) void fa2_fwd_bigd_kernel(const half_t* __re
   int voff[4];  // output block b reads chunk (4*b + cc) ^ ((row & 3) << 2) = 4*(b ^ (row&3)) + cc
 #pragma unroll
   for (int i = 0; i < 4; ++i)
-    voff[i] = v_row * G::ROW + ((((i ^ (v_row & 3)) << 2) + (((lane >> 4) & 1) * 2) + ((i16 & 3) >> 1)) << 4) +
+    voff[i] = v_row * G::VROW + ((((i ^ (v_row & 3)) << 2) + (((lane >> 4) & 1) * 2) + ((i16 & 3) >> 1)) << 4) +
               ((i16 & 1) << 3);
 
   for (int j = 0; j < T; ++j) {
     const char* kb = smem + (j & 1) * G::STAGE;
-    const char* vb = kb + G::TILE;
+    const char* vb = kb + G::KTILE;
     if (j + 1 < T) dma_tile(j + 1, (j + 1) & 1);  // its readers (tile j-1) finished before the last barrier
 
     // ---- S^T = K Q^T (32 keys x 32 queries), one accumulator chain over D/16 k-steps
@@ -163,7 +179,7 @@ __global__ __launch_bounds__(256, 1) void fa2_fwd_bigd_kernel(const half_t* __re
       // VGPR. Left alone, the compiler batches all D/2 reads (256 VGPR temporaries at D = 512 -> spills in the
       // hot loop); the empty volatile asm statements serialise the round trips to 4 live temporaries.
 #pragma unroll
-      for (int b = 0; b < D / 32; ++b)
+      for (int b = 0; b < DV / 32; ++b)
 #pragma unroll
         for (int r = 0; r < 16; r += 4) {
           float t0 = ot[b][r], t1 = ot[b][r + 1], t2 = ot[b][r + 2], t3 = ot[b][r + 3];
@@ -191,10 +207,10 @@ __global__ __launch_bounds__(256, 1) void fa2_fwd_bigd_kernel(const half_t* __re
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
 #pragma unroll
-      for (int b = 0; b < D / 32; ++b) {
+      for (int b = 0; b < DV / 32; ++b) {
         // rows 16*st + v_row and + 8 ((row + 8) & 3 == row & 3: same swizzle); 4 output blocks = 256 bytes
-        const char* vp = vb + voff[b & 3] + (16 * st) * G::ROW + (b >> 2) * 256;
-        const h8 vf = h8_cat(lds_read_tr16(vp), lds_read_tr16(vp + 8 * G::ROW));
+        const char* vp = vb + voff[b & 3] + (16 * st) * G::VROW + (b >> 2) * 256;
+        const h8 vf = h8_cat(lds_read_tr16(vp), lds_read_tr16(vp + 8 * G::VROW));
         ot[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[st], ot[b], 0, 0, 0);
         if ((b & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
@@ -216,7 +232,7 @@ __global__ __launch_bounds__(256, 1) void fa2_fwd_bigd_kernel(const half_t* __re
   const float inv = 1.0f / l_tot;
   char* ob = smem + wave * (32 * G::OS);
 #pragma unroll
-  for (int b = 0; b < D / 32; ++b) {
+  for (int b = 0; b < DV / 32; ++b) {
 #pragma unroll
     for (int rq = 0; rq < 4; ++rq) {
       h4 o;
@@ -226,8 +242,8 @@ __global__ __launch_bounds__(256, 1) void fa2_fwd_bigd_kernel(const half_t* __re
     }
     __builtin_amdgcn_sched_barrier(0);
   }
-  constexpr int LPR = D / 8;
-  half_t* og = O + head + (size_t)q_row0 * D;
+  constexpr int LPR = DV / 8;
+  half_t* og = O + head + (size_t)q_row0 * D + dv0;
 #pragma unroll 4
   for (int it = 0; it < (32 * LPR) / 64; ++it) {
     const int idx = it * 64 + lane;
@@ -237,19 +253,19 @@ __global__ __launch_bounds__(256, 1) void fa2_fwd_bigd_kernel(const half_t* __re
   }
 }
 
-template <int D, int OPT>
+template <int D, int DV, int OPT>
 int launch_bigd(const void* q, const void* k, const void* v, void* o, int B, int H, int N, hipStream_t stream) {
-  using G = GeoBig<D>;
+  using G = GeoBig<D, DV>;
   if (N % G::BR != 0) return CLN_ERR_UNSUPPORTED;
   static bool attr_done = false;
   if (!attr_done) {
-    if (cln_set_lds(reinterpret_cast<const void*>(&fa2_fwd_bigd_kernel<D, OPT>), G::LDS_BYTES) != CLN_OK)
+    if (cln_set_lds(reinterpret_cast<const void*>(&fa2_fwd_bigd_kernel<D, DV, OPT>), G::LDS_BYTES) != CLN_OK)
       return CLN_ERR_LAUNCH;
     attr_done = true;
   }
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)D);
   const int n_qblk = N / G::BR;
-  CLN_LAUNCH((fa2_fwd_bigd_kernel<D, OPT>), dim3(n_qblk * B * H), dim3(G::NT), G::LDS_BYTES, stream,
+  CLN_LAUNCH((fa2_fwd_bigd_kernel<D, DV, OPT>), dim3(n_qblk * B * H * G::NS), dim3(G::NT), G::LDS_BYTES, stream,
              (const half_t*)q, (const half_t*)k, (const half_t*)v, (half_t*)o, N, n_qblk, B * H, scale_log2e);
   return cln_check_launch();
 }

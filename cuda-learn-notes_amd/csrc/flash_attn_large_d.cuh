@@ -5,6 +5,7 @@
 // the OUTPUT head dim sliced across blockIdx.z (each workgroup recomputes S for its slice).
 #pragma once
 #include "flash_attn.cuh"
+#include "flash_attn_bigd.cuh"
 
 namespace fa {
 inline int launch_fa2_large_d(const void* q, const void* k, const void* v, void* o, int B, int H, int N, int D,
@@ -13,9 +14,11 @@ inline int launch_fa2_large_d(const void* q, const void* k, const void* v, void*
   switch (D) {
     case 320: return launch_fa2<320, 160, 64, false, false>(q, k, v, o, B, H, N, s);
     case 384: return launch_fa2<384, 192, 64, false, false>(q, k, v, o, B, H, N, s);
-    case 512: return launch_fa2<512, 256, 64, false, false>(q, k, v, o, B, H, N, s);
+    // D = 512 (config C5) and 768: register-resident Q + O-slice kernel, K/V by LDS-DMA (flash_attn_bigd.cuh):
+    // 487 vs 411 TF at [1,32,4096,512], 253 vs 129 TF at [1,8,2048,768] (profiles/r01_fa_bigd_dvsliced_probe.log)
+    case 512: return fa2::launch_bigd<512, 256, fa2::OPT_DEFAULT>(q, k, v, o, B, H, N, s);
     case 640: return launch_fa2<640, 320, 32, false, false>(q, k, v, o, B, H, N, s);
-    case 768: return launch_fa2<768, 192, 32, false, false>(q, k, v, o, B, H, N, s);
+    case 768: return fa2::launch_bigd<768, 256, fa2::OPT_DEFAULT>(q, k, v, o, B, H, N, s);
     case 1024: return launch_fa2<1024, 256, 32, false, false>(q, k, v, o, B, H, N, s);
     default: return CLN_ERR_UNSUPPORTED;
   }

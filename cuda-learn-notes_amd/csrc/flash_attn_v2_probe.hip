@@ -16,10 +16,13 @@ CLN_API int cln_fa2_variant(int D, int nw, int vt, int opt, int abl, const void*
   V2(64, 8, 13, 0) V2(64, 4, 13, 0) V2(64, 4, 77, 0) V2(128, 8, 15, 0) V2(128, 4, 15, 0) V2(128, 4, 79, 0)
   V2(64, 8, 13, 1) V2(64, 8, 13, 2) V2(64, 8, 13, 7) V2(128, 8, 15, 1) V2(128, 8, 15, 7)
   V2(64, 8, 525, 0) V2(128, 8, 527, 0) V2(64, 8, 524, 0)
-  if (D == 512 && abl == 200 && opt == 15) return fa2::launch_bigd<512, 15>(q, k, v, o, B, H, N, (hipStream_t)stream);
-  if (D == 512 && abl == 200 && opt == 13) return fa2::launch_bigd<512, 13>(q, k, v, o, B, H, N, (hipStream_t)stream);
-  if (D == 384 && abl == 200) return fa2::launch_bigd<384, 15>(q, k, v, o, B, H, N, (hipStream_t)stream);
-  if (D == 256 && abl == 200) return fa2::launch_bigd<256, 15>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 512 && abl == 200) return fa2::launch_bigd<512, 512, 15>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 512 && abl == 201) return fa2::launch_bigd<512, 256, 15>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 512 && abl == 202) return fa2::launch_bigd<512, 128, 15>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 384 && abl == 201) return fa2::launch_bigd<384, 128, 15>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 1024 && abl == 201) return fa2::launch_bigd<1024, 256, 15>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 768 && abl == 201) return fa2::launch_bigd<768, 256, 15>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 256 && abl == 200) return fa2::launch_bigd<256, 256, 15>(q, k, v, o, B, H, N, (hipStream_t)stream);
   V2(64, 8, 77, 0) V2(128, 8, 79, 0)
   V3(64, 8, 13) V3(64, 8, 269) V3(64, 8, 15) V3(64, 4, 13) V3(128, 8, 15) V3(128, 8, 13) V3(128, 8, 271) V3(128, 4, 15)
   return CLN_ERR_UNSUPPORTED;

@@ -98,7 +98,7 @@ _FA_VT = [
     "flash_attn_mma_stages_split_q_shared_kv_swizzle_qkv", "flash_attn_mma_stages_split_q_shared_qkv_swizzle_qkv",
     "flash_attn_mma_stages_split_q_tiling_qk_swizzle_qkv",
 ]
-_add("flash_attn", "FA", "fa2_fwd_v2<D<=256, 8|4|2 waves x 32 rows, dbuf K/V, deferred max> | fa2_fwd<D>256, DV-sliced> "
+_add("flash_attn", "FA", "fa2_fwd_v2<D<=256, 8|4|2 waves x 32 rows, dbuf K/V, deferred max> | fa2_fwd_bigd<D=512|768, DV=256, LDS-DMA> | fa2_fwd<other D>256, DV-sliced> "
      "mfma_32x32x16, f32 acc", *_FA_PLAIN)
 _add("flash_attn", "FA", "fa2_fwd_v2<D<=256, V transposed [B,H,D,N]>", *_FA_VT)
 

@@ -7,7 +7,7 @@ pkg = entry.load_package()
 from cuda_learn_notes_amd import bench_utils as bu, host
 dev = torch.device("cuda:0")
 fa = pkg.flash_attn_lib()
-for (B, H, N, D) in [(2, 8, 2048, 256), (4, 16, 4096, 256), (1, 32, 4096, 384), (1, 32, 4096, 512), (1, 8, 8192, 512)]:
+for (B, H, N, D) in [(1, 32, 4096, 512), (1, 8, 2048, 768), (1, 8, 2048, 1024), (1, 16, 4096, 1024)]:
     torch.manual_seed(0)
     q, k, v = (torch.randn(B, H, N, D, dtype=torch.half, device=dev) for _ in range(3))
     o = torch.zeros_like(q)
@@ -15,9 +15,9 @@ for (B, H, N, D) in [(2, 8, 2048, 256), (4, 16, 4096, 256), (1, 32, 4096, 384), 
     fl = bu.mha_flops_conventional(B, H, N, D)
     prod = fa.flash_attn_mma_stages_split_q_tiling_qkv
     cands = [("production", lambda: prod(q, k, v, o, 2)), ("sdpa", lambda: F.scaled_dot_product_attention(q, k, v)),
-             ("bigd", lambda: host.fa2_variant((4, 0, 15, 200), q, k, v, o))]
+             ("bigd dv-sliced", lambda: host.fa2_variant((4, 0, 15, 201), q, k, v, o))]
     if D == 512:
-        cands.append(("bigd noprio", lambda: host.fa2_variant((4, 0, 13, 200), q, k, v, o)))
+        cands.append(("bigd dv128", lambda: host.fa2_variant((4, 0, 15, 202), q, k, v, o)))
     for tag, fn in cands:
         if tag == "sdpa":
             continue
