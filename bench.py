@@ -127,24 +127,30 @@ def main():
             extras["rocblas_error"] = str(e)[:200]
         try:  # FA2 forward, config C4 (D=64) and the D=128 sibling
             fa = pkg.flash_attn_lib()
-            for D in (64, 128):
-                B_, H_, N_ = 4, 8, 2048
+            for tag, (B_, H_, N_, D) in (("fa2_fwd_d64", (4, 8, 2048, 64)), ("fa2_fwd_d128", (4, 8, 2048, 128)),
+                                         ("fa2_fwd_d64_large", (1, 48, 8192, 64)),
+                                         ("fa2_fwd_d128_large", (2, 32, 4096, 128)),
+                                         ("fa2_fwd_d512_c5", (1, 32, 4096, 512))):
                 q, k, v = (torch.randn(B_, H_, N_, D, dtype=torch.half, device=dev) for _ in range(3))
                 o = torch.zeros_like(q)
-                fn = lambda: fa.flash_attn_mma_stages_split_q_shared_qkv(q, k, v, o, 2)
-                ms, _, _ = bu.time_call_events(fn, 5, 30)
+                kern = (fa.flash_attn_mma_stages_split_q_shared_qkv if D <= 256
+                        else fa.flash_attn_mma_stages_split_q_tiling_qkv)
+                fn = lambda: kern(q, k, v, o, 2)
+                ms, _, _ = bu.time_call_events(fn, 5, 30 if N_ <= 2048 else 10)
                 row = {"shape": [B_, H_, N_, D], "ms": round(ms, 5),
                        "tflops_ref_model": round(bu.get_mha_tflops(B_, H_, N_, D, ms * 1e-3), 2),
                        "tflops_4bhn2d": round(bu.mha_flops_conventional(B_, H_, N_, D) / (ms * 1e-3) * 1e-12, 2)}
                 try:  # the FlashAttention-2-ROCm row available on the box: torch SDPA (reference prints it too,
                     # flash_attn_mma.py:391-398)
                     import torch.nn.functional as F
-                    ms2, _, _ = bu.time_call_events(lambda: F.scaled_dot_product_attention(q, k, v), 5, 30)
+                    ms2, _, _ = bu.time_call_events(lambda: F.scaled_dot_product_attention(q, k, v), 5,
+                                                    30 if N_ <= 2048 else 10)
                     row["torch_sdpa_tflops_4bhn2d"] = round(
                         bu.mha_flops_conventional(B_, H_, N_, D) / (ms2 * 1e-3) * 1e-12, 2)
                 except Exception as e:
                     row["torch_sdpa_error"] = str(e)[:120]
-                extras["fa2_fwd_d%d" % D] = row
+                extras[tag] = row
+                del q, k, v, o
         except Exception as e:
             extras["fa2_error"] = str(e)[:200]
         out["extras"] = extras

@@ -133,7 +133,10 @@ __global__ __launch_bounds__(256) void fa2_fwd_kernel(const half_t* __restrict__
   if constexpr (PREFETCH) {
     load_k(0);
     write_k();
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // Q + K_0 complete before the loop (see flash_attn_v2.cuh)
     load_v(0);
+  } else {
+    __builtin_amdgcn_s_waitcnt(0x0F70);
   }
 
   for (int j = 0; j < T; ++j) {

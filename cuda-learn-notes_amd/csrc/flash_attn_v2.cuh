@@ -24,8 +24,20 @@
 
 namespace fa2 {
 
-enum : int { OPT_DEFER = 1, OPT_PRIO = 2, OPT_LDS_EPI = 4, OPT_XCD = 8, OPT_STAGGER = 16, OPT_ONES = 32, OPT_SOLO = 64, OPT_PK = 512, OPT_DEFAULT = 15 };
+enum : int { OPT_DEFER = 1, OPT_PRIO = 2, OPT_LDS_EPI = 4, OPT_XCD = 8, OPT_STAGGER = 16, OPT_ONES = 32, OPT_SOLO = 64, OPT_PK = 512, OPT_VPRE = 1024, OPT_KPRE = 2048, OPT_SOFTEXP = 4096, OPT_SOFTEXP_HALF = 8192, OPT_DEFAULT = 15 };
 enum : int { ABL_NO_SOFTMAX = 1, ABL_NO_STAGE = 2, ABL_NO_FRAG_READS = 4, ABL_NO_BARRIER = 8 };
+
+// exp2 on the plain VALU (experiment): ubench/overlap.hip shows v_exp_f32 does not overlap with the SIMD partner's
+// MFMA stream while v_fma_f32 does. Round-to-nearest split x = n + r, degree-3 minimax of 2^r on [-0.5, 0.5]
+// (max rel. error 7.5e-5, below the fp16 rounding of P), exponent added with one v_lshl_add_u32.
+__device__ __forceinline__ float soft_exp2(float x) {
+  x = fmaxf(x, -126.0f);
+  const float magic = 12582912.0f;  // 1.5 * 2^23: low mantissa bits of (x + magic) hold round(x)
+  const float t = x + magic;
+  const float r = x - (t - magic);
+  const float p = fmaf(fmaf(fmaf(0.0551716481f, r, 0.242611121f), r, 0.693260989f), r, 0.999928074f);
+  return __uint_as_float(__float_as_uint(p) + (__float_as_uint(t) << 23));
+}
 
 template <int D, int NW, bool VT>
 struct Geo {
@@ -152,6 +164,11 @@ __global__ __launch_bounds__(NW * 64, (D > 128 ? 1 : 2)) void fa2_fwd_v2_kernel(
   const int T = N / 64;
   load_tile(0);
   write_tile(0);
+  // Everything issued so far (Q fragments, tile 0) must be COMPLETE in hipcc's scoreboard before the loop: the Q
+  // loads are otherwise first waited for inside the loop body (`s_waitcnt vmcnt(0)` ahead of the first MFMA that
+  // reads qf[2..]), and because vmcnt retires in order that wait also drains the K/V prefetch issued at the end
+  // of the previous iteration -- the full global-load latency was exposed once per KV tile.
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), lgkmcnt/expcnt untouched
   if (T > 1) load_tile(1);
   __syncthreads();
 
@@ -170,6 +187,26 @@ __global__ __launch_bounds__(NW * 64, (D > 128 ? 1 : 2)) void fa2_fwd_v2_kernel(
     f16v s0, s1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) s0[r] = 0.f, s1[r] = 0.f;
+    if constexpr ((OPT & OPT_KPRE) != 0) {
+      // all K fragment reads of this tile up front (in groups of 4 k-steps): the LDS latency is paid once per
+      // group instead of once per MFMA pair (hipcc otherwise issues each read two MFMAs ahead of its use)
+      constexpr int GRP = 4;
+#pragma unroll
+      for (int g0 = 0; g0 < D / 16; g0 += GRP) {
+        h8 ka[GRP], kc[GRP];
+#pragma unroll
+        for (int u = 0; u < GRP; ++u) {
+          ka[u] = *reinterpret_cast<const h8*>(kb + k_off + (g0 + u) * 32);
+          kc[u] = *reinterpret_cast<const h8*>(kb + k_off + 32 * G::KS + (g0 + u) * 32);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < GRP; ++u) {
+          s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka[u], qf[g0 + u], s0, 0, 0, 0);
+          s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kc[u], qf[g0 + u], s1, 0, 0, 0);
+        }
+      }
+    } else {
     if constexpr ((OPT & OPT_PRIO) != 0) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < D / 16; ++ks) {
@@ -184,6 +221,21 @@ __global__ __launch_bounds__(NW * 64, (D > 128 ? 1 : 2)) void fa2_fwd_v2_kernel(
       s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf1, qf[ks], s1, 0, 0, 0);
     }
     if constexpr ((OPT & OPT_PRIO) != 0) __builtin_amdgcn_s_setprio(0);
+    }
+    // V fragments of the first PRE k-steps are fetched BEFORE the softmax (V_j is already resident): they land
+    // while the VALU works
+    constexpr int PRE = (OPT & OPT_VPRE) ? (D <= 64 ? 4 : (D <= 128 ? 2 : 0)) : 0;
+    h8 vpre[PRE > 0 ? PRE : 1][D / 32];
+    if constexpr (PRE > 0 && !VT) {
+#pragma unroll
+      for (int st = 0; st < PRE; ++st)
+#pragma unroll
+        for (int b = 0; b < D / 32; ++b) {
+          const char* vp = vb + v_off + (32 * (st >> 1) + 16 * (st & 1)) * G::VS + b * 64;
+          vpre[st][b] = h8_cat(lds_read_tr16(vp), lds_read_tr16(vp + 8 * G::VS));
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
 
     // ---- online softmax (lane-local row)
     h8 pf[4];  // P^T fragments of the four 16-kv k-steps, in accumulator register order
@@ -243,10 +295,23 @@ __global__ __launch_bounds__(NW * 64, (D > 128 ? 1 : 2)) void fa2_fwd_v2_kernel(
       } else {
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
-        const float a0 = __builtin_amdgcn_exp2f(fmaf(s0[r], scale_log2e, nm));
-        const float a1 = __builtin_amdgcn_exp2f(fmaf(s0[r + 1], scale_log2e, nm));
-        const float b0 = __builtin_amdgcn_exp2f(fmaf(s1[r], scale_log2e, nm));
-        const float b1 = __builtin_amdgcn_exp2f(fmaf(s1[r + 1], scale_log2e, nm));
+        float a0, a1, b0, b1;
+        if constexpr ((OPT & OPT_SOFTEXP) != 0) {
+          a0 = soft_exp2(fmaf(s0[r], scale_log2e, nm));
+          a1 = soft_exp2(fmaf(s0[r + 1], scale_log2e, nm));
+          b0 = soft_exp2(fmaf(s1[r], scale_log2e, nm));
+          b1 = soft_exp2(fmaf(s1[r + 1], scale_log2e, nm));
+        } else if constexpr ((OPT & OPT_SOFTEXP_HALF) != 0) {
+          a0 = soft_exp2(fmaf(s0[r], scale_log2e, nm));
+          a1 = soft_exp2(fmaf(s0[r + 1], scale_log2e, nm));
+          b0 = __builtin_amdgcn_exp2f(fmaf(s1[r], scale_log2e, nm));
+          b1 = __builtin_amdgcn_exp2f(fmaf(s1[r + 1], scale_log2e, nm));
+        } else {
+          a0 = __builtin_amdgcn_exp2f(fmaf(s0[r], scale_log2e, nm));
+          a1 = __builtin_amdgcn_exp2f(fmaf(s0[r + 1], scale_log2e, nm));
+          b0 = __builtin_amdgcn_exp2f(fmaf(s1[r], scale_log2e, nm));
+          b1 = __builtin_amdgcn_exp2f(fmaf(s1[r + 1], scale_log2e, nm));
+        }
         if constexpr ((OPT & OPT_ONES) == 0) psum += (a0 + a1) + (b0 + b1);
         const h2 a = __builtin_convertvector(f2{a0, a1}, h2);
         const h2 b = __builtin_convertvector(f2{b0, b1}, h2);
@@ -269,6 +334,13 @@ __global__ __launch_bounds__(NW * 64, (D > 128 ? 1 : 2)) void fa2_fwd_v2_kernel(
         h8 vf;
         if constexpr ((ABL & ABL_NO_FRAG_READS) != 0) {
           vf = vf_const;
+        } else if constexpr (PRE > 0 && !VT) {
+          if (st < PRE) {
+            vf = vpre[st][b];
+          } else {
+            const char* vp = vb + v_off + kv0 * G::VS + b * 64;
+            vf = h8_cat(lds_read_tr16(vp), lds_read_tr16(vp + 8 * G::VS));
+          }
         } else if constexpr (VT) {
           const char* vp = vb + v_off + b * 32 * G::VS + kv0 * 2;
           vf = h8_cat(*reinterpret_cast<const h4*>(vp), *reinterpret_cast<const h4*>(vp + 16));

@@ -2,6 +2,7 @@
 //   int cln_fa2_variant(D, nw, vt, opt, abl, q, k, v, o, B, H, N, stream)
 #include "flash_attn_v3.cuh"
 #include "flash_attn_bigd.cuh"
+#include "flash_attn_v4.cuh"
 #include <type_traits>
 
 #define V3(DD, NWW, OPTT) \
@@ -23,7 +24,11 @@ CLN_API int cln_fa2_variant(int D, int nw, int vt, int opt, int abl, const void*
   if (D == 1024 && abl == 201) return fa2::launch_bigd<1024, 256, 15>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 768 && abl == 201) return fa2::launch_bigd<768, 256, 15>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 256 && abl == 200) return fa2::launch_bigd<256, 256, 15>(q, k, v, o, B, H, N, (hipStream_t)stream);
-  V2(64, 8, 77, 0) V2(128, 8, 79, 0)
+  V2(64, 8, 77, 0) V2(128, 8, 79, 0) V2(64, 8, 4109, 0) V2(64, 8, 8205, 0) V2(128, 8, 4111, 0) V2(128, 8, 8207, 0) V2(64, 8, 1037, 0) V2(64, 8, 3085, 0) V2(64, 8, 2061, 0) V2(128, 8, 1039, 0) V2(128, 8, 3087, 0) V2(128, 8, 2063, 0)
+  if (D == 64 && abl == 300 && opt == 13) return fa2::launch_v4<64, false, 13>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 64 && abl == 300 && opt == 15) return fa2::launch_v4<64, false, 15>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 128 && abl == 300 && opt == 13) return fa2::launch_v4<128, false, 13>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 128 && abl == 300 && opt == 15) return fa2::launch_v4<128, false, 15>(q, k, v, o, B, H, N, (hipStream_t)stream);
   V3(64, 8, 13) V3(64, 8, 269) V3(64, 8, 15) V3(64, 4, 13) V3(128, 8, 15) V3(128, 8, 13) V3(128, 8, 271) V3(128, 4, 15)
   return CLN_ERR_UNSUPPORTED;
 }

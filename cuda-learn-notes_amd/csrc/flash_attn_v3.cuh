@@ -248,6 +248,7 @@ __global__ __launch_bounds__(NW * 64, (D > 128 ? 1 : 2)) void fa2_fwd_v3_kernel(
   load_v(0);
   write_k(0);
   write_v(0);
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // Q + tile 0 complete in hipcc's scoreboard (see flash_attn_v2.cuh)
   if (T > 1) {
     load_k(1);
     write_k(1);

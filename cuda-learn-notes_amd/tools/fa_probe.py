@@ -17,11 +17,11 @@ dev = torch.device("cuda:0")
 fa = pkg.flash_attn_lib()
 quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
 
-VARIANTS = {
-    64: [(8, 0, 13, 0), (8, 0, 77, 0), (4, 0, 13, 0)],
-    128: [(8, 0, 15, 0), (8, 0, 79, 0), (4, 0, 15, 0)],
+VARIANTS = {  # (waves, v_transposed, OPT mask, ablation | 100 = v3 | 300 = v4)
+    64: [(8, 0, 13, 0), (4, 0, 13, 0), (8, 0, 13, 100), (8, 0, 13, 300), (8, 0, 4109, 0)],
+    128: [(8, 0, 15, 0), (4, 0, 15, 0), (8, 0, 15, 100), (8, 0, 15, 300), (8, 0, 4111, 0)],
 }
-SHAPES = [(4, 8, 2048, 64), (4, 8, 2048, 128), (2, 8, 2048, 64), (8, 8, 2048, 64)]
+SHAPES = [(4, 8, 2048, 64), (4, 8, 2048, 128), (1, 48, 8192, 64), (2, 32, 4096, 128)]
 if quick:
     SHAPES = SHAPES[:2]
 
@@ -39,7 +39,7 @@ for (B, H, N, D) in SHAPES:
                       lambda var=var: host.fa2_variant(var, q, k, v, o)))
     # correctness of the non-ablated variants
     for tag, fn in cands:
-        if tag == "sdpa" or "abl" in tag and not (tag.endswith("abl0") or tag.endswith("abl100")):
+        if tag == "sdpa" or "abl" in tag and not (tag.endswith("abl0") or tag.endswith("abl100") or tag.endswith("abl300")):
             continue
         o.zero_()
         try:

@@ -198,9 +198,9 @@ def test_probe_variants_match_production(fa, built, dev, oracle):
     """v3 (software-pipelined) and the big-D register-resident probe kernels are kept as measured alternatives;
     they must agree with the oracle like the shipped v2 kernel does."""
     from cuda_learn_notes_amd import host
-    for (B, H, N, D, variants) in ((1, 2, 512, 64, [(8, 0, 13, 100), (4, 0, 13, 100), (8, 0, 269, 100)]),
-                                   (1, 2, 512, 128, [(8, 0, 15, 100), (8, 0, 13, 100)]),
-                                   (1, 1, 256, 256, [(4, 0, 15, 200)]), (1, 1, 256, 512, [(4, 0, 15, 200)])):
+    for (B, H, N, D, variants) in ((1, 2, 512, 64, [(8, 0, 13, 100), (4, 0, 13, 100), (8, 0, 269, 100), (8, 0, 13, 300), (8, 0, 4109, 0), (8, 0, 3085, 0)]),
+                                   (1, 2, 512, 128, [(8, 0, 15, 100), (8, 0, 13, 100), (8, 0, 15, 300), (8, 0, 4111, 0)]),
+                                   (1, 1, 256, 256, [(4, 0, 15, 200)]), (1, 1, 256, 512, [(4, 0, 15, 200), (4, 0, 15, 201)])):
         q, k, v = seeded(41, B, H, N, D), seeded(42, B, H, N, D), seeded(43, B, H, N, D)
         ref = oracle.attention_fp64(q, k, v)
         for var in variants:
