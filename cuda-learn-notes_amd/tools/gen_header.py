@@ -57,7 +57,7 @@ GROUPS = [
     ("histogram", "y[a[i]] += 1 for int32 a[n]; y is int32[nbins], zeroed by the caller; values outside [0,nbins) are ignored.\n"
                   " * Replaces reference kernels/histogram/histogram.cu:56-80 (`torch::Tensor f(torch::Tensor a)`, nbins = max(a)+1)."),
     ("activation", "y = act(x), elementwise, n elements; relu / sigmoid / gelu(tanh) / swish / elu(alpha=1) / hardswish / hardshrink(0.5).\n"
-                   " * Replaces the `void f(Tensor x, Tensor y)` bindings of reference kernels/{relu,sigmoid,gelu,swish,elu,hardswish,hardshrink}/*.cu."),
+                   " * Replaces the `void f(Tensor x, Tensor y)` bindings of reference kernels/<op>/<op>.cu (relu, sigmoid, gelu, swish, elu, hardswish, hardshrink)."),
     ("sgemm", "SGEMM: C[M,N] = A[M,K] * B[K,N], fp32 row-major. Replaces reference kernels/sgemm/sgemm.cu:495-640,\n"
               " * sgemm_async.cu bindings, sgemm_wmma_tf32_stage.cu:575-700 (TF32 rungs -> exact-f32 MFMA)."),
     ("sgemm_vendor", "Vendor SGEMM rows (libcln_amd_vendor.so): reference kernels/sgemm/sgemm_cublas.cu:80-120."),
