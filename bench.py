@@ -108,7 +108,7 @@ def main():
         "roofline": roofline,
     }
 
-    if rank == 0 and not args.no_extras:
+    if rank == 0 and world == 1 and not args.no_extras:  # side measurements only in the single-GPU run
         extras = {}
         try:  # vendor row (rocBLAS) on the same operands
             hg.init_cublas_handle()
