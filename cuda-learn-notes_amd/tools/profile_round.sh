@@ -8,7 +8,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out
 T=$REPO/cuda-learn-notes_amd/tools
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -o $TAG -- python $REPO/bench.py --steps 20 --warmup 5 --no-extras > $OUT/prof_bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -o $TAG -- python $REPO/bench.py --steps 300 --warmup 100 --no-extras > $OUT/prof_bench.log 2>&1
 python - <<PY
 import csv
 rows = list(csv.DictReader(open("$OUT/prof_bench/${TAG}_kernel_stats.csv")))
