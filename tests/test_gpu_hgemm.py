@@ -200,6 +200,27 @@ def test_baseline_configs_sampled_rows(hg, dev, size):
         assert (err <= ATOL + RTOL * truth.abs()).all(), (name, err.max().item())
 
 
+@pytest.mark.parametrize("M,N,K", [(4096, 8192, 2048), (2048, 1024, 8192), (3072, 3072, 3072), (16384, 16384, 1024),
+                                   (1536, 2560, 4096), (64, 128, 64), (12800, 12800, 512)])
+def test_rectangular_and_large_shapes(hg, built, dev, M, N, K):
+    """Every tile policy branch (256x256 ping-pong, 64x128, 128x128) on non-square and large problems (the
+    reference sweeps up to M=N=12800/16384, hgemm.py MMNK): sampled rows vs the fp32 product, NN and TN agree."""
+    from cuda_learn_notes_amd.bench_utils import as_col_major, make_block_swizzle_stride
+    torch.manual_seed(M + N + K)
+    a = torch.randn(M, K, dtype=torch.half, device=dev)
+    b = torch.randn(K, N, dtype=torch.half, device=dev)
+    rows = torch.unique(torch.cat([torch.arange(0, M, max(1, M // 48)), torch.tensor([M - 1])]))
+    truth = a[rows].float() @ b.float()
+    stride = make_block_swizzle_stride(N, K)
+    c = torch.zeros(M, N, dtype=torch.half, device=dev)
+    hg.hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem(a, b, c, 2, True, stride)
+    err = (c[rows].float() - truth).abs()
+    assert (err <= ATOL + RTOL * truth.abs()).all(), err.max().item()
+    ct = torch.zeros(M, N, dtype=torch.half, device=dev)
+    hg.hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_tn_swizzle_x4(a, as_col_major(b), ct, 2, True, stride)
+    assert torch.equal(ct, c)  # same k order, same fp32 accumulation: TN and NN agree bit for bit
+
+
 @pytest.mark.parametrize("layout", [0, 1])
 def test_probe_kernels_stay_correct(built, dev, layout):
     """Tuning hooks kept in the library as measured (slower) alternatives must stay bit-identical to the shipped
