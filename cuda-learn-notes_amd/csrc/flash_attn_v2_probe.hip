@@ -29,6 +29,6 @@ CLN_API int cln_fa2_variant(int D, int nw, int vt, int opt, int abl, const void*
   if (D == 64 && abl == 300 && opt == 15) return fa2::launch_v4<64, false, 15>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 128 && abl == 300 && opt == 13) return fa2::launch_v4<128, false, 13>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 128 && abl == 300 && opt == 15) return fa2::launch_v4<128, false, 15>(q, k, v, o, B, H, N, (hipStream_t)stream);
-  V3(64, 8, 13) V3(64, 8, 269) V3(64, 8, 15) V3(64, 4, 13) V3(128, 8, 15) V3(128, 8, 13) V3(128, 8, 271) V3(128, 4, 15)
+  V3(64, 8, 16397) V3(64, 4, 16397) V3(64, 8, 13) V3(64, 8, 269) V3(64, 8, 15) V3(64, 4, 13) V3(128, 8, 15) V3(128, 8, 13) V3(128, 8, 271) V3(128, 4, 15)
   return CLN_ERR_UNSUPPORTED;
 }

@@ -23,7 +23,7 @@
 
 namespace fa2 {
 
-enum : int { OPT_SGB = 256 };
+enum : int { OPT_SGB = 256, OPT_SGB2 = 16384 };
 
 template <int D, int NW, bool VT, int OPT>
 __global__ __launch_bounds__(NW * 64, (D > 128 ? 1 : 2)) void fa2_fwd_v3_kernel(const half_t* __restrict__ Q,
@@ -180,7 +180,25 @@ __global__ __launch_bounds__(NW * 64, (D > 128 ? 1 : 2)) void fa2_fwd_v3_kernel(
     const char* kb_next = k_ring + ((j + 1) & 1) * KB;
     const char* vb = v_ring + (j & 1) * VB;
     // ---- B: next QK^T (MFMA) || exp / sums / pack of the current tile (VALU)
-    if constexpr (NEXT) qk(n0, n1, kb_next);
+    h8 kpre[(OPT & OPT_SGB2) ? D / 8 : 1];
+    if constexpr (NEXT && (OPT & OPT_SGB2) != 0) {
+      // all K fragments of the next tile first (D/8 reads in flight together), THEN the MFMA chain with the
+      // softmax VALU pinned between consecutive MFMAs: no MFMA waits on a read issued just ahead of it
+#pragma unroll
+      for (int ks = 0; ks < D / 16; ++ks) {
+        kpre[2 * ks] = *reinterpret_cast<const h8*>(kb_next + k_off + ks * 32);
+        kpre[2 * ks + 1] = *reinterpret_cast<const h8*>(kb_next + k_off + 32 * G::KS + ks * 32);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) n0[r] = 0.f, n1[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < D / 16; ++ks) {
+        n0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kpre[2 * ks], qf[ks], n0, 0, 0, 0);
+        n1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kpre[2 * ks + 1], qf[ks], n1, 0, 0, 0);
+      }
+    } else if constexpr (NEXT) {
+      qk(n0, n1, kb_next);
+    }
     h8 pf[4];
     {
       const float nm = -m_run;
@@ -198,6 +216,16 @@ __global__ __launch_bounds__(NW * 64, (D > 128 ? 1 : 2)) void fa2_fwd_v3_kernel(
         pf[2 + (r >> 3)][r & 7] = b[0], pf[2 + (r >> 3)][(r & 7) + 1] = b[1];
       }
       l_run += psum;
+    }
+    if constexpr (NEXT && (OPT & OPT_SGB2) != 0) {
+      constexpr int NM = D / 8;
+      __builtin_amdgcn_sched_group_barrier(0x100, NM, 0);  // every K fragment read up front
+#pragma unroll
+      for (int g = 0; g < NM; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, (96 + NM - 1) / NM, 0);   // plain VALU
+        __builtin_amdgcn_sched_group_barrier(0x400, (32 + NM - 1) / NM, 0);   // transcendental
+      }
     }
     if constexpr (NEXT && (OPT & OPT_SGB) != 0) {
       // D/8 MFMAs in this block; spread the 32 transcendental + ~80 plain VALU ops and the D/8 fragment reads

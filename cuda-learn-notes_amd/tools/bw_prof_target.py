@@ -1,0 +1,61 @@
+"""Launch loop for `rocprofv3 --kernel-trace --stats`: every bandwidth-bound kernel family at a reference shape,
+25 launches each, so the stats CSV carries one row per kernel with its average device time. bw_prof_summary.py
+turns that into GB/s with the algorithmic bytes of SURVEY 8(d)."""
+import ctypes
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+
+pkg = entry.load_package()
+from cuda_learn_notes_amd import _loader  # noqa: E402
+
+dev = torch.device("cuda:0")
+so = _loader.load_so("libcln_amd.so")
+st = lambda: torch.cuda.current_stream().cuda_stream
+S = K = 4096
+x = torch.randn(S, K, device=dev)
+y = torch.zeros_like(x)
+xh, yh = x.half(), y.half()
+x2 = torch.randn(S, K, device=dev)
+x2h = x2.half()
+z = torch.zeros(1, device=dev)
+idx = torch.randint(0, 4096, (4096,), device=dev, dtype=torch.int32)
+w = torch.randn(4096, 1024, device=dev)
+o = torch.zeros(4096, 1024, device=dev)
+hist_in = torch.randint(0, 1024, (1 << 24,), device=dev, dtype=torch.int32)
+hist_out = torch.zeros(1024, device=dev, dtype=torch.int32)
+f = ctypes.c_float
+n = x.numel()
+CALLS = [  # (tag, substring of the kernel name, algorithmic bytes, callable)
+    ("elementwise_add_f32x4", "add", 3 * n * 4, lambda: so.elementwise_add_f32x4(x.data_ptr(), x2.data_ptr(), y.data_ptr(), n, st())),
+    ("elementwise_add_f16x8_pack", "add", 3 * n * 2, lambda: so.elementwise_add_f16x8_pack(xh.data_ptr(), x2h.data_ptr(), yh.data_ptr(), n, st())),
+    ("block_all_reduce_sum_f32x4_f32", "reduce_sum", n * 4, lambda: so.block_all_reduce_sum_f32x4_f32(x.data_ptr(), z.data_ptr(), n, st())),
+    ("block_all_reduce_sum_f16x8_pack_f32", "reduce_sum", n * 2, lambda: so.block_all_reduce_sum_f16x8_pack_f32(xh.data_ptr(), z.data_ptr(), n, st())),
+    ("safe_softmax_f32x4_per_token", "softmax", 2 * n * 4, lambda: so.safe_softmax_f32x4_per_token(x.data_ptr(), y.data_ptr(), S, K, st())),
+    ("safe_softmax_f16x8_pack_f32_per_token", "softmax", 2 * n * 2, lambda: so.safe_softmax_f16x8_pack_f32_per_token(xh.data_ptr(), yh.data_ptr(), S, K, st())),
+    ("layer_norm_f32x4", "layer_norm", 2 * n * 4, lambda: so.layer_norm_f32x4(x.data_ptr(), y.data_ptr(), f(1.0), f(0.0), S, K, st())),
+    ("layer_norm_f16x8_pack_f32", "layer_norm", 2 * n * 2, lambda: so.layer_norm_f16x8_pack_f32(xh.data_ptr(), yh.data_ptr(), f(1.0), f(0.0), S, K, st())),
+    ("rms_norm_f32x4", "rms_norm", 2 * n * 4, lambda: so.rms_norm_f32x4(x.data_ptr(), y.data_ptr(), f(1.0), S, K, st())),
+    ("rms_norm_f16x8_pack_f32", "rms_norm", 2 * n * 2, lambda: so.rms_norm_f16x8_pack_f32(xh.data_ptr(), yh.data_ptr(), f(1.0), S, K, st())),
+    ("rope_f32x4_pack", "rope", 2 * n * 4, lambda: so.rope_f32x4_pack(x.data_ptr(), y.data_ptr(), S, K, 0, st())),
+    ("gelu_f32x4", "unary", 2 * n * 4, lambda: so.gelu_f32x4(x.data_ptr(), y.data_ptr(), n, st())),
+    ("relu_f16x8_pack", "unary", 2 * n * 2, lambda: so.relu_f16x8_pack(xh.data_ptr(), yh.data_ptr(), n, st())),
+    ("mat_transpose_f32x4_shared_bcf_col2row2d", "tr_lds", 2 * n * 4, lambda: so.mat_transpose_f32x4_shared_bcf_col2row2d(x.data_ptr(), y.data_ptr(), S, K, st())),
+    ("embedding_f32x4_pack", "embedding", 2 * o.numel() * 4, lambda: so.embedding_f32x4_pack(idx.data_ptr(), w.data_ptr(), o.data_ptr(), 4096, 1024, 4096, st())),
+    ("histogram_i32x4", "histogram", hist_in.numel() * 4, lambda: so.histogram_i32x4(hist_in.data_ptr(), hist_out.data_ptr(), hist_in.numel(), 1024, st())),
+]
+order = []
+for tag, sub, nbytes, fn in CALLS:
+    for _ in range(25):
+        rc = fn()
+        assert rc == 0, (tag, rc)
+    torch.cuda.synchronize()
+    order.append({"tag": tag, "kernel_substring": sub, "bytes": nbytes, "launches": 25})
+out = os.environ.get("BW_PROF_ORDER", os.path.join(ROOT, "gpurun_out", "bw_prof_order.json"))
+json.dump(order, open(out, "w"), indent=1)
