@@ -143,18 +143,57 @@ __global__ __launch_bounds__(256, 1) void fa2_fwd_bigd_kernel(const half_t* __re
     const char* vb = kb + G::KTILE;
     if (j + 1 < T) dma_tile(j + 1, (j + 1) & 1);  // its readers (tile j-1) finished before the last barrier
 
-    // ---- S^T = K Q^T (32 keys x 32 queries), one accumulator chain over D/16 k-steps
+    // ---- S^T = K Q^T (32 keys x 32 queries) over D/16 k-steps
     f16v s;
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    auto k_frag = [&](int ks) { return *reinterpret_cast<const h8*>(kb + koff[ks & 7] + (ks >> 3) * 256); };
+    auto v_frag = [&](int idx) {  // idx = st * (DV/32) + b
+      const int st = idx / (DV / 32), b = idx % (DV / 32);
+      // rows 16*st + v_row and + 8 ((row + 8) & 3 == row & 3: same swizzle); 4 output blocks = 256 bytes
+      const char* vp = vb + voff[b & 3] + (16 * st) * G::VROW + (b >> 2) * 256;
+      return h8_cat(lds_read_tr16(vp), lds_read_tr16(vp + 8 * G::VROW));
+    };
+    constexpr int NPV = 2 * (DV / 32);
+    constexpr int PD = 8;  // fragments kept in flight by the prefetching forms (one wave per SIMD: nobody else
+                           // hides the ~128-cycle LDS latency)
+    h8 vpre[PD];
     if constexpr ((OPT & OPT_PRIO) != 0) __builtin_amdgcn_s_setprio(1);
+    if constexpr ((OPT & OPT_KPRE) != 0) {
+      h8 kf[PD];
 #pragma unroll
-    for (int ks = 0; ks < D / 16; ++ks) {
-      const h8 kf = *reinterpret_cast<const h8*>(kb + koff[ks & 7] + (ks >> 3) * 256);
-      s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s, 0, 0, 0);
-      // fence the scheduler every 4 k-steps: without it all D/16 fragment reads are hoisted ahead of the MFMA
-      // chain and the kernel spills (the register file is full by design)
-      if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      for (int i = 0; i < PD; ++i) kf[i] = k_frag(i);
+      f16v s1;
+      if constexpr ((OPT & OPT_STAGGER) != 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s1[r] = 0.f;
+      }
+#pragma unroll
+      for (int ks = 0; ks < D / 16; ++ks) {
+        if ((OPT & OPT_STAGGER) != 0 && (ks & 1)) s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks % PD], qf[ks], s1, 0, 0, 0);
+        else s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks % PD], qf[ks], s, 0, 0, 0);
+        if (ks + PD < D / 16) kf[ks % PD] = k_frag(ks + PD);
+        else if ((OPT & OPT_VPRE) != 0) vpre[ks + PD - D / 16] = v_frag(ks + PD - D / 16);  // V under the QK^T tail
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr ((OPT & OPT_STAGGER) != 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] += s1[r];
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < D / 16; ++ks) {
+        const h8 kf = k_frag(ks);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s, 0, 0, 0);
+        // fence the scheduler every 4 k-steps: without it all D/16 fragment reads are hoisted ahead of the MFMA
+        // chain and the kernel spills (the register file is full by design)
+        if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr ((OPT & OPT_VPRE) != 0) {
+#pragma unroll
+        for (int i = 0; i < PD; ++i) vpre[i] = v_frag(i);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     if constexpr ((OPT & OPT_PRIO) != 0) __builtin_amdgcn_s_setprio(0);
 
@@ -202,15 +241,21 @@ __global__ __launch_bounds__(256, 1) void fa2_fwd_bigd_kernel(const half_t* __re
       l_run += psum;
     }
 
-    // ---- O^T += V^T P^T : 2 k-steps x D/32 output blocks
+    // ---- O^T += V^T P^T : 2 k-steps x DV/32 output blocks
     if constexpr ((OPT & OPT_PRIO) != 0) __builtin_amdgcn_s_setprio(1);
+    if constexpr ((OPT & OPT_VPRE) != 0) {
 #pragma unroll
-    for (int st = 0; st < 2; ++st) {
+      for (int idx = 0; idx < NPV; ++idx) {
+        const int st = idx / (DV / 32), b = idx % (DV / 32);
+        ot[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vpre[idx % PD], pf[st], ot[b], 0, 0, 0);
+        if (idx + PD < NPV) vpre[idx % PD] = v_frag(idx + PD);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
 #pragma unroll
-      for (int b = 0; b < DV / 32; ++b) {
-        // rows 16*st + v_row and + 8 ((row + 8) & 3 == row & 3: same swizzle); 4 output blocks = 256 bytes
-        const char* vp = vb + voff[b & 3] + (16 * st) * G::VROW + (b >> 2) * 256;
-        const h8 vf = h8_cat(lds_read_tr16(vp), lds_read_tr16(vp + 8 * G::VROW));
+      for (int idx = 0; idx < NPV; ++idx) {
+        const int st = idx / (DV / 32), b = idx % (DV / 32);
+        const h8 vf = v_frag(idx);
         ot[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[st], ot[b], 0, 0, 0);
         if ((b & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }

@@ -1,0 +1,255 @@
+// FlashAttention-2 forward for head dim 512 (BASELINE config C5 = [1,32,4096,512]), "d-split ping-pong" form.
+// Reference rungs: kernels/flash-attn/mma/basic/flash_attn_mma_tiling_qkv.cu:70, :732 (and tiling_qk.cu:72): the
+// reference streams Q, K and V in 16-wide d slices through O(1) shared memory. flash_attn_bigd.cuh keeps Q and a
+// 256-wide O^T slice in the register file of ONE wave per SIMD and pays for it with (a) S recomputed per output
+// slice (1.5x the MFMA work), (b) every LDS-DMA issue stall and the whole softmax exposed (nobody else on the SIMD).
+// This kernel splits the head dim across a PAIR of waves instead:
+//   * 8 waves = 4 pairs, a pair owns 32 query rows; wave `part` of a pair holds Q[:, part*256 .. +256) (64
+//     registers) and O^T[part*256 .. +256, :] (128 registers) -> two waves per SIMD, 256 registers each;
+//   * per 32-key tile each wave computes a PARTIAL S^T over its half of d (16 MFMAs), the partners swap partials
+//     through LDS (4 KiB each way) and both run the same softmax on the sum (identical bits: fp32 add commutes),
+//     then each does P.V for its own 256 output columns (16 MFMAs): no recomputation, MFMA work = algorithmic;
+//   * the two 4-wave groups (pairs {0,1} / {2,3}; waves w and w+4 share a SIMD) run ONE PHASE APART, ping-pong
+//     style: while a group is in its softmax + PV phase the other is in QK^T, so each SIMD always has matrix work
+//     from one wave beside the VALU / LDS-DMA work of the other. Two workgroup barriers per tile serve as the phase
+//     clock, the partial-S hand-off and the K/V ring protection at once;
+//   * K tiles are fetched by group 0 and V tiles by group 1 (LDS-DMA, 8 x 1 KiB per wave per tile, interleaved with
+//     the QK^T MFMAs), double-buffered, same source-side XOR swizzles as the big-D kernel.
+#pragma once
+#include "flash_attn_bigd.cuh"
+
+namespace fa2 {
+
+template <int D>
+struct GeoSplit {
+  static constexpr int BC = 32, NW = 8, BR = 128, NT = 512, DH = D / 2;
+  static constexpr int ROW = D * 2;            // bytes per K / V row
+  static constexpr int TILE = BC * ROW;        // one K or V tile
+  static constexpr int STAGE = 2 * TILE;       // K + V
+  static constexpr int RING = 2 * STAGE;
+  static constexpr int SX = NW * 4096;         // partial-S exchange: 4 KiB per wave
+  static constexpr int OS = DH * 2 + 16;
+  static constexpr int EPI = NW * 32 * OS;
+  static constexpr int LDS_BYTES = RING + SX;
+  static constexpr int PPW = TILE / 1024 / 4;  // DMA pieces per wave per tile (4 waves fill one operand)
+  static_assert(D == 512, "d-split kernel: D = 512 (K row = 1 KiB = one DMA piece)");
+  static_assert(EPI <= LDS_BYTES && LDS_BYTES <= 160 * 1024, "LDS");
+};
+
+template <int D, int OPT>
+__global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __restrict__ Q,
+                                                                const half_t* __restrict__ K,
+                                                                const half_t* __restrict__ V, half_t* __restrict__ O,
+                                                                int N, int n_qblk, int n_heads, float scale_log2e) {
+  using G = GeoSplit<D>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int grp = wave >> 2, widx = wave & 3, part = widx & 1, rg = grp * 2 + (widx >> 1);
+
+  int head_i, qb;
+  {
+    const int bid = blockIdx.x;
+    if ((OPT & OPT_XCD) && (n_heads & 7) == 0) {
+      const int xcd = bid & 7, k = bid >> 3;
+      head_i = (k / n_qblk) * 8 + xcd;
+      qb = k - (k / n_qblk) * n_qblk;
+    } else {
+      head_i = bid / n_qblk;
+      qb = bid - head_i * n_qblk;
+    }
+  }
+  const size_t head = (size_t)head_i * N * D;
+  const int q_row0 = qb * G::BR + rg * 32;
+  const unsigned lds0 = hgemm::lds_addr_of(smem);
+
+  // ---- LDS-DMA: wave widx of group 0 fills rows i*4 + widx of the K tile, group 1 the same rows of the V tile.
+  // A row is one 1-KiB piece; lane l carries 16-byte chunk l of the row to LDS chunk position l, reading it from
+  // the source chunk (l ^ swizzle(row)):  K: row & 15 = (i & 3)*4 + widx,   V: (row & 3) << 2 = widx << 2.
+  const char* src_h = reinterpret_cast<const char*>((grp == 0 ? K : V) + head);
+  const unsigned src_lane = grp == 0 ? (unsigned)((lane ^ widx) << 4) : (unsigned)((lane ^ (widx << 2)) << 4);
+  const unsigned kxor = grp == 0 ? 64u : 0u;  // (i & 3) << 6 for K rows, nothing for V rows
+  auto dma_piece = [&](int jt, int slot, int i) {
+    const int row = i * 4 + widx;
+    const char* s = src_h + (size_t)jt * G::TILE + row * G::ROW;
+    hgemm::glds16_asm(s, src_lane ^ ((unsigned)(i & 3) * kxor), lds0 + slot * G::STAGE + grp * G::TILE + row * 1024);
+  };
+
+  // ---- Q fragments: this wave's half of the head dim
+  h8 qf[G::DH / 16];
+  {
+    const half_t* qp = Q + head + (size_t)(q_row0 + l31) * D + part * G::DH + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < G::DH / 16; ++ks) qf[ks] = *reinterpret_cast<const h8*>(qp + ks * 16);
+  }
+  f16v ot[G::DH / 32];
+#pragma unroll
+  for (int b = 0; b < G::DH / 32; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ot[b][r] = 0.f;
+  float m_run = -1.0e30f, l_run = 0.f;
+
+  const int T = N / G::BC;
+#pragma unroll
+  for (int i = 0; i < G::PPW; ++i) dma_piece(0, 0, i);
+  hgemm::wait_vmcnt<0>();  // also covers the Q loads
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  // Lane-constant fragment offsets (see flash_attn_bigd.cuh); this wave reads d columns part*256 .. +256 of K
+  // (k-steps part*16 ..) and of V (output blocks part*8 ..): + part*512 bytes in both images.
+  int koff[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) koff[i] = l31 * G::ROW + (((2 * i + hi) ^ (l31 & 15)) << 4) + part * 512;
+  const int i16 = lane & 15;
+  const int v_row = 4 * hi + (i16 >> 2);
+  int voff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    voff[i] = v_row * G::ROW + ((((i ^ (v_row & 3)) << 2) + (((lane >> 4) & 1) * 2) + ((i16 & 3) >> 1)) << 4) +
+              ((i16 & 1) << 3) + part * 512;
+
+  char* sx_mine = smem + G::RING + wave * 4096 + lane * 16;
+  const char* sx_peer = smem + G::RING + (wave ^ 1) * 4096 + lane * 16;
+
+  if (grp == 1) {  // group 1 runs one phase behind group 0
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+
+  for (int j = 0; j < T; ++j) {
+    const char* kb = smem + (j & 1) * G::STAGE;
+    const char* vb = kb + G::TILE;
+    // ================= phase A: partial S^T = K[:, half] Q[:, half]^T; fetch this group's operand of tile j+1
+    const int jn = j + 1 < T ? j + 1 : T - 1;  // past the end: refill a dead slot with the last tile (branch-free)
+    f16v s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < G::DH / 16; ++ks) {
+      const h8 kf = *reinterpret_cast<const h8*>(kb + koff[ks & 7] + (ks >> 3) * 256);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s, 0, 0, 0);
+      if (ks & 1) dma_piece(jn, (j + 1) & 1, ks >> 1);
+      if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *reinterpret_cast<f4*>(sx_mine + q * 1024) = f4{s[4 * q], s[4 * q + 1], s[4 * q + 2], s[4 * q + 3]};
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the partial is in LDS before the barrier
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    // ================= phase B: S = own + partner's partial, softmax, O^T[half] += V[:, half]^T P^T
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f4 p = *reinterpret_cast<const f4*>(sx_peer + q * 1024);
+      s[4 * q] += p[0], s[4 * q + 1] += p[1], s[4 * q + 2] += p[2], s[4 * q + 3] += p[3];
+    }
+    float mx = s[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+    {
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+      mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
+    const float mxs = mx * scale_log2e;
+    bool grow;
+    if constexpr ((OPT & OPT_DEFER) != 0) grow = (mxs - m_run) > 8.0f;
+    else grow = mxs > m_run;
+    if (__builtin_amdgcn_ballot_w64(grow) != 0) {
+      const float m_new = fmaxf(m_run, mxs);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int b = 0; b < G::DH / 32; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; r += 4) {  // accumulators live in AGPRs: serialise the VGPR round trips
+          float t0 = ot[b][r], t1 = ot[b][r + 1], t2 = ot[b][r + 2], t3 = ot[b][r + 3];
+          asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
+          ot[b][r] = t0 * alpha, ot[b][r + 1] = t1 * alpha, ot[b][r + 2] = t2 * alpha, ot[b][r + 3] = t3 * alpha;
+        }
+    }
+    h8 pf[2];
+    {
+      const float nm = -m_run;
+      float psum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const float a0 = __builtin_amdgcn_exp2f(fmaf(s[r], scale_log2e, nm));
+        const float a1 = __builtin_amdgcn_exp2f(fmaf(s[r + 1], scale_log2e, nm));
+        psum += a0 + a1;
+        const h2 a = __builtin_convertvector(f2{a0, a1}, h2);
+        pf[r >> 3][r & 7] = a[0], pf[r >> 3][(r & 7) + 1] = a[1];
+      }
+      l_run += psum;
+    }
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+#pragma unroll
+      for (int b = 0; b < G::DH / 32; ++b) {
+        const char* vp = vb + voff[b & 3] + (16 * st) * G::ROW + (b >> 2) * 256;
+        const h8 vf = h8_cat(lds_read_tr16(vp), lds_read_tr16(vp + 8 * G::ROW));
+        ot[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[st], ot[b], 0, 0, 0);
+        if ((b & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // own DMA pieces of tile j+1 landed; everyone behind this barrier is done with what the next phase overwrites
+    hgemm::wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+  if (grp == 0) {  // group 1's last phase B: keep the barrier count equal and the ring intact until it is done
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+
+  // ---- epilogue: O = O^T / l, staged through LDS (wave-private rows)
+  float l_tot;
+  {
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
+    l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+  }
+  const float inv = 1.0f / l_tot;
+  char* ob = smem + wave * (32 * G::OS);
+#pragma unroll
+  for (int b = 0; b < G::DH / 32; ++b) {
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      h4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (half_t)(ot[b][rq * 4 + e] * inv);
+      *reinterpret_cast<h4*>(ob + l31 * G::OS + (b * 32 + rq * 8 + hi * 4) * 2) = o;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  constexpr int LPR = G::DH / 8;
+  half_t* og = O + head + (size_t)q_row0 * D + part * G::DH;
+#pragma unroll 4
+  for (int it = 0; it < (32 * LPR) / 64; ++it) {
+    const int idx = it * 64 + lane;
+    const int row = idx / LPR, c = idx % LPR;
+    const u4 v = *reinterpret_cast<const u4*>(ob + row * G::OS + c * 16);
+    *reinterpret_cast<u4*>(og + (size_t)row * D + c * 8) = v;
+  }
+}
+
+template <int D, int OPT>
+int launch_dsplit(const void* q, const void* k, const void* v, void* o, int B, int H, int N, hipStream_t stream) {
+  using G = GeoSplit<D>;
+  if (N % G::BR != 0) return CLN_ERR_UNSUPPORTED;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (cln_set_lds(reinterpret_cast<const void*>(&fa2_fwd_dsplit_kernel<D, OPT>), G::LDS_BYTES) != CLN_OK)
+      return CLN_ERR_LAUNCH;
+    attr_done = true;
+  }
+  const float scale_log2e = 1.4426950408889634f / sqrtf((float)D);
+  const int n_qblk = N / G::BR;
+  CLN_LAUNCH((fa2_fwd_dsplit_kernel<D, OPT>), dim3(n_qblk * B * H), dim3(G::NT), G::LDS_BYTES, stream,
+             (const half_t*)q, (const half_t*)k, (const half_t*)v, (half_t*)o, N, n_qblk, B * H, scale_log2e);
+  return cln_check_launch();
+}
+
+}  // namespace fa2

@@ -2,6 +2,7 @@
 //   int cln_fa2_variant(D, nw, vt, opt, abl, q, k, v, o, B, H, N, stream)
 #include "flash_attn_v3.cuh"
 #include "flash_attn_bigd.cuh"
+#include "flash_attn_dsplit.cuh"
 #include "flash_attn_v4.cuh"
 #include <type_traits>
 
@@ -19,6 +20,11 @@ CLN_API int cln_fa2_variant(int D, int nw, int vt, int opt, int abl, const void*
   V2(64, 8, 525, 0) V2(128, 8, 527, 0) V2(64, 8, 524, 0)
   if (D == 512 && abl == 200) return fa2::launch_bigd<512, 512, 15>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 512 && abl == 201) return fa2::launch_bigd<512, 256, 15>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 512 && abl == 203) return fa2::launch_bigd<512, 256, 15 | fa2::OPT_KPRE>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 512 && abl == 204) return fa2::launch_bigd<512, 256, 15 | fa2::OPT_KPRE | fa2::OPT_VPRE>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 512 && abl == 205) return fa2::launch_bigd<512, 256, 15 | fa2::OPT_KPRE | fa2::OPT_VPRE | fa2::OPT_STAGGER>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 512 && abl == 206) return fa2::launch_bigd<512, 256, 15 | fa2::OPT_VPRE>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 512 && abl == 210) return fa2::launch_dsplit<512, 15>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 512 && abl == 202) return fa2::launch_bigd<512, 128, 15>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 384 && abl == 201) return fa2::launch_bigd<384, 128, 15>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 1024 && abl == 201) return fa2::launch_bigd<1024, 256, 15>(q, k, v, o, B, H, N, (hipStream_t)stream);
