@@ -119,7 +119,12 @@ __global__ __launch_bounds__(256, 1) void fa2_fwd_bigd_kernel(const half_t* __re
 
   const int T = N / G::BC;
   dma_tile(0, 0);
-  hgemm::wait_vmcnt<0>();  // also covers the Q loads
+  // vmcnt(0) through the builtin, not inline asm: the compiler must SEE that the Q loads retired, or it guards every
+  // first use of a Q fragment inside the KV loop with a counted vmcnt that also drains the tile prefetch just issued
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  // ... and pin the fragments here: hipcc otherwise sinks the Q loads below the barrier and into the first KV iteration
+#pragma unroll
+  for (int ks = 0; ks < D / 16; ++ks) asm volatile("" : "+v"(qf[ks]));
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 

@@ -36,7 +36,7 @@ struct GeoSplit {
   static_assert(EPI <= LDS_BYTES && LDS_BYTES <= 160 * 1024, "LDS");
 };
 
-template <int D, int OPT>
+template <int D, int OPT, int ABL = 0>
 __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __restrict__ Q,
                                                                 const half_t* __restrict__ K,
                                                                 const half_t* __restrict__ V, half_t* __restrict__ O,
@@ -93,22 +93,22 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
   const int T = N / G::BC;
 #pragma unroll
   for (int i = 0; i < G::PPW; ++i) dma_piece(0, 0, i);
-  hgemm::wait_vmcnt<0>();  // also covers the Q loads
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), compiler-visible: also retires the Q loads in its bookkeeping
+  // ... and pin the fragments here: hipcc otherwise sinks the Q loads below the barrier and into the first KV iteration
+#pragma unroll
+  for (int ks = 0; ks < G::DH / 16; ++ks) asm volatile("" : "+v"(qf[ks]));
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 
-  // Lane-constant fragment offsets (see flash_attn_bigd.cuh); this wave reads d columns part*256 .. +256 of K
-  // (k-steps part*16 ..) and of V (output blocks part*8 ..): + part*512 bytes in both images.
-  int koff[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) koff[i] = l31 * G::ROW + (((2 * i + hi) ^ (l31 & 15)) << 4) + part * 512;
+  // Fragment offsets (see flash_attn_bigd.cuh for the swizzles); this wave reads d columns part*256 .. +256 of K
+  // (k-steps part*16 ..) and of V (output blocks part*8 ..): + part*512 bytes in both images. The swizzle only
+  // touches bits 5..7 (K) / 6..7 (V) of the byte offset, so fragment i is (one lane constant) ^ (i << 5 | 6) plus a
+  // compile-time immediate: two address registers instead of twelve -- the register file is full by design.
+  const int kbase = l31 * G::ROW + ((hi ^ (l31 & 15)) << 4) + part * 512;
   const int i16 = lane & 15;
   const int v_row = 4 * hi + (i16 >> 2);
-  int voff[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-    voff[i] = v_row * G::ROW + ((((i ^ (v_row & 3)) << 2) + (((lane >> 4) & 1) * 2) + ((i16 & 3) >> 1)) << 4) +
-              ((i16 & 1) << 3) + part * 512;
+  const int vbase = v_row * G::ROW + ((((v_row & 3) << 2) + (((lane >> 4) & 1) * 2) + ((i16 & 3) >> 1)) << 4) +
+                    ((i16 & 1) << 3) + part * 512;
 
   char* sx_mine = smem + G::RING + wave * 4096 + lane * 16;
   const char* sx_peer = smem + G::RING + (wave ^ 1) * 4096 + lane * 16;
@@ -118,21 +118,60 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
     asm volatile("" ::: "memory");
   }
 
+  unsigned long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // ABL & 32: s_memtime at the phase boundaries of tile 16
+  auto mark = [&](int j, int i) {
+    if constexpr ((ABL & 32) != 0)
+      if (j == 16) stamp[i] = __builtin_amdgcn_s_memtime();
+  };
   for (int j = 0; j < T; ++j) {
+    mark(j, 0);
     const char* kb = smem + (j & 1) * G::STAGE;
     const char* vb = kb + G::TILE;
     // ================= phase A: partial S^T = K[:, half] Q[:, half]^T; fetch this group's operand of tile j+1
     const int jn = j + 1 < T ? j + 1 : T - 1;  // past the end: refill a dead slot with the last tile (branch-free)
+    const int kb_j = kbase + (j & 1) * G::STAGE, vb_j = vbase + (j & 1) * G::STAGE + G::TILE;
+    auto k_frag = [&](int ks) {
+      return *reinterpret_cast<const h8*>(smem + (kb_j ^ ((ks & 7) << 5)) + (ks >> 3) * 256);
+    };
+    auto v_frag = [&](int idx) {  // idx = st * 8 + b: rows 16*st + v_row and + 8 (same swizzle), block b
+      const int st = idx / (G::DH / 32), b = idx % (G::DH / 32);
+      const char* vp = smem + (vb_j ^ ((b & 3) << 6)) + (16 * st) * G::ROW + (b >> 2) * 256;
+      return h8_cat(lds_read_tr16(vp), lds_read_tr16(vp + 8 * G::ROW));
+    };
+    constexpr int NK = G::DH / 16, NPV = 2 * (G::DH / 32);
+    constexpr int PD = (OPT & OPT_KPRE) ? 4 : 1;  // fragments in flight ahead of the MFMA that consumes them
     f16v s;
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    {
+      h8 kf[PD];
 #pragma unroll
-    for (int ks = 0; ks < G::DH / 16; ++ks) {
-      const h8 kf = *reinterpret_cast<const h8*>(kb + koff[ks & 7] + (ks >> 3) * 256);
-      s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s, 0, 0, 0);
-      if (ks & 1) dma_piece(jn, (j + 1) & 1, ks >> 1);
-      if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      for (int i = 0; i < PD; ++i) kf[i] = k_frag(i);
+      // Two accumulator chains (OPT_STAGGER): an LDS read or a DMA issue between two MFMAs on the SAME accumulator
+      // costs far more than its issue slot (the dependent MFMA loses its back-to-back forwarding window);
+      // alternating chains puts an independent MFMA in every gap.
+      f16v s1;
+      if constexpr ((OPT & OPT_STAGGER) != 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s1[r] = 0.f;
+      }
+#pragma unroll
+      for (int ks = 0; ks < NK; ++ks) {
+        if (ABL & 16) s[ks] += (float)kf[ks % PD][0];
+        else if ((OPT & OPT_STAGGER) != 0 && (ks & 1))
+          s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks % PD], qf[ks], s1, 0, 0, 0);
+        else s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks % PD], qf[ks], s, 0, 0, 0);
+        if (ks + PD < NK) kf[ks % PD] = k_frag(ks + PD);
+        if ((ks & 1) && !(ABL & 1)) dma_piece(jn, (j + 1) & 1, ks >> 1);
+        if (PD > 1 || (ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr ((OPT & OPT_STAGGER) != 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] += s1[r];
+      }
     }
+    mark(j, 1);
+    if (!(ABL & 4))
 #pragma unroll
     for (int q = 0; q < 4; ++q)
       *reinterpret_cast<f4*>(sx_mine + q * 1024) = f4{s[4 * q], s[4 * q + 1], s[4 * q + 2], s[4 * q + 3]};
@@ -140,12 +179,19 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
+    mark(j, 2);
     // ================= phase B: S = own + partner's partial, softmax, O^T[half] += V[:, half]^T P^T
+    if (!(ABL & 4))
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const f4 p = *reinterpret_cast<const f4*>(sx_peer + q * 1024);
       s[4 * q] += p[0], s[4 * q + 1] += p[1], s[4 * q + 2] += p[2], s[4 * q + 3] += p[3];
     }
+    h8 vf[PD];  // first V fragments fly under the softmax
+#pragma unroll
+    for (int i = 0; i < PD; ++i) vf[i] = v_frag(i);
+    if (PD > 1) __builtin_amdgcn_sched_barrier(0);
+    mark(j, 3);
     float mx = s[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
@@ -177,28 +223,31 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
       float psum = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
-        const float a0 = __builtin_amdgcn_exp2f(fmaf(s[r], scale_log2e, nm));
-        const float a1 = __builtin_amdgcn_exp2f(fmaf(s[r + 1], scale_log2e, nm));
+        const float a0 = (ABL & 2) ? s[r] : __builtin_amdgcn_exp2f(fmaf(s[r], scale_log2e, nm));
+        const float a1 = (ABL & 2) ? s[r + 1] : __builtin_amdgcn_exp2f(fmaf(s[r + 1], scale_log2e, nm));
         psum += a0 + a1;
         const h2 a = __builtin_convertvector(f2{a0, a1}, h2);
         pf[r >> 3][r & 7] = a[0], pf[r >> 3][(r & 7) + 1] = a[1];
       }
       l_run += psum;
     }
+    mark(j, 4);
+    if (!(ABL & 8)) {
 #pragma unroll
-    for (int st = 0; st < 2; ++st) {
-#pragma unroll
-      for (int b = 0; b < G::DH / 32; ++b) {
-        const char* vp = vb + voff[b & 3] + (16 * st) * G::ROW + (b >> 2) * 256;
-        const h8 vf = h8_cat(lds_read_tr16(vp), lds_read_tr16(vp + 8 * G::ROW));
-        ot[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[st], ot[b], 0, 0, 0);
-        if ((b & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      for (int idx = 0; idx < NPV; ++idx) {
+        const int st = idx / (G::DH / 32), b = idx % (G::DH / 32);
+        ot[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[idx % PD], pf[st], ot[b], 0, 0, 0);
+        if (idx + PD < NPV) vf[idx % PD] = v_frag(idx + PD);
+        if (PD > 1 || (idx & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
     }
+    mark(j, 5);
     // own DMA pieces of tile j+1 landed; everyone behind this barrier is done with what the next phase overwrites
     hgemm::wait_vmcnt<0>();
+    mark(j, 6);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    mark(j, 7);
   }
   if (grp == 0) {  // group 1's last phase B: keep the barrier count equal and the ring intact until it is done
     __builtin_amdgcn_s_barrier();
@@ -233,21 +282,28 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
     const u4 v = *reinterpret_cast<const u4*>(ob + row * G::OS + c * 16);
     *reinterpret_cast<u4*>(og + (size_t)row * D + c * 8) = v;
   }
+  if constexpr ((ABL & 32) != 0) {  // probe only: block 0 overwrites the head of O with its 8 x 8 time stamps
+    if (blockIdx.x == 0 && lane == 0) {
+      unsigned long long* dbg = reinterpret_cast<unsigned long long*>(O);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) dbg[wave * 8 + i] = stamp[i];
+    }
+  }
 }
 
-template <int D, int OPT>
+template <int D, int OPT, int ABL = 0>
 int launch_dsplit(const void* q, const void* k, const void* v, void* o, int B, int H, int N, hipStream_t stream) {
   using G = GeoSplit<D>;
   if (N % G::BR != 0) return CLN_ERR_UNSUPPORTED;
   static bool attr_done = false;
   if (!attr_done) {
-    if (cln_set_lds(reinterpret_cast<const void*>(&fa2_fwd_dsplit_kernel<D, OPT>), G::LDS_BYTES) != CLN_OK)
+    if (cln_set_lds(reinterpret_cast<const void*>(&fa2_fwd_dsplit_kernel<D, OPT, ABL>), G::LDS_BYTES) != CLN_OK)
       return CLN_ERR_LAUNCH;
     attr_done = true;
   }
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)D);
   const int n_qblk = N / G::BR;
-  CLN_LAUNCH((fa2_fwd_dsplit_kernel<D, OPT>), dim3(n_qblk * B * H), dim3(G::NT), G::LDS_BYTES, stream,
+  CLN_LAUNCH((fa2_fwd_dsplit_kernel<D, OPT, ABL>), dim3(n_qblk * B * H), dim3(G::NT), G::LDS_BYTES, stream,
              (const half_t*)q, (const half_t*)k, (const half_t*)v, (half_t*)o, N, n_qblk, B * H, scale_log2e);
   return cln_check_launch();
 }

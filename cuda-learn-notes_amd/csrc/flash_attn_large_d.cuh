@@ -6,6 +6,7 @@
 #pragma once
 #include "flash_attn.cuh"
 #include "flash_attn_bigd.cuh"
+#include "flash_attn_dsplit.cuh"
 
 namespace fa {
 inline int launch_fa2_large_d(const void* q, const void* k, const void* v, void* o, int B, int H, int N, int D,
@@ -14,9 +15,10 @@ inline int launch_fa2_large_d(const void* q, const void* k, const void* v, void*
   switch (D) {
     case 320: return launch_fa2<320, 160, 64, false, false>(q, k, v, o, B, H, N, s);
     case 384: return launch_fa2<384, 192, 64, false, false>(q, k, v, o, B, H, N, s);
-    // D = 512 (config C5) and 768: register-resident Q + O-slice kernel, K/V by LDS-DMA (flash_attn_bigd.cuh):
-    // 487 vs 411 TF at [1,32,4096,512], 253 vs 129 TF at [1,8,2048,768] (profiles/r01_fa_bigd_dvsliced_probe.log)
-    case 512: return fa2::launch_bigd<512, 256, fa2::OPT_DEFAULT>(q, k, v, o, B, H, N, s);
+    // D = 512 (config C5): pairs of waves split the head dim, two 4-wave groups one phase apart
+    // (flash_attn_dsplit.cuh): 990-1000 TF at [1,32,4096,512] vs 487 for the register-resident O-slice kernel
+    // (flash_attn_bigd.cuh, still used for D = 768) and 411 for the v1 path (profiles/r01_fa_dsplit_probe.log)
+    case 512: return fa2::launch_dsplit<512, fa2::OPT_DEFAULT>(q, k, v, o, B, H, N, s);
     case 640: return launch_fa2<640, 320, 32, false, false>(q, k, v, o, B, H, N, s);
     case 768: return fa2::launch_bigd<768, 256, fa2::OPT_DEFAULT>(q, k, v, o, B, H, N, s);
     case 1024: return launch_fa2<1024, 256, 32, false, false>(q, k, v, o, B, H, N, s);

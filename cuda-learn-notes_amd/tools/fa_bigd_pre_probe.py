@@ -26,7 +26,7 @@ for (B, H, N, D) in [(1, 32, 4096, 512), (1, 8, 8192, 512)]:
             print("CHK %s %-12s max|err| %.3e" % ((B, H, N, D), tag, (o.float() - ref).abs().max().item()), flush=True)
         except Exception as e:
             print("CHK", tag, "ERR", str(e)[:100], flush=True)
-    for rnd in range(3):
+    for rnd in range(2):
         for tag, fn in cands:
             try:
                 ms, mn, _ = bu.time_call_events(fn, 2, 8)

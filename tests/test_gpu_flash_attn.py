@@ -79,6 +79,23 @@ def test_large_head_dims_tiling(fa, built, dev, oracle, D):
         assert (o.double() - ref).abs().max().item() <= TOL, name
 
 
+@pytest.mark.parametrize("B,H,N", [(1, 1, 128), (2, 3, 384), (1, 8, 1024), (1, 5, 2048)])
+def test_d512_dsplit_kernel_shapes(fa, built, dev, oracle, B, H, N):
+    """D = 512 runs on the d-split ping-pong kernel (flash_attn_dsplit.cuh): one query block / 4 KV tiles, head
+    counts that do and do not divide by the 8 XCDs, odd tile counts, and a long sequence."""
+    q, k, v = seeded(17, B, H, N, 512), seeded(18, B, H, N, 512), seeded(19, B, H, N, 512)
+    ref = oracle.attention_fp64(q, k, v)
+    for name in ("flash_attn_mma_stages_split_q_tiling_qkv", "flash_attn_mma_stages_split_q_tiling_qk_swizzle_q"):
+        o = run(fa, built, name, q, k, v, 2, dev)
+        assert (o.double() - ref).abs().max().item() <= TOL, name
+
+
+def test_d512_rejects_ragged_seqlen(fa, dev):
+    q = torch.zeros(1, 1, 192, 512, dtype=torch.half, device=dev)
+    with pytest.raises(RuntimeError):
+        fa.flash_attn_mma_stages_split_q_tiling_qkv(q, q, q, q.clone(), 1)
+
+
 def test_max_headdim_table_and_unsupported_dims(fa, dev):
     q = torch.zeros(1, 1, 128, 48, dtype=torch.half, device=dev)
     with pytest.raises(RuntimeError, match="headdim not support!"):
@@ -200,7 +217,8 @@ def test_probe_variants_match_production(fa, built, dev, oracle):
     from cuda_learn_notes_amd import host
     for (B, H, N, D, variants) in ((1, 2, 512, 64, [(8, 0, 13, 100), (4, 0, 13, 100), (8, 0, 269, 100), (8, 0, 13, 300), (8, 0, 4109, 0), (8, 0, 3085, 0)]),
                                    (1, 2, 512, 128, [(8, 0, 15, 100), (8, 0, 13, 100), (8, 0, 15, 300), (8, 0, 4111, 0)]),
-                                   (1, 1, 256, 256, [(4, 0, 15, 200)]), (1, 1, 256, 512, [(4, 0, 15, 200), (4, 0, 15, 201)])):
+                                   (1, 1, 256, 256, [(4, 0, 15, 200)]),
+                                   (1, 1, 256, 512, [(4, 0, 15, 200), (4, 0, 15, 201), (4, 0, 15, 204), (4, 0, 15, 210), (4, 0, 15, 220), (4, 0, 15, 221)])):
         q, k, v = seeded(41, B, H, N, D), seeded(42, B, H, N, D), seeded(43, B, H, N, D)
         ref = oracle.attention_fp64(q, k, v)
         for var in variants:
