@@ -43,7 +43,15 @@ int fa2_dispatch(const void* q, const void* k, const void* v, void* o, int B, in
     FA_V2(64, 13)
     FA_V2(96, 15)
     FA_V2(128, 15)
-    case 256:  // needs the whole register file (one wave per SIMD): 4 waves x 32 rows only
+    case 256:
+      // two-group ping-pong kernel (flash_attn_dsplit.cuh, 8 waves x 32 rows, two waves per SIMD): 1000-1180 TF vs
+      // 630-790 for the v2 form below, once there are enough 256-row workgroups to occupy most of the chip
+      // (profiles/r01_fa_dsplit_d256_probe.log)
+      if constexpr (!VT) {
+        if (N % 256 == 0 && bh * (N / 256) >= 192)
+          return fa2::launch_dsplit<256, 1, fa2::OPT_DEFAULT | fa2::OPT_KPRE>(q, k, v, o, B, H, N, s);
+      }
+      // v2 at D = 256 needs the whole register file (one wave per SIMD): 4 waves x 32 rows only
       if (N % 128 == 0) return fa2::launch_v2<256, 4, VT, 15>(q, k, v, o, B, H, N, s);
       return CLN_ERR_UNSUPPORTED;
     default:

@@ -20,33 +20,38 @@
 
 namespace fa2 {
 
-template <int D>
+// NSP = waves sharing one 32-row query group: 2 at D = 512 (each holds half of d), 1 at D = 256 (no split, no
+// exchange: the same two-group phase structure with 8 x 32 = 256 query rows per workgroup).
+template <int D, int NSP>
 struct GeoSplit {
-  static constexpr int BC = 32, NW = 8, BR = 128, NT = 512, DH = D / 2;
+  static constexpr int BC = 32, NW = 8, BR = 32 * NW / NSP, NT = 512, DH = D / NSP;
   static constexpr int ROW = D * 2;            // bytes per K / V row
   static constexpr int TILE = BC * ROW;        // one K or V tile
   static constexpr int STAGE = 2 * TILE;       // K + V
   static constexpr int RING = 2 * STAGE;
-  static constexpr int SX = NW * 4096;         // partial-S exchange: 4 KiB per wave
+  static constexpr int SX = NSP == 2 ? NW * 4096 : 0;  // partial-S exchange: 4 KiB per wave
   static constexpr int OS = DH * 2 + 16;
   static constexpr int EPI = NW * 32 * OS;
-  static constexpr int LDS_BYTES = RING + SX;
+  static constexpr int LDS_BYTES = RING + SX > EPI ? RING + SX : EPI;
   static constexpr int PPW = TILE / 1024 / 4;  // DMA pieces per wave per tile (4 waves fill one operand)
-  static_assert(D == 512, "d-split kernel: D = 512 (K row = 1 KiB = one DMA piece)");
-  static_assert(EPI <= LDS_BYTES && LDS_BYTES <= 160 * 1024, "LDS");
+  static constexpr int RPP = 1024 / ROW;       // rows per 1-KiB DMA piece
+  static constexpr int CPR = ROW / 16;         // 16-byte chunks per row
+  static_assert((D == 512 && NSP == 2) || (D == 256 && NSP == 1), "d-split kernel: DH = 256");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
-template <int D, int OPT, int ABL = 0>
+template <int D, int NSP, int OPT, int ABL = 0>
 __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __restrict__ Q,
                                                                 const half_t* __restrict__ K,
                                                                 const half_t* __restrict__ V, half_t* __restrict__ O,
                                                                 int N, int n_qblk, int n_heads, float scale_log2e) {
-  using G = GeoSplit<D>;
+  using G = GeoSplit<D, NSP>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hi = lane >> 5;
-  const int grp = wave >> 2, widx = wave & 3, part = widx & 1, rg = grp * 2 + (widx >> 1);
+  const int grp = wave >> 2, widx = wave & 3;
+  const int part = NSP == 2 ? (widx & 1) : 0, rg = NSP == 2 ? grp * 2 + (widx >> 1) : wave;
 
   int head_i, qb;
   {
@@ -64,16 +69,19 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
   const int q_row0 = qb * G::BR + rg * 32;
   const unsigned lds0 = hgemm::lds_addr_of(smem);
 
-  // ---- LDS-DMA: wave widx of group 0 fills rows i*4 + widx of the K tile, group 1 the same rows of the V tile.
-  // A row is one 1-KiB piece; lane l carries 16-byte chunk l of the row to LDS chunk position l, reading it from
-  // the source chunk (l ^ swizzle(row)):  K: row & 15 = (i & 3)*4 + widx,   V: (row & 3) << 2 = widx << 2.
+  // ---- LDS-DMA: wave widx of group 0 fills the 1-KiB pieces i*4 + widx of the K tile, group 1 the same pieces of
+  // the V tile. A piece is RPP rows; lane l carries 16-byte chunk c = l % CPR of row (piece*RPP + l / CPR) to the
+  // lane-linear LDS position, reading it from the source chunk (c ^ swizzle(row)):
+  //   K: row & 15 = (i*4*RPP & 15) + widx*RPP + l/CPR (disjoint bits),   V: (row & 3) << 2 = ((widx*RPP + l/CPR) & 3) << 2.
   const char* src_h = reinterpret_cast<const char*>((grp == 0 ? K : V) + head);
-  const unsigned src_lane = grp == 0 ? (unsigned)((lane ^ widx) << 4) : (unsigned)((lane ^ (widx << 2)) << 4);
-  const unsigned kxor = grp == 0 ? 64u : 0u;  // (i & 3) << 6 for K rows, nothing for V rows
+  const int lr = lane / G::CPR, lc = lane % G::CPR, rlow = widx * G::RPP + lr;
+  const unsigned src_lane = (unsigned)(lr * G::ROW) + (grp == 0 ? (unsigned)((lc ^ rlow) << 4) : (unsigned)((lc ^ ((rlow & 3) << 2)) << 4));
+  const unsigned kmask = grp == 0 ? 0xFFu : 0u;  // the i-dependent part of the swizzle applies to K rows only
   auto dma_piece = [&](int jt, int slot, int i) {
-    const int row = i * 4 + widx;
-    const char* s = src_h + (size_t)jt * G::TILE + row * G::ROW;
-    hgemm::glds16_asm(s, src_lane ^ ((unsigned)(i & 3) * kxor), lds0 + slot * G::STAGE + grp * G::TILE + row * 1024);
+    const int piece = i * 4 + widx;
+    const char* s = src_h + (size_t)jt * G::TILE + piece * 1024;
+    hgemm::glds16_asm(s, src_lane ^ ((unsigned)(((i * 4 * G::RPP) & 15) << 4) & kmask),
+                      lds0 + slot * G::STAGE + grp * G::TILE + piece * 1024);
   };
 
   // ---- Q fragments: this wave's half of the head dim
@@ -162,7 +170,7 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
           s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks % PD], qf[ks], s1, 0, 0, 0);
         else s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks % PD], qf[ks], s, 0, 0, 0);
         if (ks + PD < NK) kf[ks % PD] = k_frag(ks + PD);
-        if ((ks & 1) && !(ABL & 1)) dma_piece(jn, (j + 1) & 1, ks >> 1);
+        if (!(ABL & 1) && (ks % (NK / G::PPW)) == NK / G::PPW - 1) dma_piece(jn, (j + 1) & 1, ks / (NK / G::PPW));
         if (PD > 1 || (ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
       if constexpr ((OPT & OPT_STAGGER) != 0) {
@@ -171,7 +179,7 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
       }
     }
     mark(j, 1);
-    if (!(ABL & 4))
+    if constexpr (NSP == 2 && !(ABL & 4))
 #pragma unroll
     for (int q = 0; q < 4; ++q)
       *reinterpret_cast<f4*>(sx_mine + q * 1024) = f4{s[4 * q], s[4 * q + 1], s[4 * q + 2], s[4 * q + 3]};
@@ -181,7 +189,7 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
 
     mark(j, 2);
     // ================= phase B: S = own + partner's partial, softmax, O^T[half] += V[:, half]^T P^T
-    if (!(ABL & 4))
+    if constexpr (NSP == 2 && !(ABL & 4))
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const f4 p = *reinterpret_cast<const f4*>(sx_peer + q * 1024);
@@ -291,19 +299,19 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
   }
 }
 
-template <int D, int OPT, int ABL = 0>
+template <int D, int NSP, int OPT, int ABL = 0>
 int launch_dsplit(const void* q, const void* k, const void* v, void* o, int B, int H, int N, hipStream_t stream) {
-  using G = GeoSplit<D>;
+  using G = GeoSplit<D, NSP>;
   if (N % G::BR != 0) return CLN_ERR_UNSUPPORTED;
   static bool attr_done = false;
   if (!attr_done) {
-    if (cln_set_lds(reinterpret_cast<const void*>(&fa2_fwd_dsplit_kernel<D, OPT, ABL>), G::LDS_BYTES) != CLN_OK)
+    if (cln_set_lds(reinterpret_cast<const void*>(&fa2_fwd_dsplit_kernel<D, NSP, OPT, ABL>), G::LDS_BYTES) != CLN_OK)
       return CLN_ERR_LAUNCH;
     attr_done = true;
   }
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)D);
   const int n_qblk = N / G::BR;
-  CLN_LAUNCH((fa2_fwd_dsplit_kernel<D, OPT, ABL>), dim3(n_qblk * B * H), dim3(G::NT), G::LDS_BYTES, stream,
+  CLN_LAUNCH((fa2_fwd_dsplit_kernel<D, NSP, OPT, ABL>), dim3(n_qblk * B * H), dim3(G::NT), G::LDS_BYTES, stream,
              (const half_t*)q, (const half_t*)k, (const half_t*)v, (half_t*)o, N, n_qblk, B * H, scale_log2e);
   return cln_check_launch();
 }

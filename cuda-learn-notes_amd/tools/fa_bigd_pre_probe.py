@@ -9,17 +9,20 @@ from cuda_learn_notes_amd import bench_utils as bu, host
 dev = torch.device("cuda:0")
 fa = pkg.flash_attn_lib()
 VARIANTS = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "201,203,204,205,206").split(",")]
-for (B, H, N, D) in [(1, 32, 4096, 512), (1, 8, 8192, 512)]:
+SHAPES = [tuple(int(x) for x in s.split(",")) for s in sys.argv[2].split(";")] if len(sys.argv) > 2 else [(1, 32, 4096, 512), (1, 8, 8192, 512)]
+for (B, H, N, D) in SHAPES:
     torch.manual_seed(0)
     q, k, v = (torch.randn(B, H, N, D, dtype=torch.half, device=dev) for _ in range(3))
     o = torch.zeros_like(q)
     ref = F.scaled_dot_product_attention(q.float(), k.float(), v.float())
     fl = bu.mha_flops_conventional(B, H, N, D)
-    prod = fa.flash_attn_mma_stages_split_q_tiling_qkv
-    cands = [("production", lambda: prod(q, k, v, o, 2))]
+    prod = fa.flash_attn_mma_stages_split_q_tiling_qkv if D > 256 else fa.flash_attn_mma_stages_split_q_shared_qkv
+    cands = [("production", lambda: prod(q, k, v, o, 2)), ("sdpa", lambda: F.scaled_dot_product_attention(q, k, v))]
     for a in VARIANTS:
         cands.append(("abl %d" % a, (lambda a: lambda: host.fa2_variant((4, 0, 15, a), q, k, v, o))(a)))
     for tag, fn in cands:
+        if tag == 'sdpa':
+            continue
         o.zero_()
         try:
             fn(); torch.cuda.synchronize()

@@ -90,6 +90,18 @@ def test_d512_dsplit_kernel_shapes(fa, built, dev, oracle, B, H, N):
         assert (o.double() - ref).abs().max().item() <= TOL, name
 
 
+@pytest.mark.parametrize("B,H,N", [(2, 96, 256), (1, 24, 2048), (3, 8, 2048)])
+def test_d256_pingpong_kernel_shapes(fa, built, dev, oracle, B, H, N):
+    """D = 256 with >= 192 workgroups of 256 rows runs on the two-group ping-pong kernel (flash_attn_dsplit.cuh,
+    NSP = 1); head counts that are / are not multiples of 8; one KV-tile-count of 8 and a long one. Checked on
+    a sample of heads against the fp64 oracle."""
+    q, k, v = seeded(27, B, H, N, 256), seeded(28, B, H, N, 256), seeded(29, B, H, N, 256)
+    o = run(fa, built, "flash_attn_mma_stages_split_q_shared_qkv", q, k, v, 2, dev)
+    for (b, h) in ((0, 0), (B - 1, H - 1), (B // 2, H // 3)):
+        ref = oracle.attention_fp64(q[b:b + 1, h:h + 1], k[b:b + 1, h:h + 1], v[b:b + 1, h:h + 1])
+        assert (o[b:b + 1, h:h + 1].double() - ref).abs().max().item() <= TOL, (b, h)
+
+
 def test_d512_rejects_ragged_seqlen(fa, dev):
     q = torch.zeros(1, 1, 192, 512, dtype=torch.half, device=dev)
     with pytest.raises(RuntimeError):
@@ -217,7 +229,7 @@ def test_probe_variants_match_production(fa, built, dev, oracle):
     from cuda_learn_notes_amd import host
     for (B, H, N, D, variants) in ((1, 2, 512, 64, [(8, 0, 13, 100), (4, 0, 13, 100), (8, 0, 269, 100), (8, 0, 13, 300), (8, 0, 4109, 0), (8, 0, 3085, 0)]),
                                    (1, 2, 512, 128, [(8, 0, 15, 100), (8, 0, 13, 100), (8, 0, 15, 300), (8, 0, 4111, 0)]),
-                                   (1, 1, 256, 256, [(4, 0, 15, 200)]),
+                                   (1, 1, 256, 256, [(4, 0, 15, 200), (4, 0, 15, 210), (4, 0, 15, 220)]),
                                    (1, 1, 256, 512, [(4, 0, 15, 200), (4, 0, 15, 201), (4, 0, 15, 204), (4, 0, 15, 210), (4, 0, 15, 220), (4, 0, 15, 221)])):
         q, k, v = seeded(41, B, H, N, D), seeded(42, B, H, N, D), seeded(43, B, H, N, D)
         ref = oracle.attention_fp64(q, k, v)
