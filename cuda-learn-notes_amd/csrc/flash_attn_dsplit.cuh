@@ -20,11 +20,12 @@
 
 namespace fa2 {
 
-// NSP = waves sharing one 32-row query group: 2 at D = 512 (each holds half of d), 1 at D = 256 (no split, no
-// exchange: the same two-group phase structure with 8 x 32 = 256 query rows per workgroup).
-template <int D, int NSP>
+// NSP = waves sharing one 32-row query group: 2 at D = 512 (each holds half of d), 1 at D = 256 / 128 (no split, no
+// exchange: the same two-group phase structure with 8 x 32 = 256 query rows per workgroup). BCB = 32-key blocks per
+// KV tile (2 at D = 128: 16 + 16 MFMAs per wave and tile like the larger head dims).
+template <int D, int NSP, int BCB = 1>
 struct GeoSplit {
-  static constexpr int BC = 32, NW = 8, BR = 32 * NW / NSP, NT = 512, DH = D / NSP;
+  static constexpr int BC = 32 * BCB, NW = 8, BR = 32 * NW / NSP, NT = 512, DH = D / NSP;
   static constexpr int ROW = D * 2;            // bytes per K / V row
   static constexpr int TILE = BC * ROW;        // one K or V tile
   static constexpr int STAGE = 2 * TILE;       // K + V
@@ -36,16 +37,17 @@ struct GeoSplit {
   static constexpr int PPW = TILE / 1024 / 4;  // DMA pieces per wave per tile (4 waves fill one operand)
   static constexpr int RPP = 1024 / ROW;       // rows per 1-KiB DMA piece
   static constexpr int CPR = ROW / 16;         // 16-byte chunks per row
-  static_assert((D == 512 && NSP == 2) || (D == 256 && NSP == 1), "d-split kernel: DH = 256");
+  static_assert((D == 512 && NSP == 2 && BCB == 1) || (D == 256 && NSP == 1 && BCB == 1) || (D == 128 && NSP == 1),
+                "d-split kernel: DH = 256, or 128 with 32- or 64-key tiles");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
-template <int D, int NSP, int OPT, int ABL = 0>
+template <int D, int NSP, int BCB, int OPT, int ABL = 0>
 __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __restrict__ Q,
                                                                 const half_t* __restrict__ K,
                                                                 const half_t* __restrict__ V, half_t* __restrict__ O,
                                                                 int N, int n_qblk, int n_heads, float scale_log2e) {
-  using G = GeoSplit<D, NSP>;
+  using G = GeoSplit<D, NSP, BCB>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -121,6 +123,9 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
   char* sx_mine = smem + G::RING + wave * 4096 + lane * 16;
   const char* sx_peer = smem + G::RING + (wave ^ 1) * 4096 + lane * 16;
 
+  if constexpr ((OPT & OPT_SOLO) != 0) {  // static priority for the younger half (loses every arbitration otherwise)
+    if (grp == 1) __builtin_amdgcn_s_setprio(1);
+  }
   if (grp == 1) {  // group 1 runs one phase behind group 0
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -138,51 +143,41 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
     // ================= phase A: partial S^T = K[:, half] Q[:, half]^T; fetch this group's operand of tile j+1
     const int jn = j + 1 < T ? j + 1 : T - 1;  // past the end: refill a dead slot with the last tile (branch-free)
     const int kb_j = kbase + (j & 1) * G::STAGE, vb_j = vbase + (j & 1) * G::STAGE + G::TILE;
-    auto k_frag = [&](int ks) {
-      return *reinterpret_cast<const h8*>(smem + (kb_j ^ ((ks & 7) << 5)) + (ks >> 3) * 256);
+    auto k_frag = [&](int t) {  // keys (t % BCB)*32 + l31, k-step t / BCB
+      const int ks = t / BCB;
+      return *reinterpret_cast<const h8*>(smem + (kb_j ^ ((ks & 7) << 5)) + (ks >> 3) * 256 + (t % BCB) * 32 * G::ROW);
     };
-    auto v_frag = [&](int idx) {  // idx = st * 8 + b: rows 16*st + v_row and + 8 (same swizzle), block b
+    auto v_frag = [&](int idx) {  // idx = st * (DH/32) + b: rows 16*st + v_row and + 8 (same swizzle), block b
       const int st = idx / (G::DH / 32), b = idx % (G::DH / 32);
       const char* vp = smem + (vb_j ^ ((b & 3) << 6)) + (16 * st) * G::ROW + (b >> 2) * 256;
       return h8_cat(lds_read_tr16(vp), lds_read_tr16(vp + 8 * G::ROW));
     };
-    constexpr int NK = G::DH / 16, NPV = 2 * (G::DH / 32);
+    constexpr int NK = G::DH / 16, NQK = BCB * NK, NPV = 2 * BCB * (G::DH / 32);
     constexpr int PD = (OPT & OPT_KPRE) ? 4 : 1;  // fragments in flight ahead of the MFMA that consumes them
-    f16v s;
+    f16v s[BCB];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    for (int kb2 = 0; kb2 < BCB; ++kb2)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kb2][r] = 0.f;
     {
+      // MFMA t works on k-step t / BCB of key block t % BCB (consecutive MFMAs alternate accumulators at BCB = 2)
       h8 kf[PD];
 #pragma unroll
       for (int i = 0; i < PD; ++i) kf[i] = k_frag(i);
-      // Two accumulator chains (OPT_STAGGER): an LDS read or a DMA issue between two MFMAs on the SAME accumulator
-      // costs far more than its issue slot (the dependent MFMA loses its back-to-back forwarding window);
-      // alternating chains puts an independent MFMA in every gap.
-      f16v s1;
-      if constexpr ((OPT & OPT_STAGGER) != 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s1[r] = 0.f;
-      }
-#pragma unroll
-      for (int ks = 0; ks < NK; ++ks) {
-        if (ABL & 16) s[ks] += (float)kf[ks % PD][0];
-        else if ((OPT & OPT_STAGGER) != 0 && (ks & 1))
-          s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks % PD], qf[ks], s1, 0, 0, 0);
-        else s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks % PD], qf[ks], s, 0, 0, 0);
-        if (ks + PD < NK) kf[ks % PD] = k_frag(ks + PD);
-        if (!(ABL & 1) && (ks % (NK / G::PPW)) == NK / G::PPW - 1) dma_piece(jn, (j + 1) & 1, ks / (NK / G::PPW));
-        if (PD > 1 || (ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-      }
-      if constexpr ((OPT & OPT_STAGGER) != 0) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] += s1[r];
+      for (int t = 0; t < NQK; ++t) {
+        if (ABL & 16) s[t % BCB][t / BCB] += (float)kf[t % PD][0];
+        else s[t % BCB] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[t % PD], qf[t / BCB], s[t % BCB], 0, 0, 0);
+        if (t + PD < NQK) kf[t % PD] = k_frag(t + PD);
+        if (!(ABL & 1) && (t % (NQK / G::PPW)) == NQK / G::PPW - 1) dma_piece(jn, (j + 1) & 1, t / (NQK / G::PPW));
+        if (PD > 1 || (t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
     }
     mark(j, 1);
     if constexpr (NSP == 2 && !(ABL & 4))
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-      *reinterpret_cast<f4*>(sx_mine + q * 1024) = f4{s[4 * q], s[4 * q + 1], s[4 * q + 2], s[4 * q + 3]};
+      *reinterpret_cast<f4*>(sx_mine + q * 1024) = f4{s[0][4 * q], s[0][4 * q + 1], s[0][4 * q + 2], s[0][4 * q + 3]};
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the partial is in LDS before the barrier
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -193,16 +188,18 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const f4 p = *reinterpret_cast<const f4*>(sx_peer + q * 1024);
-      s[4 * q] += p[0], s[4 * q + 1] += p[1], s[4 * q + 2] += p[2], s[4 * q + 3] += p[3];
+      s[0][4 * q] += p[0], s[0][4 * q + 1] += p[1], s[0][4 * q + 2] += p[2], s[0][4 * q + 3] += p[3];
     }
     h8 vf[PD];  // first V fragments fly under the softmax
 #pragma unroll
     for (int i = 0; i < PD; ++i) vf[i] = v_frag(i);
     if (PD > 1) __builtin_amdgcn_sched_barrier(0);
     mark(j, 3);
-    float mx = s[0];
+    float mx = s[0][0];
 #pragma unroll
-    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+    for (int kb2 = 0; kb2 < BCB; ++kb2)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb2][r]);
     {
       const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
       mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
@@ -225,18 +222,20 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
           ot[b][r] = t0 * alpha, ot[b][r + 1] = t1 * alpha, ot[b][r + 2] = t2 * alpha, ot[b][r + 3] = t3 * alpha;
         }
     }
-    h8 pf[2];
+    h8 pf[2 * BCB];
     {
       const float nm = -m_run;
       float psum = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        const float a0 = (ABL & 2) ? s[r] : __builtin_amdgcn_exp2f(fmaf(s[r], scale_log2e, nm));
-        const float a1 = (ABL & 2) ? s[r + 1] : __builtin_amdgcn_exp2f(fmaf(s[r + 1], scale_log2e, nm));
-        psum += a0 + a1;
-        const h2 a = __builtin_convertvector(f2{a0, a1}, h2);
-        pf[r >> 3][r & 7] = a[0], pf[r >> 3][(r & 7) + 1] = a[1];
-      }
+      for (int kb2 = 0; kb2 < BCB; ++kb2)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const float a0 = (ABL & 2) ? s[kb2][r] : __builtin_amdgcn_exp2f(fmaf(s[kb2][r], scale_log2e, nm));
+          const float a1 = (ABL & 2) ? s[kb2][r + 1] : __builtin_amdgcn_exp2f(fmaf(s[kb2][r + 1], scale_log2e, nm));
+          psum += a0 + a1;
+          const h2 a = __builtin_convertvector(f2{a0, a1}, h2);
+          pf[kb2 * 2 + (r >> 3)][r & 7] = a[0], pf[kb2 * 2 + (r >> 3)][(r & 7) + 1] = a[1];
+        }
       l_run += psum;
     }
     mark(j, 4);
@@ -299,19 +298,19 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
   }
 }
 
-template <int D, int NSP, int OPT, int ABL = 0>
+template <int D, int NSP, int BCB, int OPT, int ABL = 0>
 int launch_dsplit(const void* q, const void* k, const void* v, void* o, int B, int H, int N, hipStream_t stream) {
-  using G = GeoSplit<D, NSP>;
+  using G = GeoSplit<D, NSP, BCB>;
   if (N % G::BR != 0) return CLN_ERR_UNSUPPORTED;
   static bool attr_done = false;
   if (!attr_done) {
-    if (cln_set_lds(reinterpret_cast<const void*>(&fa2_fwd_dsplit_kernel<D, NSP, OPT, ABL>), G::LDS_BYTES) != CLN_OK)
+    if (cln_set_lds(reinterpret_cast<const void*>(&fa2_fwd_dsplit_kernel<D, NSP, BCB, OPT, ABL>), G::LDS_BYTES) != CLN_OK)
       return CLN_ERR_LAUNCH;
     attr_done = true;
   }
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)D);
   const int n_qblk = N / G::BR;
-  CLN_LAUNCH((fa2_fwd_dsplit_kernel<D, NSP, OPT, ABL>), dim3(n_qblk * B * H), dim3(G::NT), G::LDS_BYTES, stream,
+  CLN_LAUNCH((fa2_fwd_dsplit_kernel<D, NSP, BCB, OPT, ABL>), dim3(n_qblk * B * H), dim3(G::NT), G::LDS_BYTES, stream,
              (const half_t*)q, (const half_t*)k, (const half_t*)v, (half_t*)o, N, n_qblk, B * H, scale_log2e);
   return cln_check_launch();
 }

@@ -18,7 +18,7 @@ inline int launch_fa2_large_d(const void* q, const void* k, const void* v, void*
     // D = 512 (config C5): pairs of waves split the head dim, two 4-wave groups one phase apart
     // (flash_attn_dsplit.cuh): 990-1000 TF at [1,32,4096,512] vs 487 for the register-resident O-slice kernel
     // (flash_attn_bigd.cuh, still used for D = 768) and 411 for the v1 path (profiles/r01_fa_dsplit_probe.log)
-    case 512: return fa2::launch_dsplit<512, 2, fa2::OPT_DEFAULT>(q, k, v, o, B, H, N, s);
+    case 512: return fa2::launch_dsplit<512, 2, 1, fa2::OPT_DEFAULT>(q, k, v, o, B, H, N, s);
     case 640: return launch_fa2<640, 320, 32, false, false>(q, k, v, o, B, H, N, s);
     case 768: return fa2::launch_bigd<768, 256, fa2::OPT_DEFAULT>(q, k, v, o, B, H, N, s);
     case 1024: return launch_fa2<1024, 256, 32, false, false>(q, k, v, o, B, H, N, s);

@@ -24,22 +24,25 @@ CLN_API int cln_fa2_variant(int D, int nw, int vt, int opt, int abl, const void*
   if (D == 512 && abl == 204) return fa2::launch_bigd<512, 256, 15 | fa2::OPT_KPRE | fa2::OPT_VPRE>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 512 && abl == 205) return fa2::launch_bigd<512, 256, 15 | fa2::OPT_KPRE | fa2::OPT_VPRE | fa2::OPT_STAGGER>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 512 && abl == 206) return fa2::launch_bigd<512, 256, 15 | fa2::OPT_VPRE>(q, k, v, o, B, H, N, (hipStream_t)stream);
-  if (D == 512 && abl == 210) return fa2::launch_dsplit<512, 2, 15>(q, k, v, o, B, H, N, (hipStream_t)stream);
-  if (D == 512 && abl == 220) return fa2::launch_dsplit<512, 2, 15 | fa2::OPT_KPRE>(q, k, v, o, B, H, N, (hipStream_t)stream);
-  if (D == 512 && abl == 242) return fa2::launch_dsplit<512, 2, 15, 32>(q, k, v, o, B, H, N, (hipStream_t)stream);
-  if (D == 512 && abl == 243) return fa2::launch_dsplit<512, 2, 15 | fa2::OPT_KPRE, 32>(q, k, v, o, B, H, N, (hipStream_t)stream);
-  if (D == 512 && abl == 221) return fa2::launch_dsplit<512, 2, 15 | fa2::OPT_STAGGER>(q, k, v, o, B, H, N, (hipStream_t)stream);
-  if (D == 512 && abl == 222) return fa2::launch_dsplit<512, 2, 15 | fa2::OPT_STAGGER | fa2::OPT_KPRE>(q, k, v, o, B, H, N, (hipStream_t)stream);
-  if (D == 512 && abl == 244) return fa2::launch_dsplit<512, 2, 15 | fa2::OPT_STAGGER, 32>(q, k, v, o, B, H, N, (hipStream_t)stream);
-  if (D == 512 && abl == 211) return fa2::launch_dsplit<512, 2, 15, 1>(q, k, v, o, B, H, N, (hipStream_t)stream);
-  if (D == 512 && abl == 212) return fa2::launch_dsplit<512, 2, 15, 2>(q, k, v, o, B, H, N, (hipStream_t)stream);
-  if (D == 512 && abl == 214) return fa2::launch_dsplit<512, 2, 15, 4>(q, k, v, o, B, H, N, (hipStream_t)stream);
-  if (D == 512 && abl == 218) return fa2::launch_dsplit<512, 2, 15, 8>(q, k, v, o, B, H, N, (hipStream_t)stream);
-  if (D == 512 && abl == 226) return fa2::launch_dsplit<512, 2, 15, 16>(q, k, v, o, B, H, N, (hipStream_t)stream);
-  if (D == 512 && abl == 234) return fa2::launch_dsplit<512, 2, 15, 24>(q, k, v, o, B, H, N, (hipStream_t)stream);
-  if (D == 512 && abl == 241) return fa2::launch_dsplit<512, 2, 15, 31>(q, k, v, o, B, H, N, (hipStream_t)stream);
-  if (D == 256 && abl == 210) return fa2::launch_dsplit<256, 1, 15>(q, k, v, o, B, H, N, (hipStream_t)stream);
-  if (D == 256 && abl == 220) return fa2::launch_dsplit<256, 1, 15 | fa2::OPT_KPRE>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 512 && abl == 210) return fa2::launch_dsplit<512, 2, 1, 15>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 512 && abl == 220) return fa2::launch_dsplit<512, 2, 1, 15 | fa2::OPT_KPRE>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 512 && abl == 242) return fa2::launch_dsplit<512, 2, 1, 15, 32>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 512 && abl == 243) return fa2::launch_dsplit<512, 2, 1, 15 | fa2::OPT_KPRE, 32>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 512 && abl == 223) return fa2::launch_dsplit<512, 2, 1, 15 | fa2::OPT_SOLO>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 256 && abl == 223) return fa2::launch_dsplit<256, 1, 1, 15 | fa2::OPT_KPRE | fa2::OPT_SOLO>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 128 && abl == 210) return fa2::launch_dsplit<128, 1, 1, 15>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 128 && abl == 220) return fa2::launch_dsplit<128, 1, 1, 15 | fa2::OPT_KPRE>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 128 && abl == 230) return fa2::launch_dsplit<128, 1, 2, 15>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 128 && abl == 231) return fa2::launch_dsplit<128, 1, 2, 15 | fa2::OPT_KPRE>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 512 && abl == 211) return fa2::launch_dsplit<512, 2, 1, 15, 1>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 512 && abl == 212) return fa2::launch_dsplit<512, 2, 1, 15, 2>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 512 && abl == 214) return fa2::launch_dsplit<512, 2, 1, 15, 4>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 512 && abl == 218) return fa2::launch_dsplit<512, 2, 1, 15, 8>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 512 && abl == 226) return fa2::launch_dsplit<512, 2, 1, 15, 16>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 512 && abl == 234) return fa2::launch_dsplit<512, 2, 1, 15, 24>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 512 && abl == 241) return fa2::launch_dsplit<512, 2, 1, 15, 31>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 256 && abl == 210) return fa2::launch_dsplit<256, 1, 1, 15>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 256 && abl == 220) return fa2::launch_dsplit<256, 1, 1, 15 | fa2::OPT_KPRE>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 512 && abl == 202) return fa2::launch_bigd<512, 128, 15>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 384 && abl == 201) return fa2::launch_bigd<384, 128, 15>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 1024 && abl == 201) return fa2::launch_bigd<1024, 256, 15>(q, k, v, o, B, H, N, (hipStream_t)stream);

@@ -102,6 +102,16 @@ def test_d256_pingpong_kernel_shapes(fa, built, dev, oracle, B, H, N):
         assert (o[b:b + 1, h:h + 1].double() - ref).abs().max().item() <= TOL, (b, h)
 
 
+@pytest.mark.parametrize("B,H,N", [(2, 96, 256), (1, 24, 2048), (3, 8, 2048), (1, 7, 8192)])
+def test_d128_pingpong_kernel_shapes(fa, built, dev, oracle, B, H, N):
+    """D = 128 with >= 192 workgroups of 256 rows runs on the ping-pong kernel with 64-key tiles (BCB = 2)."""
+    q, k, v = seeded(37, B, H, N, 128), seeded(38, B, H, N, 128), seeded(39, B, H, N, 128)
+    o = run(fa, built, "flash_attn_mma_stages_split_q_shared_qkv", q, k, v, 2, dev)
+    for (b, h) in ((0, 0), (B - 1, H - 1), (B // 2, H // 3)):
+        ref = oracle.attention_fp64(q[b:b + 1, h:h + 1], k[b:b + 1, h:h + 1], v[b:b + 1, h:h + 1])
+        assert (o[b:b + 1, h:h + 1].double() - ref).abs().max().item() <= TOL, (b, h)
+
+
 def test_d512_rejects_ragged_seqlen(fa, dev):
     q = torch.zeros(1, 1, 192, 512, dtype=torch.half, device=dev)
     with pytest.raises(RuntimeError):
@@ -228,9 +238,9 @@ def test_probe_variants_match_production(fa, built, dev, oracle):
     they must agree with the oracle like the shipped v2 kernel does."""
     from cuda_learn_notes_amd import host
     for (B, H, N, D, variants) in ((1, 2, 512, 64, [(8, 0, 13, 100), (4, 0, 13, 100), (8, 0, 269, 100), (8, 0, 13, 300), (8, 0, 4109, 0), (8, 0, 3085, 0)]),
-                                   (1, 2, 512, 128, [(8, 0, 15, 100), (8, 0, 13, 100), (8, 0, 15, 300), (8, 0, 4111, 0)]),
+                                   (1, 2, 512, 128, [(8, 0, 15, 100), (8, 0, 13, 100), (8, 0, 15, 300), (8, 0, 4111, 0), (8, 0, 15, 210), (8, 0, 15, 230), (8, 0, 15, 231)]),
                                    (1, 1, 256, 256, [(4, 0, 15, 200), (4, 0, 15, 210), (4, 0, 15, 220)]),
-                                   (1, 1, 256, 512, [(4, 0, 15, 200), (4, 0, 15, 201), (4, 0, 15, 204), (4, 0, 15, 210), (4, 0, 15, 220), (4, 0, 15, 221)])):
+                                   (1, 1, 256, 512, [(4, 0, 15, 200), (4, 0, 15, 201), (4, 0, 15, 204), (4, 0, 15, 210), (4, 0, 15, 220)])):
         q, k, v = seeded(41, B, H, N, D), seeded(42, B, H, N, D), seeded(43, B, H, N, D)
         ref = oracle.attention_fp64(q, k, v)
         for var in variants:
