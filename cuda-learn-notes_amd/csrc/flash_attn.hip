@@ -38,14 +38,17 @@ int fa2_dispatch(const void* q, const void* k, const void* v, void* o, int B, in
     if (nw == 8) return fa2::launch_v2<DD, 8, VT, OPTT>(q, k, v, o, B, H, N, s);                   \
     if (nw == 4) return fa2::launch_v2<DD, 4, VT, OPTT>(q, k, v, o, B, H, N, s);                   \
     return fa2::launch_v2<DD, 2, VT, OPTT>(q, k, v, o, B, H, N, s);
-  // Head dims 128 / 256 with enough 256-row workgroups to occupy most of the chip: two-group ping-pong kernel
+  // Head dims 64 / 128 / 256 with enough 256-row workgroups to occupy most of the chip: two-group ping-pong kernel
   // (flash_attn_dsplit.cuh: 8 waves x 32 rows, K/V by LDS-DMA, the two 4-wave groups one phase apart).
   // D = 256: 1000-1180 TF vs 630-790 for v2 (which needs one wave per SIMD there); D = 128: 970-1100 vs 900-1045
-  // (profiles/r01_fa_dsplit_d256_probe.log, r01_fa_dsplit_d128_probe.log).
+  // (profiles/r01_fa_dsplit_d256_probe.log, r01_fa_dsplit_d128_probe.log, r01_fa_dsplit_d64_probe.log).
   if constexpr (!VT) {
     if (N % 256 == 0 && bh * (N / 256) >= 192) {
       if (D == 256) return fa2::launch_dsplit<256, 1, 1, fa2::OPT_DEFAULT | fa2::OPT_KPRE>(q, k, v, o, B, H, N, s);
       if (D == 128) return fa2::launch_dsplit<128, 1, 2, fa2::OPT_DEFAULT | fa2::OPT_KPRE>(q, k, v, o, B, H, N, s);
+      // D = 64 (config C4): 128-key tiles, half of the exponentials moved into the QK^T phase (OPT_STAGGER):
+      // 730-775 TF at [4,8,2048,64] vs 620-665 for v2, 950 vs 915-940 at [1,48,8192,64]
+      if (D == 64) return fa2::launch_dsplit<64, 1, 4, 13 | fa2::OPT_STAGGER>(q, k, v, o, B, H, N, s);
     }
   }
   switch (D) {

@@ -37,8 +37,15 @@ struct GeoSplit {
   static constexpr int PPW = TILE / 1024 / 4;  // DMA pieces per wave per tile (4 waves fill one operand)
   static constexpr int RPP = 1024 / ROW;       // rows per 1-KiB DMA piece
   static constexpr int CPR = ROW / 16;         // 16-byte chunks per row
-  static_assert((D == 512 && NSP == 2 && BCB == 1) || (D == 256 && NSP == 1 && BCB == 1) || (D == 128 && NSP == 1),
-                "d-split kernel: DH = 256, or 128 with 32- or 64-key tiles");
+  static_assert((D == 512 && NSP == 2 && BCB == 1) || (D == 256 && NSP == 1 && BCB == 1) || (D == 128 && NSP == 1) ||
+                    (D == 64 && NSP == 1 && BCB >= 2),
+                "d-split kernel: DH = 256, 128 with 32- or 64-key tiles, 64 with 64- or 128-key tiles");
+  // XOR swizzles of the 16-byte chunk index (LDS images are lane-linear, so the swizzle is applied to the DMA source
+  // address and to the fragment read). Rows of >= 256 bytes: K chunk ^= row & 15, V chunk ^= (row & 3) << 2
+  // (flash_attn_bigd.cuh). 128-byte rows (D = 64): two rows span the 64 banks, so K uses (row >> 1) & 7 and V moves
+  // the 64-byte block by (row >> 1) & 1.
+  static __device__ __forceinline__ int swz_k(int row) { return CPR >= 16 ? (row & 15) : ((row >> 1) & 7); }
+  static __device__ __forceinline__ int swz_v(int row) { return CPR >= 16 ? ((row & 3) << 2) : (((row >> 1) & 1) << 2); }
   static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
@@ -77,7 +84,7 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
   //   K: row & 15 = (i*4*RPP & 15) + widx*RPP + l/CPR (disjoint bits),   V: (row & 3) << 2 = ((widx*RPP + l/CPR) & 3) << 2.
   const char* src_h = reinterpret_cast<const char*>((grp == 0 ? K : V) + head);
   const int lr = lane / G::CPR, lc = lane % G::CPR, rlow = widx * G::RPP + lr;
-  const unsigned src_lane = (unsigned)(lr * G::ROW) + (grp == 0 ? (unsigned)((lc ^ rlow) << 4) : (unsigned)((lc ^ ((rlow & 3) << 2)) << 4));
+  const unsigned src_lane = (unsigned)(lr * G::ROW) + (grp == 0 ? (unsigned)((lc ^ G::swz_k(rlow)) << 4) : (unsigned)((lc ^ G::swz_v(rlow)) << 4));
   const unsigned kmask = grp == 0 ? 0xFFu : 0u;  // the i-dependent part of the swizzle applies to K rows only
   auto dma_piece = [&](int jt, int slot, int i) {
     const int piece = i * 4 + widx;
@@ -114,10 +121,10 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
   // (k-steps part*16 ..) and of V (output blocks part*8 ..): + part*512 bytes in both images. The swizzle only
   // touches bits 5..7 (K) / 6..7 (V) of the byte offset, so fragment i is (one lane constant) ^ (i << 5 | 6) plus a
   // compile-time immediate: two address registers instead of twelve -- the register file is full by design.
-  const int kbase = l31 * G::ROW + ((hi ^ (l31 & 15)) << 4) + part * 512;
+  const int kbase = l31 * G::ROW + ((hi ^ G::swz_k(l31)) << 4) + part * 512;
   const int i16 = lane & 15;
   const int v_row = 4 * hi + (i16 >> 2);
-  const int vbase = v_row * G::ROW + ((((v_row & 3) << 2) + (((lane >> 4) & 1) * 2) + ((i16 & 3) >> 1)) << 4) +
+  const int vbase = v_row * G::ROW + ((G::swz_v(v_row) + (((lane >> 4) & 1) * 2) + ((i16 & 3) >> 1)) << 4) +
                     ((i16 & 1) << 3) + part * 512;
 
   char* sx_mine = smem + G::RING + wave * 4096 + lane * 16;
@@ -174,6 +181,62 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
       }
     }
     mark(j, 1);
+    // ---- softmax pieces. The P^T fragment of k-step u (16 keys) comes from accumulator registers
+    // s[u / 2][(u & 1) * 8 .. + 8]; the 2*BCB fragments are produced in two halves.
+    // SPLIT (OPT_STAGGER, NSP = 1 only): row max, rescale decision and the FIRST half of the exponentials run in
+    // phase A behind the QK^T MFMAs, the second half in phase B between the two halves of the PV MFMAs -- phase A is
+    // otherwise matrix-only and short, and the partner group idles at the barrier for the length of the softmax.
+    constexpr bool SPLIT = NSP == 1 && (OPT & OPT_STAGGER) != 0;
+    h8 pf[2 * BCB];
+    auto row_max_and_rescale = [&]() {
+      float mx = s[0][0];
+#pragma unroll
+      for (int kb2 = 0; kb2 < BCB; ++kb2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb2][r]);
+      {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+        mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+      }
+      const float mxs = mx * scale_log2e;
+      bool grow;
+      if constexpr ((OPT & OPT_DEFER) != 0) grow = (mxs - m_run) > 8.0f;
+      else grow = mxs > m_run;
+      if (__builtin_amdgcn_ballot_w64(grow) != 0) {
+        const float m_new = fmaxf(m_run, mxs);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        l_run *= alpha;
+#pragma unroll
+        for (int b = 0; b < G::DH / 32; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; r += 4) {  // serialise the register round trips of the rescale
+            float t0 = ot[b][r], t1 = ot[b][r + 1], t2 = ot[b][r + 2], t3 = ot[b][r + 3];
+            asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
+            ot[b][r] = t0 * alpha, ot[b][r + 1] = t1 * alpha, ot[b][r + 2] = t2 * alpha, ot[b][r + 3] = t3 * alpha;
+          }
+      }
+    };
+    auto p_half = [&](int h) {  // fragments u = h*BCB .. (h+1)*BCB - 1
+      const float nm = -m_run;
+      float psum = 0.f;
+#pragma unroll
+      for (int u = h * BCB; u < (h + 1) * BCB; ++u)
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          const int kb2 = u >> 1, r = (u & 1) * 8 + e;
+          const float a0 = (ABL & 2) ? s[kb2][r] : __builtin_amdgcn_exp2f(fmaf(s[kb2][r], scale_log2e, nm));
+          const float a1 = (ABL & 2) ? s[kb2][r + 1] : __builtin_amdgcn_exp2f(fmaf(s[kb2][r + 1], scale_log2e, nm));
+          psum += a0 + a1;
+          const h2 a = __builtin_convertvector(f2{a0, a1}, h2);
+          pf[u][e] = a[0], pf[u][e + 1] = a[1];
+        }
+      l_run += psum;
+    };
+    if constexpr (SPLIT) {
+      row_max_and_rescale();
+      p_half(0);
+    }
     if constexpr (NSP == 2 && !(ABL & 4))
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -195,58 +258,30 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
     for (int i = 0; i < PD; ++i) vf[i] = v_frag(i);
     if (PD > 1) __builtin_amdgcn_sched_barrier(0);
     mark(j, 3);
-    float mx = s[0][0];
-#pragma unroll
-    for (int kb2 = 0; kb2 < BCB; ++kb2)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb2][r]);
-    {
-      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-      mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-    }
-    const float mxs = mx * scale_log2e;
-    bool grow;
-    if constexpr ((OPT & OPT_DEFER) != 0) grow = (mxs - m_run) > 8.0f;
-    else grow = mxs > m_run;
-    if (__builtin_amdgcn_ballot_w64(grow) != 0) {
-      const float m_new = fmaxf(m_run, mxs);
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-      m_run = m_new;
-      l_run *= alpha;
-#pragma unroll
-      for (int b = 0; b < G::DH / 32; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; r += 4) {  // accumulators live in AGPRs: serialise the VGPR round trips
-          float t0 = ot[b][r], t1 = ot[b][r + 1], t2 = ot[b][r + 2], t3 = ot[b][r + 3];
-          asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
-          ot[b][r] = t0 * alpha, ot[b][r + 1] = t1 * alpha, ot[b][r + 2] = t2 * alpha, ot[b][r + 3] = t3 * alpha;
-        }
-    }
-    h8 pf[2 * BCB];
-    {
-      const float nm = -m_run;
-      float psum = 0.f;
-#pragma unroll
-      for (int kb2 = 0; kb2 < BCB; ++kb2)
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          const float a0 = (ABL & 2) ? s[kb2][r] : __builtin_amdgcn_exp2f(fmaf(s[kb2][r], scale_log2e, nm));
-          const float a1 = (ABL & 2) ? s[kb2][r + 1] : __builtin_amdgcn_exp2f(fmaf(s[kb2][r + 1], scale_log2e, nm));
-          psum += a0 + a1;
-          const h2 a = __builtin_convertvector(f2{a0, a1}, h2);
-          pf[kb2 * 2 + (r >> 3)][r & 7] = a[0], pf[kb2 * 2 + (r >> 3)][(r & 7) + 1] = a[1];
-        }
-      l_run += psum;
+    if constexpr (!SPLIT) {
+      row_max_and_rescale();
+      p_half(0);
+      p_half(1);
     }
     mark(j, 4);
-    if (!(ABL & 8)) {
+    auto pv_range = [&](int i0, int i1) {
+      if (!(ABL & 8)) {
 #pragma unroll
-      for (int idx = 0; idx < NPV; ++idx) {
-        const int st = idx / (G::DH / 32), b = idx % (G::DH / 32);
-        ot[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[idx % PD], pf[st], ot[b], 0, 0, 0);
-        if (idx + PD < NPV) vf[idx % PD] = v_frag(idx + PD);
-        if (PD > 1 || (idx & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        for (int idx = i0; idx < i1; ++idx) {
+          const int st = idx / (G::DH / 32), b = idx % (G::DH / 32);
+          ot[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[idx % PD], pf[st], ot[b], 0, 0, 0);
+          if (idx + PD < NPV) vf[idx % PD] = v_frag(idx + PD);
+          if (PD > 1 || (idx & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
       }
+    };
+    if constexpr (SPLIT) {
+      pv_range(0, NPV / 2);  // fragments of the first half are ready since phase A
+      p_half(1);             // VALU under those MFMAs
+      __builtin_amdgcn_sched_barrier(0);
+      pv_range(NPV / 2, NPV);
+    } else {
+      pv_range(0, NPV);
     }
     mark(j, 5);
     // own DMA pieces of tile j+1 landed; everyone behind this barrier is done with what the next phase overwrites

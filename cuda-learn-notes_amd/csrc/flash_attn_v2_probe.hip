@@ -3,6 +3,7 @@
 #include "flash_attn_v3.cuh"
 #include "flash_attn_bigd.cuh"
 #include "flash_attn_dsplit.cuh"
+#include "flash_attn_pipe.cuh"
 #include "flash_attn_v4.cuh"
 #include <type_traits>
 
@@ -34,6 +35,32 @@ CLN_API int cln_fa2_variant(int D, int nw, int vt, int opt, int abl, const void*
   if (D == 128 && abl == 220) return fa2::launch_dsplit<128, 1, 1, 15 | fa2::OPT_KPRE>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 128 && abl == 230) return fa2::launch_dsplit<128, 1, 2, 15>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 128 && abl == 231) return fa2::launch_dsplit<128, 1, 2, 15 | fa2::OPT_KPRE>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 64 && abl == 230) return fa2::launch_dsplit<64, 1, 2, 13>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 64 && abl == 231) return fa2::launch_dsplit<64, 1, 2, 13 | fa2::OPT_KPRE>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 64 && abl == 232) return fa2::launch_dsplit<64, 1, 4, 13>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 64 && abl == 233) return fa2::launch_dsplit<64, 1, 4, 13 | fa2::OPT_KPRE>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 64 && abl == 240) return fa2::launch_dsplit<64, 1, 2, 13 | fa2::OPT_KPRE, 32>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 128 && abl == 240) return fa2::launch_dsplit<128, 1, 2, 15 | fa2::OPT_KPRE, 32>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 256 && abl == 240) return fa2::launch_dsplit<256, 1, 1, 15 | fa2::OPT_KPRE, 32>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 64 && abl == 250) return fa2::launch_dsplit<64, 1, 2, 13 | fa2::OPT_STAGGER>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 64 && abl == 251) return fa2::launch_dsplit<64, 1, 2, 13 | fa2::OPT_STAGGER | fa2::OPT_KPRE>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 64 && abl == 252) return fa2::launch_dsplit<64, 1, 4, 13 | fa2::OPT_STAGGER>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 64 && abl == 253) return fa2::launch_dsplit<64, 1, 4, 13 | fa2::OPT_STAGGER | fa2::OPT_KPRE>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 128 && abl == 250) return fa2::launch_dsplit<128, 1, 2, 15 | fa2::OPT_STAGGER>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 128 && abl == 251) return fa2::launch_dsplit<128, 1, 2, 15 | fa2::OPT_STAGGER | fa2::OPT_KPRE>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 256 && abl == 250) return fa2::launch_dsplit<256, 1, 1, 15 | fa2::OPT_STAGGER>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 256 && abl == 251) return fa2::launch_dsplit<256, 1, 1, 15 | fa2::OPT_STAGGER | fa2::OPT_KPRE>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 64 && abl == 262) return fa2::launch_dsplit<64, 1, 4, 13 | fa2::OPT_STAGGER, 2>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 64 && abl == 268) return fa2::launch_dsplit<64, 1, 4, 13 | fa2::OPT_STAGGER, 8>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 64 && abl == 276) return fa2::launch_dsplit<64, 1, 4, 13 | fa2::OPT_STAGGER, 16>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 64 && abl == 284) return fa2::launch_dsplit<64, 1, 4, 13 | fa2::OPT_STAGGER, 24>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 64 && abl == 286) return fa2::launch_dsplit<64, 1, 4, 13 | fa2::OPT_STAGGER, 26>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 64 && abl == 261) return fa2::launch_dsplit<64, 1, 4, 13 | fa2::OPT_STAGGER, 1>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 64 && abl == 292) return fa2::launch_dsplit<64, 1, 4, 13 | fa2::OPT_STAGGER, 32>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 64 && abl == 270) return fa2::launch_pipe<64, 2, 13>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 64 && abl == 271) return fa2::launch_pipe<64, 4, 13>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 128 && abl == 270) return fa2::launch_pipe<128, 2, 15>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 256 && abl == 270) return fa2::launch_pipe<256, 1, 15>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 512 && abl == 211) return fa2::launch_dsplit<512, 2, 1, 15, 1>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 512 && abl == 212) return fa2::launch_dsplit<512, 2, 1, 15, 2>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 512 && abl == 214) return fa2::launch_dsplit<512, 2, 1, 15, 4>(q, k, v, o, B, H, N, (hipStream_t)stream);

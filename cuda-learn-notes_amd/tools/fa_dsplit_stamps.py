@@ -7,7 +7,7 @@ import __graft_entry__ as entry
 pkg = entry.load_package()
 from cuda_learn_notes_amd import host
 dev = torch.device("cuda:0")
-B, H, N, D = 1, 32, 4096, 512
+B, H, N, D = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "1,32,4096,512").split(",")]
 torch.manual_seed(0)
 q, k, v = (torch.randn(B, H, N, D, dtype=torch.half, device=dev) for _ in range(3))
 o = torch.zeros_like(q)

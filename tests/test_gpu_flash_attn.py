@@ -112,6 +112,17 @@ def test_d128_pingpong_kernel_shapes(fa, built, dev, oracle, B, H, N):
         assert (o[b:b + 1, h:h + 1].double() - ref).abs().max().item() <= TOL, (b, h)
 
 
+@pytest.mark.parametrize("B,H,N", [(2, 96, 256), (4, 8, 2048), (1, 7, 8192)])
+def test_d64_pingpong_kernel_shapes(fa, built, dev, oracle, B, H, N):
+    """D = 64 with >= 192 workgroups of 256 rows (config C4 = [4,8,2048,64] among them) runs on the ping-pong
+    kernel with 128-key tiles and the softmax split over the two phases."""
+    q, k, v = seeded(47, B, H, N, 64), seeded(48, B, H, N, 64), seeded(49, B, H, N, 64)
+    o = run(fa, built, "flash_attn_mma_stages_split_q_shared_qkv", q, k, v, 2, dev)
+    for (b, h) in ((0, 0), (B - 1, H - 1), (B // 2, H // 3)):
+        ref = oracle.attention_fp64(q[b:b + 1, h:h + 1], k[b:b + 1, h:h + 1], v[b:b + 1, h:h + 1])
+        assert (o[b:b + 1, h:h + 1].double() - ref).abs().max().item() <= TOL, (b, h)
+
+
 def test_d512_rejects_ragged_seqlen(fa, dev):
     q = torch.zeros(1, 1, 192, 512, dtype=torch.half, device=dev)
     with pytest.raises(RuntimeError):
@@ -237,9 +248,9 @@ def test_probe_variants_match_production(fa, built, dev, oracle):
     """v3 (software-pipelined) and the big-D register-resident probe kernels are kept as measured alternatives;
     they must agree with the oracle like the shipped v2 kernel does."""
     from cuda_learn_notes_amd import host
-    for (B, H, N, D, variants) in ((1, 2, 512, 64, [(8, 0, 13, 100), (4, 0, 13, 100), (8, 0, 269, 100), (8, 0, 13, 300), (8, 0, 4109, 0), (8, 0, 3085, 0)]),
-                                   (1, 2, 512, 128, [(8, 0, 15, 100), (8, 0, 13, 100), (8, 0, 15, 300), (8, 0, 4111, 0), (8, 0, 15, 210), (8, 0, 15, 230), (8, 0, 15, 231)]),
-                                   (1, 1, 256, 256, [(4, 0, 15, 200), (4, 0, 15, 210), (4, 0, 15, 220)]),
+    for (B, H, N, D, variants) in ((1, 2, 512, 64, [(8, 0, 13, 100), (4, 0, 13, 100), (8, 0, 269, 100), (8, 0, 13, 300), (8, 0, 4109, 0), (8, 0, 3085, 0), (8, 0, 13, 230), (8, 0, 13, 233), (8, 0, 13, 250), (8, 0, 13, 252), (8, 0, 13, 270), (8, 0, 13, 271)]),
+                                   (1, 2, 512, 128, [(8, 0, 15, 100), (8, 0, 13, 100), (8, 0, 15, 300), (8, 0, 4111, 0), (8, 0, 15, 210), (8, 0, 15, 230), (8, 0, 15, 231), (8, 0, 15, 250), (8, 0, 15, 270)]),
+                                   (1, 1, 256, 256, [(4, 0, 15, 200), (4, 0, 15, 210), (4, 0, 15, 220), (4, 0, 15, 250), (4, 0, 15, 270)]),
                                    (1, 1, 256, 512, [(4, 0, 15, 200), (4, 0, 15, 201), (4, 0, 15, 204), (4, 0, 15, 210), (4, 0, 15, 220)])):
         q, k, v = seeded(41, B, H, N, D), seeded(42, B, H, N, D), seeded(43, B, H, N, D)
         ref = oracle.attention_fp64(q, k, v)
