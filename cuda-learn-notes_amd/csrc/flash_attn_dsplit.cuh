@@ -187,6 +187,16 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
     // phase A behind the QK^T MFMAs, the second half in phase B between the two halves of the PV MFMAs -- phase A is
     // otherwise matrix-only and short, and the partner group idles at the barrier for the length of the softmax.
     constexpr bool SPLIT = NSP == 1 && (OPT & OPT_STAGGER) != 0;
+    // OPT_ONES: the softmax sections run at raised priority. On one SIMD the arbiter otherwise lets the OLDER wave's
+    // ready-but-blocked MFMA hold the VALU port, and the partner's VALU work does not overlap with the matrix pipe at
+    // all (tools/ubench/overlap2.hip: MFMA wave + softmax-mix wave 380 us = the sum; with the VALU wave at
+    // s_setprio 3: 262 us, MFMA hidden).
+    auto valu_prio = [&](bool on) {
+      if constexpr ((OPT & OPT_ONES) != 0) {
+        if (on) __builtin_amdgcn_s_setprio(3);
+        else __builtin_amdgcn_s_setprio(0);
+      }
+    };
     h8 pf[2 * BCB];
     auto row_max_and_rescale = [&]() {
       float mx = s[0][0];
@@ -234,8 +244,10 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
       l_run += psum;
     };
     if constexpr (SPLIT) {
+      valu_prio(true);
       row_max_and_rescale();
       p_half(0);
+      valu_prio(false);
     }
     if constexpr (NSP == 2 && !(ABL & 4))
 #pragma unroll
@@ -259,9 +271,11 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
     if (PD > 1) __builtin_amdgcn_sched_barrier(0);
     mark(j, 3);
     if constexpr (!SPLIT) {
+      valu_prio(true);
       row_max_and_rescale();
       p_half(0);
       p_half(1);
+      valu_prio(false);
     }
     mark(j, 4);
     auto pv_range = [&](int i0, int i1) {
@@ -277,7 +291,9 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
     };
     if constexpr (SPLIT) {
       pv_range(0, NPV / 2);  // fragments of the first half are ready since phase A
+      valu_prio(true);
       p_half(1);             // VALU under those MFMAs
+      valu_prio(false);
       __builtin_amdgcn_sched_barrier(0);
       pv_range(NPV / 2, NPV);
     } else {

@@ -61,6 +61,13 @@ CLN_API int cln_fa2_variant(int D, int nw, int vt, int opt, int abl, const void*
   if (D == 64 && abl == 271) return fa2::launch_pipe<64, 4, 13>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 128 && abl == 270) return fa2::launch_pipe<128, 2, 15>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 256 && abl == 270) return fa2::launch_pipe<256, 1, 15>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 64 && abl == 280) return fa2::launch_dsplit<64, 1, 4, 13 | fa2::OPT_STAGGER | fa2::OPT_ONES>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 64 && abl == 281) return fa2::launch_dsplit<64, 1, 4, 13 | fa2::OPT_ONES>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 64 && abl == 282) return fa2::launch_dsplit<64, 1, 2, 13 | fa2::OPT_ONES>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 128 && abl == 280) return fa2::launch_dsplit<128, 1, 2, 15 | fa2::OPT_KPRE | fa2::OPT_ONES>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 128 && abl == 281) return fa2::launch_dsplit<128, 1, 2, 15 | fa2::OPT_KPRE | fa2::OPT_STAGGER | fa2::OPT_ONES>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 256 && abl == 280) return fa2::launch_dsplit<256, 1, 1, 15 | fa2::OPT_KPRE | fa2::OPT_ONES>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 512 && abl == 280) return fa2::launch_dsplit<512, 2, 1, 15 | fa2::OPT_ONES>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 512 && abl == 211) return fa2::launch_dsplit<512, 2, 1, 15, 1>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 512 && abl == 212) return fa2::launch_dsplit<512, 2, 1, 15, 2>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 512 && abl == 214) return fa2::launch_dsplit<512, 2, 1, 15, 4>(q, k, v, o, B, H, N, (hipStream_t)stream);

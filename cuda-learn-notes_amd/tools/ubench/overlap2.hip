@@ -52,10 +52,13 @@ __device__ __forceinline__ void run_valu(float* out, int n) {
   for (int i = 0; i < 16; ++i) s += a[i];
   out[threadIdx.x] = s;
 }
-template <int ACC, int GA, int GB>
+template <int ACC, int GA, int GB, int PRIO = 0>
 __global__ __launch_bounds__(512) void k(float* out, int nm, int nv) {
   const int grp = threadIdx.x >> 8;
   float* o = out + blockIdx.x * 512;
+  // PRIO 1: the VALU group raises its priority; PRIO 2: the MFMA group raises its priority
+  if constexpr (PRIO == 1) { if ((grp == 0 ? GA : GB) >= 2) __builtin_amdgcn_s_setprio(3); }
+  if constexpr (PRIO == 2) { if ((grp == 0 ? GA : GB) == 1) __builtin_amdgcn_s_setprio(3); }
   if (grp == 0) {
     if constexpr (GA == 1) run_mfma<ACC>(o, nm);
     if constexpr (GA >= 2) run_valu<GA>(o, nv);
@@ -64,17 +67,17 @@ __global__ __launch_bounds__(512) void k(float* out, int nm, int nv) {
     if constexpr (GB >= 2) run_valu<GB>(o, nv);
   }
 }
-template <int ACC, int GA, int GB>
+template <int ACC, int GA, int GB, int PRIO = 0>
 void run(const char* tag, int nm, int nv) {
   float* out;
   hipMalloc(&out, 256 * 512 * 4);
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  for (int r = 0; r < 3; ++r) hipLaunchKernelGGL((k<ACC, GA, GB>), dim3(256), dim3(512), 0, 0, out, nm, nv);
+  for (int r = 0; r < 3; ++r) hipLaunchKernelGGL((k<ACC, GA, GB, PRIO>), dim3(256), dim3(512), 0, 0, out, nm, nv);
   hipDeviceSynchronize();
   hipEventRecord(e0);
-  for (int r = 0; r < 10; ++r) hipLaunchKernelGGL((k<ACC, GA, GB>), dim3(256), dim3(512), 0, 0, out, nm, nv);
+  for (int r = 0; r < 10; ++r) hipLaunchKernelGGL((k<ACC, GA, GB, PRIO>), dim3(256), dim3(512), 0, 0, out, nm, nv);
   hipEventRecord(e1);
   hipDeviceSynchronize();
   float ms;
@@ -97,6 +100,13 @@ int main() {
     run<1, 1, 3>("A: MFMA acc=AGPR   B: exp x32000", nm, 2000);
     run<0, 1, 4>("A: MFMA acc=VGPR   B: softmax-mix", nm, 1000);
     run<1, 1, 4>("A: MFMA acc=AGPR   B: softmax-mix", nm, 1000);
+    run<0, 2, 1>("A: fma x80000      B: MFMA (younger)", nm, 5000);
+    run<0, 4, 1>("A: softmax-mix     B: MFMA (younger)", nm, 1000);
+    run<0, 1, 2, 1>("A: MFMA            B: fma, fma wave at prio 3", nm, 5000);
+    run<0, 1, 4, 1>("A: MFMA            B: softmax-mix at prio 3", nm, 1000);
+    run<0, 1, 3, 1>("A: MFMA            B: exp at prio 3", nm, 2000);
+    run<0, 1, 2, 2>("A: MFMA at prio 3  B: fma", nm, 5000);
+    run<0, 2, 1, 1>("A: fma at prio 3   B: MFMA (younger)", nm, 5000);
     run<0, 1, 1>("A: MFMA acc=VGPR   B: MFMA acc=VGPR", nm, 0);
     run<1, 1, 1>("A: MFMA acc=AGPR   B: MFMA acc=AGPR", nm, 0);
   }
