@@ -130,6 +130,7 @@ def main():
             for tag, (B_, H_, N_, D) in (("fa2_fwd_d64", (4, 8, 2048, 64)), ("fa2_fwd_d128", (4, 8, 2048, 128)),
                                          ("fa2_fwd_d64_large", (1, 48, 8192, 64)),
                                          ("fa2_fwd_d128_large", (2, 32, 4096, 128)),
+                                         ("fa2_fwd_d256", (2, 32, 4096, 256)),
                                          ("fa2_fwd_d512_c5", (1, 32, 4096, 512))):
                 q, k, v = (torch.randn(B_, H_, N_, D, dtype=torch.half, device=dev) for _ in range(3))
                 o = torch.zeros_like(q)

@@ -32,4 +32,10 @@ for D in 64 128; do
   pmc fa${D}_sq SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE -- $FA
   python $T/pmc_summary.py fa2 $OUT/${TAG}_pmc_fa_d$D.json $OUT/pmc_fa${D}_fetch $OUT/pmc_fa${D}_write $OUT/pmc_fa${D}_sq > /dev/null
 done
+# config C5 (D = 512)
+FA="fa 1 32 4096 512 2 6"
+pmc fa512_fetch FETCH_SIZE -- $FA
+pmc fa512_write WRITE_SIZE -- $FA
+pmc fa512_sq SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE -- $FA
+python $T/pmc_summary.py fa2 $OUT/${TAG}_pmc_fa_d512.json $OUT/pmc_fa512_fetch $OUT/pmc_fa512_write $OUT/pmc_fa512_sq > /dev/null
 ls -la $OUT/${TAG}_*
