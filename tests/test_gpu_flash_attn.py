@@ -189,6 +189,40 @@ def test_deferred_max_paths(fa, built, dev, oracle):
         assert (o.double() - ref).abs().max().item() <= TOL, name
 
 
+@pytest.mark.parametrize("D,H", [(64, 48), (128, 48), (256, 48), (512, 2)])
+def test_pingpong_kernels_deferred_max_and_rescale(fa, built, dev, oracle, D, H):
+    """Same three regimes as test_deferred_max_paths, on shapes that dispatch to the ping-pong kernels
+    (flash_attn_dsplit.cuh; >= 192 workgroups of 256 rows at D <= 256): creeping max below the 2^8 threshold, one
+    late jump that forces a rescale with a non-trivial alpha, an early spike that leaves every later score ~ -inf.
+    D = 64 runs the split softmax (the rescale happens in the QK^T phase), D = 512 the partial-S exchange."""
+    B, N = 1, 1024
+    q, k, v = seeded(51, B, H, N, D), seeded(52, B, H, N, D), seeded(53, B, H, N, D)
+    ramp = torch.linspace(0.2, 1.6, N).view(1, 1, N, 1)
+    k = (k.float() * ramp).half()
+    k[0, 0, 900] = q[0, 0, 5] * 3.0
+    k[0, 0, 70] = q[0, 0, 130] * 2.0
+    k[0, 1, 10] = q[0, 1, 300] * 5.0
+    k[0, H - 1, 1000] = q[0, H - 1, 1023] * 4.0
+    name = "flash_attn_mma_stages_split_q_tiling_qk" if D > 256 else "flash_attn_mma_stages_split_q_shared_qkv"
+    o = run(fa, built, name, q, k, v, 2, dev)
+    assert torch.isfinite(o).all()
+    for h in (0, 1, H - 1):
+        ref = oracle.attention_fp64(q[:, h:h + 1], k[:, h:h + 1], v[:, h:h + 1])
+        assert (o[:, h:h + 1].double() - ref).abs().max().item() <= TOL, h
+
+
+@pytest.mark.parametrize("D,H", [(64, 48), (128, 48), (256, 48), (512, 2)])
+def test_pingpong_kernels_uniform_softmax(fa, built, dev, D, H):
+    """All-ones Q and K (reference --no-rand-q/k): O = column mean of V, through the ping-pong kernels."""
+    B, N = 1, 1024
+    q = torch.ones(B, H, N, D).half()
+    v = seeded(54, B, H, N, D)
+    name = "flash_attn_mma_stages_split_q_tiling_qk" if D > 256 else "flash_attn_mma_stages_split_q_shared_qkv"
+    o = run(fa, built, name, q, q, v, 2, dev)
+    expect = v.double().mean(dim=2, keepdim=True).expand(B, H, N, D)
+    assert (o.double() - expect).abs().max().item() <= 1e-3
+
+
 def test_all_ones_qk_gives_column_mean_of_v(fa, built, dev):
     """Reference debug mode --no-rand-q/k (flash_attn_mma.py:353-369): uniform softmax => O = mean_n V."""
     B, H, N, D = 1, 2, 512, 64
