@@ -7,6 +7,7 @@
 #include "flash_attn.cuh"
 #include "flash_attn_bigd.cuh"
 #include "flash_attn_dsplit.cuh"
+#include "flash_attn_dwide.cuh"
 
 namespace fa {
 inline int launch_fa2_large_d(const void* q, const void* k, const void* v, void* o, int B, int H, int N, int D,
@@ -20,8 +21,10 @@ inline int launch_fa2_large_d(const void* q, const void* k, const void* v, void*
     // (flash_attn_bigd.cuh, still used for D = 768) and 411 for the v1 path (profiles/r01_fa_dsplit_probe.log)
     case 512: return fa2::launch_dsplit<512, 2, 1, fa2::OPT_DEFAULT>(q, k, v, o, B, H, N, s);
     case 640: return launch_fa2<640, 320, 32, false, false>(q, k, v, o, B, H, N, s);
-    case 768: return fa2::launch_bigd<768, 256, fa2::OPT_DEFAULT>(q, k, v, o, B, H, N, s);
-    case 1024: return launch_fa2<1024, 256, 32, false, false>(q, k, v, o, B, H, N, s);
+    // D = 768 / 1024: three / four waves split the head dim of a 32-row group (flash_attn_dwide.cuh): 675-690 TF
+    // at [1,16,4096,768] (big-D kernel 223-295), 706-776 TF at D = 1024 (v1 path 100-131, below torch SDPA)
+    case 768: return fa2::launch_dwide<768, fa2::OPT_DEFAULT>(q, k, v, o, B, H, N, s);
+    case 1024: return fa2::launch_dwide<1024, fa2::OPT_DEFAULT>(q, k, v, o, B, H, N, s);
     default: return CLN_ERR_UNSUPPORTED;
   }
 }

@@ -4,6 +4,7 @@
 #include "flash_attn_bigd.cuh"
 #include "flash_attn_dsplit.cuh"
 #include "flash_attn_pipe.cuh"
+#include "flash_attn_dwide.cuh"
 #include "flash_attn_v4.cuh"
 #include <type_traits>
 
@@ -68,6 +69,8 @@ CLN_API int cln_fa2_variant(int D, int nw, int vt, int opt, int abl, const void*
   if (D == 128 && abl == 281) return fa2::launch_dsplit<128, 1, 2, 15 | fa2::OPT_KPRE | fa2::OPT_STAGGER | fa2::OPT_ONES>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 256 && abl == 280) return fa2::launch_dsplit<256, 1, 1, 15 | fa2::OPT_KPRE | fa2::OPT_ONES>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 512 && abl == 280) return fa2::launch_dsplit<512, 2, 1, 15 | fa2::OPT_ONES>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 768 && abl == 210) return fa2::launch_dwide<768, 15>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 1024 && abl == 210) return fa2::launch_dwide<1024, 15>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 512 && abl == 211) return fa2::launch_dsplit<512, 2, 1, 15, 1>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 512 && abl == 212) return fa2::launch_dsplit<512, 2, 1, 15, 2>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 512 && abl == 214) return fa2::launch_dsplit<512, 2, 1, 15, 4>(q, k, v, o, B, H, N, (hipStream_t)stream);

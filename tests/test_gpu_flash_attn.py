@@ -123,6 +123,17 @@ def test_d64_pingpong_kernel_shapes(fa, built, dev, oracle, B, H, N):
         assert (o[b:b + 1, h:h + 1].double() - ref).abs().max().item() <= TOL, (b, h)
 
 
+@pytest.mark.parametrize("D", [768, 1024])
+@pytest.mark.parametrize("B,H,N", [(1, 1, 64), (2, 3, 192), (1, 8, 1024)])
+def test_d768_d1024_dwide_kernel_shapes(fa, built, dev, oracle, D, B, H, N):
+    """D = 768 / 1024 (flash_attn_dwide.cuh): one 64-row workgroup / 2 KV tiles, odd tile counts, head counts that do
+    and do not divide by 8."""
+    q, k, v = seeded(61, B, H, N, D), seeded(62, B, H, N, D), seeded(63, B, H, N, D)
+    ref = oracle.attention_fp64(q, k, v)
+    o = run(fa, built, "flash_attn_mma_stages_split_q_tiling_qkv", q, k, v, 2, dev)
+    assert (o.double() - ref).abs().max().item() <= TOL
+
+
 def test_d512_rejects_ragged_seqlen(fa, dev):
     q = torch.zeros(1, 1, 192, 512, dtype=torch.half, device=dev)
     with pytest.raises(RuntimeError):
@@ -189,12 +200,13 @@ def test_deferred_max_paths(fa, built, dev, oracle):
         assert (o.double() - ref).abs().max().item() <= TOL, name
 
 
-@pytest.mark.parametrize("D,H", [(64, 48), (128, 48), (256, 48), (512, 2)])
+@pytest.mark.parametrize("D,H", [(64, 48), (128, 48), (256, 48), (512, 2), (768, 2), (1024, 3)])
 def test_pingpong_kernels_deferred_max_and_rescale(fa, built, dev, oracle, D, H):
     """Same three regimes as test_deferred_max_paths, on shapes that dispatch to the ping-pong kernels
     (flash_attn_dsplit.cuh; >= 192 workgroups of 256 rows at D <= 256): creeping max below the 2^8 threshold, one
     late jump that forces a rescale with a non-trivial alpha, an early spike that leaves every later score ~ -inf.
-    D = 64 runs the split softmax (the rescale happens in the QK^T phase), D = 512 the partial-S exchange."""
+    D = 64 runs the split softmax (the rescale happens in the QK^T phase), D = 512 the partial-S exchange, D = 768 /
+    1024 the three- / four-way exchange of flash_attn_dwide.cuh."""
     B, N = 1, 1024
     q, k, v = seeded(51, B, H, N, D), seeded(52, B, H, N, D), seeded(53, B, H, N, D)
     ramp = torch.linspace(0.2, 1.6, N).view(1, 1, N, 1)
@@ -211,7 +223,7 @@ def test_pingpong_kernels_deferred_max_and_rescale(fa, built, dev, oracle, D, H)
         assert (o[:, h:h + 1].double() - ref).abs().max().item() <= TOL, h
 
 
-@pytest.mark.parametrize("D,H", [(64, 48), (128, 48), (256, 48), (512, 2)])
+@pytest.mark.parametrize("D,H", [(64, 48), (128, 48), (256, 48), (512, 2), (768, 2), (1024, 3)])
 def test_pingpong_kernels_uniform_softmax(fa, built, dev, D, H):
     """All-ones Q and K (reference --no-rand-q/k): O = column mean of V, through the ping-pong kernels."""
     B, N = 1, 1024
@@ -285,7 +297,8 @@ def test_probe_variants_match_production(fa, built, dev, oracle):
     for (B, H, N, D, variants) in ((1, 2, 512, 64, [(8, 0, 13, 100), (4, 0, 13, 100), (8, 0, 269, 100), (8, 0, 13, 300), (8, 0, 4109, 0), (8, 0, 3085, 0), (8, 0, 13, 230), (8, 0, 13, 233), (8, 0, 13, 250), (8, 0, 13, 252), (8, 0, 13, 270), (8, 0, 13, 271)]),
                                    (1, 2, 512, 128, [(8, 0, 15, 100), (8, 0, 13, 100), (8, 0, 15, 300), (8, 0, 4111, 0), (8, 0, 15, 210), (8, 0, 15, 230), (8, 0, 15, 231), (8, 0, 15, 250), (8, 0, 15, 270)]),
                                    (1, 1, 256, 256, [(4, 0, 15, 200), (4, 0, 15, 210), (4, 0, 15, 220), (4, 0, 15, 250), (4, 0, 15, 270)]),
-                                   (1, 1, 256, 512, [(4, 0, 15, 200), (4, 0, 15, 201), (4, 0, 15, 204), (4, 0, 15, 210), (4, 0, 15, 220)])):
+                                   (1, 1, 256, 512, [(4, 0, 15, 200), (4, 0, 15, 201), (4, 0, 15, 204), (4, 0, 15, 210), (4, 0, 15, 220)]),
+                                   (1, 1, 256, 768, [(4, 0, 15, 201), (4, 0, 15, 210)]), (1, 1, 256, 1024, [(4, 0, 15, 201), (4, 0, 15, 210)])):
         q, k, v = seeded(41, B, H, N, D), seeded(42, B, H, N, D), seeded(43, B, H, N, D)
         ref = oracle.attention_fp64(q, k, v)
         for var in variants:
