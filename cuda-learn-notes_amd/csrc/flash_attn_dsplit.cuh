@@ -152,10 +152,12 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
     const int kb_j = kbase + (j & 1) * G::STAGE, vb_j = vbase + (j & 1) * G::STAGE + G::TILE;
     auto k_frag = [&](int t) {  // keys (t % BCB)*32 + l31, k-step t / BCB
       const int ks = t / BCB;
+      if constexpr ((ABL & 64) != 0) return qf[ks];  // ablation: no K fragment reads
       return *reinterpret_cast<const h8*>(smem + (kb_j ^ ((ks & 7) << 5)) + (ks >> 3) * 256 + (t % BCB) * 32 * G::ROW);
     };
     auto v_frag = [&](int idx) {  // idx = st * (DH/32) + b: rows 16*st + v_row and + 8 (same swizzle), block b
       const int st = idx / (G::DH / 32), b = idx % (G::DH / 32);
+      if constexpr ((ABL & 64) != 0) return qf[idx % (G::DH / 16)];  // ablation: no V fragment reads
       const char* vp = smem + (vb_j ^ ((b & 3) << 6)) + (16 * st) * G::ROW + (b >> 2) * 256;
       return h8_cat(lds_read_tr16(vp), lds_read_tr16(vp + 8 * G::ROW));
     };
