@@ -1,4 +1,7 @@
-// FlashAttention-2 forward for head dims 384 / 512 (BASELINE config C5 = [1,32,4096,512]): the reference's
+// FlashAttention-2 forward for large head dims, register-resident form. PROBE ONLY since the d-split kernels
+// (flash_attn_dsplit.cuh, flash_attn_dwide.cuh) took over D = 512 / 768 / 1024; kept, tested, as the measured
+// alternative and as the home of the LDS-DMA swizzles those kernels reuse. Written for config C5
+// ([1,32,4096,512]): the reference's
 // "fine-grained QKV tiling" rungs (kernels/flash-attn/mma/basic/flash_attn_mma_tiling_qkv.cu:70, :732;
 // tiling_qk.cu:72) keep O(1) shared memory by streaming Q, K and V in 16-wide d slices and re-reading Q for
 // every KV tile. On MI355X the register file is the big resource, so the roles are inverted:

@@ -1,8 +1,12 @@
 // Head dims above 256 ("fine-grained tiling" rungs of the reference:
 // kernels/flash-attn/mma/basic/flash_attn_mma_tiling_qk.cu:72, flash_attn_mma_tiling_qkv.cu:70 --
-// config C5 is D = 512). Round-1 implementation: the same split-Q kernel with the whole K row in
-// LDS (160 KiB LDS makes the reference's 16-wide d-slicing of K unnecessary up to D = 1024) and
-// the OUTPUT head dim sliced across blockIdx.z (each workgroup recomputes S for its slice).
+// config C5 is D = 512). The reference streams Q, K and V through O(1) shared memory in 16-wide d slices; here
+// the head dim is split across the waves of a query-row group instead (each wave keeps its 256 columns of Q and of
+// O^T in registers and the partial S^T tiles are summed through LDS):
+//   512        pairs of waves, two 4-wave groups one phase apart, K/V double-buffered   (flash_attn_dsplit.cuh)
+//   768, 1024  triples / quads of waves, one K and one V tile in the 160 KiB LDS         (flash_attn_dwide.cuh)
+//   320, 384, 640  round-1 kernel: whole K row block in LDS, output head dim sliced over blockIdx.z, S recomputed
+//                  per slice (flash_attn.cuh)
 #pragma once
 #include "flash_attn.cuh"
 #include "flash_attn_bigd.cuh"
