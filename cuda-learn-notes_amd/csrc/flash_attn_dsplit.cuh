@@ -49,12 +49,18 @@ struct GeoSplit {
   static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
-template <int D, int NSP, int BCB, int OPT, int ABL = 0>
+// PAD (D = 512 only): the tensors have `dreal` < D columns (320 / 384); Q columns >= dreal are loaded as zeros, K/V
+// source chunks are clamped into the row (what lands in the padding is multiplied by those zeros / never stored), O is
+// stored for the real columns only. The MFMAs over the padding are wasted (25 % at 384), the structure is unchanged.
+template <int D, int NSP, int BCB, int OPT, int ABL = 0, bool PAD = false>
 __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __restrict__ Q,
                                                                 const half_t* __restrict__ K,
                                                                 const half_t* __restrict__ V, half_t* __restrict__ O,
-                                                                int N, int n_qblk, int n_heads, float scale_log2e) {
+                                                                int N, int n_qblk, int n_heads, float scale_log2e,
+                                                                int dreal) {
   using G = GeoSplit<D, NSP, BCB>;
+  static_assert(!PAD || (D == 512 && NSP == 2), "padded head dims ride on the D = 512 instantiation");
+  const int DR = PAD ? dreal : D;  // columns per row in memory
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -74,7 +80,7 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
       qb = bid - head_i * n_qblk;
     }
   }
-  const size_t head = (size_t)head_i * N * D;
+  const size_t head = (size_t)head_i * N * DR;
   const int q_row0 = qb * G::BR + rg * 32;
   const unsigned lds0 = hgemm::lds_addr_of(smem);
 
@@ -88,17 +94,26 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
   const unsigned kmask = grp == 0 ? 0xFFu : 0u;  // the i-dependent part of the swizzle applies to K rows only
   auto dma_piece = [&](int jt, int slot, int i) {
     const int piece = i * 4 + widx;
-    const char* s = src_h + (size_t)jt * G::TILE + piece * 1024;
-    hgemm::glds16_asm(s, src_lane ^ ((unsigned)(((i * 4 * G::RPP) & 15) << 4) & kmask),
-                      lds0 + slot * G::STAGE + grp * G::TILE + piece * 1024);
+    unsigned voff = src_lane ^ ((unsigned)(((i * 4 * G::RPP) & 15) << 4) & kmask);
+    const char* s;
+    if constexpr (PAD) {  // a piece is one LDS row (RPP = 1); the memory row is DR*2 bytes: clamp the chunk into it
+      voff = min(voff, (unsigned)(DR * 2 - 16));
+      s = src_h + (size_t)jt * (G::BC * DR * 2) + piece * (DR * 2);
+    } else {
+      s = src_h + (size_t)jt * G::TILE + piece * 1024;
+    }
+    hgemm::glds16_asm(s, voff, lds0 + slot * G::STAGE + grp * G::TILE + piece * 1024);
   };
 
   // ---- Q fragments: this wave's half of the head dim
   h8 qf[G::DH / 16];
   {
-    const half_t* qp = Q + head + (size_t)(q_row0 + l31) * D + part * G::DH + hi * 8;
+    const half_t* qp = Q + head + (size_t)(q_row0 + l31) * DR + part * G::DH + hi * 8;
 #pragma unroll
-    for (int ks = 0; ks < G::DH / 16; ++ks) qf[ks] = *reinterpret_cast<const h8*>(qp + ks * 16);
+    for (int ks = 0; ks < G::DH / 16; ++ks) {
+      if (!PAD || part * G::DH + ks * 16 < DR) qf[ks] = *reinterpret_cast<const h8*>(qp + ks * 16);
+      else qf[ks] = h8{0, 0, 0, 0, 0, 0, 0, 0};  // DR is a multiple of 16: the predicate is wave-uniform
+    }
   }
   f16v ot[G::DH / 32];
 #pragma unroll
@@ -334,13 +349,13 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
     __builtin_amdgcn_sched_barrier(0);
   }
   constexpr int LPR = G::DH / 8;
-  half_t* og = O + head + (size_t)q_row0 * D + part * G::DH;
+  half_t* og = O + head + (size_t)q_row0 * DR + part * G::DH;
 #pragma unroll 4
   for (int it = 0; it < (32 * LPR) / 64; ++it) {
     const int idx = it * 64 + lane;
     const int row = idx / LPR, c = idx % LPR;
     const u4 v = *reinterpret_cast<const u4*>(ob + row * G::OS + c * 16);
-    *reinterpret_cast<u4*>(og + (size_t)row * D + c * 8) = v;
+    if (!PAD || part * G::DH + c * 8 < DR) *reinterpret_cast<u4*>(og + (size_t)row * DR + c * 8) = v;
   }
   if constexpr ((ABL & 32) != 0) {  // probe only: block 0 overwrites the head of O with its 8 x 8 time stamps
     if (blockIdx.x == 0 && lane == 0) {
@@ -351,20 +366,22 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
   }
 }
 
-template <int D, int NSP, int BCB, int OPT, int ABL = 0>
-int launch_dsplit(const void* q, const void* k, const void* v, void* o, int B, int H, int N, hipStream_t stream) {
+template <int D, int NSP, int BCB, int OPT, int ABL = 0, bool PAD = false>
+int launch_dsplit(const void* q, const void* k, const void* v, void* o, int B, int H, int N, hipStream_t stream,
+                  int dreal = D) {
   using G = GeoSplit<D, NSP, BCB>;
   if (N % G::BR != 0) return CLN_ERR_UNSUPPORTED;
+  if (PAD ? (dreal % 64 != 0 || dreal <= D / 2 || dreal >= D) : dreal != D) return CLN_ERR_UNSUPPORTED;
   static bool attr_done = false;
   if (!attr_done) {
-    if (cln_set_lds(reinterpret_cast<const void*>(&fa2_fwd_dsplit_kernel<D, NSP, BCB, OPT, ABL>), G::LDS_BYTES) != CLN_OK)
+    if (cln_set_lds(reinterpret_cast<const void*>(&fa2_fwd_dsplit_kernel<D, NSP, BCB, OPT, ABL, PAD>), G::LDS_BYTES) != CLN_OK)
       return CLN_ERR_LAUNCH;
     attr_done = true;
   }
-  const float scale_log2e = 1.4426950408889634f / sqrtf((float)D);
+  const float scale_log2e = 1.4426950408889634f / sqrtf((float)dreal);
   const int n_qblk = N / G::BR;
-  CLN_LAUNCH((fa2_fwd_dsplit_kernel<D, NSP, BCB, OPT, ABL>), dim3(n_qblk * B * H), dim3(G::NT), G::LDS_BYTES, stream,
-             (const half_t*)q, (const half_t*)k, (const half_t*)v, (half_t*)o, N, n_qblk, B * H, scale_log2e);
+  CLN_LAUNCH((fa2_fwd_dsplit_kernel<D, NSP, BCB, OPT, ABL, PAD>), dim3(n_qblk * B * H), dim3(G::NT), G::LDS_BYTES, stream,
+             (const half_t*)q, (const half_t*)k, (const half_t*)v, (half_t*)o, N, n_qblk, B * H, scale_log2e, dreal);
   return cln_check_launch();
 }
 

@@ -33,12 +33,15 @@ struct GeoWide {
   static_assert(EPI <= LDS_BYTES && LDS_BYTES <= 160 * 1024, "LDS");
 };
 
-template <int D, int OPT>
+// PAD (D = 768 only): the tensors have dreal = 640 columns; see flash_attn_dsplit.cuh for the padding rules.
+template <int D, int OPT, bool PAD = false>
 __global__ __launch_bounds__(GeoWide<D>::NT, 1) void fa2_fwd_dwide_kernel(const half_t* __restrict__ Q,
                                                                const half_t* __restrict__ K,
                                                                const half_t* __restrict__ V, half_t* __restrict__ O,
-                                                               int N, int n_qblk, int n_heads, float scale_log2e) {
+                                                               int N, int n_qblk, int n_heads, float scale_log2e,
+                                                               int dreal) {
   using G = GeoWide<D>;
+  const int DR = PAD ? dreal : D;  // columns per row in memory
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -57,7 +60,7 @@ __global__ __launch_bounds__(GeoWide<D>::NT, 1) void fa2_fwd_dwide_kernel(const 
       qb = bid - head_i * n_qblk;
     }
   }
-  const size_t head = (size_t)head_i * N * D;
+  const size_t head = (size_t)head_i * N * DR;
   const int q_row0 = qb * G::BR + rg * 32;
   const unsigned lds0 = hgemm::lds_addr_of(smem);
   const char* Kh = reinterpret_cast<const char*>(K + head);
@@ -72,18 +75,33 @@ __global__ __launch_bounds__(GeoWide<D>::NT, 1) void fa2_fwd_dwide_kernel(const 
   const unsigned k_src_lane = (unsigned)(row0 * G::ROW + ((c0 ^ row0) << 4));
   const unsigned v_src_lane = (unsigned)(row0 * G::ROW + ((c0 ^ (row0 << 2)) << 4));
   auto dma_k = [&](int jt, int i) {
-    hgemm::glds16_asm(Kh + (size_t)jt * G::TILE + i * 4 * G::ROW, k_src_lane ^ (unsigned)(((4 * i) & 15) << 4),
-                      lds0 + (i * G::NW + wave) * 1024);
+    if constexpr (PAD) {  // memory rows are DR*2 bytes: row base from row0, source chunk clamped into the row
+      const unsigned chunk = min((unsigned)((c0 ^ row0) ^ ((4 * i) & 15)), (unsigned)(DR / 8 - 1));
+      hgemm::glds16_asm(Kh + (size_t)jt * (G::BC * DR * 2) + i * 4 * (DR * 2), (unsigned)(row0 * DR * 2) + (chunk << 4),
+                        lds0 + (i * G::NW + wave) * 1024);
+    } else {
+      hgemm::glds16_asm(Kh + (size_t)jt * G::TILE + i * 4 * G::ROW, k_src_lane ^ (unsigned)(((4 * i) & 15) << 4),
+                        lds0 + (i * G::NW + wave) * 1024);
+    }
   };
   auto dma_v = [&](int jt, int i) {
-    hgemm::glds16_asm(Vh + (size_t)jt * G::TILE + i * 4 * G::ROW, v_src_lane, lds0 + G::TILE + (i * G::NW + wave) * 1024);
+    if constexpr (PAD) {
+      const unsigned chunk = min((unsigned)(c0 ^ (row0 << 2)), (unsigned)(DR / 8 - 1));
+      hgemm::glds16_asm(Vh + (size_t)jt * (G::BC * DR * 2) + i * 4 * (DR * 2), (unsigned)(row0 * DR * 2) + (chunk << 4),
+                        lds0 + G::TILE + (i * G::NW + wave) * 1024);
+    } else {
+      hgemm::glds16_asm(Vh + (size_t)jt * G::TILE + i * 4 * G::ROW, v_src_lane, lds0 + G::TILE + (i * G::NW + wave) * 1024);
+    }
   };
 
   h8 qf[G::DH / 16];
   {
-    const half_t* qp = Q + head + (size_t)(q_row0 + l31) * D + part * G::DH + hi * 8;
+    const half_t* qp = Q + head + (size_t)(q_row0 + l31) * DR + part * G::DH + hi * 8;
 #pragma unroll
-    for (int ks = 0; ks < G::DH / 16; ++ks) qf[ks] = *reinterpret_cast<const h8*>(qp + ks * 16);
+    for (int ks = 0; ks < G::DH / 16; ++ks) {
+      if (!PAD || part * G::DH + ks * 16 < DR) qf[ks] = *reinterpret_cast<const h8*>(qp + ks * 16);
+      else qf[ks] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
   }
   f16v ot[G::DH / 32];
 #pragma unroll
@@ -219,30 +237,32 @@ __global__ __launch_bounds__(GeoWide<D>::NT, 1) void fa2_fwd_dwide_kernel(const 
     __builtin_amdgcn_sched_barrier(0);
   }
   constexpr int LPR = G::DH / 8;
-  half_t* og = O + head + (size_t)q_row0 * D + part * G::DH;
+  half_t* og = O + head + (size_t)q_row0 * DR + part * G::DH;
 #pragma unroll 4
   for (int it = 0; it < (32 * LPR) / 64; ++it) {
     const int idx = it * 64 + lane;
     const int row = idx / LPR, c = idx % LPR;
     const u4 v = *reinterpret_cast<const u4*>(ob + row * G::OS + c * 16);
-    *reinterpret_cast<u4*>(og + (size_t)row * D + c * 8) = v;
+    if (!PAD || part * G::DH + c * 8 < DR) *reinterpret_cast<u4*>(og + (size_t)row * DR + c * 8) = v;
   }
 }
 
-template <int D, int OPT>
-int launch_dwide(const void* q, const void* k, const void* v, void* o, int B, int H, int N, hipStream_t stream) {
+template <int D, int OPT, bool PAD = false>
+int launch_dwide(const void* q, const void* k, const void* v, void* o, int B, int H, int N, hipStream_t stream,
+                 int dreal = D) {
   using G = GeoWide<D>;
   if (N % G::BR != 0) return CLN_ERR_UNSUPPORTED;
+  if (PAD ? (dreal % 64 != 0 || dreal <= D - 256 || dreal >= D) : dreal != D) return CLN_ERR_UNSUPPORTED;
   static bool attr_done = false;
   if (!attr_done) {
-    if (cln_set_lds(reinterpret_cast<const void*>(&fa2_fwd_dwide_kernel<D, OPT>), G::LDS_BYTES) != CLN_OK)
+    if (cln_set_lds(reinterpret_cast<const void*>(&fa2_fwd_dwide_kernel<D, OPT, PAD>), G::LDS_BYTES) != CLN_OK)
       return CLN_ERR_LAUNCH;
     attr_done = true;
   }
-  const float scale_log2e = 1.4426950408889634f / sqrtf((float)D);
+  const float scale_log2e = 1.4426950408889634f / sqrtf((float)dreal);
   const int n_qblk = N / G::BR;
-  CLN_LAUNCH((fa2_fwd_dwide_kernel<D, OPT>), dim3(n_qblk * B * H), dim3(G::NT), G::LDS_BYTES, stream,
-             (const half_t*)q, (const half_t*)k, (const half_t*)v, (half_t*)o, N, n_qblk, B * H, scale_log2e);
+  CLN_LAUNCH((fa2_fwd_dwide_kernel<D, OPT, PAD>), dim3(n_qblk * B * H), dim3(G::NT), G::LDS_BYTES, stream,
+             (const half_t*)q, (const half_t*)k, (const half_t*)v, (half_t*)o, N, n_qblk, B * H, scale_log2e, dreal);
   return cln_check_launch();
 }
 

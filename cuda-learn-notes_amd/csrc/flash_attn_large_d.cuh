@@ -5,8 +5,7 @@
 // O^T in registers and the partial S^T tiles are summed through LDS):
 //   512        pairs of waves, two 4-wave groups one phase apart, K/V double-buffered   (flash_attn_dsplit.cuh)
 //   768, 1024  triples / quads of waves, one K and one V tile in the 160 KiB LDS         (flash_attn_dwide.cuh)
-//   320, 384, 640  round-1 kernel: whole K row block in LDS, output head dim sliced over blockIdx.z, S recomputed
-//                  per slice (flash_attn.cuh)
+//   320, 384   the D = 512 kernel with the head dim padded in registers / LDS only (PAD); 640 likewise on D = 768
 #pragma once
 #include "flash_attn.cuh"
 #include "flash_attn_bigd.cuh"
@@ -18,13 +17,16 @@ inline int launch_fa2_large_d(const void* q, const void* k, const void* v, void*
                               int stages, hipStream_t s) {
   (void)stages;
   switch (D) {
-    case 320: return launch_fa2<320, 160, 64, false, false>(q, k, v, o, B, H, N, s);
-    case 384: return launch_fa2<384, 192, 64, false, false>(q, k, v, o, B, H, N, s);
+    // D = 320 / 384 ride on the D = 512 kernel, D = 640 on the D = 768 kernel, with the missing columns padded in
+    // registers / LDS only (PAD): 585 / 695 / 593 TF at [1,16,4096,D] vs 368 / 418 / 217 for the round-1 kernel,
+    // (profiles/r01_fa_padded_dims.log); same N % 128 == 0 requirement as that kernel had
+    case 320: return fa2::launch_dsplit<512, 2, 1, fa2::OPT_DEFAULT, 0, true>(q, k, v, o, B, H, N, s, 320);
+    case 384: return fa2::launch_dsplit<512, 2, 1, fa2::OPT_DEFAULT, 0, true>(q, k, v, o, B, H, N, s, 384);
     // D = 512 (config C5): pairs of waves split the head dim, two 4-wave groups one phase apart
     // (flash_attn_dsplit.cuh): 990-1000 TF at [1,32,4096,512] vs 487 for the register-resident O-slice kernel
     // (flash_attn_bigd.cuh, still used for D = 768) and 411 for the v1 path (profiles/r01_fa_dsplit_probe.log)
     case 512: return fa2::launch_dsplit<512, 2, 1, fa2::OPT_DEFAULT>(q, k, v, o, B, H, N, s);
-    case 640: return launch_fa2<640, 320, 32, false, false>(q, k, v, o, B, H, N, s);
+    case 640: return fa2::launch_dwide<768, fa2::OPT_DEFAULT, true>(q, k, v, o, B, H, N, s, 640);
     // D = 768 / 1024: three / four waves split the head dim of a 32-row group (flash_attn_dwide.cuh): 675-690 TF
     // at [1,16,4096,768] (big-D kernel 223-295), 706-776 TF at D = 1024 (v1 path 100-131, below torch SDPA)
     case 768: return fa2::launch_dwide<768, fa2::OPT_DEFAULT>(q, k, v, o, B, H, N, s);

@@ -81,6 +81,8 @@ CLN_API int cln_fa2_variant(int D, int nw, int vt, int opt, int abl, const void*
   if (D == 256 && abl == 302) return fa2::launch_dsplit<256, 1, 1, 15 | fa2::OPT_KPRE, 2>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 128 && abl == 301) return fa2::launch_dsplit<128, 1, 2, 15 | fa2::OPT_KPRE, 1>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 256 && abl == 301) return fa2::launch_dsplit<256, 1, 1, 15 | fa2::OPT_KPRE, 1>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if ((D == 384 || D == 320) && abl == 210) return fa2::launch_dsplit<512, 2, 1, 15, 0, true>(q, k, v, o, B, H, N, (hipStream_t)stream, D);
+  if (D == 640 && abl == 210) return fa2::launch_dwide<768, 15, true>(q, k, v, o, B, H, N, (hipStream_t)stream, D);
   if (D == 512 && abl == 211) return fa2::launch_dsplit<512, 2, 1, 15, 1>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 512 && abl == 212) return fa2::launch_dsplit<512, 2, 1, 15, 2>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 512 && abl == 214) return fa2::launch_dsplit<512, 2, 1, 15, 4>(q, k, v, o, B, H, N, (hipStream_t)stream);

@@ -69,7 +69,7 @@ def test_head_dims(fa, built, dev, oracle, name, D):
         assert (o.double() - ref).abs().max().item() <= TOL
 
 
-@pytest.mark.parametrize("D", [320, 512, 768, 1024])
+@pytest.mark.parametrize("D", [320, 384, 512, 640, 768, 1024])
 def test_large_head_dims_tiling(fa, built, dev, oracle, D):
     B, H, N = 1, 2, 256
     q, k, v = seeded(7, B, H, N, D), seeded(8, B, H, N, D), seeded(9, B, H, N, D)
@@ -129,6 +129,18 @@ def test_d768_d1024_dwide_kernel_shapes(fa, built, dev, oracle, D, B, H, N):
     """D = 768 / 1024 (flash_attn_dwide.cuh): one 64-row workgroup / 2 KV tiles, odd tile counts, head counts that do
     and do not divide by 8."""
     q, k, v = seeded(61, B, H, N, D), seeded(62, B, H, N, D), seeded(63, B, H, N, D)
+    ref = oracle.attention_fp64(q, k, v)
+    o = run(fa, built, "flash_attn_mma_stages_split_q_tiling_qkv", q, k, v, 2, dev)
+    assert (o.double() - ref).abs().max().item() <= TOL
+
+
+@pytest.mark.parametrize("D,N", [(320, 128), (320, 640), (384, 384), (384, 1152), (640, 64), (640, 320)])
+def test_padded_head_dims(fa, built, dev, oracle, D, N):
+    """D = 320 / 384 run on the D = 512 kernel and D = 640 on the D = 768 kernel with the head dim padded in
+    registers / LDS (reads past a row are clamped into it, padding never reaches memory). Odd tile counts, one
+    workgroup, and every row checked -- the last rows are where an unclamped read would leave the tensor."""
+    B, H = 1, 3
+    q, k, v = seeded(71, B, H, N, D), seeded(72, B, H, N, D), seeded(73, B, H, N, D)
     ref = oracle.attention_fp64(q, k, v)
     o = run(fa, built, "flash_attn_mma_stages_split_q_tiling_qkv", q, k, v, 2, dev)
     assert (o.double() - ref).abs().max().item() <= TOL
@@ -200,7 +212,7 @@ def test_deferred_max_paths(fa, built, dev, oracle):
         assert (o.double() - ref).abs().max().item() <= TOL, name
 
 
-@pytest.mark.parametrize("D,H", [(64, 48), (128, 48), (256, 48), (512, 2), (768, 2), (1024, 3)])
+@pytest.mark.parametrize("D,H", [(64, 48), (128, 48), (256, 48), (512, 2), (768, 2), (1024, 3), (320, 2), (384, 3), (640, 2)])
 def test_pingpong_kernels_deferred_max_and_rescale(fa, built, dev, oracle, D, H):
     """Same three regimes as test_deferred_max_paths, on shapes that dispatch to the ping-pong kernels
     (flash_attn_dsplit.cuh; >= 192 workgroups of 256 rows at D <= 256): creeping max below the 2^8 threshold, one
@@ -223,7 +235,7 @@ def test_pingpong_kernels_deferred_max_and_rescale(fa, built, dev, oracle, D, H)
         assert (o[:, h:h + 1].double() - ref).abs().max().item() <= TOL, h
 
 
-@pytest.mark.parametrize("D,H", [(64, 48), (128, 48), (256, 48), (512, 2), (768, 2), (1024, 3)])
+@pytest.mark.parametrize("D,H", [(64, 48), (128, 48), (256, 48), (512, 2), (768, 2), (1024, 3), (320, 2), (384, 3), (640, 2)])
 def test_pingpong_kernels_uniform_softmax(fa, built, dev, D, H):
     """All-ones Q and K (reference --no-rand-q/k): O = column mean of V, through the ping-pong kernels."""
     B, N = 1, 1024
