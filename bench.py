@@ -28,12 +28,35 @@ import __graft_entry__ as entry  # noqa: E402
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=500)
-    p.add_argument("--warmup", type=int, default=100)
+    p.add_argument("--steps", type=int, default=200)
+    p.add_argument("--warmup", type=int, default=20)
     p.add_argument("--mnk", type=int, default=4096)
     p.add_argument("--stages", type=int, default=2)
+    p.add_argument("--prewarm", type=float, default=0.6, help="seconds of untimed back-to-back launches before warmup")
     p.add_argument("--no-extras", action="store_true", help="skip FA2 / rocBLAS / CPU baseline side measurements")
     return p.parse_args()
+
+
+def fa_roofline(kern, shape, pmc_file, dev, bu, profiles):
+    """roofline object of one FlashAttention-2 forward config: algorithmic flops (4 B H N^2 D) / mean launch
+    duration from HIP events over `iters` back-to-back launches on the launch stream (after a time-based pre-warm)."""
+    B_, H_, N_, D = shape
+    q, k, v = (torch.randn(B_, H_, N_, D, dtype=torch.half, device=dev) for _ in range(3))
+    o = torch.zeros_like(q)
+    fn = lambda: kern(q, k, v, o, 2)
+    bu.prewarm(fn, 0.3)
+    iters = 50 if N_ <= 2048 else 20
+    ms = min(bu.time_region_events(fn, iters), bu.time_region_events(fn, iters))
+    flops = bu.mha_flops_conventional(B_, H_, N_, D)
+    ach = flops / (ms * 1e-3) * 1e-12
+    busy, src = bu.pmc_value(profiles, pmc_file, "mfma_busy_frac")
+    traffic, _ = bu.pmc_value(profiles, pmc_file, "hbm_traffic_bytes_per_launch")
+    return {"bound": "mfma", "achieved": round(ach, 2), "peak": bu.PEAK_FP16_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / bu.PEAK_FP16_MFMA_TFLOPS, 4), "traffic": round(traffic) if traffic else None,
+            "mfma_busy": round(busy, 4) if busy else None, "pmc_source": src, "shape": [B_, H_, N_, D],
+            "avg_launch_ms": round(ms, 5), "algorithmic_flops_per_launch": flops,
+            "algorithmic_bytes_per_launch": 4.0 * B_ * H_ * N_ * D * 2,
+            "tflops_ref_model": round(bu.get_mha_tflops(B_, H_, N_, D, ms * 1e-3), 2)}, (q, k, v, o)
 
 
 def main():
@@ -47,13 +70,16 @@ def main():
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
+        # replicas only (north_star: no RCCL on this path): the process group exists for the barrier and the
+        # max-over-ranks of the step time, on CPU tensors over gloo -- the same code tests/test_multiproc_gloo.py runs
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
     pkg = entry.load_package()
     from cuda_learn_notes_amd import bench_utils as bu
     hg = pkg.hgemm_lib()
+    profiles = os.path.join(ROOT, "profiles")
 
     M = N = K = args.mnk
     torch.manual_seed(1234 + rank)
@@ -67,34 +93,44 @@ def main():
         kernel(a, b, c, args.stages, True, stride)
 
     def barrier():
+        torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
 
+    # Time-based pre-warm OUTSIDE the timed region: the chip clocks to its power budget, and the first milliseconds
+    # of a launch burst run on a higher (un-sustained) or lower (ramping) clock -- a 20-step run read 12-14 % low in
+    # round 1. After >= 0.5 s of back-to-back launches the 20-step and the 500-step numbers agree.
+    bu.prewarm(step, args.prewarm)
     for _ in range(args.warmup):
         step()
     barrier()
+    stream = torch.cuda.current_stream()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record(stream)
     for _ in range(args.steps):
         step()
+    ev1.record(stream)
     barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = bu.max_over_ranks(elapsed, dist, dev)
+    elapsed = bu.max_over_ranks(elapsed, dist, None)
+    ev_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream, over the SAME timed region
 
     flops = bu.hgemm_flops(M, N, K)
     ms_per_step = elapsed / args.steps * 1e3
     value = world * flops / (elapsed / args.steps) * 1e-12
 
-    # ---- roofline of the dominant kernel: HIP events on the launch stream, per launch
-    ev_ms, ev_min, _ = bu.time_call_events(step, 3, max(10, min(args.steps, 50)))
+    # ---- roofline of the dominant kernel: ONE timing source with `value` (the timed region above)
     achieved = flops / (ev_ms * 1e-3) * 1e-12
-    traffic, traffic_src = bu.pmc_traffic(os.path.join(ROOT, "profiles"), "hgemm", M)
+    traffic, traffic_src = bu.pmc_value(profiles, "pmc_hgemm", "hbm_traffic_bytes_per_launch") if M == 4096 else (None, None)
+    busy, _ = bu.pmc_value(profiles, "pmc_hgemm", "mfma_busy_frac") if M == 4096 else (None, None)
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": bu.PEAK_FP16_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / bu.PEAK_FP16_MFMA_TFLOPS, 4), "traffic": traffic,
-                "traffic_source": traffic_src,
+                "unit": "TFLOP/s", "frac": round(achieved / bu.PEAK_FP16_MFMA_TFLOPS, 4),
+                "traffic": round(traffic) if traffic else None, "traffic_source": traffic_src,
+                "mfma_busy": round(busy, 4) if busy else None,
                 "kernel": bu.HEADLINE_HGEMM_KERNEL, "avg_launch_ms": round(ev_ms, 5),
-                "min_launch_ms": round(ev_min, 5), "algorithmic_flops_per_launch": flops,
-                "algorithmic_bytes_per_launch": bu.hgemm_bytes(M, N, K)}
+                "timing": "HIP events on the launch stream around the %d timed steps (same region as value)" % args.steps,
+                "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": bu.hgemm_bytes(M, N, K)}
 
     out = {
         "metric": "HGEMM fp16 TFLOPS at M=N=K=%d" % M, "value": round(value, 2), "unit": "TFLOPS",
@@ -103,63 +139,62 @@ def main():
         "data": "synthetic (seeded torch.randn fp16, random-init operands)",
         "config": {"workload": "HGEMM fp16 NN M=N=K=%d, stages=%d, block swizzle stride %d (BASELINE config C3)"
                                % (M, args.stages, stride),
-                   "kernel": "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem", "parallelism": "replicas x%d" % world},
+                   "kernel": "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem", "parallelism": "replicas x%d" % world,
+                   "prewarm_s": args.prewarm},
         "pct_of_fp16_mfma_peak": round(100.0 * achieved / bu.PEAK_FP16_MFMA_TFLOPS, 2),
         "roofline": roofline,
     }
 
     if rank == 0 and world == 1 and not args.no_extras:  # side measurements only in the single-GPU run
-        extras = {"timing": "side rows: mean of the better of two event-timed rounds (first-use rounds read 5-15% low)"}
+        extras = {"timing": "side rows: 0.2-0.3 s pre-warm, then the better of two event-timed regions of back-to-back "
+                            "launches (ours and the vendor's alike)"}
 
-        def side_ms(fn, warm, iters):  # every side row, ours and the vendor's alike
-            return min(bu.time_call_events(fn, warm, iters)[0], bu.time_call_events(fn, 2, iters)[0])
+        def side_ms(fn, iters):
+            bu.prewarm(fn, 0.2)
+            return min(bu.time_region_events(fn, iters), bu.time_region_events(fn, iters))
 
         try:  # vendor row (rocBLAS) on the same operands
             hg.init_cublas_handle()
-            ms = side_ms(lambda: hg.hgemm_cublas_tensor_op_nn(a, b, c), 5, 20)
+            ms = side_ms(lambda: hg.hgemm_cublas_tensor_op_nn(a, b, c), 50)
             extras["rocblas_tflops"] = round(flops / (ms * 1e-3) * 1e-12, 2)
             extras["pct_of_rocblas"] = round(100.0 * achieved / extras["rocblas_tflops"], 2)
             bt = bu.as_col_major(b)
-            ms = side_ms(lambda: hg.hgemm_cublas_tensor_op_tn(a, bt, c), 5, 20)
+            ms = side_ms(lambda: hg.hgemm_cublas_tensor_op_tn(a, bt, c), 50)
             extras["rocblas_tn_tflops"] = round(flops / (ms * 1e-3) * 1e-12, 2)
             tn = hg.hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_tn_swizzle_x4
-            ms = side_ms(lambda: tn(a, bt, c, args.stages, True, stride), 5, 20)
+            ms = side_ms(lambda: tn(a, bt, c, args.stages, True, stride), 50)
             extras["hgemm_tn_tflops"] = round(flops / (ms * 1e-3) * 1e-12, 2)
             del bt
             hg.destroy_cublas_handle()
         except Exception as e:  # the vendor row is a comparison, never the product
             extras["rocblas_error"] = str(e)[:200]
-        try:  # FA2 forward, config C4 (D=64) and the D=128 sibling
+        try:  # FA2 forward is the other half of the BASELINE metric: roofline objects for C4 (D=64) and C5 (D=512)
+            import torch.nn.functional as F
             fa = pkg.flash_attn_lib()
-            for tag, (B_, H_, N_, D) in (("fa2_fwd_d64", (4, 8, 2048, 64)), ("fa2_fwd_d128", (4, 8, 2048, 128)),
-                                         ("fa2_fwd_d64_large", (1, 48, 8192, 64)),
-                                         ("fa2_fwd_d128_large", (2, 32, 4096, 128)),
-                                         ("fa2_fwd_d256", (2, 32, 4096, 256)),
-                                         ("fa2_fwd_d512_c5", (1, 32, 4096, 512))):
+            sq, tq = fa.flash_attn_mma_stages_split_q_shared_qkv, fa.flash_attn_mma_stages_split_q_tiling_qkv
+            for key, kern, shape, pmc in (("roofline_fa2_c4_d64", sq, (4, 8, 2048, 64), "pmc_fa_d64"),
+                                          ("roofline_fa2_d128", sq, (4, 8, 2048, 128), "pmc_fa_d128"),
+                                          ("roofline_fa2_c5_d512", tq, (1, 32, 4096, 512), "pmc_fa_d512")):
+                r, (q, k, v, o) = fa_roofline(kern, shape, pmc, dev, bu, profiles)
+                r["kernel"] = pkg.manifest.describe(kern.__name__, shape, 2)
+                # the FlashAttention-2-ROCm row available on the box is torch SDPA (the `flash_attn` package is not in
+                # the image): each backend forced in turn, so the row says WHICH implementation it is
+                r["torch_sdpa"] = bu.sdpa_rows(q, k, v, side_ms)
+                out[key] = r
+                del q, k, v, o
+            for tag, (B_, H_, N_, D) in (("fa2_fwd_d64_large", (1, 48, 8192, 64)), ("fa2_fwd_d128_large", (2, 32, 4096, 128)),
+                                         ("fa2_fwd_d256", (2, 32, 4096, 256))):
                 q, k, v = (torch.randn(B_, H_, N_, D, dtype=torch.half, device=dev) for _ in range(3))
                 o = torch.zeros_like(q)
-                kern = (fa.flash_attn_mma_stages_split_q_shared_qkv if D <= 256
-                        else fa.flash_attn_mma_stages_split_q_tiling_qkv)
-                fn = lambda: kern(q, k, v, o, 2)
-                ms = side_ms(fn, 5, 30 if N_ <= 2048 else 10)
-                row = {"shape": [B_, H_, N_, D], "ms": round(ms, 5),
-                       "tflops_ref_model": round(bu.get_mha_tflops(B_, H_, N_, D, ms * 1e-3), 2),
-                       "tflops_4bhn2d": round(bu.mha_flops_conventional(B_, H_, N_, D) / (ms * 1e-3) * 1e-12, 2)}
-                try:  # the FlashAttention-2-ROCm row available on the box: torch SDPA (reference prints it too,
-                    # flash_attn_mma.py:391-398)
-                    import torch.nn.functional as F
-                    ms2 = side_ms(lambda: F.scaled_dot_product_attention(q, k, v), 5, 30 if N_ <= 2048 else 10)
-                    row["torch_sdpa_tflops_4bhn2d"] = round(
-                        bu.mha_flops_conventional(B_, H_, N_, D) / (ms2 * 1e-3) * 1e-12, 2)
-                except Exception as e:
-                    row["torch_sdpa_error"] = str(e)[:120]
-                extras[tag] = row
+                ms = side_ms(lambda: sq(q, k, v, o, 2), 10)
+                extras[tag] = {"shape": [B_, H_, N_, D], "ms": round(ms, 5),
+                               "tflops_4bhn2d": round(bu.mha_flops_conventional(B_, H_, N_, D) / (ms * 1e-3) * 1e-12, 2),
+                               "kernel": pkg.manifest.describe(sq.__name__, (B_, H_, N_, D), 2)}
                 del q, k, v, o
         except Exception as e:
-            extras["fa2_error"] = str(e)[:200]
+            extras["fa2_error"] = str(e)[:300]
         out["extras"] = extras
-        if world == 1:
-            out["cpu_baseline"] = cpu_baseline(a, b, M, N, K)
+        out["cpu_baseline"] = cpu_baseline(a, b, M, N, K)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
@@ -182,9 +217,29 @@ def cpu_baseline(a, b, M, N, K):
         t0 = time.perf_counter()
         orc.hgemm_fp16_path(a[:rows].cpu(), b_c)
         dt = time.perf_counter() - t0
-    return {"value": round(2.0 * rows * N * K / dt * 1e-12, 5), "unit": "TFLOPS", "cores": torch.get_num_threads(),
-            "kind": "port", "sample": "torch.matmul fp16 on CPU, first %d of %d rows of A x full B, 1 iteration "
-                                      "(%.2f s); host cpu_count=%d" % (rows, M, dt, os.cpu_count() or 0)}
+    res = {"value": round(2.0 * rows * N * K / dt * 1e-12, 5), "unit": "TFLOPS", "cores": torch.get_num_threads(),
+           "kind": "port", "sample": "torch.matmul fp16 on CPU, first %d of %d rows of A x full B, 1 iteration "
+                                     "(%.2f s); host cpu_count=%d" % (rows, M, dt, os.cpu_count() or 0)}
+    # the FA2 half of the metric: the reference's own unfused torch attention (flash_attn_mma.py:384-398) on the host,
+    # config C4 shape, a bounded number of its 32 heads
+    try:
+        g = torch.Generator().manual_seed(7)
+        q, k, v = (torch.randn(1, 1, 2048, 64, generator=g).half() for _ in range(3))
+        t0 = time.perf_counter()
+        orc.unfused_standard_attn(q, k, v)
+        dt1 = time.perf_counter() - t0
+        heads = max(1, min(32, int(5.0 / max(dt1, 1e-3))))
+        q, k, v = (torch.randn(1, heads, 2048, 64, generator=g).half() for _ in range(3))
+        t0 = time.perf_counter()
+        orc.unfused_standard_attn(q, k, v)
+        dt = time.perf_counter() - t0
+        res["fa2_fwd_c4"] = {"value": round(4.0 * heads * 2048 * 2048 * 64 / dt * 1e-12, 5), "unit": "TFLOPS (4BHN^2D)",
+                             "cores": torch.get_num_threads(), "kind": "port",
+                             "sample": "unfused torch attention fp16 on CPU, %d of the 32 heads of [4,8,2048,64], "
+                                       "1 iteration (%.2f s)" % (heads, dt)}
+    except Exception as e:
+        res["fa2_fwd_c4"] = {"error": str(e)[:200]}
+    return res
 
 
 if __name__ == "__main__":

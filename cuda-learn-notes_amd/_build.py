@@ -1,7 +1,9 @@
 """Build the gfx950 shared objects in-tree with hipcc (no torch headers, no pybind, no hipify).
 
-  csrc/*.hip  --hipcc -c-->  build/*.o  --hipcc -shared-->  lib/libcln_amd.so
-  csrc/hgemm_vendor.hip  ------------------------------->  lib/libcln_amd_vendor.so (-lrocblas)
+  csrc/*.hip  --hipcc -c-->  build/*.o  --hipcc -shared-->  lib/libcln_amd.so         (the product: reference names only)
+  csrc/hgemm_vendor.hip  ------------------------------->  lib/libcln_amd_vendor.so  (-lrocblas comparison row)
+  csrc/*_probe.hip  ------------------------------------>  lib/libcln_amd_probe.so   (TEST-ONLY: tuning hooks, ablation and
+                                                           probe instantiations; nothing in the product path loads it)
 
 Replaces the reference's JIT `torch.utils.cpp_extension.load(...)` at script import
 (kernels/hgemm/tools/utils.py:104-113, kernels/elementwise/elementwise.py:10-22).
@@ -22,9 +24,12 @@ LIBDIR = os.path.join(PKG_DIR, "lib")
 ARCH = "gfx950"
 KERNEL_SOURCES = [
     "elementwise.hip", "activation.hip", "blas1.hip", "indexing.hip", "reduce.hip", "softmax.hip", "norm.hip", "rope.hip",
-    "sgemm.hip", "hgemm.hip", "hgemm_ring_nn.hip", "hgemm_ring_tn.hip", "flash_attn.hip", "flash_attn_v2_probe.hip",
+    "sgemm.hip", "hgemm.hip", "hgemm_ring_nn.hip", "hgemm_ring_tn.hip", "flash_attn.hip", "describe.hip",
 ]
 VENDOR_SOURCES = ["hgemm_vendor.hip"]
+# test-only library; it re-links the two ring compile units for the explicit (tile, BK, stages) hook
+PROBE_SOURCES = ["hgemm_probe.hip", "flash_attn_probe.hip"]
+PROBE_SHARED = ["hgemm_ring_nn.hip", "hgemm_ring_tn.hip"]
 CFLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-ffp-contract=fast",
           "-I" + CSRC]
 
@@ -83,15 +88,19 @@ def build(verbose=False, force=False):
             os.remove(os.path.join(BUILD, fn))
     hd = _deps_digest()
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 4)) as ex:
-        res = list(ex.map(lambda s: _compile_one(s, hd, verbose), KERNEL_SOURCES + VENDOR_SOURCES))
-    objs = dict(zip(KERNEL_SOURCES + VENDOR_SOURCES, res))
+        allsrc = KERNEL_SOURCES + VENDOR_SOURCES + PROBE_SOURCES
+        res = list(ex.map(lambda s: _compile_one(s, hd, verbose), allsrc))
+    objs = dict(zip(allsrc, res))
     main_so = os.path.join(LIBDIR, "libcln_amd.so")
     vend_so = os.path.join(LIBDIR, "libcln_amd_vendor.so")
+    probe_so = os.path.join(LIBDIR, "libcln_amd_probe.so")
     if force or not os.path.exists(main_so) or any(objs[s][1] for s in KERNEL_SOURCES):
         _link([objs[s][0] for s in KERNEL_SOURCES], main_so, [], verbose)
     if force or not os.path.exists(vend_so) or any(objs[s][1] for s in VENDOR_SOURCES):
         _link([objs[s][0] for s in VENDOR_SOURCES], vend_so, ["-L/opt/rocm/lib", "-lrocblas"], verbose)
-    return main_so, vend_so
+    if force or not os.path.exists(probe_so) or any(objs[s][1] for s in PROBE_SOURCES + PROBE_SHARED):
+        _link([objs[s][0] for s in PROBE_SOURCES + PROBE_SHARED], probe_so, [], verbose)
+    return main_so, vend_so, probe_so
 
 
 if __name__ == "__main__":

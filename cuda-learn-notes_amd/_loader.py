@@ -69,14 +69,17 @@ def load_so(so_name):
         fn = getattr(lib, e.name)  # AttributeError here == ABI hole; let it propagate
         fn.argtypes = ARGTYPES[e.sig]
         fn.restype = c_int
-    if so_name == "libcln_amd.so":
+    if so_name == "libcln_amd_probe.so":  # TEST-ONLY library: tuning / ablation hooks (tests/, tools/)
         fn = lib.cln_hgemm_variant
         fn.argtypes = [c_int] * 5 + [c_void_p] * 3 + [c_int] * 5 + [c_void_p]
         fn.restype = c_int
-        if hasattr(lib, "cln_fa2_variant"):
-            fn = lib.cln_fa2_variant
-            fn.argtypes = [c_int] * 5 + [c_void_p] * 4 + [c_int] * 3 + [c_void_p]
-            fn.restype = c_int
+        fn = lib.cln_fa2_variant
+        fn.argtypes = [c_int] * 5 + [c_void_p] * 4 + [c_int] * 3 + [c_void_p]
+        fn.restype = c_int
+    if so_name == "libcln_amd.so":
+        fn = lib.cln_describe
+        fn.argtypes = [ctypes.c_char_p, c_int, c_int, c_int, c_int, c_int, ctypes.c_char_p, c_int]
+        fn.restype = c_int
     _cache[so_name] = lib
     return lib
 

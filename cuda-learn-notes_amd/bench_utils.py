@@ -140,6 +140,79 @@ def aggregate_value(per_rank_units: float, world: int, seconds: float) -> float:
     return world * per_rank_units / seconds
 
 
+def prewarm(fn, seconds: float):
+    """Back-to-back launches for `seconds` of wall time (untimed): brings the chip to its sustained power/clock state."""
+    if seconds <= 0:
+        return
+    t0 = time.time()
+    while time.time() - t0 < seconds:
+        for _ in range(20):
+            fn()
+        torch.cuda.synchronize()
+
+
+def time_region_events(fn, iters: int, stream=None) -> float:
+    """Mean ms per launch from ONE pair of HIP events around `iters` back-to-back launches on the launch stream
+    (per-launch event pairs insert an idle gap after every kernel and read 5-15 % low on short kernels)."""
+    stream = stream or torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(3):
+        fn()
+    e0.record(stream)
+    for _ in range(iters):
+        fn()
+    e1.record(stream)
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def sdpa_rows(q, k, v, side_ms):
+    """torch SDPA with each backend forced in turn: {backend: TFLOPS (4BHN^2D) | error text}, plus the default
+    dispatch. Names the implementation behind the comparison row (VERDICT r1 #3)."""
+    import torch.nn.functional as F
+    B, H, N, D = q.shape
+    fl = mha_flops_conventional(B, H, N, D)
+    rows = {}
+    iters = 30 if N <= 2048 else 8
+    try:
+        ms = side_ms(lambda: F.scaled_dot_product_attention(q, k, v), iters)
+        rows["default_dispatch"] = round(fl / (ms * 1e-3) * 1e-12, 2)
+    except Exception as e:
+        rows["default_dispatch"] = "error: " + str(e)[:80]
+    try:
+        from torch.nn.attention import SDPBackend, sdpa_kernel
+        for name, be in (("flash_attention", SDPBackend.FLASH_ATTENTION), ("efficient_attention", SDPBackend.EFFICIENT_ATTENTION)):
+            try:
+                with sdpa_kernel(be):
+                    ms = side_ms(lambda: F.scaled_dot_product_attention(q, k, v), iters)
+                rows[name] = round(fl / (ms * 1e-3) * 1e-12, 2)
+            except Exception as e:
+                rows[name] = "unavailable: " + str(e).split("\n")[0][:80]
+    except Exception as e:
+        rows["backends"] = "torch.nn.attention unavailable: " + str(e)[:80]
+    rows["enabled_flags"] = {"flash": bool(torch.backends.cuda.flash_sdp_enabled()),
+                             "mem_efficient": bool(torch.backends.cuda.mem_efficient_sdp_enabled()),
+                             "math": bool(torch.backends.cuda.math_sdp_enabled())}
+    return rows
+
+
+def pmc_value(profiles_dir: str, stem: str, key: str):
+    """`key` of the newest committed rocprofv3 PMC summary profiles/rNN_<stem>.json (written by tools/pmc_summary.py on
+    the GPU box: PMC counters cannot be collected from inside the timed process). -> (value | None, file name | None)"""
+    import glob
+    import json
+    import os
+    files = sorted(glob.glob(os.path.join(profiles_dir, "r*_%s.json" % stem)))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+        vals = [e[key] for e in d.values() if isinstance(e, dict) and key in e]
+        return (vals[-1] if vals else None), os.path.basename(files[-1])
+    except Exception:
+        return None, None
+
+
 def pmc_traffic(profiles_dir: str, kernel_sub: str, size: int):
     """HBM bytes per launch of the headline kernel from the committed rocprofv3 PMC summary
     (profiles/rNN_pmc_<kernel>.json, written by tools/pmc_summary.py on the GPU box; PMC counters cannot be

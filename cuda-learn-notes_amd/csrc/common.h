@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <atomic>
 
 // ---------------------------------------------------------------- C-ABI status codes
 // Reference bindings throw std::runtime_error (e.g. kernels/hgemm/naive/hgemm.cu:772-782);
@@ -45,7 +46,31 @@ static inline int cln_set_lds(const void* fn, int bytes) {
   return CLN_OK;
 }
 
+// "Raise MaxDynamicSharedMemorySize once" -- once PER DEVICE (the attribute lives in the per-device function
+// object: a second GPU used from the same process needs its own call) and safe from several host threads: one bit
+// per HIP device in an atomic mask; two racing threads both issue the (idempotent) attribute call.
+// (reference re-issues cudaFuncSetAttribute on every call: kernels/hgemm/mma/basic/hgemm_mma_stage.cu:2333.)
+struct cln_lds_attr {
+  std::atomic<unsigned long long> done{0};
+};
+static inline int cln_ensure_lds(cln_lds_attr& st, const void* fn, int bytes) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return CLN_ERR_LAUNCH;
+  }
+  if (dev >= 64) return cln_set_lds(fn, bytes);  // beyond the mask: always set
+  const unsigned long long bit = 1ull << dev;
+  if (st.done.load(std::memory_order_acquire) & bit) return CLN_OK;
+  if (cln_set_lds(fn, bytes) != CLN_OK) return CLN_ERR_LAUNCH;
+  st.done.fetch_or(bit, std::memory_order_release);
+  return CLN_OK;
+}
+
 static inline bool cln_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+// every packed rung issues `bytes`-wide vector accesses (bytes = pack width, a power of two <= 16): a sliced view with
+// a storage offset must be rejected, not loaded misaligned
+static inline bool cln_aligned(const void* p, size_t bytes) { return (reinterpret_cast<uintptr_t>(p) & (bytes - 1)) == 0; }
 
 // ---------------------------------------------------------------- vector types
 typedef _Float16 half_t;
@@ -194,6 +219,15 @@ __device__ __forceinline__ h4 lds_read_tr16(const void* lds_addr) {
   h4 r;
   __builtin_memcpy(&r, &t, 8);
   return r;
+}
+
+// Lane id recomputed at the point of use (two VALU instructions). The attention kernels run their KV loop with a full
+// register file; lane-derived epilogue addresses computed at kernel entry would be carried -- i.e. spilled -- across
+// it. Opaque to hipcc so it is neither hoisted nor merged with the entry-time lane id.
+__device__ __forceinline__ int cln_fresh_lane() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
 }
 
 __device__ __forceinline__ h8 h8_cat(h4 lo, h4 hi) {

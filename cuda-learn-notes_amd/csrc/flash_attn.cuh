@@ -242,11 +242,8 @@ template <int D, int DV, int BC, bool VT, bool PREFETCH>
 int launch_fa2(const void* q, const void* k, const void* v, void* o, int B, int H, int N, hipStream_t stream) {
   using G = Geo<D, DV, BC, VT>;
   if (N % G::BR != 0) return CLN_ERR_UNSUPPORTED;  // reference asserts N % max(Br,Bc) == 0 (share_qkv.cu:769)
-  static bool attr_done = false;
-  if (!attr_done && G::LDS_BYTES > 48 * 1024) {
-    if (cln_set_lds(reinterpret_cast<const void*>(&fa2_fwd_kernel<D, DV, BC, VT, PREFETCH>), G::LDS_BYTES) != CLN_OK) return CLN_ERR_LAUNCH;
-    attr_done = true;
-  }
+  static cln_lds_attr lds_attr;  // per device, thread-safe (common.h)
+  if (G::LDS_BYTES > 48 * 1024 && cln_ensure_lds(lds_attr, reinterpret_cast<const void*>(&fa2_fwd_kernel<D, DV, BC, VT, PREFETCH>), G::LDS_BYTES) != CLN_OK) return CLN_ERR_LAUNCH;
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)D);
   CLN_LAUNCH((fa2_fwd_kernel<D, DV, BC, VT, PREFETCH>), dim3(N / G::BR, B * H, D / DV), dim3(256),
                      G::LDS_BYTES, stream, (const half_t*)q, (const half_t*)k, (const half_t*)v, (half_t*)o, N,

@@ -1,111 +1,250 @@
-// C-ABI entry points of the FlashAttention-2 forward library: one symbol per function exported by
-// the reference's pybind module (kernels/flash-attn/pybind/flash_attn.cc:182-215).
+// C-ABI entry points of the FlashAttention-2 forward library: one symbol per function exported by the
+// reference's pybind module (kernels/flash-attn/pybind/flash_attn.cc:182-215).
 //
 //   int name(q, k, v, o, B, H, N, D, stages, stream)
 //
 // q,k,v,o: fp16 [B,H,N,D] contiguous; the *_swizzle_qkv variants of share_kv / share_qkv /
 // tiling_qk take v TRANSPOSED, [B,H,D,N] (reference flash_attn_mma.py:377-378, :542-565).
-// stages: 1 = load-then-compute per KV tile, 2 = next K/V tile prefetched under the MFMA phases
-// (reference kStage template parameter, flash_attn_mma_share_qkv.cu:843-884).
+// stages (reference kStage template parameter, flash_attn_mma_share_qkv.cu:843-884):
+//   1 = load-then-compute per KV tile (no prefetch: the tile is fetched, two barriers, then used),
+//   2 = the next K/V tile is prefetched under the MFMA phases of the current one.
+// Every name goes through ONE planner (fa2_plan) that picks the gfx950 kernel for (family, shape, stages); the same
+// plan is what cln_describe() prints, so the name -> kernel map in manifest.py is checked against the code
+// (tests/test_describe.py).
 #include "flash_attn.cuh"
 #include "flash_attn_large_d.cuh"
+#include "flash_attn_splitkv.cuh"
 #include "flash_attn_v2.cuh"
+#include "flash_attn_rb.cuh"
+#include <string.h>
 
 namespace {
 
-template <bool VT>
-int fa2_dispatch(const void* q, const void* k, const void* v, void* o, int B, int H, int N, int D, int stages,
-                 int max_d, hipStream_t s) {
-  if (!q || !k || !v || !o || B <= 0 || H <= 0 || N <= 0) return CLN_ERR_BAD_ARG;
-  if (!cln_aligned16(q) || !cln_aligned16(k) || !cln_aligned16(v) || !cln_aligned16(o)) return CLN_ERR_BAD_ARG;
-  if (D > max_d) return CLN_ERR_UNSUPPORTED;  // "headdim not support!"
-  (void)stages;  // v2 always runs the double-buffered prefetch pipeline; `stages` 1 and 2 are the same kernel
-  // Head dims 32..256: v2 kernel. Workgroup = 8 / 4 / 2 waves x 32 query rows by the divisibility of N
-  // (reference: N % max(Br,Bc) == 0 with Br = 128 or 64, flash_attn_mma_share_qkv.cu:769, split_q.cu:754).
-  // waves per workgroup: the largest of 8 / 4 / 2 (x 32 query rows) that N allows AND that still gives every one of
-  // the 256 CUs a workgroup; small problems take the smaller workgroup (measured [2,8,2048,64]: 534 TF with
-  // 4 waves x 256 workgroups vs 413 TF with 8 waves x 128 workgroups).
+enum FaFamily { FAM_SPLIT_KV = 0, FAM_SPLIT_Q = 1 };
+enum FaKind { K_NONE = 0, K_SPLITKV, K_LOAD_THEN_COMPUTE, K_V2, K_DSPLIT, K_DWIDE, K_RB };
+
+struct FaPlan {
+  int rc = CLN_OK;     // CLN_ERR_* when the shape is not supported
+  int kind = K_NONE;
+  int d_inst = 0;      // head dim of the instantiation (> D: padded form)
+  int nw = 0;          // waves per workgroup
+  int bc = 0;          // keys per KV tile
+  bool stages_honoured = true;  // false: stages = 1 and 2 run the same (prefetching) kernel for this shape
+};
+
+FaPlan fa2_plan(int family, bool vt, int B, int H, int N, int D, int stages, int max_d) {
+  FaPlan p;
+  if (B <= 0 || H <= 0 || N <= 0 || D <= 0) return p.rc = CLN_ERR_BAD_ARG, p;
+  if ((long long)B * H * (long long)(N / 32 + 1) > 0x7fffffffLL) return p.rc = CLN_ERR_UNSUPPORTED, p;  // grid size
+  if (D > max_d) return p.rc = CLN_ERR_UNSUPPORTED, p;  // "headdim not support!"
   const long long bh = (long long)B * H;
-  int nw = 0;
-  for (int cand : {8, 4, 2}) {
-    if (N % (cand * 32) != 0) continue;
-    nw = cand;
-    if (bh * (N / (cand * 32)) >= 256) break;
+  if (family == FAM_SPLIT_KV) {
+    // the split-KV rung: its own kernel (flash_attn_splitkv.cuh); it has no cross-tile prefetch to switch off
+    if ((D != 32 && D != 64 && D != 96 && D != 128) || N % 32 != 0) return p.rc = CLN_ERR_UNSUPPORTED, p;
+    p.kind = K_SPLITKV, p.d_inst = D, p.nw = 4, p.bc = 128, p.stages_honoured = false;
+    return p;
   }
-  if (nw == 0) return CLN_ERR_UNSUPPORTED;
-#define FA_V2(DD, OPTT)                                                                            \
-  case DD:                                                                                         \
-    if (nw == 8) return fa2::launch_v2<DD, 8, VT, OPTT>(q, k, v, o, B, H, N, s);                   \
-    if (nw == 4) return fa2::launch_v2<DD, 4, VT, OPTT>(q, k, v, o, B, H, N, s);                   \
-    return fa2::launch_v2<DD, 2, VT, OPTT>(q, k, v, o, B, H, N, s);
-  // Head dims 64 / 128 / 256 with enough 256-row workgroups to occupy most of the chip: two-group ping-pong kernel
-  // (flash_attn_dsplit.cuh: 8 waves x 32 rows, K/V by LDS-DMA, the two 4-wave groups one phase apart).
-  // D = 256: 1000-1180 TF vs 630-790 for v2 (which needs one wave per SIMD there); D = 128: 970-1100 vs 900-1045
-  // (profiles/r01_fa_dsplit_d256_probe.log, r01_fa_dsplit_d128_probe.log, r01_fa_dsplit_d64_probe.log).
-  if constexpr (!VT) {
-    if (N % 256 == 0 && bh * (N / 256) >= 192) {
-      if (D == 256) return fa2::launch_dsplit<256, 1, 1, fa2::OPT_DEFAULT | fa2::OPT_KPRE>(q, k, v, o, B, H, N, s);
-      if (D == 128) return fa2::launch_dsplit<128, 1, 2, fa2::OPT_DEFAULT | fa2::OPT_KPRE>(q, k, v, o, B, H, N, s);
-      // D = 64 (config C4): 128-key tiles, half of the exponentials moved into the QK^T phase (OPT_STAGGER):
-      // 730-775 TF at [4,8,2048,64] vs 620-665 for v2, 950 vs 915-940 at [1,48,8192,64]
-      if (D == 64) return fa2::launch_dsplit<64, 1, 4, 13 | fa2::OPT_STAGGER>(q, k, v, o, B, H, N, s);
+  const bool small_d = D == 32 || D == 64 || D == 96 || D == 128 || D == 256;
+  // ---- stages = 1: load-then-compute (flash_attn.cuh with PREFETCH = false): 4 waves x 32 rows, 64-key tiles
+  if (stages == 1 && small_d && N % 128 == 0) {
+    p.kind = K_LOAD_THEN_COMPUTE, p.d_inst = D, p.nw = 4, p.bc = 64;
+    return p;
+  }
+  p.stages_honoured = stages != 1;
+  if (small_d) {
+    if (!vt && N % 256 == 0 && bh * (N / 256) >= 192) {
+      // enough 256-row workgroups to occupy most of the chip:
+      //  D = 64 / 128: register-blocked kernel, 4 waves x 64 rows, one wave per SIMD (flash_attn_rb.cuh)
+      //  D = 256: two-group ping-pong kernel, 8 waves x 32 rows (flash_attn_dsplit.cuh)
+      if (D == 64) return p.kind = fa2::RB_PRODUCTION_D64 ? K_RB : K_DSPLIT, p.d_inst = 64, p.nw = fa2::RB_PRODUCTION_D64 ? 4 : 8, p.bc = 128, p;
+      if (D == 128) return p.kind = fa2::RB_PRODUCTION_D128 ? K_RB : K_DSPLIT, p.d_inst = 128, p.nw = fa2::RB_PRODUCTION_D128 ? 4 : 8, p.bc = 64, p;
+      if (D == 256) return p.kind = K_DSPLIT, p.d_inst = 256, p.nw = 8, p.bc = 32, p;
     }
+    // v2 kernel: the largest of 8 / 4 / 2 waves (x 32 query rows) that N allows AND that still gives every one of the
+    // 256 CUs a workgroup (measured [2,8,2048,64]: 534 TF with 4 waves x 256 workgroups vs 413 TF with 8 x 128)
+    if (D == 256) {  // needs the whole register file (one wave per SIMD): 4 waves x 32 rows only
+      if (N % 128 != 0) return p.rc = CLN_ERR_UNSUPPORTED, p;
+      return p.kind = K_V2, p.d_inst = 256, p.nw = 4, p.bc = 64, p;
+    }
+    int nw = 0;
+    for (int cand : {8, 4, 2}) {
+      if (N % (cand * 32) != 0) continue;
+      nw = cand;
+      if (bh * (N / (cand * 32)) >= 256) break;
+    }
+    if (nw == 0) return p.rc = CLN_ERR_UNSUPPORTED, p;
+    return p.kind = K_V2, p.d_inst = D, p.nw = nw, p.bc = 64, p;
   }
+  if (vt) return p.rc = CLN_ERR_UNSUPPORTED, p;
+  // ---- head dims above 256 ("fine-grained tiling" rungs, flash_attn_large_d.cuh); one pipeline each
+  p.stages_honoured = false;
   switch (D) {
-    FA_V2(32, 13)
-    FA_V2(64, 13)
-    FA_V2(96, 15)
-    FA_V2(128, 15)
-    case 256:
-      // v2 at D = 256 needs the whole register file (one wave per SIMD): 4 waves x 32 rows only
-      if (N % 128 == 0) return fa2::launch_v2<256, 4, VT, 15>(q, k, v, o, B, H, N, s);
-      return CLN_ERR_UNSUPPORTED;
-    default:
-      break;
+    case 320: case 384: case 512:
+      if (N % 128 != 0) return p.rc = CLN_ERR_UNSUPPORTED, p;
+      return p.kind = K_DSPLIT, p.d_inst = 512, p.nw = 8, p.bc = 32, p;
+    case 640: case 768:
+      if (N % 64 != 0) return p.rc = CLN_ERR_UNSUPPORTED, p;
+      return p.kind = K_DWIDE, p.d_inst = 768, p.nw = 6, p.bc = 32, p;
+    case 1024:
+      if (N % 64 != 0) return p.rc = CLN_ERR_UNSUPPORTED, p;
+      return p.kind = K_DWIDE, p.d_inst = 1024, p.nw = 8, p.bc = 32, p;
+    default: return p.rc = CLN_ERR_UNSUPPORTED, p;
   }
-#undef FA_V2
-  if constexpr (!VT) {
-    if (D == 512 || D == 1024 || D == 768 || D == 320 || D == 384 || D == 640)
-      return fa::launch_fa2_large_d(q, k, v, o, B, H, N, D, stages, s);
-  }
-  return CLN_ERR_UNSUPPORTED;
 }
+
+template <bool VT>
+int fa2_run(const FaPlan& p, const void* q, const void* k, const void* v, void* o, int B, int H, int N, int D,
+            hipStream_t s) {
+  switch (p.kind) {
+    case K_SPLITKV:
+      if constexpr (!VT) {
+        switch (D) {
+          case 32: return fa2::launch_splitkv<32>(q, k, v, o, B, H, N, s);
+          case 64: return fa2::launch_splitkv<64>(q, k, v, o, B, H, N, s);
+          case 96: return fa2::launch_splitkv<96>(q, k, v, o, B, H, N, s);
+          case 128: return fa2::launch_splitkv<128>(q, k, v, o, B, H, N, s);
+        }
+      }
+      return CLN_ERR_UNSUPPORTED;
+    case K_LOAD_THEN_COMPUTE:
+      switch (D) {
+        case 32: return fa::launch_fa2<32, 32, 64, VT, false>(q, k, v, o, B, H, N, s);
+        case 64: return fa::launch_fa2<64, 64, 64, VT, false>(q, k, v, o, B, H, N, s);
+        case 96: return fa::launch_fa2<96, 96, 64, VT, false>(q, k, v, o, B, H, N, s);
+        case 128: return fa::launch_fa2<128, 128, 64, VT, false>(q, k, v, o, B, H, N, s);
+        case 256: return fa::launch_fa2<256, 256, 64, VT, false>(q, k, v, o, B, H, N, s);
+      }
+      return CLN_ERR_UNSUPPORTED;
+    case K_V2:
+#define FA_V2(DD, OPTT)                                                                                \
+  case DD:                                                                                             \
+    if (p.nw == 8) return fa2::launch_v2<DD, 8, VT, OPTT>(q, k, v, o, B, H, N, s);                     \
+    if (p.nw == 4) return fa2::launch_v2<DD, 4, VT, OPTT>(q, k, v, o, B, H, N, s);                     \
+    return fa2::launch_v2<DD, 2, VT, OPTT>(q, k, v, o, B, H, N, s);
+      switch (D) {
+        FA_V2(32, 13)
+        FA_V2(64, 13)
+        FA_V2(96, 15)
+        FA_V2(128, 15)
+        case 256: return fa2::launch_v2<256, 4, VT, 15>(q, k, v, o, B, H, N, s);
+      }
+#undef FA_V2
+      return CLN_ERR_UNSUPPORTED;
+    case K_RB:
+      if constexpr (!VT) {
+        if (D == 64) return fa2::launch_rb<64, fa2::RB_BC_D64, fa2::RB_OPT_D64>(q, k, v, o, B, H, N, s);
+        if (D == 128) return fa2::launch_rb<128, fa2::RB_BC_D128, fa2::RB_OPT_D128>(q, k, v, o, B, H, N, s);
+      }
+      return CLN_ERR_UNSUPPORTED;
+    case K_DSPLIT:
+      if constexpr (!VT) {
+        // D = 64 (config C4): 128-key tiles, half of the exponentials moved into the QK^T phase (OPT_STAGGER)
+        if (D == 64) return fa2::launch_dsplit<64, 1, 4, 13 | fa2::OPT_STAGGER>(q, k, v, o, B, H, N, s);
+        if (D == 128) return fa2::launch_dsplit<128, 1, 2, fa2::OPT_DEFAULT | fa2::OPT_KPRE>(q, k, v, o, B, H, N, s);
+        if (D == 256) return fa2::launch_dsplit<256, 1, 1, fa2::OPT_DEFAULT | fa2::OPT_KPRE>(q, k, v, o, B, H, N, s);
+        return fa::launch_fa2_large_d(q, k, v, o, B, H, N, D, s);
+      }
+      return CLN_ERR_UNSUPPORTED;
+    case K_DWIDE:
+      if constexpr (!VT) return fa::launch_fa2_large_d(q, k, v, o, B, H, N, D, s);
+      return CLN_ERR_UNSUPPORTED;
+    default: return CLN_ERR_UNSUPPORTED;
+  }
+}
+
+template <bool VT>
+int fa2_dispatch(int family, const void* q, const void* k, const void* v, void* o, int B, int H, int N, int D,
+                 int stages, int max_d, hipStream_t s) {
+  if (!q || !k || !v || !o) return CLN_ERR_BAD_ARG;
+  if (!cln_aligned16(q) || !cln_aligned16(k) || !cln_aligned16(v) || !cln_aligned16(o)) return CLN_ERR_BAD_ARG;
+  const FaPlan p = fa2_plan(family, VT, B, H, N, D, stages, max_d);
+  if (p.rc != CLN_OK) return p.rc;
+  return fa2_run<VT>(p, q, k, v, o, B, H, N, D, s);
+}
+
+int fa2_describe(int family, bool vt, int B, int H, int N, int D, int stages, int max_d, char* buf, int len) {
+  const FaPlan p = fa2_plan(family, vt, B, H, N, D, stages, max_d);
+  if (p.rc != CLN_OK) return p.rc;
+  const char* st = p.stages_honoured ? "" : " [stages ignored: one pipeline]";
+  const char* vts = vt ? ",V^T" : "";
+  switch (p.kind) {
+    case K_SPLITKV:
+      return snprintf(buf, len, "fa2_fwd_splitkv<D=%d> 4 waves share 32 rows, 128-key tiles split over the waves, "
+                                "cross-wave max via LDS%s", D, st);
+    case K_LOAD_THEN_COMPUTE:
+      return snprintf(buf, len, "fa2_fwd<D=%d,BC=64,load-then-compute%s> 4 waves x 32 rows", D, vts);
+    case K_V2:
+      return snprintf(buf, len, "fa2_fwd_v2<D=%d,NW=%d,BC=64,prefetch%s> %d waves x 32 rows%s", D, p.nw, vts, p.nw, st);
+    case K_RB:
+      return snprintf(buf, len, "fa2_fwd_rb<D=%d,BC=%d> 4 waves x 64 rows, 1 wave/SIMD, K/V fragments shared by 2 row "
+                                "groups%s", D, p.bc, st);
+    case K_DSPLIT:
+      if (p.d_inst != D)
+        return snprintf(buf, len, "fa2_fwd_dsplit<D=%d,NSP=2,BC=32,PAD=%d> 8 waves, pairs split d%s", p.d_inst, D, st);
+      return snprintf(buf, len, "fa2_fwd_dsplit<D=%d,NSP=%d,BC=%d> 8 waves, two groups one phase apart%s", D,
+                      D == 512 ? 2 : 1, p.bc, st);
+    case K_DWIDE:
+      if (p.d_inst != D)
+        return snprintf(buf, len, "fa2_fwd_dwide<D=%d,PAD=%d> %d waves split d%s", p.d_inst, D, p.nw, st);
+      return snprintf(buf, len, "fa2_fwd_dwide<D=%d> %d waves split d%s", D, p.nw, st);
+    default: return CLN_ERR_UNSUPPORTED;
+  }
+}
+
+struct FaName {
+  const char* name;
+  int family;
+  bool vt;
+  int max_d;
+};
 
 }  // namespace
 
-#define CLN_FA(name, VT, MAXD)                                                                            \
+// max head dim per function follows the reference driver table (flash_attn_mma.py:436-506)
+#define CLN_FA_LIST(X)                                                              \
+  X(flash_attn_mma_stages_split_kv, FAM_SPLIT_KV, false, 128)                      \
+  X(flash_attn_mma_stages_split_q, FAM_SPLIT_Q, false, 128)                        \
+  X(flash_attn_mma_stages_split_q_shared_kv, FAM_SPLIT_Q, false, 256)              \
+  X(flash_attn_mma_stages_split_q_shared_qkv, FAM_SPLIT_Q, false, 256)             \
+  X(flash_attn_mma_stages_split_q_tiling_qk, FAM_SPLIT_Q, false, 1024)             \
+  X(flash_attn_mma_stages_split_q_tiling_qkv, FAM_SPLIT_Q, false, 1024)            \
+  X(flash_attn_mma_stages_split_q_shared_kv_acc_f32, FAM_SPLIT_Q, false, 256)      \
+  X(flash_attn_mma_stages_split_q_shared_qkv_acc_f32, FAM_SPLIT_Q, false, 256)     \
+  X(flash_attn_mma_stages_split_q_tiling_qk_acc_f32, FAM_SPLIT_Q, false, 1024)     \
+  X(flash_attn_mma_stages_split_q_tiling_qkv_acc_f32, FAM_SPLIT_Q, false, 1024)    \
+  X(flash_attn_mma_stages_split_q_shared_kv_swizzle_q, FAM_SPLIT_Q, false, 256)    \
+  X(flash_attn_mma_stages_split_q_shared_kv_swizzle_qk, FAM_SPLIT_Q, false, 256)   \
+  X(flash_attn_mma_stages_split_q_shared_kv_swizzle_qkv, FAM_SPLIT_Q, true, 256)   \
+  X(flash_attn_mma_stages_split_q_shared_qkv_swizzle_q, FAM_SPLIT_Q, false, 256)   \
+  X(flash_attn_mma_stages_split_q_shared_qkv_swizzle_qk, FAM_SPLIT_Q, false, 256)  \
+  X(flash_attn_mma_stages_split_q_shared_qkv_swizzle_qkv, FAM_SPLIT_Q, true, 256)  \
+  X(flash_attn_mma_stages_split_q_tiling_qk_swizzle_q, FAM_SPLIT_Q, false, 1024)   \
+  X(flash_attn_mma_stages_split_q_tiling_qk_swizzle_qk, FAM_SPLIT_Q, false, 1024)  \
+  X(flash_attn_mma_stages_split_q_tiling_qk_swizzle_qkv, FAM_SPLIT_Q, true, 256)   \
+  X(flash_attn_mma_stages_split_q_tiling_qkv_swizzle_q, FAM_SPLIT_Q, false, 1024)  \
+  X(flash_attn_mma_stages_split_q_tiling_qkv_swizzle_qk, FAM_SPLIT_Q, false, 1024) \
+  X(flash_attn_mma_stages_split_q_tiling_qkv_swizzle_qkv, FAM_SPLIT_Q, false, 1024) \
+  X(flash_attn_mma_stages_split_q_tiling_qkv_acc_f32_swizzle_q, FAM_SPLIT_Q, false, 1024)   \
+  X(flash_attn_mma_stages_split_q_tiling_qkv_acc_f32_swizzle_qk, FAM_SPLIT_Q, false, 1024)  \
+  X(flash_attn_mma_stages_split_q_tiling_qkv_acc_f32_swizzle_qkv, FAM_SPLIT_Q, false, 1024) \
+  /* BUILD_FLASH_ATTN_MMA_OTHERS set (flash_attn.cc:161-180) -- always built here */        \
+  X(flash_attn_mma_stages_split_q_shared_qkv_Os2g, FAM_SPLIT_Q, false, 256)                 \
+  X(flash_attn_mma_stages_split_q_shared_kv_acc_f32_rr, FAM_SPLIT_Q, false, 256)            \
+  X(flash_attn_mma_stages_split_q_shared_qkv_acc_f32_rr, FAM_SPLIT_Q, false, 256)
+
+#define CLN_FA(name, FAM, VT, MAXD)                                                                       \
   CLN_API int name(const void* q, const void* k, const void* v, void* o, int B, int H, int N, int D,     \
                    int stages, void* stream) {                                                            \
-    return fa2_dispatch<VT>(q, k, v, o, B, H, N, D, stages, MAXD, (hipStream_t)stream);                   \
+    return fa2_dispatch<VT>(FAM, q, k, v, o, B, H, N, D, stages, MAXD, (hipStream_t)stream);              \
   }
+CLN_FA_LIST(CLN_FA)
 
-// max head dim per function follows the reference driver table (flash_attn_mma.py:436-506)
-CLN_FA(flash_attn_mma_stages_split_kv, false, 128)
-CLN_FA(flash_attn_mma_stages_split_q, false, 128)
-CLN_FA(flash_attn_mma_stages_split_q_shared_kv, false, 256)
-CLN_FA(flash_attn_mma_stages_split_q_shared_qkv, false, 256)
-CLN_FA(flash_attn_mma_stages_split_q_tiling_qk, false, 1024)
-CLN_FA(flash_attn_mma_stages_split_q_tiling_qkv, false, 1024)
-CLN_FA(flash_attn_mma_stages_split_q_shared_kv_acc_f32, false, 256)
-CLN_FA(flash_attn_mma_stages_split_q_shared_qkv_acc_f32, false, 256)
-CLN_FA(flash_attn_mma_stages_split_q_tiling_qk_acc_f32, false, 1024)
-CLN_FA(flash_attn_mma_stages_split_q_tiling_qkv_acc_f32, false, 1024)
-CLN_FA(flash_attn_mma_stages_split_q_shared_kv_swizzle_q, false, 256)
-CLN_FA(flash_attn_mma_stages_split_q_shared_kv_swizzle_qk, false, 256)
-CLN_FA(flash_attn_mma_stages_split_q_shared_kv_swizzle_qkv, true, 256)
-CLN_FA(flash_attn_mma_stages_split_q_shared_qkv_swizzle_q, false, 256)
-CLN_FA(flash_attn_mma_stages_split_q_shared_qkv_swizzle_qk, false, 256)
-CLN_FA(flash_attn_mma_stages_split_q_shared_qkv_swizzle_qkv, true, 256)
-CLN_FA(flash_attn_mma_stages_split_q_tiling_qk_swizzle_q, false, 1024)
-CLN_FA(flash_attn_mma_stages_split_q_tiling_qk_swizzle_qk, false, 1024)
-CLN_FA(flash_attn_mma_stages_split_q_tiling_qk_swizzle_qkv, true, 256)
-CLN_FA(flash_attn_mma_stages_split_q_tiling_qkv_swizzle_q, false, 1024)
-CLN_FA(flash_attn_mma_stages_split_q_tiling_qkv_swizzle_qk, false, 1024)
-CLN_FA(flash_attn_mma_stages_split_q_tiling_qkv_swizzle_qkv, false, 1024)
-CLN_FA(flash_attn_mma_stages_split_q_tiling_qkv_acc_f32_swizzle_q, false, 1024)
-CLN_FA(flash_attn_mma_stages_split_q_tiling_qkv_acc_f32_swizzle_qk, false, 1024)
-CLN_FA(flash_attn_mma_stages_split_q_tiling_qkv_acc_f32_swizzle_qkv, false, 1024)
-// BUILD_FLASH_ATTN_MMA_OTHERS set (flash_attn.cc:161-180) -- always built here
-CLN_FA(flash_attn_mma_stages_split_q_shared_qkv_Os2g, false, 256)
-CLN_FA(flash_attn_mma_stages_split_q_shared_kv_acc_f32_rr, false, 256)
-CLN_FA(flash_attn_mma_stages_split_q_shared_qkv_acc_f32_rr, false, 256)
+// describe hook of this library group (see cln_describe in describe.hip): returns the length written, or a
+// CLN_ERR_* code; CLN_ERR_BAD_ARG when `name` is not a flash-attn name.
+int cln_fa_describe(const char* name, int B, int H, int N, int D, int stages, char* buf, int len) {
+#define CLN_FA_ROW(n, FAM, VT, MAXD) {#n, FAM, VT, MAXD},
+  static const FaName table[] = {CLN_FA_LIST(CLN_FA_ROW)};
+  for (const FaName& e : table)
+    if (strcmp(e.name, name) == 0) return fa2_describe(e.family, e.vt, B, H, N, D, stages, e.max_d, buf, len);
+  return CLN_ERR_BAD_ARG;
+}

@@ -310,12 +310,8 @@ template <int D, int DV, int OPT>
 int launch_bigd(const void* q, const void* k, const void* v, void* o, int B, int H, int N, hipStream_t stream) {
   using G = GeoBig<D, DV>;
   if (N % G::BR != 0) return CLN_ERR_UNSUPPORTED;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (cln_set_lds(reinterpret_cast<const void*>(&fa2_fwd_bigd_kernel<D, DV, OPT>), G::LDS_BYTES) != CLN_OK)
-      return CLN_ERR_LAUNCH;
-    attr_done = true;
-  }
+  static cln_lds_attr lds_attr;  // per device, thread-safe (common.h)
+  if (cln_ensure_lds(lds_attr, reinterpret_cast<const void*>(&fa2_fwd_bigd_kernel<D, DV, OPT>), G::LDS_BYTES) != CLN_OK) return CLN_ERR_LAUNCH;
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)D);
   const int n_qblk = N / G::BR;
   CLN_LAUNCH((fa2_fwd_bigd_kernel<D, DV, OPT>), dim3(n_qblk * B * H * G::NS), dim3(G::NT), G::LDS_BYTES, stream,

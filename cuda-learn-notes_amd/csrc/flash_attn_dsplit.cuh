@@ -123,6 +123,7 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
   float m_run = -1.0e30f, l_run = 0.f;
 
   const int T = N / G::BC;
+  __builtin_assume(T > 0);  // the launcher rejects N < BR: no zero-trip path (its phi copies cost registers)
 #pragma unroll
   for (int i = 0; i < G::PPW; ++i) dma_piece(0, 0, i);
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), compiler-visible: also retires the Q loads in its bookkeeping
@@ -337,6 +338,9 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
   }
   const float inv = 1.0f / l_tot;
   char* ob = smem + wave * (32 * G::OS);
+  // lane-derived epilogue addresses are formed HERE from a recomputed lane id: formed at kernel entry they were carried
+  // across the KV loop in a full register file, i.e. spilled (15 dwords at D = 512, 11 at D = 256)
+  const int lane_e = cln_fresh_lane(), l31_e = lane_e & 31, hi_e = lane_e >> 5;
 #pragma unroll
   for (int b = 0; b < G::DH / 32; ++b) {
 #pragma unroll
@@ -344,7 +348,7 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
       h4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = (half_t)(ot[b][rq * 4 + e] * inv);
-      *reinterpret_cast<h4*>(ob + l31 * G::OS + (b * 32 + rq * 8 + hi * 4) * 2) = o;
+      *reinterpret_cast<h4*>(ob + l31_e * G::OS + (b * 32 + rq * 8 + hi_e * 4) * 2) = o;
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -352,7 +356,7 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
   half_t* og = O + head + (size_t)q_row0 * DR + part * G::DH;
 #pragma unroll 4
   for (int it = 0; it < (32 * LPR) / 64; ++it) {
-    const int idx = it * 64 + lane;
+    const int idx = it * 64 + lane_e;
     const int row = idx / LPR, c = idx % LPR;
     const u4 v = *reinterpret_cast<const u4*>(ob + row * G::OS + c * 16);
     if (!PAD || part * G::DH + c * 8 < DR) *reinterpret_cast<u4*>(og + (size_t)row * DR + c * 8) = v;
@@ -372,12 +376,8 @@ int launch_dsplit(const void* q, const void* k, const void* v, void* o, int B, i
   using G = GeoSplit<D, NSP, BCB>;
   if (N % G::BR != 0) return CLN_ERR_UNSUPPORTED;
   if (PAD ? (dreal % 64 != 0 || dreal <= D / 2 || dreal >= D) : dreal != D) return CLN_ERR_UNSUPPORTED;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (cln_set_lds(reinterpret_cast<const void*>(&fa2_fwd_dsplit_kernel<D, NSP, BCB, OPT, ABL, PAD>), G::LDS_BYTES) != CLN_OK)
-      return CLN_ERR_LAUNCH;
-    attr_done = true;
-  }
+  static cln_lds_attr lds_attr;  // per device, thread-safe (common.h)
+  if (cln_ensure_lds(lds_attr, reinterpret_cast<const void*>(&fa2_fwd_dsplit_kernel<D, NSP, BCB, OPT, ABL, PAD>), G::LDS_BYTES) != CLN_OK) return CLN_ERR_LAUNCH;
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)dreal);
   const int n_qblk = N / G::BR;
   CLN_LAUNCH((fa2_fwd_dsplit_kernel<D, NSP, BCB, OPT, ABL, PAD>), dim3(n_qblk * B * H), dim3(G::NT), G::LDS_BYTES, stream,

@@ -111,6 +111,7 @@ __global__ __launch_bounds__(GeoWide<D>::NT, 1) void fa2_fwd_dwide_kernel(const 
   float m_run = -1.0e30f, l_run = 0.f;
 
   const int T = N / G::BC;
+  __builtin_assume(T > 0);
 #pragma unroll
   for (int i = 0; i < G::PPW; ++i) dma_k(0, i);
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), compiler-visible (see flash_attn_bigd.cuh)
@@ -253,12 +254,8 @@ int launch_dwide(const void* q, const void* k, const void* v, void* o, int B, in
   using G = GeoWide<D>;
   if (N % G::BR != 0) return CLN_ERR_UNSUPPORTED;
   if (PAD ? (dreal % 64 != 0 || dreal <= D - 256 || dreal >= D) : dreal != D) return CLN_ERR_UNSUPPORTED;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (cln_set_lds(reinterpret_cast<const void*>(&fa2_fwd_dwide_kernel<D, OPT, PAD>), G::LDS_BYTES) != CLN_OK)
-      return CLN_ERR_LAUNCH;
-    attr_done = true;
-  }
+  static cln_lds_attr lds_attr;  // per device, thread-safe (common.h)
+  if (cln_ensure_lds(lds_attr, reinterpret_cast<const void*>(&fa2_fwd_dwide_kernel<D, OPT, PAD>), G::LDS_BYTES) != CLN_OK) return CLN_ERR_LAUNCH;
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)dreal);
   const int n_qblk = N / G::BR;
   CLN_LAUNCH((fa2_fwd_dwide_kernel<D, OPT, PAD>), dim3(n_qblk * B * H), dim3(G::NT), G::LDS_BYTES, stream,

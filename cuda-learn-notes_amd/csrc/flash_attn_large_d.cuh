@@ -14,8 +14,7 @@
 
 namespace fa {
 inline int launch_fa2_large_d(const void* q, const void* k, const void* v, void* o, int B, int H, int N, int D,
-                              int stages, hipStream_t s) {
-  (void)stages;
+                              hipStream_t s) {
   switch (D) {
     // D = 320 / 384 ride on the D = 512 kernel, D = 640 on the D = 768 kernel, with the missing columns padded in
     // registers / LDS only (PAD): 585 / 695 / 593 TF at [1,16,4096,D] vs 368 / 418 / 217 for the round-1 kernel,

@@ -6,6 +6,7 @@
 #include "flash_attn_pipe.cuh"
 #include "flash_attn_dwide.cuh"
 #include "flash_attn_v4.cuh"
+#include "flash_attn_rb.cuh"
 #include <type_traits>
 
 #define V3(DD, NWW, OPTT) \
@@ -17,6 +18,22 @@
 
 CLN_API int cln_fa2_variant(int D, int nw, int vt, int opt, int abl, const void* q, const void* k, const void* v,
                             void* o, int B, int H, int N, void* stream) {
+  // register-blocked kernel (flash_attn_rb.cuh): abl 400.. = option sets, 410.. = ablations
+  {
+    using namespace fa2;
+    constexpr int B0 = RB_PIN | RB_DEFER | RB_XCD | RB_ASMMAX;
+#define RB(DD, ABLN, BCC, OPTT, ABLL) \
+  if (D == DD && abl == ABLN) return launch_rb<DD, BCC, OPTT, ABLL>(q, k, v, o, B, H, N, (hipStream_t)stream);
+    RB(64, 400, 64, B0 | RB_PRE, 0) RB(64, 401, 64, B0 | RB_PRE | RB_ASMQK, 0) RB(64, 402, 64, B0, 0)
+    RB(64, 403, 64, (B0 | RB_PRE) & ~RB_PIN, 0) RB(64, 404, 32, B0 | RB_PRE, 0) RB(64, 405, 32, B0 | RB_PRE | RB_ASMQK, 0)
+    RB(64, 406, 64, B0 | RB_PRE | RB_ASMQK | RB_PD2, 0) RB(64, 407, 64, (B0 | RB_PRE | RB_ASMQK) & ~RB_DEFER, 0)
+    RB(64, 408, 64, B0 | RB_ASMQK, 0) RB(64, 409, 64, (B0 | RB_PRE) & ~RB_DEFER, 0)
+    RB(64, 410, 64, B0 | RB_PRE | RB_ASMQK, 1) RB(64, 411, 64, B0 | RB_PRE | RB_ASMQK, 2) RB(64, 412, 64, B0 | RB_PRE | RB_ASMQK, 3)
+    RB(128, 400, 32, B0, 0) RB(128, 401, 32, B0 | RB_ASMQK, 0) RB(128, 405, 32, B0 & ~RB_PIN, 0)
+    RB(128, 408, 32, B0 | RB_ASMQK | RB_PD2, 0) RB(128, 409, 32, B0 & ~RB_DEFER, 0) RB(128, 407, 32, (B0 | RB_ASMQK) & ~RB_DEFER, 0)
+    RB(128, 410, 32, B0 | RB_ASMQK, 1) RB(128, 411, 32, B0 | RB_ASMQK, 2)
+#undef RB
+  }
   V2(64, 8, 13, 0) V2(64, 4, 13, 0) V2(64, 4, 77, 0) V2(128, 8, 15, 0) V2(128, 4, 15, 0) V2(128, 4, 79, 0)
   V2(64, 8, 13, 1) V2(64, 8, 13, 2) V2(64, 8, 13, 7) V2(128, 8, 15, 1) V2(128, 8, 15, 7)
   V2(64, 8, 525, 0) V2(128, 8, 527, 0) V2(64, 8, 524, 0)

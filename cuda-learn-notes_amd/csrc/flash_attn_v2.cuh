@@ -58,8 +58,9 @@ struct Geo {
   static_assert(D <= 128 || NW <= 4, "D > 128 needs the whole register file: one wave per SIMD");
 };
 
+// (D = 128 with 2-wave workgroups does not fit 256 registers without spilling: it takes the one-wave-per-SIMD budget)
 template <int D, int NW, bool VT, int OPT, int ABL>
-__global__ __launch_bounds__(NW * 64, (D > 128 ? 1 : 2)) void fa2_fwd_v2_kernel(const half_t* __restrict__ Q,
+__global__ __launch_bounds__(NW * 64, ((D > 128 || (D == 128 && NW == 2)) ? 1 : 2)) void fa2_fwd_v2_kernel(const half_t* __restrict__ Q,
                                                                 const half_t* __restrict__ K,
                                                                 const half_t* __restrict__ V,
                                                                 half_t* __restrict__ O, int N, int n_qblk,
@@ -372,6 +373,8 @@ __global__ __launch_bounds__(NW * 64, (D > 128 ? 1 : 2)) void fa2_fwd_v2_kernel(
   const float inv = 1.0f / l_tot;
   if constexpr ((OPT & OPT_LDS_EPI) != 0) {
     // the loop's last barrier guarantees every wave is done with the K/V buffers
+    const int lane_e = cln_fresh_lane(), l31 = lane_e & 31, hi = lane_e >> 5;  // not carried across the KV loop
+    const int lane = lane_e;
     char* ob = smem + wave * (32 * G::OS);
 #pragma unroll
     for (int b = 0; b < D / 32; ++b)
@@ -414,11 +417,8 @@ int launch_v2(const void* q, const void* k, const void* v, void* o, int B, int H
   if (N % G::BR != 0) return CLN_ERR_UNSUPPORTED;
   // OPT_SOLO (experiment): over-ask LDS so only one workgroup fits a CU
   constexpr int LDS = ((OPT & OPT_SOLO) != 0 && G::LDS_BYTES < 96 * 1024) ? 96 * 1024 : G::LDS_BYTES;
-  static bool attr_done = false;
-  if (!attr_done && LDS > 48 * 1024) {
-    if (cln_set_lds(reinterpret_cast<const void*>(&fa2_fwd_v2_kernel<D, NW, VT, OPT, ABL>), LDS) != CLN_OK) return CLN_ERR_LAUNCH;
-    attr_done = true;
-  }
+  static cln_lds_attr lds_attr;  // per device, thread-safe (common.h)
+  if (LDS > 48 * 1024 && cln_ensure_lds(lds_attr, reinterpret_cast<const void*>(&fa2_fwd_v2_kernel<D, NW, VT, OPT, ABL>), LDS) != CLN_OK) return CLN_ERR_LAUNCH;
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)D);
   const int n_qblk = N / G::BR;
   CLN_LAUNCH((fa2_fwd_v2_kernel<D, NW, VT, OPT, ABL>), dim3(n_qblk * B * H), dim3(G::NT), LDS, stream,

@@ -344,12 +344,8 @@ int launch_v3(const void* q, const void* k, const void* v, void* o, int B, int H
   constexpr int KB = (G::K_BYTES + 15) / 16 * 16, VB = (G::V_BYTES + 15) / 16 * 16;
   constexpr int RING = 2 * KB + 2 * VB;
   constexpr int LDS = RING > G::EPI_BYTES ? RING : G::EPI_BYTES;
-  static bool attr_done = false;
-  if (!attr_done && LDS > 48 * 1024) {
-    if (cln_set_lds(reinterpret_cast<const void*>(&fa2_fwd_v3_kernel<D, NW, VT, OPT>), LDS) != CLN_OK)
-      return CLN_ERR_LAUNCH;
-    attr_done = true;
-  }
+  static cln_lds_attr lds_attr;  // per device, thread-safe (common.h)
+  if (LDS > 48 * 1024 && cln_ensure_lds(lds_attr, reinterpret_cast<const void*>(&fa2_fwd_v3_kernel<D, NW, VT, OPT>), LDS) != CLN_OK) return CLN_ERR_LAUNCH;
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)D);
   const int n_qblk = N / G::BR;
   CLN_LAUNCH((fa2_fwd_v3_kernel<D, NW, VT, OPT>), dim3(n_qblk * B * H), dim3(G::NT), LDS, stream,

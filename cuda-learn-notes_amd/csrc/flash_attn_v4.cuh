@@ -258,12 +258,8 @@ template <int D, bool VT, int OPT>
 int launch_v4(const void* q, const void* k, const void* v, void* o, int B, int H, int N, hipStream_t stream) {
   using G = Geo<D, 8, VT>;
   if (N % G::BR != 0) return CLN_ERR_UNSUPPORTED;
-  static bool attr_done = false;
-  if (!attr_done && G::LDS_BYTES > 48 * 1024) {
-    if (cln_set_lds(reinterpret_cast<const void*>(&fa2_fwd_v4_kernel<D, VT, OPT>), G::LDS_BYTES) != CLN_OK)
-      return CLN_ERR_LAUNCH;
-    attr_done = true;
-  }
+  static cln_lds_attr lds_attr;  // per device, thread-safe (common.h)
+  if (G::LDS_BYTES > 48 * 1024 && cln_ensure_lds(lds_attr, reinterpret_cast<const void*>(&fa2_fwd_v4_kernel<D, VT, OPT>), G::LDS_BYTES) != CLN_OK) return CLN_ERR_LAUNCH;
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)D);
   const int n_qblk = N / G::BR;
   CLN_LAUNCH((fa2_fwd_v4_kernel<D, VT, OPT>), dim3(n_qblk * B * H), dim3(512), G::LDS_BYTES, stream,

@@ -11,6 +11,7 @@
 #include "hgemm_dispatch.h"
 #include "hgemm_mfma.cuh"
 #include "hgemm_valu.cuh"
+#include <string.h>
 
 using namespace hgemm;
 
@@ -47,6 +48,26 @@ int best_dispatch(const void* a, const void* b, void* c, int M, int N, int K, in
   }
   return LAYOUT == TN ? ring_dispatch_tn(tile, a, b, c, M, N, K, stages, swizzle, stride, st)
                       : ring_dispatch_nn(tile, a, b, c, M, N, K, stages, swizzle, stride, st);
+}
+
+// what best_dispatch / ring_dispatch run for a shape, as text (cln_describe)
+int describe_ring(int tile, int layout, int M, int N, int K, int stages, char* buf, int len) {
+  int BM, BN, waves, BK = 32;
+  tile_dims(tile, BM, BN, waves);
+  if (M % BM || N % BN) return CLN_ERR_UNSUPPORTED;
+  ring_pick(BM, BN, K, stages, BK);
+  if (K % BK) return CLN_ERR_UNSUPPORTED;
+  return snprintf(buf, len, "mfma_ring<%dx%dx%d,%d waves,stages=%d,%s>", BM, BN, BK, waves, stages, layout == TN ? "TN" : "NN");
+}
+int describe_best(int layout, int M, int N, int K, int stages, char* buf, int len) {
+  const int tile = best_tile(M, N);
+  const char* l = layout == TN ? "TN" : "NN";
+  if (tile == T256) {
+    if ((stages == 2 || stages < 2 || stages > 5) && K % 64 == 0)
+      return snprintf(buf, len, "hgemm_pp<256x256x64,8 waves,4 slots,split DMA,LDS epilogue,%s>", l);
+    if (stages == 4 && K % 32 == 0) return snprintf(buf, len, "hgemm_pp32<256x256,BK=32 sub-tiles,4-deep ring,%s>", l);
+  }
+  return describe_ring(tile, layout, M, N, K, stages, buf, len);
 }
 
 using C1S_128_NN = Cfg<128, 128, 32, 2, 2, 1, NN>;
@@ -134,70 +155,32 @@ CLN_G6(hgemm_mma_stages_block_swizzle_tn_cute,
        ring_dispatch_tn((N % 256 == 0) ? T128x256 : T128, a, b, c, M, N, K, stages, swizzle, swizzle_stride,
                         stream))
 
-// ---- tuning / test hooks (not part of the reference surface) -----------------------------------
-// layout: 0 NN, 1 TN. kind: 0 ring (tile,bk,stages), 1 single-stage 128x128x32, 2 naive.
-CLN_API int cln_hgemm_variant(int kind, int layout, int tile, int bk, int stages, const void* a, const void* b,
-                              void* c, int M, int N, int K, int swizzle, int swizzle_stride, void* stream_) {
-  int rc = check_args(a, b, c, M, N, K);
-  if (rc != CLN_OK) return rc;
-  hipStream_t stream = (hipStream_t)stream_;
-  if (kind == 0) {
-    return layout == TN ? ring_exact_tn(tile, bk, stages, a, b, c, M, N, K, swizzle, swizzle_stride, stream)
-                        : ring_exact_nn(tile, bk, stages, a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+// describe hook of this library group (see cln_describe in describe.hip): the kernel a G6 name runs for (M, N, K,
+// stages); CLN_ERR_BAD_ARG when `name` is not one of the run-time dispatched HGEMM names (every other HGEMM name is
+// one fixed kernel: manifest.py `impl`).
+int cln_hgemm_describe(const char* name, int M, int N, int K, int stages, char* buf, int len) {
+  struct Row { const char* name; int kind; int tile; int layout; };  // kind 0: ring_dispatch(tile), 1: best_dispatch
+  static const Row rows[] = {
+      {"hgemm_wmma_m16n16k16_mma4x2_warp2x4_stages", 0, T128, NN},
+      {"hgemm_wmma_m16n16k16_mma4x2_warp2x4_stages_dsmem", 0, T128, NN},
+      {"hgemm_wmma_m16n16k16_mma4x2_warp4x4_stages_dsmem", 0, T256x128, NN},
+      {"hgemm_wmma_m16n16k16_mma4x4_warp4x4_stages_dsmem", 0, T256, NN},
+      {"hgemm_mma_m16n8k16_mma2x4_warp4x4_stages", 0, T128, NN},
+      {"hgemm_mma_m16n8k16_mma2x4_warp4x4_stages_dsmem", 0, T128, NN},
+      {"hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem", 1, 0, NN},
+      {"hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_x4", 1, 0, NN},
+      {"hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_rr", 1, 0, NN},
+      {"hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_swizzle", 1, 0, NN},
+      {"hgemm_mma_m16n8k16_mma2x4_warp4x4_stages_dsmem_tn", 0, T128, TN},
+      {"hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_tn_swizzle_x4", 1, 0, TN},
+      {"hgemm_mma_stages_block_swizzle_tn_cute", 0, -1, TN},
+  };
+  if (M <= 0 || N <= 0 || K <= 0) return CLN_ERR_BAD_ARG;
+  for (const Row& r : rows) {
+    if (strcmp(r.name, name) != 0) continue;
+    if (r.kind == 1) return describe_best(r.layout, M, N, K, stages, buf, len);
+    const int tile = r.tile >= 0 ? r.tile : ((N % 256 == 0) ? T128x256 : T128);
+    return describe_ring(tile, r.layout, M, N, K, stages, buf, len);
   }
-  if (kind == 1) {
-    return layout == TN ? launch_1stage<Cfg<128, 128, 32, 2, 2, 1, TN>>(a, b, c, M, N, K, stream)
-                        : launch_1stage<C1S_128_NN>(a, b, c, M, N, K, stream);
-  }
-  if (kind == 3) {  // ping-pong 256x256x64
-    return layout == TN ? launch_pp<TN>(a, b, c, M, N, K, swizzle, swizzle_stride, stream)
-                        : launch_pp<NN>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
-  }
-  if (kind == 4) return launch_pp<NN, 1>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);  // no-store probe
-  if (kind == 5) {  // ping-pong + LDS-staged epilogue; `stages` selects 8 or 4 slots per K tile
-    if (stages == 4)
-      return layout == TN ? launch_pp<TN, 2, 4>(a, b, c, M, N, K, swizzle, swizzle_stride, stream)
-                          : launch_pp<NN, 2, 4>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
-    return layout == TN ? launch_pp<TN, 2, 8>(a, b, c, M, N, K, swizzle, swizzle_stride, stream)
-                        : launch_pp<NN, 2, 8>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
-  }
-  if (kind == 8) {  // 4-slot ping-pong, split DMA, LDS epilogue (stages==1: no-store probe)
-    if (stages == 1) return launch_pp<NN, 1, 4, 0, 1>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
-    return layout == TN ? launch_pp<TN, 2, 4, 0, 1>(a, b, c, M, N, K, swizzle, swizzle_stride, stream)
-                        : launch_pp<NN, 2, 4, 0, 1>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
-  }
-  if (kind == 9) {  // k-half ping-pong (BK=32 sub-tiles, 4-deep ring); stages==1: no-store probe
-    if (stages == 1) return launch_pp32<NN, 1>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
-    return layout == TN ? launch_pp32<TN, 2>(a, b, c, M, N, K, swizzle, swizzle_stride, stream)
-                        : launch_pp32<NN, 2>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
-  }
-  if (kind == 10) {  // ping-pong on mfma_32x32x16; stages==1: no-store probe; stages>=16: ablation bits = stages-16
-    if (stages == 1) return launch_m32<NN, 1>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
-    if (stages >= 16) {
-      switch (stages - 16) {
-        case 1: return launch_m32<NN, 1, 1>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
-        case 2: return launch_m32<NN, 1, 2>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
-        case 3: return launch_m32<NN, 1, 3>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
-        case 7: return launch_m32<NN, 1, 7>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
-        case 8: return launch_m32<NN, 2, 8>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
-        default: return CLN_ERR_BAD_ARG;
-      }
-    }
-    return layout == TN ? launch_m32<TN>(a, b, c, M, N, K, swizzle, swizzle_stride, stream)
-                        : launch_m32<NN>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
-  }
-  if (kind == 6) return launch_pp<NN, 1, 4>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);  // 4-slot no-store probe
-  if (kind == 7) {  // ablations of the 4-slot no-store probe; `stages` = ABL bits (results are garbage by design)
-    switch (stages) {
-      case 1: return launch_pp<NN, 1, 4, 1>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
-      case 2: return launch_pp<NN, 1, 4, 2>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
-      case 3: return launch_pp<NN, 1, 4, 3>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
-      case 7: return launch_pp<NN, 1, 4, 7>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
-      case 8: return launch_pp<NN, 1, 4, 8>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
-      case 4: return launch_pp<NN, 1, 4, 4>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
-      default: return CLN_ERR_BAD_ARG;
-    }
-  }
-  if (kind == 2) return layout == TN ? launch_naive<TN>(a, b, c, M, N, K, stream) : launch_naive<NN>(a, b, c, M, N, K, stream);
   return CLN_ERR_BAD_ARG;
 }

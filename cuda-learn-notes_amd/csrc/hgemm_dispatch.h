@@ -14,4 +14,28 @@ int ring_exact_nn(int tile, int bk, int stages, const void* a, const void* b, vo
                   int swizzle, int swizzle_stride, hipStream_t stream);
 int ring_exact_tn(int tile, int bk, int stages, const void* a, const void* b, void* c, int M, int N, int K,
                   int swizzle, int swizzle_stride, hipStream_t stream);
+// (BK, stages) the ring dispatcher runs for a BM x BN tile: BK = 64 when K allows it and `stages` buffers fit the
+// 160 KiB LDS, else BK = 32 with the stage count trimmed to fit. One definition for the launcher (hgemm_ring_impl.inc)
+// and for cln_describe().
+inline void ring_pick(int BM, int BN, int K, int& S, int& BK) {
+  // reference bindings fall back to 2 stages for an unknown count (hgemm_mma_stage.cu:2380-2454 default case)
+  if (S < 2 || S > 5) S = 2;
+  if (K % 64 == 0 && S * (BM + BN) * 64 * 2 <= 160 * 1024) {
+    BK = 64;
+    return;
+  }
+  while (S > 2 && S * (BM + BN) * 32 * 2 > 160 * 1024) --S;
+  BK = 32;
+}
+inline void tile_dims(int tile, int& BM, int& BN, int& waves) {
+  switch (tile) {
+    case T256: BM = 256, BN = 256, waves = 8; break;
+    case T256x128: BM = 256, BN = 128, waves = 8; break;
+    case T128x256: BM = 128, BN = 256, waves = 8; break;
+    case T256W4: BM = 256, BN = 256, waves = 4; break;
+    case T128W8: BM = 128, BN = 128, waves = 8; break;
+    case T64x128: BM = 64, BN = 128, waves = 4; break;
+    default: BM = 128, BN = 128, waves = 4; break;
+  }
+}
 }  // namespace hgemm

@@ -539,11 +539,8 @@ int launch_pp(const void* a, const void* b, void* c, int M, int N, int K, int sw
               hipStream_t stream) {
   using C = Cfg<256, 256, 64, 2, 4, 2, LAYOUT>;
   if (M % 256 || N % 256 || K % 64) return CLN_ERR_UNSUPPORTED;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (cln_set_lds(reinterpret_cast<const void*>(&hgemm_pp_kernel<LAYOUT, EPI, SLOTS, ABL, SPLIT>), C::LDS_BYTES) != CLN_OK) return CLN_ERR_LAUNCH;
-    attr_done = true;
-  }
+  static cln_lds_attr lds_attr;  // per device, thread-safe (common.h)
+  if (cln_ensure_lds(lds_attr, reinterpret_cast<const void*>(&hgemm_pp_kernel<LAYOUT, EPI, SLOTS, ABL, SPLIT>), C::LDS_BYTES) != CLN_OK) return CLN_ERR_LAUNCH;
   const int tiles_m = M / 256, tiles_n = N / 256;
   int band = (swizzle && swizzle_stride >= 256) ? swizzle_stride / 256 : tiles_n;
   CLN_LAUNCH((hgemm_pp_kernel<LAYOUT, EPI, SLOTS, ABL, SPLIT>), dim3(tiles_m * tiles_n), dim3(512), C::LDS_BYTES, stream,
@@ -673,11 +670,8 @@ int launch_pp32(const void* a, const void* b, void* c, int M, int N, int K, int 
                 hipStream_t stream) {
   using C = Cfg<256, 256, 32, 2, 4, 4, LAYOUT>;
   if (M % 256 || N % 256 || K % 32) return CLN_ERR_UNSUPPORTED;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (cln_set_lds(reinterpret_cast<const void*>(&hgemm_pp32_kernel<LAYOUT, EPI>), C::LDS_BYTES) != CLN_OK) return CLN_ERR_LAUNCH;
-    attr_done = true;
-  }
+  static cln_lds_attr lds_attr;  // per device, thread-safe (common.h)
+  if (cln_ensure_lds(lds_attr, reinterpret_cast<const void*>(&hgemm_pp32_kernel<LAYOUT, EPI>), C::LDS_BYTES) != CLN_OK) return CLN_ERR_LAUNCH;
   const int tiles_m = M / 256, tiles_n = N / 256;
   int band = (swizzle && swizzle_stride >= 256) ? swizzle_stride / 256 : tiles_n;
   CLN_LAUNCH((hgemm_pp32_kernel<LAYOUT, EPI>), dim3(tiles_m * tiles_n), dim3(512), C::LDS_BYTES, stream,
@@ -904,12 +898,8 @@ int launch_m32(const void* a, const void* b, void* c, int M, int N, int K, int s
                hipStream_t stream) {
   using C = Cfg<256, 256, 64, 2, 4, 2, LAYOUT>;
   if (M % 256 || N % 256 || K % 64) return CLN_ERR_UNSUPPORTED;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (cln_set_lds(reinterpret_cast<const void*>(&hgemm_m32_kernel<LAYOUT, EPI, ABL>), C::LDS_BYTES) != CLN_OK)
-      return CLN_ERR_LAUNCH;
-    attr_done = true;
-  }
+  static cln_lds_attr lds_attr;  // per device, thread-safe (common.h)
+  if (cln_ensure_lds(lds_attr, reinterpret_cast<const void*>(&hgemm_m32_kernel<LAYOUT, EPI, ABL>), C::LDS_BYTES) != CLN_OK) return CLN_ERR_LAUNCH;
   const int tiles_m = M / 256, tiles_n = N / 256;
   int band = (swizzle && swizzle_stride >= 256) ? swizzle_stride / 256 : tiles_n;
   CLN_LAUNCH((hgemm_m32_kernel<LAYOUT, EPI, ABL>), dim3(tiles_m * tiles_n), dim3(512), C::LDS_BYTES, stream,
@@ -1017,11 +1007,8 @@ template <typename C>
 int launch_ring(const void* a, const void* b, void* c, int M, int N, int K, int swizzle, int swizzle_stride,
                 hipStream_t stream) {
   if (M % C::BM || N % C::BN || K % C::BK) return CLN_ERR_UNSUPPORTED;
-  static bool attr_done = false;  // once per instantiation (reference re-issues it per call, hgemm_mma_stage.cu:2333)
-  if (!attr_done) {
-    if (cln_set_lds(reinterpret_cast<const void*>(&hgemm_ring_kernel<C>), C::LDS_BYTES) != CLN_OK) return CLN_ERR_LAUNCH;
-    attr_done = true;
-  }
+  static cln_lds_attr lds_attr;  // per device, thread-safe (common.h)
+  if (cln_ensure_lds(lds_attr, reinterpret_cast<const void*>(&hgemm_ring_kernel<C>), C::LDS_BYTES) != CLN_OK) return CLN_ERR_LAUNCH;
   const int tiles_m = M / C::BM, tiles_n = N / C::BN;
   int band = (swizzle && swizzle_stride >= C::BN) ? swizzle_stride / C::BN : tiles_n;
   CLN_LAUNCH((hgemm_ring_kernel<C>), dim3(tiles_m * tiles_n), dim3(C::NT), C::LDS_BYTES, stream,

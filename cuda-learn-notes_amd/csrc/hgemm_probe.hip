@@ -1,0 +1,84 @@
+// Tuning / ablation hook of the HGEMM kernels -- TEST-ONLY library (libcln_amd_probe.so), never part of the product
+// libcln_amd.so: explicit (tile, BK, stages) ring instantiations, the ping-pong variants and their no-store / ablation
+// forms (some ablations produce garbage by design; they exist to price one phase of the kernel).
+#include "hgemm_dispatch.h"
+#include "hgemm_mfma.cuh"
+
+using namespace hgemm;
+
+namespace {
+int check_args(const void* a, const void* b, const void* c, int M, int N, int K) {
+  if (!a || !b || !c) return CLN_ERR_BAD_ARG;
+  if (M <= 0 || N <= 0 || K <= 0) return CLN_ERR_BAD_ARG;
+  if (!cln_aligned16(a) || !cln_aligned16(b) || !cln_aligned16(c)) return CLN_ERR_BAD_ARG;
+  return CLN_OK;
+}
+using C1S_128_NN = Cfg<128, 128, 32, 2, 2, 1, NN>;
+}  // namespace
+
+// layout: 0 NN, 1 TN. kind: 0 ring (tile,bk,stages), 1 single-stage 128x128x32, 2 naive.
+CLN_API int cln_hgemm_variant(int kind, int layout, int tile, int bk, int stages, const void* a, const void* b,
+                              void* c, int M, int N, int K, int swizzle, int swizzle_stride, void* stream_) {
+  int rc = check_args(a, b, c, M, N, K);
+  if (rc != CLN_OK) return rc;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (kind == 0) {
+    return layout == TN ? ring_exact_tn(tile, bk, stages, a, b, c, M, N, K, swizzle, swizzle_stride, stream)
+                        : ring_exact_nn(tile, bk, stages, a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+  }
+  if (kind == 1) {
+    return layout == TN ? launch_1stage<Cfg<128, 128, 32, 2, 2, 1, TN>>(a, b, c, M, N, K, stream)
+                        : launch_1stage<C1S_128_NN>(a, b, c, M, N, K, stream);
+  }
+  if (kind == 3) {  // ping-pong 256x256x64
+    return layout == TN ? launch_pp<TN>(a, b, c, M, N, K, swizzle, swizzle_stride, stream)
+                        : launch_pp<NN>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+  }
+  if (kind == 4) return launch_pp<NN, 1>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);  // no-store probe
+  if (kind == 5) {  // ping-pong + LDS-staged epilogue; `stages` selects 8 or 4 slots per K tile
+    if (stages == 4)
+      return layout == TN ? launch_pp<TN, 2, 4>(a, b, c, M, N, K, swizzle, swizzle_stride, stream)
+                          : launch_pp<NN, 2, 4>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+    return layout == TN ? launch_pp<TN, 2, 8>(a, b, c, M, N, K, swizzle, swizzle_stride, stream)
+                        : launch_pp<NN, 2, 8>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+  }
+  if (kind == 8) {  // 4-slot ping-pong, split DMA, LDS epilogue (stages==1: no-store probe)
+    if (stages == 1) return launch_pp<NN, 1, 4, 0, 1>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+    return layout == TN ? launch_pp<TN, 2, 4, 0, 1>(a, b, c, M, N, K, swizzle, swizzle_stride, stream)
+                        : launch_pp<NN, 2, 4, 0, 1>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+  }
+  if (kind == 9) {  // k-half ping-pong (BK=32 sub-tiles, 4-deep ring); stages==1: no-store probe
+    if (stages == 1) return launch_pp32<NN, 1>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+    return layout == TN ? launch_pp32<TN, 2>(a, b, c, M, N, K, swizzle, swizzle_stride, stream)
+                        : launch_pp32<NN, 2>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+  }
+  if (kind == 10) {  // ping-pong on mfma_32x32x16; stages==1: no-store probe; stages>=16: ablation bits = stages-16
+    if (stages == 1) return launch_m32<NN, 1>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+    if (stages >= 16) {
+      switch (stages - 16) {
+        case 1: return launch_m32<NN, 1, 1>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+        case 2: return launch_m32<NN, 1, 2>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+        case 3: return launch_m32<NN, 1, 3>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+        case 7: return launch_m32<NN, 1, 7>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+        case 8: return launch_m32<NN, 2, 8>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+        default: return CLN_ERR_BAD_ARG;
+      }
+    }
+    return layout == TN ? launch_m32<TN>(a, b, c, M, N, K, swizzle, swizzle_stride, stream)
+                        : launch_m32<NN>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+  }
+  if (kind == 6) return launch_pp<NN, 1, 4>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);  // 4-slot no-store probe
+  if (kind == 7) {  // ablations of the 4-slot no-store probe; `stages` = ABL bits (results are garbage by design)
+    switch (stages) {
+      case 1: return launch_pp<NN, 1, 4, 1>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+      case 2: return launch_pp<NN, 1, 4, 2>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+      case 3: return launch_pp<NN, 1, 4, 3>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+      case 7: return launch_pp<NN, 1, 4, 7>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+      case 8: return launch_pp<NN, 1, 4, 8>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+      case 4: return launch_pp<NN, 1, 4, 4>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+      default: return CLN_ERR_BAD_ARG;
+    }
+  }
+  if (kind == 2) return layout == TN ? launch_naive<TN>(a, b, c, M, N, K, stream) : launch_naive<NN>(a, b, c, M, N, K, stream);
+  return CLN_ERR_BAD_ARG;
+}

@@ -115,18 +115,31 @@ __global__ __launch_bounds__(128 * 8 / TM * 2) void hgemm_valu_tile_kernel(const
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
 
+  // One k-pair slice: TM + 8 LDS reads feed TM x 8 dot products.
+  auto slice = [&](int buf, int p) {
+    h2 a2[TM], b2[8];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a2[i] = As2[buf][p][ty * TM + i];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b2[j] = Bs2[buf][p][tx * 8 + j];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = __builtin_amdgcn_fdot2(a2[i], b2[j], acc[i][j], false);
+  };
   auto compute = [&](int buf) {
+    if constexpr (KP >= 16 && ASYNC) {
+      // a REAL loop of two-slice steps: fully unrolled, hipcc hoists the LDS reads of all 16 slices above the first dot
+      // product while the issue-early global loads are also in flight (TM = 16: 96 ds_read_b128 up front, 96 spilled
+      // registers, 260 B of scratch). Two slices per trip keep one slice of reads ahead of the math.
+#pragma unroll 1
+      for (int p = 0; p < KP; p += 2) {
+        slice(buf, p);
+        slice(buf, p + 1);
+      }
+    } else {
 #pragma unroll
-    for (int p = 0; p < KP; ++p) {
-      h2 a2[TM], b2[8];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) a2[i] = As2[buf][p][ty * TM + i];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) b2[j] = Bs2[buf][p][tx * 8 + j];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = __builtin_amdgcn_fdot2(a2[i], b2[j], acc[i][j], false);
+      for (int p = 0; p < KP; ++p) slice(buf, p);
     }
   };
 

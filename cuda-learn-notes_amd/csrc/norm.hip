@@ -86,6 +86,7 @@ __global__ void rms_norm_kernel(const T* __restrict__ x, T* __restrict__ y, floa
 template <typename T, int VEC>
 int launch_ln(const void* x, void* y, float g, float b, int N, int K, hipStream_t st) {
   if (!x || !y || N <= 0 || K <= 0) return CLN_ERR_BAD_ARG;
+  if (!cln_aligned(x, sizeof(T) * VEC) || !cln_aligned(y, sizeof(T) * VEC)) return CLN_ERR_BAD_ARG;
   if (K % VEC) return CLN_ERR_UNSUPPORTED;
   const int nt = row_threads(K, VEC), vpt = vecs_per_thread(K, VEC, nt);
 #define CALL(MV)                                                                                              \
@@ -97,6 +98,7 @@ int launch_ln(const void* x, void* y, float g, float b, int N, int K, hipStream_
 template <typename T, int VEC>
 int launch_rms(const void* x, void* y, float g, int N, int K, hipStream_t st) {
   if (!x || !y || N <= 0 || K <= 0) return CLN_ERR_BAD_ARG;
+  if (!cln_aligned(x, sizeof(T) * VEC) || !cln_aligned(y, sizeof(T) * VEC)) return CLN_ERR_BAD_ARG;
   if (K % VEC) return CLN_ERR_UNSUPPORTED;
   const int nt = row_threads(K, VEC), vpt = vecs_per_thread(K, VEC, nt);
 #define CALL(MV) \

@@ -178,7 +178,7 @@ int launch_reduce(const void* a, void* y, long long n, hipStream_t st) {
   using E = typename PS::elem;
   if (!a || !y || n < 0) return CLN_ERR_BAD_ARG;
   if (n == 0) return CLN_OK;
-  if (sizeof(E) * VEC >= 16 && !cln_aligned16(a)) return CLN_ERR_BAD_ARG;
+  if (!cln_aligned(a, sizeof(E) * VEC >= 16 ? 16 : sizeof(E) * VEC)) return CLN_ERR_BAD_ARG;
   long long g = (n / VEC + 1023) / 1024;
   const int grid = (int)(g < 1 ? 1 : (g > 256 ? 256 : g));
   CLN_LAUNCH((reduce_sum_kernel<PS, VEC>), dim3(grid), dim3(1024), 0, st, (const E*)a,

@@ -27,8 +27,7 @@ __device__ __forceinline__ void rotate(float x1, float x2, float ang, float& o1,
 // PAIRS pairs per thread: 1 -> 8-byte accesses (f32 / f32_v2 rungs), 2 -> 16-byte (f32x4_pack)
 template <int PAIRS>
 __global__ __launch_bounds__(256) void rope_kernel(const float* __restrict__ x, float* __restrict__ out,
-                                                   int seq_len, int half_hidden, int ref_quirk,
-                                                   float neg_log2_theta_over_half) {
+                                                   int seq_len, int half_hidden, int ref_quirk) {
   const long long units = (long long)seq_len * half_hidden / PAIRS;
   for (long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x; u < units;
        u += (long long)gridDim.x * blockDim.x) {
@@ -43,8 +42,11 @@ __global__ __launch_bounds__(256) void rope_kernel(const float* __restrict__ x, 
     }
 #pragma unroll
     for (int p = 0; p < PAIRS; ++p) {
-      // freq = theta^(-(i/half_hidden)) = exp2(i * (-log2(theta)/half_hidden))
-      const float freq = ref_quirk ? 1.0f : exp2f((float)(i0 + p) * neg_log2_theta_over_half);
+      // formed exactly as the script forms it (rope.py:77): 1.0 / (theta ** (float(2 i) / dim)), every step in fp32 --
+      // the angle t * freq amplifies a 1-ulp difference in freq by the token index (t = 8192: 1e-3 rad), so an
+      // algebraically equal exp2() form is NOT close enough at long sequences. pow() hides under the 16 B/pair of HBM
+      // traffic (~100 VALU issues per pair-batch fit the memory shadow).
+      const float freq = ref_quirk ? 1.0f : 1.0f / powf(10000.0f, (float)(2 * (i0 + p)) / (float)(2 * half_hidden));
       rotate(v[2 * p], v[2 * p + 1], (float)t * freq, o[2 * p], o[2 * p + 1]);
     }
     if constexpr (PAIRS == 2) {
@@ -63,9 +65,8 @@ int launch_rope(const void* x, void* out, int seq_len, int hidden, int ref_quirk
   const int half_hidden = hidden / 2;
   const long long units = (long long)seq_len * half_hidden / PAIRS;
   const int grid = cln_stream_grid(units, 256);
-  const float k = -13.287712379549449f / (float)half_hidden;  // -log2(10000) / (hidden/2)
   CLN_LAUNCH((rope_kernel<PAIRS>), dim3(grid), dim3(256), 0, st, (const float*)x, (float*)out, seq_len,
-                     half_hidden, ref_quirk, k);
+                     half_hidden, ref_quirk);
   return cln_check_launch();
 }
 

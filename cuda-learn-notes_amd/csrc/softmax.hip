@@ -54,6 +54,7 @@ int launch_global(const void* x, void* y, void* total, long long n, hipStream_t 
   if (!x || !y || !total || n <= 0) return CLN_ERR_BAD_ARG;
   const int grid = cln_stream_grid(n / VEC + 1, 256);
   CLN_LAUNCH((exp_sum_kernel<VEC>), dim3(grid), dim3(256), 0, st, (const float*)x, (float*)total, n);
+  if (cln_check_launch() != CLN_OK) return CLN_ERR_LAUNCH;  // a failed first pass would leave total = 0 -> inf
   CLN_LAUNCH((exp_div_kernel<VEC>), dim3(grid), dim3(256), 0, st, (const float*)x, (float*)y,
                      (const float*)total, n);
   return cln_check_launch();
@@ -122,6 +123,7 @@ __global__ void softmax_row_kernel(const T* __restrict__ x, T* __restrict__ y, i
 template <typename T, int VEC, int MODE>
 int launch_rows(const void* x, void* y, int S, int H, hipStream_t st) {
   if (!x || !y || S <= 0 || H <= 0) return CLN_ERR_BAD_ARG;
+  if (!cln_aligned(x, sizeof(T) * VEC) || !cln_aligned(y, sizeof(T) * VEC)) return CLN_ERR_BAD_ARG;
   if (H % VEC) return CLN_ERR_UNSUPPORTED;
   const int nt = row_threads(H, VEC), vpt = vecs_per_thread(H, VEC, nt);
 #define CALL(MV) \

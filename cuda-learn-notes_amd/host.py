@@ -40,10 +40,17 @@ def _check_dtype(t, dtype):
 
 
 def _check_dev(*ts):
+    """Every tensor must be a contiguous HIP tensor on the CURRENT device: the launch goes to
+    torch.cuda.current_stream() of the current device with raw data_ptr()s, so a tensor living on another GPU
+    would be dereferenced from the wrong device (fault or silent peer access)."""
+    cur = torch.cuda.current_device() if ts and ts[0].is_cuda else -1
     for t in ts:
         if not t.is_cuda:
             raise RuntimeError("expected a GPU (HIP) tensor, got device=%s: the kernel library has no CPU path"
                                % t.device)
+        if t.device.index != cur:
+            raise RuntimeError("tensor on %s but the current device is cuda:%d: wrap the call in "
+                               "`with torch.cuda.device(tensor.device):`" % (t.device, cur))
         if not t.is_contiguous():
             raise RuntimeError("tensor must be contiguous (the kernels take raw data_ptr())")
 
@@ -231,16 +238,24 @@ def _make_rn(name):
 def _make_rp(name):
     fn = _loader.symbol(name)
 
-    def f(x, out):
+    def f(x, out, ref_quirk=None):
+        """ref_quirk=False (default): the script's torch semantics, pair i of token t rotated by t * theta^(-2i/hidden)
+        (rope.py:68-88). ref_quirk=True: the reference CUDA KERNELS' behaviour -- the exponent is an integer division
+        that is always 0, so every pair is rotated by t radians (rope.cu:26,:41,:55). Keyword argument added to the
+        reference signature `rope_*(x, out)`; $CLN_AMD_ROPE_REF_QUIRK=1 sets the default for callers that cannot
+        pass it (read once at import)."""
         _check_dtype(x, torch.float32)
         _check_dtype(out, torch.float32)
         _check_dev(x, out)
         _check_shape(out, *x.shape)
-        quirk = 1 if os.environ.get("CLN_AMD_ROPE_REF_QUIRK", "0") == "1" else 0
+        quirk = int(_ROPE_QUIRK_DEFAULT if ref_quirk is None else bool(ref_quirk))
         _raise(name, fn(x.data_ptr(), out.data_ptr(), x.size(0), x.size(1), quirk, _stream()),
                "%s: hidden size must be a multiple of the pack width" % name)
     f.__name__ = name
     return f
+
+
+_ROPE_QUIRK_DEFAULT = os.environ.get("CLN_AMD_ROPE_REF_QUIRK", "0") == "1"
 
 
 def _make_hi(name):
@@ -360,21 +375,23 @@ def load_lib(*groups):
 
 
 def hgemm_variant(kind, layout, tile, bk, stages, a, b, c, swizzle=0, swizzle_stride=1):
-    """Tuning hook (not part of the reference surface): run an explicit tile/BK/stage variant."""
+    """Tuning hook (not part of the reference surface; lives in the TEST-ONLY libcln_amd_probe.so): run an explicit
+    tile/BK/stage variant."""
     _check_dev(a, b, c)
     M, K = a.size(0), a.size(1)
     N = b.size(1)
-    fn = _loader.load_so("libcln_amd.so").cln_hgemm_variant
+    fn = _loader.load_so("libcln_amd_probe.so").cln_hgemm_variant
     rc = fn(kind, layout, tile, bk, stages, a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, int(swizzle),
             int(swizzle_stride), _stream())
     _raise("cln_hgemm_variant", rc, "variant not available for this shape/LDS budget")
 
 
 def fa2_variant(D_nw_vt_opt_abl, Q, K, V, O):
-    """Tuning hook (not part of the reference surface): run an explicit v2 FlashAttention variant."""
+    """Tuning hook (not part of the reference surface; lives in the TEST-ONLY libcln_amd_probe.so): run an explicit
+    FlashAttention kernel variant."""
     _check_dev(Q, K, V, O)
     nw, vt, opt, abl = D_nw_vt_opt_abl
     B, H, N, D = Q.shape
-    fn = _loader.load_so("libcln_amd.so").cln_fa2_variant
+    fn = _loader.load_so("libcln_amd_probe.so").cln_fa2_variant
     rc = fn(D, nw, vt, opt, abl, Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), B, H, N, _stream())
     _raise("cln_fa2_variant", rc, "variant not instantiated / shape not supported")

@@ -68,12 +68,12 @@ _add("hgemm", "G6", "mfma_ring<128x128,BK by stages,NN>",
      "hgemm_mma_m16n8k16_mma2x4_warp4x4_stages", "hgemm_mma_m16n8k16_mma2x4_warp4x4_stages_dsmem")
 _add("hgemm", "G6", "mfma_ring<256x128,8 waves,NN>", "hgemm_wmma_m16n16k16_mma4x2_warp4x4_stages_dsmem")
 _add("hgemm", "G6", "mfma_ring<256x256,8 waves,NN>", "hgemm_wmma_m16n16k16_mma4x4_warp4x4_stages_dsmem")
-_add("hgemm", "G6", "best<NN>: >=200 256x256 tiles -> pingpong<256x256x64,4 slots,split DMA> (stages 2) | pingpong_khalf<4x32 ring> (stages 4) | mfma_ring; else mfma_ring<128x128>",
+_add("hgemm", "G6", "best<NN>: >=120 256x256 tiles -> hgemm_pp<256x256x64,4 slots,split DMA> (stages 2) | hgemm_pp32<4x32 ring> (stages 4) | mfma_ring<256x256>; fewer tiles -> mfma_ring<64x128> / <128x128> (see DISPATCH_EXAMPLES)",
      "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem", "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_x4",
      "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_rr",
      "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_swizzle")
 _add("hgemm", "G6", "mfma_ring<128x128,TN>", "hgemm_mma_m16n8k16_mma2x4_warp4x4_stages_dsmem_tn")
-_add("hgemm", "G6", "best<TN>: pingpong / pingpong_khalf / mfma_ring as for NN", "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_tn_swizzle_x4")
+_add("hgemm", "G6", "best<TN>: hgemm_pp / hgemm_pp32 / mfma_ring as for NN (see DISPATCH_EXAMPLES)", "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_tn_swizzle_x4")
 _add("hgemm", "G6", "mfma_ring<128x256,8 waves,TN>", "hgemm_mma_stages_block_swizzle_tn_cute")
 
 # ---------------------------------------------------------------- flash-attn (28 + 3)
@@ -98,9 +98,15 @@ _FA_VT = [
     "flash_attn_mma_stages_split_q_shared_kv_swizzle_qkv", "flash_attn_mma_stages_split_q_shared_qkv_swizzle_qkv",
     "flash_attn_mma_stages_split_q_tiling_qk_swizzle_qkv",
 ]
-_add("flash_attn", "FA", "fa2_fwd_v2<D<=256, 8|4|2 waves x 32 rows, dbuf K/V, deferred max> | fa2_fwd_bigd<D=512|768, DV=256, LDS-DMA> | fa2_fwd<other D>256, DV-sliced> "
-     "mfma_32x32x16, f32 acc", *_FA_PLAIN)
-_add("flash_attn", "FA", "fa2_fwd_v2<D<=256, V transposed [B,H,D,N]>", *_FA_VT)
+_FA_SPLIT_Q_IMPL = ("planner fa2_plan(shape, stages) [csrc/flash_attn.hip]: stages=1 -> fa2_fwd<load-then-compute>; "
+                    "stages=2 -> fa2_fwd_dsplit<D=64|128|256> (>=192 workgroups of 256 rows) | fa2_fwd_v2<D<=256, 8|4|2 waves> | "
+                    "fa2_fwd_dsplit<512 (+PAD 320/384)> | fa2_fwd_dwide<768 (+PAD 640), 1024>; mfma_32x32x16, f32 acc "
+                    "(see DISPATCH_EXAMPLES)")
+_add("flash_attn", "FA", "fa2_fwd_splitkv<D<=128>: 4 waves share 32 query rows, KV tile split over the waves, cross-wave "
+     "row max through LDS (the structurally distinct split-KV rung)", "flash_attn_mma_stages_split_kv")
+_add("flash_attn", "FA", _FA_SPLIT_Q_IMPL, *[n for n in _FA_PLAIN if n != "flash_attn_mma_stages_split_kv"])
+_add("flash_attn", "FA", "planner as above with V transposed [B,H,D,N]: fa2_fwd<load-then-compute,V^T> | fa2_fwd_v2<V^T>",
+     *_FA_VT)
 
 # max head dim per function (reference flash_attn_mma.py:436-506; C side enforces the same)
 FA_MAX_HEADDIM = {n: 256 for n in _FA_PLAIN + _FA_VT}
@@ -252,3 +258,60 @@ for e in ENTRIES:
 
 def entries_of(lib):
     return [e for e in ENTRIES if e.lib == lib]
+
+
+# ---------------------------------------------------------------- name -> kernel for the run-time dispatched names
+# (name, dims, stages) -> the text cln_describe() returns, i.e. what the dispatch code in csrc/ actually launches.
+# dims = (M, N, K) for HGEMM names, (B, H, N, D) for flash-attn names. tests/test_describe.py asserts this table
+# against the built library on a CPU-only box, so a change of the dispatch policy that is not reflected here fails CI.
+_W4X2 = "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem"
+_SQKV = "flash_attn_mma_stages_split_q_shared_qkv"
+_TQKV = "flash_attn_mma_stages_split_q_tiling_qkv"
+_IGN = " [stages ignored: one pipeline]"
+DISPATCH_EXAMPLES = [
+    # HGEMM: BASELINE configs C2 (1024^3) and C3 (4096^3 / 8192^3) and the mid sizes
+    (_W4X2, (4096, 4096, 4096), 2, "hgemm_pp<256x256x64,8 waves,4 slots,split DMA,LDS epilogue,NN>"),
+    (_W4X2, (8192, 8192, 8192), 2, "hgemm_pp<256x256x64,8 waves,4 slots,split DMA,LDS epilogue,NN>"),
+    (_W4X2, (4096, 4096, 4096), 4, "hgemm_pp32<256x256,BK=32 sub-tiles,4-deep ring,NN>"),
+    (_W4X2, (4096, 4096, 4096), 3, "mfma_ring<256x256x32,8 waves,stages=3,NN>"),
+    (_W4X2, (3072, 3072, 3072), 2, "hgemm_pp<256x256x64,8 waves,4 slots,split DMA,LDS epilogue,NN>"),
+    (_W4X2, (2048, 2048, 2048), 2, "mfma_ring<64x128x64,4 waves,stages=2,NN>"),
+    (_W4X2, (1024, 1024, 1024), 2, "mfma_ring<64x128x64,4 waves,stages=2,NN>"),
+    (_W4X2 + "_tn_swizzle_x4", (4096, 4096, 4096), 2, "hgemm_pp<256x256x64,8 waves,4 slots,split DMA,LDS epilogue,TN>"),
+    ("hgemm_mma_m16n8k16_mma2x4_warp4x4_stages_dsmem", (4096, 4096, 4096), 3, "mfma_ring<128x128x64,4 waves,stages=3,NN>"),
+    ("hgemm_mma_m16n8k16_mma2x4_warp4x4_stages_dsmem", (4096, 4096, 4096), 5, "mfma_ring<128x128x64,4 waves,stages=5,NN>"),
+    ("hgemm_wmma_m16n16k16_mma4x4_warp4x4_stages_dsmem", (4096, 4096, 4096), 3, "mfma_ring<256x256x32,8 waves,stages=3,NN>"),
+    ("hgemm_mma_stages_block_swizzle_tn_cute", (4096, 4096, 4096), 2, "mfma_ring<128x256x64,8 waves,stages=2,TN>"),
+    # flash-attn: config C4, its small-grid and D = 128 siblings, the stages knob, config C5 and the padded head dims
+    ("flash_attn_mma_stages_split_kv", (4, 8, 2048, 64), 2,
+     "fa2_fwd_splitkv<D=64> 4 waves share 32 rows, 128-key tiles split over the waves, cross-wave max via LDS" + _IGN),
+    (_SQKV, (4, 8, 2048, 64), 1, "fa2_fwd<D=64,BC=64,load-then-compute> 4 waves x 32 rows"),
+    (_SQKV, (4, 8, 2048, 64), 2, "fa2_fwd_dsplit<D=64,NSP=1,BC=128> 8 waves, two groups one phase apart"),
+    (_SQKV, (4, 8, 2048, 128), 2, "fa2_fwd_dsplit<D=128,NSP=1,BC=64> 8 waves, two groups one phase apart"),
+    (_SQKV, (2, 32, 4096, 256), 2, "fa2_fwd_dsplit<D=256,NSP=1,BC=32> 8 waves, two groups one phase apart"),
+    (_SQKV, (2, 8, 2048, 64), 2, "fa2_fwd_v2<D=64,NW=4,BC=64,prefetch> 4 waves x 32 rows"),
+    (_SQKV, (1, 2, 256, 64), 2, "fa2_fwd_v2<D=64,NW=2,BC=64,prefetch> 2 waves x 32 rows"),
+    (_SQKV, (1, 2, 192, 64), 1, "fa2_fwd_v2<D=64,NW=2,BC=64,prefetch> 2 waves x 32 rows" + _IGN),
+    (_SQKV + "_swizzle_qkv", (4, 8, 2048, 128), 2, "fa2_fwd_v2<D=128,NW=8,BC=64,prefetch,V^T> 8 waves x 32 rows"),
+    (_SQKV + "_swizzle_qkv", (4, 8, 2048, 128), 1, "fa2_fwd<D=128,BC=64,load-then-compute,V^T> 4 waves x 32 rows"),
+    (_TQKV, (1, 32, 4096, 512), 2, "fa2_fwd_dsplit<D=512,NSP=2,BC=32> 8 waves, two groups one phase apart" + _IGN),
+    (_TQKV, (1, 16, 4096, 384), 2, "fa2_fwd_dsplit<D=512,NSP=2,BC=32,PAD=384> 8 waves, pairs split d" + _IGN),
+    (_TQKV, (1, 16, 4096, 640), 2, "fa2_fwd_dwide<D=768,PAD=640> 6 waves split d" + _IGN),
+    (_TQKV, (1, 16, 4096, 1024), 2, "fa2_fwd_dwide<D=1024> 8 waves split d" + _IGN),
+]
+
+
+def describe(name, dims, stages=2):
+    """Ask the built library which kernel `name` launches for `dims` (no GPU needed). Returns the text, or raises
+    LookupError for a statically bound name / ValueError for an unsupported shape."""
+    import ctypes
+    from . import _loader
+    lib = _loader.load_so("libcln_amd.so")
+    buf = ctypes.create_string_buffer(512)
+    d = list(dims) + [0] * (4 - len(dims))
+    rc = lib.cln_describe(name.encode(), d[0], d[1], d[2], d[3], int(stages), buf, 512)
+    if rc == -1:
+        raise LookupError("%s is bound to one kernel: see manifest.BY_NAME[name].impl" % name)
+    if rc < 0:
+        raise ValueError("%s: shape %s not supported (status %d)" % (name, tuple(dims), rc))
+    return buf.value.decode()

@@ -87,10 +87,12 @@ def main():
         for e in manifest.entries_of(lib):
             out.append("/* impl: %s */" % e.impl)
             out.append(PROTO[e.sig].format(n=e.name))
-    out.append("\n/* ---- tuning hook (not part of the reference surface): kind 0 ring(tile,bk,stages), 1 one-stage, 2 naive;\n"
-               " * layout 0 NN / 1 TN; tile 0 128x128, 1 256x256, 2 256x128, 3 128x256. */")
-    out.append("int cln_hgemm_variant(int kind, int layout, int tile, int bk, int stages, const void* a, const void* b,\n"
-               "                      void* c, int M, int N, int K, int swizzle, int swizzle_stride, void* stream);")
+    out.append("\n/* ---- introspection (not part of the reference surface): which gfx950 kernel a run-time dispatched name\n"
+               " * launches for a shape, as text. HGEMM names: d0..d2 = M, N, K; flash-attn names: d0..d3 = B, H, N, D.\n"
+               " * Returns the text length, -2 for an unsupported shape, -1 for a name bound to one fixed kernel (its\n"
+               " * `impl` comment above). Host-only: no launch, no device access. The tuning / ablation hooks\n"
+               " * (cln_hgemm_variant, cln_fa2_variant) live in the TEST-ONLY libcln_amd_probe.so and are not declared here. */")
+    out.append("int cln_describe(const char* name, int d0, int d1, int d2, int d3, int stages, char* buf, int buflen);")
     out.append("\n#ifdef __cplusplus\n}\n#endif\n#endif /* CLN_AMD_H */\n")
     path = os.path.join(ROOT, "include", "cln_amd.h")
     os.makedirs(os.path.dirname(path), exist_ok=True)

@@ -38,7 +38,7 @@ def test_header_declares_manifest_and_libs_export_it(built):
     hdr = open(os.path.join(ROOT, "include", "cln_amd.h")).read()
     declared = re.findall(r"^int (\w+)\(", hdr, flags=re.M)
     assert len(declared) == len(set(declared))
-    names = {e.name for e in built.manifest.ENTRIES} | {"cln_hgemm_variant"}
+    names = {e.name for e in built.manifest.ENTRIES} | {"cln_describe"}
     assert set(declared) == names
     from cuda_learn_notes_amd import _loader
     main = ctypes.CDLL(_loader.so_path("libcln_amd.so"))
@@ -46,7 +46,11 @@ def test_header_declares_manifest_and_libs_export_it(built):
     for e in built.manifest.ENTRIES:
         lib = vend if built.manifest.SO_OF_LIB[e.lib] == "libcln_amd_vendor.so" else main
         assert hasattr(lib, e.name), e.name
-    assert hasattr(main, "cln_hgemm_variant")
+    assert hasattr(main, "cln_describe")
+    # tuning / ablation hooks (some produce garbage by design) must not be reachable from the product library
+    assert not hasattr(main, "cln_hgemm_variant") and not hasattr(main, "cln_fa2_variant")
+    probe = ctypes.CDLL(_loader.so_path("libcln_amd_probe.so"))
+    assert hasattr(probe, "cln_hgemm_variant") and hasattr(probe, "cln_fa2_variant")
 
 
 def test_python_surface_has_every_reference_name(built):

@@ -199,30 +199,43 @@ def test_norm_full_size_properties(lib, dev):
 
 # ------------------------------------------------------------------ rope
 @pytest.mark.parametrize("shape", [(64, 128), (4096, 512), (8192, 1024), (17, 64)])
-def test_rope_matches_torch_oracle(lib, dev, oracle, shape, monkeypatch):
-    monkeypatch.delenv("CLN_AMD_ROPE_REF_QUIRK", raising=False)
+def test_rope_matches_torch_oracle(lib, dev, oracle, shape):
+    """Default mode = the script's torch semantics (rope.py:68-88), PINNED by tests/golden. freq is formed as the
+    script forms it (1 / theta ** (2i/dim), fp32 pow): wherever the device pow and torch's CPU pow agree to the bit
+    the outputs agree to 2e-4 at EVERY position; where they differ by an ulp (torch's vectorised CPU pow is itself
+    off the correctly rounded value in ~1 % of the columns) the angle t * freq differs by t * ulp(freq), which is the
+    only slack the bound below allows."""
     x = seeded(41, *shape)
     ref = oracle.rope_torch(x)
+    S, Hd = shape
+    t = torch.arange(S, dtype=torch.float64).view(S, 1)
+    freq = (1.0 / (10000.0 ** (torch.arange(0, Hd, 2).float() / Hd))).double().view(1, Hd // 2)
+    pair_norm = x.double().view(S, -1, 2).norm(dim=-1)
+    # 2e-4 + |pair| * t * (2 ulp of freq): 2e-4 alone for the first positions, 3e-3 at t = 8192 in the first columns
+    bound = (2e-4 + pair_norm * t * freq * 2.4e-7).repeat_interleave(2, dim=1)
     for name in ("rope_f32", "rope_f32_v2", "rope_f32x4_pack"):
         out = torch.zeros(shape, device=dev)
         getattr(lib, name)(x.to(dev), out)
-        d = (out.cpu() - ref).abs()
-        # angle = t*freq is formed in fp32 on both sides; freq differs by ~2 ulp (exp2 vs pow), so the angle
-        # error grows like t * 2.4e-7 rad and the output error like |x| * that: 1e-2 covers t = 8192, |x| < 5
-        assert d.max() < 1e-2, (name, d.max())
-        small_t = min(64, shape[0])
-        assert d[:small_t].max() < 2e-4, (name, d[:small_t].max())
+        d = (out.cpu().double() - ref.double()).abs()
+        assert bool((d <= bound).all()), (name, float((d - bound).max()))
+        # most columns carry a bit-identical freq: there the error is 2e-4 at all positions
+        colmax = d.max(dim=0).values
+        assert float((colmax <= 2e-4).double().mean()) >= 0.75, (name, float(colmax.max()))
         # rotation preserves each pair's norm
         n_in = x.view(shape[0], -1, 2).norm(dim=-1)
         n_out = out.cpu().view(shape[0], -1, 2).norm(dim=-1)
         assert torch.allclose(n_in, n_out, atol=1e-4, rtol=1e-4)
 
 
-def test_rope_reference_kernel_quirk_mode(lib, dev, oracle, monkeypatch):
-    monkeypatch.setenv("CLN_AMD_ROPE_REF_QUIRK", "1")
+def test_rope_reference_kernel_quirk_mode(lib, dev, oracle):
+    """ref_quirk=True: the reference CUDA kernels' integer-division behaviour (every pair rotated by t radians,
+    rope.cu:26); both modes are reachable per call, no process-wide switch needed."""
     x = seeded(42, 512, 256)
     ref = oracle.rope_kernel(x)
     for name in ("rope_f32", "rope_f32x4_pack"):
         out = torch.zeros(512, 256, device=dev)
-        getattr(lib, name)(x.to(dev), out)
+        getattr(lib, name)(x.to(dev), out, ref_quirk=True)
         assert (out.cpu() - ref).abs().max() < 5e-4, name
+        out2 = torch.zeros(512, 256, device=dev)
+        getattr(lib, name)(x.to(dev), out2, ref_quirk=False)
+        assert (out2.cpu() - oracle.rope_torch(x)).abs().max() < 2e-3, name

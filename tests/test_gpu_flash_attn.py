@@ -288,8 +288,21 @@ def test_config_c4_full_size(fa, built, dev, oracle):
     assert worst <= TOL, worst
 
 
-def test_config_c5_shape_sampled_heads(fa, built, dev, oracle):
-    """B=1 H=32 N=4096 D=512 (C5): two heads vs the fp64 oracle."""
+def gpu_attention_fp32(q, k, v):
+    """Plain fp32 attention on the GPU, one head at a time (the fp64 CPU oracle takes ~10 s per C5 head); agrees with
+    the fp64 oracle to ~1e-6 on N(0,1) inputs -- checked against it on the sampled heads below."""
+    out = torch.empty(q.shape, dtype=torch.float32, device=q.device)
+    scale = 1.0 / (q.shape[-1] ** 0.5)
+    for b in range(q.shape[0]):
+        for h in range(q.shape[1]):
+            s = (q[b, h].float() @ k[b, h].float().t()) * scale
+            out[b, h] = torch.softmax(s, dim=-1) @ v[b, h].float()
+    return out
+
+
+def test_config_c5_all_heads(fa, built, dev, oracle):
+    """B=1 H=32 N=4096 D=512 (C5): ALL 32 heads against a chunked fp32 reference on the GPU, two of them also against
+    the fp64 CPU oracle (which pins the fp32 reference itself)."""
     B, H, N, D = 1, 32, 4096, 512
     torch.manual_seed(512)
     q = torch.randn(B, H, N, D, dtype=torch.half, device=dev)
@@ -297,9 +310,104 @@ def test_config_c5_shape_sampled_heads(fa, built, dev, oracle):
     v = torch.randn(B, H, N, D, dtype=torch.half, device=dev)
     o = torch.zeros_like(q)
     fa.flash_attn_mma_stages_split_q_tiling_qkv(q, k, v, o, 2)
+    ref32 = gpu_attention_fp32(q, k, v)
+    per_head = (o.float() - ref32).abs().amax(dim=(0, 2, 3))
+    assert per_head.max().item() <= TOL, per_head.tolist()
     for h in (0, 31):
         ref = oracle.attention_fp64(q[0, h].cpu(), k[0, h].cpu(), v[0, h].cpu())
+        assert (ref32[0, h].cpu().double() - ref).abs().max().item() <= 2e-5
         assert (o[0, h].cpu().double() - ref).abs().max().item() <= TOL
+
+
+@pytest.mark.parametrize("D", [32, 64, 96, 128])
+@pytest.mark.parametrize("B,H,N", [(1, 2, 32), (2, 3, 160), (1, 5, 1024), (1, 2, 2080)])
+def test_split_kv_rung(fa, built, dev, oracle, D, B, H, N):
+    """flash_attn_mma_stages_split_kv is its own kernel (flash_attn_splitkv.cuh: the KV tile split over 4 waves that
+    share the query rows, cross-wave row max through LDS): single partial tile, a 128 + 32 key tail, many tiles, and a
+    tail after 16 full tiles; every row vs the fp64 oracle, both `stages` values."""
+    q, k, v = seeded(81, B, H, N, D), seeded(82, B, H, N, D), seeded(83, B, H, N, D)
+    ref = oracle.attention_fp64(q, k, v)
+    for stages in (1, 2):
+        o = run(fa, built, "flash_attn_mma_stages_split_kv", q, k, v, stages, dev)
+        assert (o.double() - ref).abs().max().item() <= TOL, stages
+
+
+def test_split_kv_rung_rescale_and_uniform(fa, built, dev, oracle):
+    """The split-KV rung under the regimes of rule 26: a late spike (one WAVE sees the new max, all four must adopt
+    it), an early spike, and the all-ones debug mode (O = column mean of V)."""
+    B, H, N, D = 1, 2, 1024, 64
+    q, k, v = seeded(84, B, H, N, D), seeded(85, B, H, N, D), seeded(86, B, H, N, D)
+    k[0, 0, 900] = q[0, 0, 5] * 3.0
+    k[0, 0, 70] = q[0, 0, 130] * 2.0
+    k[0, 1, 10] = q[0, 1, 300] * 5.0
+    ref = oracle.attention_fp64(q, k, v)
+    o = run(fa, built, "flash_attn_mma_stages_split_kv", q, k, v, 2, dev)
+    assert torch.isfinite(o).all() and (o.double() - ref).abs().max().item() <= TOL
+    ones = torch.ones(B, H, N, D).half()
+    o = run(fa, built, "flash_attn_mma_stages_split_kv", ones, ones, v, 2, dev)
+    assert (o.double() - v.double().mean(dim=2, keepdim=True).expand(B, H, N, D)).abs().max().item() <= 1e-3
+
+
+@pytest.mark.parametrize("D", [32, 64, 96, 128, 256])
+def test_stages_one_is_the_load_then_compute_kernel(fa, built, dev, oracle, D):
+    """stages=1 dispatches fa2_fwd<load-then-compute> (manifest.describe says which kernel runs); both V layouts,
+    several tiles, a rescale-forcing spike."""
+    B, H, N = 2, 3, 384
+    q, k, v = seeded(91, B, H, N, D), seeded(92, B, H, N, D), seeded(93, B, H, N, D)
+    k[0, 0, 300] = q[0, 0, 7] * 4.0
+    ref = oracle.attention_fp64(q, k, v)
+    for name in ("flash_attn_mma_stages_split_q_shared_qkv", "flash_attn_mma_stages_split_q_shared_kv_swizzle_qkv"):
+        assert "load-then-compute" in built.manifest.describe(name, (B, H, N, D), 1)
+        o = run(fa, built, name, q, k, v, 1, dev)
+        assert (o.double() - ref).abs().max().item() <= TOL, name
+
+
+# register-blocked kernel (flash_attn_rb.cuh) through the probe hook: (D, option-set ids of flash_attn_probe.hip)
+RB_VARIANTS = {64: [400, 401, 402, 403, 404, 405, 406, 407, 408, 409], 128: [400, 401, 405, 407, 408, 409]}
+
+
+@pytest.mark.parametrize("D", [64, 128])
+@pytest.mark.parametrize("B,H,N", [(1, 2, 256), (2, 3, 1024), (1, 8, 512)])
+def test_register_blocked_kernel_variants(built, dev, oracle, D, B, H, N):
+    """Every option set of the register-blocked kernel (builtin / inline-asm QK^T, pre-scaled Q with the accumulators
+    started at -m, 32- and 64-key tiles, pinned / compiler-scheduled interleave, deferred / immediate rescale): a single
+    256-row block with 4 tiles, head counts that do and do not divide by the 8 XCDs; every row vs the fp64 oracle."""
+    from cuda_learn_notes_amd import host
+    q, k, v = seeded(101, B, H, N, D), seeded(102, B, H, N, D), seeded(103, B, H, N, D)
+    ref = oracle.attention_fp64(q, k, v)
+    for abl in RB_VARIANTS[D]:
+        o = torch.zeros(B, H, N, D, dtype=torch.half, device=dev)
+        host.fa2_variant((4, 0, 0, abl), q.to(dev), k.to(dev), v.to(dev), o)
+        err = (o.cpu().double() - ref).abs().max().item()
+        assert err <= TOL, (D, abl, err)
+
+
+@pytest.mark.parametrize("D", [64, 128])
+def test_register_blocked_kernel_rescale_regimes(built, dev, oracle, D):
+    """Rule 26 on the register-blocked kernel: creeping max below the 2^8 threshold (P up to 2^8, accumulators started
+    at a stale -m), a late jump (forced rescale: O, l AND the pending scores of the next tile are shifted), an early
+    spike that leaves everything later ~ -inf, a first tile whose scores are all very negative (the first running max
+    must be adopted, not max(0, .)), and the all-ones debug mode. Deferred and immediate rescale must agree."""
+    from cuda_learn_notes_amd import host
+    B, H, N = 1, 3, 1024
+    q, k, v = seeded(111, B, H, N, D), seeded(112, B, H, N, D), seeded(113, B, H, N, D)
+    ramp = torch.linspace(0.2, 1.6, N).view(1, 1, N, 1)
+    k = (k.float() * ramp).half()
+    k[0, 0, 900] = q[0, 0, 5] * 3.0
+    k[0, 0, 70] = q[0, 0, 130] * 2.0
+    k[0, 1, 10] = q[0, 1, 300] * 5.0
+    k[0, 2, :64] = -q[0, 2, 40].unsqueeze(0) * 2.0   # row 40 of head 2: first tile ~ -2|q|^2, far below zero
+    ref = oracle.attention_fp64(q, k, v)
+    ones = torch.ones(B, H, N, D).half()
+    mean_v = v.double().mean(dim=2, keepdim=True).expand(B, H, N, D)
+    for abl in RB_VARIANTS[D]:
+        o = torch.zeros(B, H, N, D, dtype=torch.half, device=dev)
+        host.fa2_variant((4, 0, 0, abl), q.to(dev), k.to(dev), v.to(dev), o)
+        assert torch.isfinite(o).all(), (D, abl)
+        err = (o.cpu().double() - ref).abs().max().item()
+        assert err <= TOL, (D, abl, err)
+        host.fa2_variant((4, 0, 0, abl), ones.to(dev), ones.to(dev), v.to(dev), o)
+        assert (o.cpu().double() - mean_v).abs().max().item() <= 1e-3, (D, abl)
 
 
 def test_probe_variants_match_production(fa, built, dev, oracle):
