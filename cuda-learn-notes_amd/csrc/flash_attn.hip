@@ -138,9 +138,11 @@ int fa2_run(const FaPlan& p, const void* q, const void* k, const void* v, void* 
       return CLN_ERR_UNSUPPORTED;
     case K_DSPLIT:
       if constexpr (!VT) {
-        // D = 64 (config C4): 128-key tiles, half of the exponentials moved into the QK^T phase (OPT_STAGGER)
-        if (D == 64) return fa2::launch_dsplit<64, 1, 4, 13 | fa2::OPT_STAGGER>(q, k, v, o, B, H, N, s);
-        if (D == 128) return fa2::launch_dsplit<128, 1, 2, fa2::OPT_DEFAULT | fa2::OPT_KPRE>(q, k, v, o, B, H, N, s);
+        // D = 64 (config C4): 128-key tiles, half of the exponentials moved into the QK^T phase (OPT_STAGGER).
+        // OPT_PRE (Q pre-scaled, accumulators started at -m: 2 of ~5 VALU instructions per score gone): +6-8 % at
+        // D = 64 (834 vs 787 TF at C4, 981 vs 904 at [1,48,8192,64]), +3-4 % at D = 128 (profiles/r02_fa_probe_pre.log)
+        if (D == 64) return fa2::launch_dsplit<64, 1, 4, 13 | fa2::OPT_STAGGER | fa2::OPT_PRE>(q, k, v, o, B, H, N, s);
+        if (D == 128) return fa2::launch_dsplit<128, 1, 2, fa2::OPT_DEFAULT | fa2::OPT_KPRE | fa2::OPT_PRE>(q, k, v, o, B, H, N, s);
         if (D == 256) return fa2::launch_dsplit<256, 1, 1, fa2::OPT_DEFAULT | fa2::OPT_KPRE>(q, k, v, o, B, H, N, s);
         return fa::launch_fa2_large_d(q, k, v, o, B, H, N, D, s);
       }
@@ -181,8 +183,8 @@ int fa2_describe(int family, bool vt, int B, int H, int N, int D, int stages, in
     case K_DSPLIT:
       if (p.d_inst != D)
         return snprintf(buf, len, "fa2_fwd_dsplit<D=%d,NSP=2,BC=32,PAD=%d> 8 waves, pairs split d%s", p.d_inst, D, st);
-      return snprintf(buf, len, "fa2_fwd_dsplit<D=%d,NSP=%d,BC=%d> 8 waves, two groups one phase apart%s", D,
-                      D == 512 ? 2 : 1, p.bc, st);
+      return snprintf(buf, len, "fa2_fwd_dsplit<D=%d,NSP=%d,BC=%d%s> 8 waves, two groups one phase apart%s", D,
+                      D == 512 ? 2 : 1, p.bc, D <= 128 ? ",pre-scaled Q" : "", st);
     case K_DWIDE:
       if (p.d_inst != D)
         return snprintf(buf, len, "fa2_fwd_dwide<D=%d,PAD=%d> %d waves split d%s", p.d_inst, D, p.nw, st);

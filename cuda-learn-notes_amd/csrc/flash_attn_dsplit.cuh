@@ -115,18 +115,34 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
       else qf[ks] = h8{0, 0, 0, 0, 0, 0, 0, 0};  // DR is a multiple of 16: the predicate is wave-uniform
     }
   }
+  // OPT_PRE (the VALU diet; the D = 64 kernel is VALU-bound: ~10 VALU instructions per MFMA, 49 VALU cycles against
+  // 32 matrix cycles, profiles/r01_pmc_fa_v2_variants.json): Q is multiplied by log2(e)/sqrt(d) ONCE here and the S^T
+  // accumulators of every tile START at -m through the C operand of their first MFMA (m = the deferred running row
+  // max, a per-lane constant because a lane owns one query row) -- so P = exp2(acc): no per-element v_fma and no
+  // accumulator zeroing (2 of the ~5 VALU instructions per score). A rescale (rare) also shifts the pending scores.
+  constexpr bool PRE = (OPT & OPT_PRE) != 0;
+  static_assert(!PRE || NSP == 1, "OPT_PRE: one wave per row group");
   f16v ot[G::DH / 32];
 #pragma unroll
   for (int b = 0; b < G::DH / 32; ++b)
 #pragma unroll
     for (int r = 0; r < 16; ++r) ot[b][r] = 0.f;
-  float m_run = -1.0e30f, l_run = 0.f;
+  float m_run = PRE ? 0.f : -1.0e30f, l_run = 0.f;
+  f16v minit;  // OPT_PRE: -m in all 16 registers (opaque to hipcc: otherwise the splat is re-materialised per tile)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) minit[r] = 0.f;
+  if constexpr (PRE) asm volatile("" : "+v"(minit));
 
   const int T = N / G::BC;
   __builtin_assume(T > 0);  // the launcher rejects N < BR: no zero-trip path (its phi copies cost registers)
 #pragma unroll
   for (int i = 0; i < G::PPW; ++i) dma_piece(0, 0, i);
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), compiler-visible: also retires the Q loads in its bookkeeping
+  if constexpr (PRE) {
+    const half_t sc = (half_t)scale_log2e;
+#pragma unroll
+    for (int ks = 0; ks < G::DH / 16; ++ks) qf[ks] = qf[ks] * sc;
+  }
   // ... and pin the fragments here: hipcc otherwise sinks the Q loads below the barrier and into the first KV iteration
 #pragma unroll
   for (int ks = 0; ks < G::DH / 16; ++ks) asm volatile("" : "+v"(qf[ks]));
@@ -180,10 +196,12 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
     constexpr int NK = G::DH / 16, NQK = BCB * NK, NPV = 2 * BCB * (G::DH / 32);
     constexpr int PD = (OPT & OPT_KPRE) ? 4 : 1;  // fragments in flight ahead of the MFMA that consumes them
     f16v s[BCB];
+    if constexpr (!PRE) {
 #pragma unroll
-    for (int kb2 = 0; kb2 < BCB; ++kb2)
+      for (int kb2 = 0; kb2 < BCB; ++kb2)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[kb2][r] = 0.f;
+        for (int r = 0; r < 16; ++r) s[kb2][r] = 0.f;
+    }
     {
       // MFMA t works on k-step t / BCB of key block t % BCB (consecutive MFMAs alternate accumulators at BCB = 2)
       h8 kf[PD];
@@ -192,6 +210,7 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
 #pragma unroll
       for (int t = 0; t < NQK; ++t) {
         if (ABL & 16) s[t % BCB][t / BCB] += (float)kf[t % PD][0];
+        else if (PRE && t < BCB) s[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[t % PD], qf[0], minit, 0, 0, 0);  // chain starts at -m
         else s[t % BCB] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[t % PD], qf[t / BCB], s[t % BCB], 0, 0, 0);
         if (t + PD < NQK) kf[t % PD] = k_frag(t + PD);
         if (!(ABL & 1) && (t % (NQK / G::PPW)) == NQK / G::PPW - 1) dma_piece(jn, (j + 1) & 1, t / (NQK / G::PPW));
@@ -226,15 +245,26 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
         const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
         mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
       }
-      const float mxs = mx * scale_log2e;
+      // growth of the row max over the running one, in the log2 domain (OPT_PRE: the scores are already relative)
+      const float d = PRE ? mx : mx * scale_log2e - m_run;
       bool grow;
-      if constexpr ((OPT & OPT_DEFER) != 0) grow = (mxs - m_run) > 8.0f;
-      else grow = mxs > m_run;
-      if (__builtin_amdgcn_ballot_w64(grow) != 0) {
-        const float m_new = fmaxf(m_run, mxs);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
+      if constexpr ((OPT & OPT_DEFER) != 0) grow = d > 8.0f;
+      else grow = d > 0.f;
+      const bool first = PRE && j == 0;  // tile 0 adopts its max unconditionally (the accumulators started at 0)
+      if (first || __builtin_amdgcn_ballot_w64(grow) != 0) {
+        const float delta = first ? d : fmaxf(d, 0.f);
+        const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-delta);
+        m_run += delta;
         l_run *= alpha;
+        if constexpr (PRE) {  // the pending scores were accumulated from the old -m
+#pragma unroll
+          for (int kb2 = 0; kb2 < BCB; ++kb2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb2][r] -= delta;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) minit[r] = -m_run;
+          asm volatile("" : "+v"(minit));
+        }
 #pragma unroll
         for (int b = 0; b < G::DH / 32; ++b)
 #pragma unroll
@@ -253,8 +283,10 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
 #pragma unroll
         for (int e = 0; e < 8; e += 2) {
           const int kb2 = u >> 1, r = (u & 1) * 8 + e;
-          const float a0 = (ABL & 2) ? s[kb2][r] : __builtin_amdgcn_exp2f(fmaf(s[kb2][r], scale_log2e, nm));
-          const float a1 = (ABL & 2) ? s[kb2][r + 1] : __builtin_amdgcn_exp2f(fmaf(s[kb2][r + 1], scale_log2e, nm));
+          const float x0 = PRE ? s[kb2][r] : fmaf(s[kb2][r], scale_log2e, nm);
+          const float x1 = PRE ? s[kb2][r + 1] : fmaf(s[kb2][r + 1], scale_log2e, nm);
+          const float a0 = (ABL & 2) ? s[kb2][r] : __builtin_amdgcn_exp2f(x0);
+          const float a1 = (ABL & 2) ? s[kb2][r + 1] : __builtin_amdgcn_exp2f(x1);
           psum += a0 + a1;
           const h2 a = __builtin_convertvector(f2{a0, a1}, h2);
           pf[u][e] = a[0], pf[u][e + 1] = a[1];

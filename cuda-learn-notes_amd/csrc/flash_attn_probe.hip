@@ -29,11 +29,28 @@ CLN_API int cln_fa2_variant(int D, int nw, int vt, int opt, int abl, const void*
     RB(64, 406, 64, B0 | RB_PRE | RB_ASMQK | RB_PD2, 0) RB(64, 407, 64, (B0 | RB_PRE | RB_ASMQK) & ~RB_DEFER, 0)
     RB(64, 408, 64, B0 | RB_ASMQK, 0) RB(64, 409, 64, (B0 | RB_PRE) & ~RB_DEFER, 0)
     RB(64, 410, 64, B0 | RB_PRE | RB_ASMQK, 1) RB(64, 411, 64, B0 | RB_PRE | RB_ASMQK, 2) RB(64, 412, 64, B0 | RB_PRE | RB_ASMQK, 3)
+    RB(64, 420, 64, B0 | RB_PRE | RB_HALF, 0) RB(64, 421, 64, B0 | RB_PRE | RB_HALF | RB_ASMQK, 0)
+    RB(64, 422, 64, B0 | RB_PRE | RB_HALF | RB_ASMQK | RB_PD2, 0) RB(128, 420, 32, B0 | RB_HALF, 0) RB(128, 421, 32, B0 | RB_HALF | RB_ASMQK, 0)
     RB(128, 400, 32, B0, 0) RB(128, 401, 32, B0 | RB_ASMQK, 0) RB(128, 405, 32, B0 & ~RB_PIN, 0)
     RB(128, 408, 32, B0 | RB_ASMQK | RB_PD2, 0) RB(128, 409, 32, B0 & ~RB_DEFER, 0) RB(128, 407, 32, (B0 | RB_ASMQK) & ~RB_DEFER, 0)
     RB(128, 410, 32, B0 | RB_ASMQK, 1) RB(128, 411, 32, B0 | RB_ASMQK, 2)
 #undef RB
   }
+  // ping-pong kernel with the VALU diet (OPT_PRE): abl 500.. 
+  if (D == 64 && abl == 500) return fa2::launch_dsplit<64, 1, 4, 13 | fa2::OPT_STAGGER | fa2::OPT_PRE>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 64 && abl == 501) return fa2::launch_dsplit<64, 1, 4, 13 | fa2::OPT_PRE>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 64 && abl == 502) return fa2::launch_dsplit<64, 1, 2, 13 | fa2::OPT_STAGGER | fa2::OPT_PRE>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 64 && abl == 503) return fa2::launch_dsplit<64, 1, 4, 13 | fa2::OPT_STAGGER | fa2::OPT_PRE | fa2::OPT_KPRE>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 64 && abl == 504) return fa2::launch_dsplit<64, 1, 4, 12 | fa2::OPT_STAGGER | fa2::OPT_PRE>(q, k, v, o, B, H, N, (hipStream_t)stream);  // no deferral
+  if (D == 64 && abl == 505) return fa2::launch_dsplit<64, 1, 4, 13 | fa2::OPT_STAGGER | fa2::OPT_PRE | fa2::OPT_ONES>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 64 && abl == 506) return fa2::launch_dsplit<64, 1, 4, 13 | fa2::OPT_STAGGER | fa2::OPT_PRE | fa2::OPT_SOLO>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 64 && abl == 507) return fa2::launch_dsplit<64, 1, 4, 13 | fa2::OPT_PRE | fa2::OPT_ONES>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 128 && abl == 505) return fa2::launch_dsplit<128, 1, 2, 15 | fa2::OPT_KPRE | fa2::OPT_PRE | fa2::OPT_ONES>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 128 && abl == 500) return fa2::launch_dsplit<128, 1, 2, 15 | fa2::OPT_KPRE | fa2::OPT_PRE>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 128 && abl == 501) return fa2::launch_dsplit<128, 1, 2, 15 | fa2::OPT_KPRE | fa2::OPT_PRE | fa2::OPT_STAGGER>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 128 && abl == 504) return fa2::launch_dsplit<128, 1, 2, 14 | fa2::OPT_KPRE | fa2::OPT_PRE>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 256 && abl == 500) return fa2::launch_dsplit<256, 1, 1, 15 | fa2::OPT_KPRE | fa2::OPT_PRE>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 256 && abl == 504) return fa2::launch_dsplit<256, 1, 1, 14 | fa2::OPT_KPRE | fa2::OPT_PRE>(q, k, v, o, B, H, N, (hipStream_t)stream);
   V2(64, 8, 13, 0) V2(64, 4, 13, 0) V2(64, 4, 77, 0) V2(128, 8, 15, 0) V2(128, 4, 15, 0) V2(128, 4, 79, 0)
   V2(64, 8, 13, 1) V2(64, 8, 13, 2) V2(64, 8, 13, 7) V2(128, 8, 15, 1) V2(128, 8, 15, 7)
   V2(64, 8, 525, 0) V2(128, 8, 527, 0) V2(64, 8, 524, 0)

@@ -27,7 +27,7 @@
 
 namespace fa2 {
 
-enum : int { RB_PRE = 1, RB_PIN = 2, RB_DEFER = 4, RB_XCD = 8, RB_ASMMAX = 16, RB_PD2 = 32, RB_ASMQK = 64 };
+enum : int { RB_PRE = 1, RB_PIN = 2, RB_DEFER = 4, RB_XCD = 8, RB_ASMMAX = 16, RB_PD2 = 32, RB_ASMQK = 64, RB_HALF = 128 };
 constexpr int RB_OPT_D64 = RB_PRE | RB_PIN | RB_DEFER | RB_XCD | RB_ASMMAX;
 constexpr int RB_OPT_D128 = RB_PIN | RB_DEFER | RB_XCD | RB_ASMMAX;
 constexpr int RB_BC_D64 = 64, RB_BC_D128 = 32;
@@ -225,6 +225,28 @@ __global__ __launch_bounds__(256, 1) void fa2_fwd_rb_kernel(const half_t* __rest
       }
     }
   };
+  // the same, ONE row group at a time (RB_HALF: every MFMA gets its own share of the softmax work behind it -- two
+  // MFMAs back to back leave the second one waiting ~28 cycles for the matrix pipe with nothing issued meanwhile)
+  auto qk_one = [&](int set, const h8& kf, int t, int g) {
+    const int ks = t / G::KB, kb = t % G::KB;
+    if constexpr (ASMQK) {
+      if (ks == 0) {
+        if constexpr (PRE)
+          asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(s_acc[set][g][kb]) : "v"(kf), "a"(qf[g][0]), "v"(minit[g]));
+        else
+          asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(s_acc[set][g][kb]) : "v"(kf), "a"(qf[g][0]));
+      } else {
+        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(s_acc[set][g][kb]) : "v"(kf), "a"(qf[g][ks]));
+      }
+    } else {
+      if (ks == 0) {
+        if constexpr (PRE) s_acc[set][g][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[g][0], minit[g], 0, 0, 0);
+        else s_acc[set][g][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[g][0], f16v{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0);
+      } else {
+        s_acc[set][g][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[g][ks], s_acc[set][g][kb], 0, 0, 0);
+      }
+    }
+  };
   // RB_ASMQK: nothing may read score set `set` before the last asm MFMA that wrote it has retired (XDL write -> VALU
   // read: up to 19 wait states for a 16-pass MFMA; hipcc does not see the MFMA). The operands tie every later read of
   // the set to this statement.
@@ -340,11 +362,23 @@ __global__ __launch_bounds__(256, 1) void fa2_fwd_rb_kernel(const half_t* __rest
       constexpr int DSTEP = NQK / (2 * G::PPW);  // one DMA piece every DSTEP steps
 #pragma unroll
       for (int t = 0; t < NQK; ++t) {
-        qk_step(NXT, kf[t % PD], t);
-        if (t + PD < NQK) kf[t % PD] = k_frag(kb_j, t + PD);
-        if (t % DSTEP == 0) dma_piece(t / DSTEP, jd, s2);
-        p_slice(CUR, t * EPS, EPS);
-        if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
+        if constexpr ((OPT & RB_HALF) != 0) {
+          qk_one(NXT, kf[t % PD], t, 0);
+          p_slice(CUR, t * EPS, EPS / 2);
+          if (t % DSTEP == 0) dma_piece(t / DSTEP, jd, s2);
+          __builtin_amdgcn_sched_barrier(0);
+          qk_one(NXT, kf[t % PD], t, 1);
+          __builtin_amdgcn_sched_barrier(0);  // the fragment register is re-filled only after both MFMAs were issued
+          if (t + PD < NQK) kf[t % PD] = k_frag(kb_j, t + PD);
+          p_slice(CUR, t * EPS + EPS / 2, EPS / 2);
+          __builtin_amdgcn_sched_barrier(0);
+        } else {
+          qk_step(NXT, kf[t % PD], t);
+          if (t + PD < NQK) kf[t % PD] = k_frag(kb_j, t + PD);
+          if (t % DSTEP == 0) dma_piece(t / DSTEP, jd, s2);
+          p_slice(CUR, t * EPS, EPS);
+          if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
     l_run[0] += psum[0], l_run[1] += psum[1];
@@ -359,13 +393,26 @@ __global__ __launch_bounds__(256, 1) void fa2_fwd_rb_kernel(const half_t* __rest
 #pragma unroll
       for (int i = 0; i < NPV; ++i) {
         const int st = i / G::NDB, b = i % G::NDB;
-        ot[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[i % PD], pf[0][st], ot[0][b], 0, 0, 0);
-        ot[1][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[i % PD], pf[1][st], ot[1][b], 0, 0, 0);
-        if (i + PD < NPV) vf[i % PD] = v_frag(vb_j, i + PD);
-        if (ASMQK && i == 0) rb_fence(NXT);
-        if (i >= FENCE_AT) out_slice(NXT, (i - FENCE_AT) * MPS, MPS);
-        if (FENCE_AT && i == NPV - 1) out_slice(NXT, (NPV - FENCE_AT) * MPS, FENCE_AT * MPS);
-        if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
+        if constexpr ((OPT & RB_HALF) != 0) {
+          ot[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[i % PD], pf[0][st], ot[0][b], 0, 0, 0);
+          if (ASMQK && i == 0) rb_fence(NXT);
+          if (i >= FENCE_AT) out_slice(NXT, (i - FENCE_AT) * MPS, MPS / 2);
+          __builtin_amdgcn_sched_barrier(0);
+          ot[1][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[i % PD], pf[1][st], ot[1][b], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (i + PD < NPV) vf[i % PD] = v_frag(vb_j, i + PD);
+          if (i >= FENCE_AT) out_slice(NXT, (i - FENCE_AT) * MPS + MPS / 2, MPS / 2);
+          if (FENCE_AT && i == NPV - 1) out_slice(NXT, (NPV - FENCE_AT) * MPS, FENCE_AT * MPS);
+          __builtin_amdgcn_sched_barrier(0);
+        } else {
+          ot[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[i % PD], pf[0][st], ot[0][b], 0, 0, 0);
+          ot[1][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[i % PD], pf[1][st], ot[1][b], 0, 0, 0);
+          if (i + PD < NPV) vf[i % PD] = v_frag(vb_j, i + PD);
+          if (ASMQK && i == 0) rb_fence(NXT);
+          if (i >= FENCE_AT) out_slice(NXT, (i - FENCE_AT) * MPS, MPS);
+          if (FENCE_AT && i == NPV - 1) out_slice(NXT, (NPV - FENCE_AT) * MPS, FENCE_AT * MPS);
+          if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
     __builtin_amdgcn_sched_barrier(0);

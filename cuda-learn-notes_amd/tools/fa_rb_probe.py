@@ -25,10 +25,13 @@ quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
 
 NAMES = {400: "builtin", 401: "asmqk", 402: "builtin no-pre", 403: "builtin unpinned", 404: "builtin bc32", 405: "asmqk bc32",
          406: "asmqk pd2", 407: "asmqk no-defer", 408: "asmqk no-pre", 409: "builtin no-defer", 410: "asmqk ABL no-dma",
-         411: "asmqk ABL no-exp", 412: "asmqk ABL no-dma no-exp"}
+         411: "asmqk ABL no-exp", 412: "asmqk ABL no-dma no-exp", 420: "builtin half-step", 421: "asmqk half-step",
+         422: "asmqk half-step pd2"}
 NAMES128 = {400: "builtin", 401: "asmqk", 405: "builtin unpinned", 407: "asmqk no-defer", 408: "asmqk pd2", 409: "builtin no-defer",
-            410: "asmqk ABL no-dma", 411: "asmqk ABL no-exp"}
-VARIANTS = {64: [400, 401, 402, 403, 404, 405, 406, 408, 410, 411, 412], 128: [400, 401, 405, 408, 410, 411]}
+            410: "asmqk ABL no-dma", 411: "asmqk ABL no-exp", 420: "builtin half-step", 421: "asmqk half-step"}
+VARIANTS = {64: [403, 420, 421, 422], 128: [405, 420, 421]} if os.environ.get("RB_FEW") else {64: [400, 401, 402, 403, 404, 405, 406, 408, 410, 411, 412], 128: [400, 401, 405, 408, 410, 411]}
+PP = {64: [(500, "pre stagger bc128"), (501, "pre bc128"), (505, "pre stagger prio3"), (506, "pre stagger young-prio"), (507, "pre prio3")],
+      128: [(500, "pre kpre bc64"), (505, "pre kpre prio3")]}
 SHAPES = [(4, 8, 2048, 64), (1, 48, 8192, 64), (4, 8, 2048, 128), (2, 32, 4096, 128)]
 if quick:
     SHAPES = [(4, 8, 2048, 64), (4, 8, 2048, 128)]
@@ -53,6 +56,8 @@ for (B, H, N, D) in SHAPES:
              ("sdpa", lambda: F.scaled_dot_product_attention(q, k, v))]
     for abl in VARIANTS[D]:
         cands.append(("rb %d %s" % (abl, names[abl]), lambda abl=abl: host.fa2_variant((4, 0, 0, abl), q, k, v, o)))
+    for abl, nm in PP[D]:
+        cands.append(("pp %d %s" % (abl, nm), lambda abl=abl: host.fa2_variant((8, 0, 0, abl), q, k, v, o)))
     ok = {}
     for tag, fn in cands:
         if tag == "sdpa":

