@@ -193,8 +193,11 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
       const char* vp = smem + (vb_j ^ ((b & 3) << 6)) + (16 * st) * G::ROW + (b >> 2) * 256;
       return h8_cat(lds_read_tr16(vp), lds_read_tr16(vp + 8 * G::ROW));
     };
-    constexpr int NK = G::DH / 16, NQK = BCB * NK, NPV = 2 * BCB * (G::DH / 32);
-    constexpr int PD = (OPT & OPT_KPRE) ? 4 : 1;  // fragments in flight ahead of the MFMA that consumes them
+    constexpr int NK = G::DH / 16, NQK = BCB * NK, NPV = 2 * BCB * (G::DH / 32), NQK0 = NQK < NPV ? NQK : NPV;
+    // fragments in flight ahead of the MFMA that consumes them (the phase stamps of round 1 show the MFMA loops running
+    // at 2-3x their matrix time: every MFMA waits for an LDS fragment read issued only a few MFMAs earlier)
+    constexpr int PD0 = (OPT & OPT_PD16) ? 16 : (OPT & OPT_PD8) ? 8 : (OPT & OPT_KPRE) ? 4 : 1;
+    constexpr int PD = PD0 < NQK0 ? PD0 : NQK0;
     f16v s[BCB];
     if constexpr (!PRE) {
 #pragma unroll

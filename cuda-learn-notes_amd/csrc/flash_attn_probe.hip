@@ -45,6 +45,12 @@ CLN_API int cln_fa2_variant(int D, int nw, int vt, int opt, int abl, const void*
   if (D == 64 && abl == 505) return fa2::launch_dsplit<64, 1, 4, 13 | fa2::OPT_STAGGER | fa2::OPT_PRE | fa2::OPT_ONES>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 64 && abl == 506) return fa2::launch_dsplit<64, 1, 4, 13 | fa2::OPT_STAGGER | fa2::OPT_PRE | fa2::OPT_SOLO>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 64 && abl == 507) return fa2::launch_dsplit<64, 1, 4, 13 | fa2::OPT_PRE | fa2::OPT_ONES>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 64 && abl == 508) return fa2::launch_dsplit<64, 1, 4, 13 | fa2::OPT_STAGGER | fa2::OPT_PRE | fa2::OPT_PD8>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 64 && abl == 509) return fa2::launch_dsplit<64, 1, 4, 13 | fa2::OPT_STAGGER | fa2::OPT_PRE | fa2::OPT_PD16>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 64 && abl == 510) return fa2::launch_dsplit<64, 1, 4, 13 | fa2::OPT_PRE | fa2::OPT_PD16>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 64 && abl == 511) return fa2::launch_dsplit<64, 1, 2, 13 | fa2::OPT_STAGGER | fa2::OPT_PRE | fa2::OPT_PD8>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 128 && abl == 508) return fa2::launch_dsplit<128, 1, 2, 15 | fa2::OPT_PRE | fa2::OPT_PD8>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 128 && abl == 509) return fa2::launch_dsplit<128, 1, 2, 15 | fa2::OPT_PRE | fa2::OPT_PD16>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 128 && abl == 505) return fa2::launch_dsplit<128, 1, 2, 15 | fa2::OPT_KPRE | fa2::OPT_PRE | fa2::OPT_ONES>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 128 && abl == 500) return fa2::launch_dsplit<128, 1, 2, 15 | fa2::OPT_KPRE | fa2::OPT_PRE>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 128 && abl == 501) return fa2::launch_dsplit<128, 1, 2, 15 | fa2::OPT_KPRE | fa2::OPT_PRE | fa2::OPT_STAGGER>(q, k, v, o, B, H, N, (hipStream_t)stream);

@@ -24,14 +24,45 @@ int check_args(const void* a, const void* b, const void* c, int M, int N, int K)
   return CLN_OK;
 }
 
-// "best" policy shared by the reference's top rungs (warp4x4x2 family), from the size sweep in
-// profiles/r01_hgemm_midsize_probe.log: 256x256 ping-pong tiles once they cover about half of the 256 CUs
-// (3072^3: 144 tiles -> 969 TF vs 783 with 128x128); below that, 64x128 tiles while 128x128 tiles would leave
-// CUs with fewer than two workgroups (2048^3: 712 vs 647 TF; 1024^3: 182 vs 155), else 128x128.
-int best_tile(int M, int N) {
-  if (M % 256 == 0 && N % 256 == 0 && (M / 256) * (N / 256) >= 120) return T256;
-  if (M % 64 == 0 && N % 128 == 0 && (long long)((M + 127) / 128) * (N / 128) < 512) return T64x128;
-  return T128;
+// "best" policy shared by the reference's top rungs (warp4x4x2 family): pick the tile shape with the best estimated
+// throughput for (M, N) on 256 CUs. score = eff x util x (1 + (1 - util) / 2):
+//   util = tiles / (rounds x slots)   -- slots = 256 workgroups in flight for the 8-wave kernels (one per CU), 512 for
+//                                        the 4-wave 64x128 / 128x128 rings (two per CU);
+//   eff  = measured rate at full occupancy relative to the 256x256 ping-pong kernel (4096^3, same box):
+//          ping-pong 256x256 1.00 | 192x256 0.97 | ring 128x256 0.84 | ring 64x128 0.58 | ring 128x128 0.56;
+//   the last factor: with CUs idle the busy ones clock higher (measured 1.2-1.3x at util 0.4-0.55).
+// It reproduces the measured winner at every size of profiles/r02_hgemm_midsize_probe.log (1024..6144): 64x128 below
+// 2048, 128x256 at 2560 (895 TF vs 613 for the round-1 policy and 840-884 for rocBLAS), 192x256 at 3072 / 6144
+// (968-980 vs 875, rocBLAS 970 / 1218 vs 1146, rocBLAS 1162), 256x256 at 3584 / 4096 / 8192.
+enum BestPlan { PLAN_PP256 = 0, PLAN_PP192, PLAN_R128x256, PLAN_R64x128, PLAN_R128 };
+int best_plan(int M, int N, int K) {
+  auto score = [](long long tiles, int slots, double eff) {
+    if (tiles <= 0) return 0.0;
+    const long long rounds = (tiles + slots - 1) / slots;
+    const double util = (double)tiles / (double)(rounds * slots);
+    return eff * util * (1.0 + 0.5 * (1.0 - util));
+  };
+  double best = -1.0;
+  int plan = PLAN_R128;
+  auto offer = [&](int p, double sc) {
+    if (sc > best) best = sc, plan = p;
+  };
+  if (M % 128 == 0 && N % 128 == 0) offer(PLAN_R128, score((long long)(M / 128) * (N / 128), 512, 0.56));
+  if (M % 64 == 0 && N % 128 == 0) offer(PLAN_R64x128, score((long long)(M / 64) * (N / 128), 512, 0.58));
+  if (M % 128 == 0 && N % 256 == 0) offer(PLAN_R128x256, score((long long)(M / 128) * (N / 256), 256, 0.84));
+  if (K % 64 == 0 && N % 256 == 0) {
+    if (M % 192 == 0) offer(PLAN_PP192, score((long long)(M / 192) * (N / 256), 256, 0.97));
+    if (M % 256 == 0) offer(PLAN_PP256, score((long long)(M / 256) * (N / 256), 256, 1.00));
+  }
+  return plan;
+}
+int plan_tile(int plan) {
+  switch (plan) {
+    case PLAN_R128x256: return T128x256;
+    case PLAN_R64x128: return T64x128;
+    case PLAN_PP256: case PLAN_PP192: return T256;
+    default: return T128;
+  }
 }
 
 // Top rungs (reference warp4x4x2 family): for 256x256-tileable problems the `stages` knob selects a
@@ -40,12 +71,13 @@ int best_tile(int M, int N) {
 template <int LAYOUT>
 int best_dispatch(const void* a, const void* b, void* c, int M, int N, int K, int stages, int swizzle, int stride,
                   hipStream_t st) {
-  const int tile = best_tile(M, N);
-  if (tile == T256) {
-    if ((stages == 2 || stages < 2 || stages > 5) && K % 64 == 0)
-      return launch_pp<LAYOUT, 2, 4, 0, 1>(a, b, c, M, N, K, swizzle, stride, st);
+  const int plan = best_plan(M, N, K);
+  if (plan == PLAN_PP192) return launch_pp<LAYOUT, 2, 4, 0, 0, 192>(a, b, c, M, N, K, swizzle, stride, st);
+  if (plan == PLAN_PP256) {
+    if (stages == 2 || stages < 2 || stages > 5) return launch_pp<LAYOUT, 2, 4, 0, 1>(a, b, c, M, N, K, swizzle, stride, st);
     if (stages == 4 && K % 32 == 0) return launch_pp32<LAYOUT, 2>(a, b, c, M, N, K, swizzle, stride, st);
   }
+  const int tile = plan_tile(plan);
   return LAYOUT == TN ? ring_dispatch_tn(tile, a, b, c, M, N, K, stages, swizzle, stride, st)
                       : ring_dispatch_nn(tile, a, b, c, M, N, K, stages, swizzle, stride, st);
 }
@@ -60,14 +92,15 @@ int describe_ring(int tile, int layout, int M, int N, int K, int stages, char* b
   return snprintf(buf, len, "mfma_ring<%dx%dx%d,%d waves,stages=%d,%s>", BM, BN, BK, waves, stages, layout == TN ? "TN" : "NN");
 }
 int describe_best(int layout, int M, int N, int K, int stages, char* buf, int len) {
-  const int tile = best_tile(M, N);
+  const int plan = best_plan(M, N, K);
   const char* l = layout == TN ? "TN" : "NN";
-  if (tile == T256) {
-    if ((stages == 2 || stages < 2 || stages > 5) && K % 64 == 0)
+  if (plan == PLAN_PP192) return snprintf(buf, len, "hgemm_pp<192x256x64,8 waves,4 slots,LDS epilogue,%s>", l);
+  if (plan == PLAN_PP256) {
+    if (stages == 2 || stages < 2 || stages > 5)
       return snprintf(buf, len, "hgemm_pp<256x256x64,8 waves,4 slots,split DMA,LDS epilogue,%s>", l);
     if (stages == 4 && K % 32 == 0) return snprintf(buf, len, "hgemm_pp32<256x256,BK=32 sub-tiles,4-deep ring,%s>", l);
   }
-  return describe_ring(tile, layout, M, N, K, stages, buf, len);
+  return describe_ring(plan_tile(plan), layout, M, N, K, stages, buf, len);
 }
 
 using C1S_128_NN = Cfg<128, 128, 32, 2, 2, 1, NN>;

@@ -231,23 +231,29 @@ __device__ __forceinline__ void store_tile(half_t* Cmat, int N, int m0, int n0, 
 template <int FM, int FN>
 __device__ __forceinline__ void store_tile_via_lds(half_t* Cmat, int N, int row0, int col0, int lane, char* wave_lds,
                                                    const f4 (&acc)[FM][FN]) {
-  static_assert(FN == 4 && FM % 4 == 0, "wave tile N must be 64");
+  static_assert(FN == 4, "wave tile N must be 64");
   constexpr int RS = 144;  // row stride: 128 B of data + 16 B pad (keeps 16-B alignment, 2-way write conflict)
 #pragma unroll
-  for (int h = 0; h < FM / 4; ++h) {
+  for (int h0 = 0; h0 < FM; h0 += 4) {  // passes of up to 64 rows (the last one may be shorter: FM = 6 -> 64 + 32)
+    constexpr int NF_FULL = 4;
+    const int nf = FM - h0 < NF_FULL ? FM - h0 : NF_FULL;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NF_FULL; ++i)
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
-        const f4 v = acc[h * 4 + i][j];
-        h4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-        *reinterpret_cast<h4*>(wave_lds + (i * 16 + (lane & 15)) * RS + (j * 16 + 4 * (lane >> 4)) * 2) = o;
+        if (i < nf) {
+          const f4 v = acc[(h0 + i) < FM ? (h0 + i) : 0][j];
+          h4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+          *reinterpret_cast<h4*>(wave_lds + (i * 16 + (lane & 15)) * RS + (j * 16 + 4 * (lane >> 4)) * 2) = o;
+        }
       }
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
-      const int r = it * 8 + (lane >> 3);
-      const u4 v = *reinterpret_cast<const u4*>(wave_lds + r * RS + (lane & 7) * 16);
-      *reinterpret_cast<u4*>(Cmat + (size_t)(row0 + h * 64 + r) * N + col0 + (lane & 7) * 8) = v;
+      if (it < nf * 2) {
+        const int r = it * 8 + (lane >> 3);
+        const u4 v = *reinterpret_cast<const u4*>(wave_lds + r * RS + (lane & 7) * 16);
+        *reinterpret_cast<u4*>(Cmat + (size_t)(row0 + h0 * 16 + r) * N + col0 + (lane & 7) * 8) = v;
+      }
     }
   }
 }
@@ -343,11 +349,16 @@ __global__ __launch_bounds__(C::NT, (C::NT >= 512 ? 2 : 1)) void hgemm_ring_kern
 // buffer tile t-1 was read from (its last reads, L(q2), ended >= 2 barriers earlier for both
 // groups); every wave drains its own DMA with vmcnt(0) BEFORE the barrier that ends slot 6, which
 // for group 1 is one rendezvous earlier than group 0's first read of tile t+1.
-template <int LAYOUT, int EPI = 0, int SLOTS = 8, int ABL = 0, int SPLIT = 0>
+// BM = 256 (default) or 192: the 192-row form (wave tile 96x64, quadrants of 48x32 = 12 MFMAs) exists for problem
+// sizes whose 256x256 tiling leaves CUs idle: 3072^3 is 144 tiles of 256x256 on 256 CUs (56 %) but 192 tiles of 192x256
+// (75 %, each 3/4 of the work): one round either way, so the launch is ~25 % shorter.
+template <int LAYOUT, int EPI = 0, int SLOTS = 8, int ABL = 0, int SPLIT = 0, int BM = 256>
 __global__ __launch_bounds__(512, 2) void hgemm_pp_kernel(const half_t* __restrict__ A, const half_t* __restrict__ B,
                                                           half_t* __restrict__ Cmat, int M, int N, int K,
                                                           int tiles_m, int tiles_n, int swizzle, int band) {
-  using C = Cfg<256, 256, 64, 2, 4, 2, LAYOUT>;
+  using C = Cfg<BM, 256, 64, 2, 4, 2, LAYOUT>;
+  constexpr int WR = C::WTM, HM = WR / 2, NI = HM / 16;  // wave rows, rows per A half, 16-row fragments per half
+  static_assert(BM == 256 || (BM == 192 && SPLIT == 0 && SLOTS == 4), "192-row form: 4 slots, un-split DMA");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -377,13 +388,13 @@ __global__ __launch_bounds__(512, 2) void hgemm_pp_kernel(const half_t* __restri
     b_src += b_step;
   };
 
-  f4 acc[8][4];
+  f4 acc[2 * NI][4];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < 2 * NI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
 
-  h8 af[2][4];     // A half (4 row-fragments) x 2 k-steps, re-used for A0 then A1
+  h8 af[2][NI];    // A half (NI row-fragments) x 2 k-steps, re-used for A0 then A1
   h8 bf[2][2][2];  // [B half][k-step][2 col-fragments], both halves stay live
 
   bool first_tile = true;  // ablation builds only
@@ -392,8 +403,8 @@ __global__ __launch_bounds__(512, 2) void hgemm_pp_kernel(const half_t* __restri
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        af[kk][i] = read_kfrag<64>(a_img, wm * 128 + half * 64 + i * 16 + (lane & 15), lane, kk);
+      for (int i = 0; i < NI; ++i)
+        af[kk][i] = read_kfrag<64>(a_img, wm * WR + half * HM + i * 16 + (lane & 15), lane, kk);
   };
   auto load_b = [&](const char* b_img, int half) {
     if constexpr ((ABL & 1) != 0) { if (!first_tile) return; }
@@ -412,11 +423,11 @@ __global__ __launch_bounds__(512, 2) void hgemm_pp_kernel(const half_t* __restri
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[ah * 4 + i][bh * 2 + j] =
-              __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[bh][kk][j], af[kk][i], acc[ah * 4 + i][bh * 2 + j], 0, 0, 0);
+          acc[ah * NI + i][bh * 2 + j] =
+              __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[bh][kk][j], af[kk][i], acc[ah * NI + i][bh * 2 + j], 0, 0, 0);
     if constexpr ((ABL & 8) == 0) __builtin_amdgcn_s_setprio(0);
   };
 #define PP_BARRIER()                          \
@@ -523,27 +534,27 @@ __global__ __launch_bounds__(512, 2) void hgemm_pp_kernel(const half_t* __restri
     store_tile<C>(Cmat, N, m0, n0, wm, wn, lane, acc);
   } else if constexpr (EPI == 2) {
     // every wave is past its last fragment read of the final K tile (see the slot table above)
-    store_tile_via_lds<8, 4>(Cmat, N, m0 + wm * 128, n0 + wn * 64, lane, smem + wave * (64 * 144), acc);
+    store_tile_via_lds<2 * NI, 4>(Cmat, N, m0 + wm * WR, n0 + wn * 64, lane, smem + wave * (64 * 144), acc);
   } else {  // measurement-only variant: keep the accumulators live, store (almost) nothing
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 2 * NI; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
     if (s == 123.456f) Cmat[(size_t)m0 * N + n0] = (half_t)s;
   }
 }
 
-template <int LAYOUT, int EPI = 0, int SLOTS = 8, int ABL = 0, int SPLIT = 0>
+template <int LAYOUT, int EPI = 0, int SLOTS = 8, int ABL = 0, int SPLIT = 0, int BM = 256>
 int launch_pp(const void* a, const void* b, void* c, int M, int N, int K, int swizzle, int swizzle_stride,
               hipStream_t stream) {
-  using C = Cfg<256, 256, 64, 2, 4, 2, LAYOUT>;
-  if (M % 256 || N % 256 || K % 64) return CLN_ERR_UNSUPPORTED;
+  using C = Cfg<BM, 256, 64, 2, 4, 2, LAYOUT>;
+  if (M % BM || N % 256 || K % 64) return CLN_ERR_UNSUPPORTED;
   static cln_lds_attr lds_attr;  // per device, thread-safe (common.h)
-  if (cln_ensure_lds(lds_attr, reinterpret_cast<const void*>(&hgemm_pp_kernel<LAYOUT, EPI, SLOTS, ABL, SPLIT>), C::LDS_BYTES) != CLN_OK) return CLN_ERR_LAUNCH;
-  const int tiles_m = M / 256, tiles_n = N / 256;
+  if (cln_ensure_lds(lds_attr, reinterpret_cast<const void*>(&hgemm_pp_kernel<LAYOUT, EPI, SLOTS, ABL, SPLIT, BM>), C::LDS_BYTES) != CLN_OK) return CLN_ERR_LAUNCH;
+  const int tiles_m = M / BM, tiles_n = N / 256;
   int band = (swizzle && swizzle_stride >= 256) ? swizzle_stride / 256 : tiles_n;
-  CLN_LAUNCH((hgemm_pp_kernel<LAYOUT, EPI, SLOTS, ABL, SPLIT>), dim3(tiles_m * tiles_n), dim3(512), C::LDS_BYTES, stream,
+  CLN_LAUNCH((hgemm_pp_kernel<LAYOUT, EPI, SLOTS, ABL, SPLIT, BM>), dim3(tiles_m * tiles_n), dim3(512), C::LDS_BYTES, stream,
                      (const half_t*)a, (const half_t*)b, (half_t*)c, M, N, K, tiles_m, tiles_n, swizzle ? 1 : 0, band);
   return cln_check_launch();
 }

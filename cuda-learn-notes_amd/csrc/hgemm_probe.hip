@@ -67,6 +67,12 @@ CLN_API int cln_hgemm_variant(int kind, int layout, int tile, int bk, int stages
     return layout == TN ? launch_m32<TN>(a, b, c, M, N, K, swizzle, swizzle_stride, stream)
                         : launch_m32<NN>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
   }
+  if (kind == 11) {  // 192-row ping-pong (4 slots, un-split DMA, LDS epilogue); stages == 1: the 256-row kernel in the same form
+    if (stages == 1) return layout == TN ? launch_pp<TN, 2, 4, 0, 0, 256>(a, b, c, M, N, K, swizzle, swizzle_stride, stream)
+                                         : launch_pp<NN, 2, 4, 0, 0, 256>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+    return layout == TN ? launch_pp<TN, 2, 4, 0, 0, 192>(a, b, c, M, N, K, swizzle, swizzle_stride, stream)
+                        : launch_pp<NN, 2, 4, 0, 0, 192>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+  }
   if (kind == 6) return launch_pp<NN, 1, 4>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);  // 4-slot no-store probe
   if (kind == 7) {  // ablations of the 4-slot no-store probe; `stages` = ABL bits (results are garbage by design)
     switch (stages) {

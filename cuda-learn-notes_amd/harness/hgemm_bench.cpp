@@ -73,8 +73,21 @@ static float max_err_vs_vendor(g6_fn fn, int M, int N, int K) {
   return e;
 }
 
+#include <chrono>
+// time-based pre-warm (0.25 s of back-to-back launches): the chip clocks to its power budget, and a cold 20-launch
+// warm-up measures the ramp, not the kernel (bench.py does the same)
+template <typename F>
+static void prewarm(F launch, double seconds) {
+  const auto t0 = std::chrono::steady_clock::now();
+  while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
+    for (int i = 0; i < 20; ++i) launch();
+    (void)hipDeviceSynchronize();
+  }
+}
+
 template <typename F>
 static double time_sec(F launch, int repeat, int warmup) {
+  prewarm(launch, 0.25);
   for (int i = 0; i < warmup; ++i) launch();
   (void)hipDeviceSynchronize();
   hipEvent_t e0, e1;
@@ -95,7 +108,7 @@ int main(int argc, char** argv) {
   const int repeat = argc > 1 ? atoi(argv[1]) : 200;
   std::vector<int> sizes;
   for (int i = 2; i < argc; ++i) sizes.push_back(atoi(argv[i]));
-  if (sizes.empty()) sizes = {1024, 2048, 4096, 8192};
+  if (sizes.empty()) sizes = {1024, 2048, 2560, 3072, 4096, 6144, 8192};
   if (init_cublas_handle() != 0) { fprintf(stderr, "vendor handle failed\n"); return 2; }
   const g6_fn best = hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem;
   printf("error check vs vendor GEMM (hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem, stages=2, swizzle):\n");

@@ -29,9 +29,9 @@ NAMES = {400: "builtin", 401: "asmqk", 402: "builtin no-pre", 403: "builtin unpi
          422: "asmqk half-step pd2"}
 NAMES128 = {400: "builtin", 401: "asmqk", 405: "builtin unpinned", 407: "asmqk no-defer", 408: "asmqk pd2", 409: "builtin no-defer",
             410: "asmqk ABL no-dma", 411: "asmqk ABL no-exp", 420: "builtin half-step", 421: "asmqk half-step"}
-VARIANTS = {64: [403, 420, 421, 422], 128: [405, 420, 421]} if os.environ.get("RB_FEW") else {64: [400, 401, 402, 403, 404, 405, 406, 408, 410, 411, 412], 128: [400, 401, 405, 408, 410, 411]}
-PP = {64: [(500, "pre stagger bc128"), (501, "pre bc128"), (505, "pre stagger prio3"), (506, "pre stagger young-prio"), (507, "pre prio3")],
-      128: [(500, "pre kpre bc64"), (505, "pre kpre prio3")]}
+VARIANTS = {64: [], 128: []} if os.environ.get("RB_FEW") else {64: [400, 401, 402, 403, 404, 405, 406, 408, 410, 411, 412], 128: [400, 401, 405, 408, 410, 411]}
+PP = {64: [(500, "pre stagger bc128"), (508, "pre stagger pd8"), (509, "pre stagger pd16"), (510, "pre pd16"), (511, "pre stagger bc64 pd8")],
+      128: [(500, "pre kpre bc64"), (508, "pre pd8"), (509, "pre pd16")]}
 SHAPES = [(4, 8, 2048, 64), (1, 48, 8192, 64), (4, 8, 2048, 128), (2, 32, 4096, 128)]
 if quick:
     SHAPES = [(4, 8, 2048, 64), (4, 8, 2048, 128)]

@@ -365,7 +365,7 @@ def test_stages_one_is_the_load_then_compute_kernel(fa, built, dev, oracle, D):
 # register-blocked kernel (flash_attn_rb.cuh) through the probe hook: (D, option-set ids of flash_attn_probe.hip)
 RB_VARIANTS = {64: [400, 401, 402, 403, 404, 405, 406, 407, 408, 409, 420, 421, 422], 128: [400, 401, 405, 407, 408, 409, 420, 421]}
 # ping-pong kernel with OPT_PRE (pre-scaled Q, accumulators started at -m): option-set ids 500..
-PRE_VARIANTS = {64: [500, 501, 502, 503, 504, 505, 506, 507], 128: [500, 501, 504, 505], 256: [500, 504]}
+PRE_VARIANTS = {64: [500, 501, 502, 503, 504, 505, 506, 507, 508, 509, 510, 511], 128: [500, 501, 504, 505, 508, 509], 256: [500, 504]}
 
 
 @pytest.mark.parametrize("D", [64, 128, 256])

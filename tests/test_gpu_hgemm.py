@@ -201,10 +201,13 @@ def test_baseline_configs_sampled_rows(hg, dev, size):
 
 
 @pytest.mark.parametrize("M,N,K", [(4096, 8192, 2048), (2048, 1024, 8192), (3072, 3072, 3072), (16384, 16384, 1024),
-                                   (1536, 2560, 4096), (64, 128, 64), (12800, 12800, 512)])
+                                   (1536, 2560, 4096), (64, 128, 64), (12800, 12800, 512), (2560, 2560, 2560),
+                                   (6144, 6144, 512), (192, 256, 64), (3072, 4096, 192), (4096, 4096, 96),
+                                   (3584, 3584, 1024)])
 def test_rectangular_and_large_shapes(hg, built, dev, M, N, K):
-    """Every tile policy branch (256x256 ping-pong, 64x128, 128x128) on non-square and large problems (the
-    reference sweeps up to M=N=12800/16384, hgemm.py MMNK): sampled rows vs the fp32 product, NN and TN agree."""
+    """Every tile policy branch (256x256 and 192x256 ping-pong, ring 128x256, 64x128, 128x128) on non-square and large
+    problems (the reference sweeps up to M=N=12800/16384, hgemm.py MMNK): sampled rows vs the fp32 product, NN and TN
+    agree. manifest.describe() says which kernel each shape runs (tests/test_describe.py pins the policy)."""
     from cuda_learn_notes_amd.bench_utils import as_col_major, make_block_swizzle_stride
     torch.manual_seed(M + N + K)
     a = torch.randn(M, K, dtype=torch.half, device=dev)
