@@ -122,10 +122,10 @@ int fa2_run(const FaPlan& p, const void* q, const void* k, const void* v, void* 
     if (p.nw == 4) return fa2::launch_v2<DD, 4, VT, OPTT>(q, k, v, o, B, H, N, s);                     \
     return fa2::launch_v2<DD, 2, VT, OPTT>(q, k, v, o, B, H, N, s);
       switch (D) {
-        FA_V2(32, 13)
-        FA_V2(64, 13)
-        FA_V2(96, 15)
-        FA_V2(128, 15)
+        FA_V2(32, 13 | fa2::OPT_PRE)
+        FA_V2(64, 13 | fa2::OPT_PRE)
+        FA_V2(96, 15 | fa2::OPT_PRE)
+        FA_V2(128, 15 | fa2::OPT_PRE)
         case 256: return fa2::launch_v2<256, 4, VT, 15>(q, k, v, o, B, H, N, s);
       }
 #undef FA_V2
@@ -176,7 +176,8 @@ int fa2_describe(int family, bool vt, int B, int H, int N, int D, int stages, in
     case K_LOAD_THEN_COMPUTE:
       return snprintf(buf, len, "fa2_fwd<D=%d,BC=64,load-then-compute%s> 4 waves x 32 rows", D, vts);
     case K_V2:
-      return snprintf(buf, len, "fa2_fwd_v2<D=%d,NW=%d,BC=64,prefetch%s> %d waves x 32 rows%s", D, p.nw, vts, p.nw, st);
+      return snprintf(buf, len, "fa2_fwd_v2<D=%d,NW=%d,BC=64,prefetch%s%s> %d waves x 32 rows%s", D, p.nw,
+                      D <= 128 ? ",pre-scaled Q" : "", vts, p.nw, st);
     case K_RB:
       return snprintf(buf, len, "fa2_fwd_rb<D=%d,BC=%d> 4 waves x 64 rows, 1 wave/SIMD, K/V fragments shared by 2 row "
                                 "groups%s", D, p.bc, st);

@@ -255,9 +255,12 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
       else grow = d > 0.f;
       const bool first = PRE && j == 0;  // tile 0 adopts its max unconditionally (the accumulators started at 0)
       if (first || __builtin_amdgcn_ballot_w64(grow) != 0) {
+        // OPT_PRE: m_run += delta (delta is exact: the scores are relative). Without it m_run starts at the -1e30
+        // sentinel, where "m_run + (mxs - m_run)" would cancel catastrophically: take the max directly.
         const float delta = first ? d : fmaxf(d, 0.f);
-        const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-delta);
-        m_run += delta;
+        const float m_new = PRE ? m_run + delta : fmaxf(m_run, mx * scale_log2e);
+        const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
         l_run *= alpha;
         if constexpr (PRE) {  // the pending scores were accumulated from the old -m
 #pragma unroll

@@ -146,8 +146,15 @@ __global__ __launch_bounds__(NW * 64, ((D > 128 || (D == 128 && NW == 2)) ? 1 : 
 #pragma unroll
   for (int r = 0; r < 16; ++r) lacc[r] = 0.f;
   const h8 ones = {(half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f};
-  float m_run = -1.0e30f;  // running max, scaled log2 domain (finite sentinel: no inf arithmetic)
+  // OPT_PRE (see flash_attn_dsplit.cuh): Q pre-multiplied by log2(e)/sqrt(d), both S^T accumulators of a tile start at
+  // -m through the C operand of their first MFMA: P = exp2(acc), no per-score v_fma, no accumulator zeroing
+  constexpr bool QPRE = (OPT & OPT_PRE) != 0;
+  float m_run = QPRE ? 0.f : -1.0e30f;  // running max, scaled log2 domain (finite sentinel: no inf arithmetic)
   float l_run = 0.f;       // per-lane partial row sum (this lane's half of each kv tile)
+  f16v minit;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) minit[r] = 0.f;
+  if constexpr (QPRE) asm volatile("" : "+v"(minit));
 
   // lane-constant LDS offsets
   const int k_off = l31 * G::KS + hi * 16;
@@ -170,6 +177,11 @@ __global__ __launch_bounds__(NW * 64, ((D > 128 || (D == 128 && NW == 2)) ? 1 : 
   // reads qf[2..]), and because vmcnt retires in order that wait also drains the K/V prefetch issued at the end
   // of the previous iteration -- the full global-load latency was exposed once per KV tile.
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), lgkmcnt/expcnt untouched
+  if constexpr (QPRE) {
+    const half_t sc = (half_t)scale_log2e;
+#pragma unroll
+    for (int ks = 0; ks < D / 16; ++ks) qf[ks] = qf[ks] * sc;
+  }
   if (T > 1) load_tile(1);
   __syncthreads();
 
@@ -186,8 +198,12 @@ __global__ __launch_bounds__(NW * 64, ((D > 128 || (D == 128 && NW == 2)) ? 1 : 
 
     // ---- S^T = K Q^T : two 32-kv sub-tiles
     f16v s0, s1;
+    if constexpr (QPRE) {
+      s0 = minit, s1 = minit;  // consumed as the C operand of the first MFMA pair: no moves
+    } else {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s0[r] = 0.f, s1[r] = 0.f;
+      for (int r = 0; r < 16; ++r) s0[r] = 0.f, s1[r] = 0.f;
+    }
     if constexpr ((OPT & OPT_KPRE) != 0) {
       // all K fragment reads of this tile up front (in groups of 4 k-steps): the LDS latency is paid once per
       // group instead of once per MFMA pair (hipcc otherwise issues each read two MFMAs ahead of its use)
@@ -257,15 +273,25 @@ __global__ __launch_bounds__(NW * 64, ((D > 128 || (D == 128 && NW == 2)) ? 1 : 
         const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
         mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
       }
-      const float mxs = mx * scale_log2e;
+      const float dgrow = QPRE ? mx : mx * scale_log2e - m_run;  // growth of the row max (log2 domain)
       bool grow;
-      if constexpr ((OPT & OPT_DEFER) != 0) grow = (mxs - m_run) > 8.0f;
-      else grow = mxs > m_run;
-      if (__builtin_amdgcn_ballot_w64(grow) != 0) {  // wave-uniform: some row's max moved
-        const float m_new = fmaxf(m_run, mxs);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      if constexpr ((OPT & OPT_DEFER) != 0) grow = dgrow > 8.0f;
+      else grow = dgrow > 0.f;
+      const bool first = QPRE && j == 0;  // tile 0 adopts its max unconditionally (the accumulators started at 0)
+      if (first || __builtin_amdgcn_ballot_w64(grow) != 0) {  // wave-uniform: some row's max moved
+        // (without OPT_PRE m_run starts at the -1e30 sentinel: take the max directly, "m_run + delta" would cancel)
+        const float delta = first ? dgrow : fmaxf(dgrow, 0.f);
+        const float m_new = QPRE ? m_run + delta : fmaxf(m_run, mx * scale_log2e);
+        const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);
         m_run = m_new;
         l_run *= alpha;
+        if constexpr (QPRE) {  // the pending scores were accumulated from the old -m
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s0[r] -= delta, s1[r] -= delta;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) minit[r] = -m_run;
+          asm volatile("" : "+v"(minit));
+        }
         if constexpr ((OPT & OPT_ONES) != 0) lacc[0] *= alpha;
 #pragma unroll
         for (int b = 0; b < D / 32; ++b)
@@ -308,10 +334,10 @@ __global__ __launch_bounds__(NW * 64, ((D > 128 || (D == 128 && NW == 2)) ? 1 : 
           b0 = __builtin_amdgcn_exp2f(fmaf(s1[r], scale_log2e, nm));
           b1 = __builtin_amdgcn_exp2f(fmaf(s1[r + 1], scale_log2e, nm));
         } else {
-          a0 = __builtin_amdgcn_exp2f(fmaf(s0[r], scale_log2e, nm));
-          a1 = __builtin_amdgcn_exp2f(fmaf(s0[r + 1], scale_log2e, nm));
-          b0 = __builtin_amdgcn_exp2f(fmaf(s1[r], scale_log2e, nm));
-          b1 = __builtin_amdgcn_exp2f(fmaf(s1[r + 1], scale_log2e, nm));
+          a0 = __builtin_amdgcn_exp2f(QPRE ? s0[r] : fmaf(s0[r], scale_log2e, nm));
+          a1 = __builtin_amdgcn_exp2f(QPRE ? s0[r + 1] : fmaf(s0[r + 1], scale_log2e, nm));
+          b0 = __builtin_amdgcn_exp2f(QPRE ? s1[r] : fmaf(s1[r], scale_log2e, nm));
+          b1 = __builtin_amdgcn_exp2f(QPRE ? s1[r + 1] : fmaf(s1[r + 1], scale_log2e, nm));
         }
         if constexpr ((OPT & OPT_ONES) == 0) psum += (a0 + a1) + (b0 + b1);
         const h2 a = __builtin_convertvector(f2{a0, a1}, h2);

@@ -293,10 +293,10 @@ DISPATCH_EXAMPLES = [
     (_SQKV, (4, 8, 2048, 64), 2, "fa2_fwd_dsplit<D=64,NSP=1,BC=128,pre-scaled Q> 8 waves, two groups one phase apart"),
     (_SQKV, (4, 8, 2048, 128), 2, "fa2_fwd_dsplit<D=128,NSP=1,BC=64,pre-scaled Q> 8 waves, two groups one phase apart"),
     (_SQKV, (2, 32, 4096, 256), 2, "fa2_fwd_dsplit<D=256,NSP=1,BC=32> 8 waves, two groups one phase apart"),
-    (_SQKV, (2, 8, 2048, 64), 2, "fa2_fwd_v2<D=64,NW=4,BC=64,prefetch> 4 waves x 32 rows"),
-    (_SQKV, (1, 2, 256, 64), 2, "fa2_fwd_v2<D=64,NW=2,BC=64,prefetch> 2 waves x 32 rows"),
-    (_SQKV, (1, 2, 192, 64), 1, "fa2_fwd_v2<D=64,NW=2,BC=64,prefetch> 2 waves x 32 rows" + _IGN),
-    (_SQKV + "_swizzle_qkv", (4, 8, 2048, 128), 2, "fa2_fwd_v2<D=128,NW=8,BC=64,prefetch,V^T> 8 waves x 32 rows"),
+    (_SQKV, (2, 8, 2048, 64), 2, "fa2_fwd_v2<D=64,NW=4,BC=64,prefetch,pre-scaled Q> 4 waves x 32 rows"),
+    (_SQKV, (1, 2, 256, 64), 2, "fa2_fwd_v2<D=64,NW=2,BC=64,prefetch,pre-scaled Q> 2 waves x 32 rows"),
+    (_SQKV, (1, 2, 192, 64), 1, "fa2_fwd_v2<D=64,NW=2,BC=64,prefetch,pre-scaled Q> 2 waves x 32 rows" + _IGN),
+    (_SQKV + "_swizzle_qkv", (4, 8, 2048, 128), 2, "fa2_fwd_v2<D=128,NW=8,BC=64,prefetch,pre-scaled Q,V^T> 8 waves x 32 rows"),
     (_SQKV + "_swizzle_qkv", (4, 8, 2048, 128), 1, "fa2_fwd<D=128,BC=64,load-then-compute,V^T> 4 waves x 32 rows"),
     (_TQKV, (1, 32, 4096, 512), 2, "fa2_fwd_dsplit<D=512,NSP=2,BC=32> 8 waves, two groups one phase apart" + _IGN),
     (_TQKV, (1, 16, 4096, 384), 2, "fa2_fwd_dsplit<D=512,NSP=2,BC=32,PAD=384> 8 waves, pairs split d" + _IGN),

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Everything the round's evidence files are made of, in one GPU call:  round_evidence.sh <tag, e.g. r02>
+#   1. pytest -m gpu log                        -> gpurun_out/<tag>_pytest_gpu.log
+#   2. bench.py lines (driver-style 20 steps, default, no-extras)  -> <tag>_bench_*.json
+#   3. rocprofv3 kernel-trace stats of the bench command + PMC passes (profile_round.sh)  -> <tag>_bench_kernel_stats.csv, <tag>_pmc_*.json
+#   4. rocprofv3 kernel-trace of the attention kernels at the bench shapes (fa_trace.sh)   -> <tag>_fa_kernel_trace.csv
+#   5. rocprofv3 kernel-trace of the bandwidth kernels (bw_prof_*)                         -> <tag>_bw_rocprof.json
+#   6. the re-authored reference scripts on the GPU (run_all_scripts.sh)                   -> <tag>_reference_style_scripts_on_gpu.log
+#   7. C++ harness                                                                         -> <tag>_hgemm_bench_cpp.log
+TAG=${1:-r02}
+REPO=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$REPO/gpurun_out; T=$REPO/cuda-learn-notes_amd/tools
+mkdir -p $OUT; cd $REPO; export PYTHONUNBUFFERED=1
+timeout 1500 python -m pytest tests -m gpu -q > $OUT/${TAG}_pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $OUT/${TAG}_pytest_gpu.log
+timeout 300 python bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_20steps.json 2> $OUT/${TAG}_bench_20steps.err; echo "bench20 rc=$?"
+timeout 300 python bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/${TAG}_bench_default.err; echo "bench rc=$?"
+timeout 900 bash $T/profile_round.sh $TAG > $OUT/${TAG}_profile_round.log 2>&1; echo "profile_round rc=$?"
+timeout 600 bash $T/fa_trace.sh $TAG > $OUT/${TAG}_fa_trace.log 2>&1; echo "fa_trace rc=$?"
+( cd /tmp && export TMPDIR=/tmp && BW_PROF_ORDER=$OUT/bw_prof_order.json timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/bwprof -o bw -- python $T/bw_prof_target.py > $OUT/${TAG}_bw_prof.log 2>&1 )
+python $T/bw_prof_summary.py $(ls $OUT/bwprof/*kernel_trace.csv $OUT/bwprof/*/*kernel_trace.csv 2>/dev/null | head -1) $OUT/bw_prof_order.json $OUT/${TAG}_bw_rocprof.json > $OUT/${TAG}_bw_rocprof.txt 2>&1; echo "bw rc=$?"
+timeout 900 bash $T/run_all_scripts.sh > $OUT/${TAG}_reference_style_scripts_on_gpu.log 2>&1; echo "scripts rc=$?"
+timeout 300 $REPO/cuda-learn-notes_amd/harness/hgemm_bench 200 > $OUT/${TAG}_hgemm_bench_cpp.log 2>&1; echo "harness rc=$?"
+cut -c1-1500 $OUT/${TAG}_bench_20steps.json; echo; cat $OUT/${TAG}_fa_kernel_trace.csv; cat $OUT/${TAG}_bw_rocprof.txt
+ls -la $OUT/${TAG}_* | head -40

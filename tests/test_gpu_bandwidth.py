@@ -2,6 +2,8 @@
 CPU oracle on the same seeded inputs. Tolerances are stated per test."""
 import os
 
+import math
+
 import pytest
 import torch
 
@@ -154,6 +156,10 @@ def test_layer_norm(lib, dev, oracle, K):
         getattr(lib, name)(x.to(dev), y, g, b)
         assert torch.allclose(y.cpu(), ref_k, atol=2e-5, rtol=1e-5), name
         assert torch.allclose(y.cpu(), ref_t, atol=6.0 / K + 1e-4), name  # sqrt((K-1)/K) factor on |y| <~ 6
+        # ... and TIGHT against the pinned script oracle once the analytic difference between the two definitions is
+        # applied: the kernel divides sum((x-mean)^2) by (K + 1e-5), the script by (K - 1), nothing else differs
+        derived = b + (ref_t - b) * math.sqrt((K + 1e-5) / (K - 1))
+        assert torch.allclose(y.cpu(), derived, atol=3e-5, rtol=1e-5), name
     if K % 8 == 0:
         xh = x.half()
         ref_kh = oracle.layer_norm_kernel(xh, g, b)

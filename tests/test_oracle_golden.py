@@ -93,3 +93,18 @@ def test_embedding_is_a_row_gather(oracle):
     out = oracle.embedding(idx, w)
     for r, i in enumerate(idx.tolist()):
         assert torch.equal(out[r], w[i])
+
+
+def test_kernel_restatement_of_layer_norm_is_tied_to_the_pinned_script_oracle(oracle):
+    """`layer_norm_kernel` (the CUDA kernel's arithmetic, layer_norm.cu:53-72: population variance with eps added to
+    K) cannot be run here, but it differs from the golden-pinned script function `layer_norm_torch` (unbiased std, no
+    eps) by ONE analytic factor: y_kernel - b = (y_script - b) * sqrt((K + 1e-5) / (K - 1)). Checking that identity ties
+    the restatement the GPU tests assert tightly against to the pinned oracle."""
+    import math
+    import torch
+    g, b = 1.5, -0.25
+    for K in (64, 1000, 4096):
+        x = torch.randn(7, K, generator=torch.Generator().manual_seed(K)) * 2 + 0.5
+        yk, yt = oracle.layer_norm_kernel(x, g, b), oracle.layer_norm_torch(x, g, b)
+        derived = b + (yt - b) * math.sqrt((K + 1e-5) / (K - 1))
+        assert torch.allclose(yk, derived, atol=2e-6, rtol=1e-6), K
