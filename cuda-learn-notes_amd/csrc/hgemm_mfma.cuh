@@ -358,7 +358,8 @@ __global__ __launch_bounds__(512, 2) void hgemm_pp_kernel(const half_t* __restri
                                                           int tiles_m, int tiles_n, int swizzle, int band) {
   using C = Cfg<BM, 256, 64, 2, 4, 2, LAYOUT>;
   constexpr int WR = C::WTM, HM = WR / 2, NI = HM / 16;  // wave rows, rows per A half, 16-row fragments per half
-  static_assert(BM == 256 || (BM == 192 && SPLIT == 0 && SLOTS == 4), "192-row form: 4 slots, un-split DMA");
+  static_assert(BM == 256 || (BM == 192 && SPLIT != 1 && (SLOTS == 4 || SLOTS == 2)), "192-row form: un-split or in-compute DMA");
+  static_assert(SLOTS != 2 || SPLIT == 0, "2-slot form: un-split DMA");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -394,6 +395,7 @@ __global__ __launch_bounds__(512, 2) void hgemm_pp_kernel(const half_t* __restri
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
 
+  h8 af2[2][SLOTS == 2 ? 2 * NI : 1], bf2[2][SLOTS == 2 ? 4 : 1];  // SLOTS == 2: every fragment of a K tile live at once
   h8 af[2][NI];    // A half (NI row-fragments) x 2 k-steps, re-used for A0 then A1
   h8 bf[2][2][2];  // [B half][k-step][2 col-fragments], both halves stay live
 
@@ -447,7 +449,7 @@ __global__ __launch_bounds__(512, 2) void hgemm_pp_kernel(const half_t* __restri
   for (int t = 0; t < nt; ++t) {
     const char* a_img = smem + (t & 1) * C::STAGE_BYTES;
     const char* b_img = a_img + C::A_BYTES;
-    if constexpr ((ABL & 2) == 0 && SPLIT == 0) { if (t + 1 < nt) stage((t + 1) & 1); }
+    if constexpr ((ABL & 2) == 0 && SPLIT == 0 && SLOTS != 2) { if (t + 1 < nt) stage((t + 1) & 1); }
     if constexpr (SLOTS == 8) {
       load_a(a_img, 0);
       load_b(b_img, 0);
@@ -466,7 +468,7 @@ __global__ __launch_bounds__(512, 2) void hgemm_pp_kernel(const half_t* __restri
       PP_BARRIER();
       mma(1, 0);
       PP_BARRIER();
-    } else if constexpr (SPLIT == 0) {
+    } else if constexpr (SPLIT == 0 && SLOTS == 4) {
       // 4 slots per tile, 32 MFMAs per compute slot: half the barriers per tile.
       //   G0:  DMA+L(A0,B0,B1)   M(q0,q1)   L(A1)+wait DMA   M(q2,q3)
       // Reads are drained (lgkmcnt(0)) BEFORE the barrier that ends a read slot: the partner group
@@ -478,6 +480,101 @@ __global__ __launch_bounds__(512, 2) void hgemm_pp_kernel(const half_t* __restri
       PP_BARRIER();
       mma(0, 0);
       mma(0, 1);
+      PP_BARRIER();
+      load_a(a_img, 1);
+      wait_vmcnt<0>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      PP_BARRIER();
+      mma(1, 1);
+      mma(1, 0);
+      PP_BARRIER();
+    }
+    if constexpr (SLOTS == 2) {
+      // 2 slots per tile: ONE read slot (next tile's DMA, all 24 fragments of this tile) and ONE compute slot of 64
+      // MFMAs -- half the barriers of the 4-slot form, at the price of all fragments live at once (96 registers).
+      // Ring: DMA(t+1) goes to the buffer tile t-1 was read from; both groups finished those reads (lgkmcnt(0)
+      // before the barrier that ended their read slot) at least one slot earlier. Every wave drains its own DMA
+      // before the barrier that ends its READ slot: the pieces had the partner's whole compute slot to land.
+      if (t + 1 < nt) stage((t + 1) & 1);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int i = 0; i < 2 * NI; ++i)
+          af2[kk][i] = read_kfrag<64>(a_img, wm * WR + i * 16 + (lane & 15), lane, kk);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if constexpr (LAYOUT == TN) bf2[kk][j] = read_kfrag<64>(b_img, wn * 64 + j * 16 + (lane & 15), lane, kk);
+          else bf2[kk][j] = read_nfrag<256>(b_img, wn * 64 + j * 16, lane, kk);
+        }
+      }
+      wait_vmcnt<0>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      PP_BARRIER();
+      if constexpr ((ABL & 8) == 0) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 2 * NI; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf2[kk][j], af2[kk][i], acc[i][j], 0, 0, 0);
+      if constexpr ((ABL & 8) == 0) __builtin_amdgcn_s_setprio(0);
+      PP_BARRIER();
+    }
+    if constexpr (SLOTS == 4 && SPLIT == 2) {
+      // Same 4 slots, but the next tile's DMA is issued INSIDE the first compute slot, one 1-KiB piece behind every
+      // fourth MFMA: an LDS-DMA issue costs 60-180 cycles of the issuing wave (MI355X_MICROARCH "LDS-DMA piece"), which
+      // in a read slot is exposed (the partner's 32 MFMAs take ~512 cycles, 6-8 pieces + 16 fragment reads more) but
+      // behind an MFMA only uses issue slots the matrix pipe leaves free. Ring: the pieces of tile t+1 go to the buffer
+      // of tile t-1, whose last reads (slot 2 of tile t-1 of the younger group) ended before this slot began; every wave
+      // drains its own pieces at the end of its NEXT read slot (a full slot later), one rendezvous before the older
+      // group reads tile t+1.
+      const bool more = (t + 1 < nt);
+      const unsigned nimg = lds0 + ((t + 1) & 1) * C::STAGE_BYTES;
+      auto issue_piece = [&](int n) {  // n < A_LOADS: A piece n, else B piece n - A_LOADS
+        if (!more) return;
+        if (n < C::A_LOADS) {
+          glds16_asm(a_src, fa.voff[n < C::A_LOADS ? n : 0], nimg + (unsigned)(n * C::NW + wave) * 1024u);
+        } else {
+          const int m = n - C::A_LOADS;
+          if constexpr (LAYOUT == TN) glds16_asm(b_src, fbt.voff[m < C::B_LOADS ? m : 0], nimg + C::A_BYTES + (unsigned)(m * C::NW + wave) * 1024u);
+          else glds16_asm(b_src, fbn.voff[m < C::B_LOADS ? m : 0], nimg + C::A_BYTES + (unsigned)(m * C::NW + wave) * 1024u);
+        }
+      };
+      auto mma_dma = [&](int ah, int bh, int piece0) {
+        if constexpr ((ABL & 8) == 0) __builtin_amdgcn_s_setprio(1);
+        int cnt = 0;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              acc[ah * NI + i][bh * 2 + j] =
+                  __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[bh][kk][j], af[kk][i], acc[ah * NI + i][bh * 2 + j], 0, 0, 0);
+              if ((cnt & 3) == 3) {
+                const int pc = piece0 + (cnt >> 2);
+                if (pc < C::A_LOADS + C::B_LOADS && (cnt >> 2) < (2 * NI * 2) / 4) issue_piece(pc);
+                __builtin_amdgcn_sched_barrier(0);
+              }
+              ++cnt;
+            }
+        if constexpr ((ABL & 8) == 0) __builtin_amdgcn_s_setprio(0);
+      };
+      load_a(a_img, 0);
+      load_b(b_img, 0);
+      load_b(b_img, 1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      PP_BARRIER();
+      constexpr int PER_MMA = (2 * NI * 2) / 4, NP = C::A_LOADS + C::B_LOADS;  // pieces behind one quadrant's MFMAs
+      mma_dma(0, 0, 0);
+      mma_dma(0, 1, PER_MMA);
+#pragma unroll
+      for (int pc = 2 * PER_MMA; pc < NP; ++pc) issue_piece(pc);  // 192-row form: 7 pieces, 6 slots behind MFMAs
+      if (more) {
+        a_src += a_step;
+        b_src += b_step;
+      }
       PP_BARRIER();
       load_a(a_img, 1);
       wait_vmcnt<0>();

@@ -73,6 +73,18 @@ CLN_API int cln_hgemm_variant(int kind, int layout, int tile, int bk, int stages
     return layout == TN ? launch_pp<TN, 2, 4, 0, 0, 192>(a, b, c, M, N, K, swizzle, swizzle_stride, stream)
                         : launch_pp<NN, 2, 4, 0, 0, 192>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
   }
+  if (kind == 12) {  // 2-slot ping-pong (64 MFMAs per compute slot); stages == 2: 192-row form
+    if (stages == 2) return layout == TN ? launch_pp<TN, 2, 2, 0, 0, 192>(a, b, c, M, N, K, swizzle, swizzle_stride, stream)
+                                         : launch_pp<NN, 2, 2, 0, 0, 192>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+    return layout == TN ? launch_pp<TN, 2, 2, 0, 0, 256>(a, b, c, M, N, K, swizzle, swizzle_stride, stream)
+                        : launch_pp<NN, 2, 2, 0, 0, 256>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+  }
+  if (kind == 13) {  // 4-slot ping-pong with the DMA issued inside the first compute slot; stages == 2: 192-row form
+    if (stages == 2) return layout == TN ? launch_pp<TN, 2, 4, 0, 2, 192>(a, b, c, M, N, K, swizzle, swizzle_stride, stream)
+                                         : launch_pp<NN, 2, 4, 0, 2, 192>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+    return layout == TN ? launch_pp<TN, 2, 4, 0, 2, 256>(a, b, c, M, N, K, swizzle, swizzle_stride, stream)
+                        : launch_pp<NN, 2, 4, 0, 2, 256>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+  }
   if (kind == 6) return launch_pp<NN, 1, 4>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);  // 4-slot no-store probe
   if (kind == 7) {  // ablations of the 4-slot no-store probe; `stages` = ABL bits (results are garbage by design)
     switch (stages) {

@@ -7,7 +7,8 @@
 // (`token_idx / (N * 2)`, rope.cu:26, :41, :55-56) which is always 0, so every pair is rotated by
 // t radians; `ref_quirk != 0` reproduces that behaviour bit-for-bit in structure for users who
 // depend on it. HBM-bound (1 read + 1 write); sincos is computed in-kernel because the API passes
-// no table (two v_sin/v_cos per pair hide under the 8 B/pair of traffic at ~6 TB/s).
+// no table (two v_sin/v_cos per pair hide under the 8 B/pair of traffic at ~6 TB/s); the frequency (one pow per
+// column) is formed once per thread, which owns a column and walks the rows.
 #include "common.h"
 
 namespace {
@@ -24,35 +25,38 @@ __device__ __forceinline__ void rotate(float x1, float x2, float ang, float& o1,
   o2 = x1 * s + x2 * c;
 }
 
-// PAIRS pairs per thread: 1 -> 8-byte accesses (f32 / f32_v2 rungs), 2 -> 16-byte (f32x4_pack)
+// PAIRS pairs per thread: 1 -> 8-byte accesses (f32 / f32_v2 rungs), 2 -> 16-byte (f32x4_pack).
+// A thread owns ONE column unit (PAIRS adjacent pairs) and walks rows blockIdx.y, + gridDim.y, ...: its rotation
+// frequencies are formed once (PAIRS calls of pow), exactly as the script forms them (rope.py:77):
+//   1.0 / (theta ** (float(2 i) / dim)), every step in fp32
+// -- the angle t * freq amplifies a 1-ulp difference in freq by the token index (t = 8192: 1e-3 rad), so an algebraically
+// equal exp2() form is NOT close enough at long sequences, and pow() per ELEMENT (the first version of this fix) cost more
+// than the memory traffic (43 us vs 20 us at 4096 x 4096). A row of threads still reads a row of x contiguously.
 template <int PAIRS>
 __global__ __launch_bounds__(256) void rope_kernel(const float* __restrict__ x, float* __restrict__ out,
                                                    int seq_len, int half_hidden, int ref_quirk) {
-  const long long units = (long long)seq_len * half_hidden / PAIRS;
-  for (long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x; u < units;
-       u += (long long)gridDim.x * blockDim.x) {
-    const long long pair0 = u * PAIRS;
-    const int t = (int)(pair0 / half_hidden);
-    const int i0 = (int)(pair0 - (long long)t * half_hidden);
+  const int units_per_row = half_hidden / PAIRS;
+  const int u = blockIdx.x * 256 + threadIdx.x;
+  if (u >= units_per_row) return;
+  float freq[PAIRS];
+#pragma unroll
+  for (int p = 0; p < PAIRS; ++p)
+    freq[p] = ref_quirk ? 1.0f : 1.0f / powf(10000.0f, (float)(2 * (u * PAIRS + p)) / (float)(2 * half_hidden));
+#pragma unroll 4  // independent rows: four loads in flight per lane (x and out are __restrict__)
+  for (int t = blockIdx.y; t < seq_len; t += gridDim.y) {
+    const size_t off = ((size_t)t * half_hidden + (size_t)u * PAIRS) * 2;
     float v[2 * PAIRS], o[2 * PAIRS];
     if constexpr (PAIRS == 2) {
-      *reinterpret_cast<f4*>(v) = *reinterpret_cast<const f4*>(x + pair0 * 2);
+      *reinterpret_cast<f4*>(v) = *reinterpret_cast<const f4*>(x + off);
     } else {
-      *reinterpret_cast<f2*>(v) = *reinterpret_cast<const f2*>(x + pair0 * 2);
+      *reinterpret_cast<f2*>(v) = *reinterpret_cast<const f2*>(x + off);
     }
 #pragma unroll
-    for (int p = 0; p < PAIRS; ++p) {
-      // formed exactly as the script forms it (rope.py:77): 1.0 / (theta ** (float(2 i) / dim)), every step in fp32 --
-      // the angle t * freq amplifies a 1-ulp difference in freq by the token index (t = 8192: 1e-3 rad), so an
-      // algebraically equal exp2() form is NOT close enough at long sequences. pow() hides under the 16 B/pair of HBM
-      // traffic (~100 VALU issues per pair-batch fit the memory shadow).
-      const float freq = ref_quirk ? 1.0f : 1.0f / powf(10000.0f, (float)(2 * (i0 + p)) / (float)(2 * half_hidden));
-      rotate(v[2 * p], v[2 * p + 1], (float)t * freq, o[2 * p], o[2 * p + 1]);
-    }
+    for (int p = 0; p < PAIRS; ++p) rotate(v[2 * p], v[2 * p + 1], (float)t * freq[p], o[2 * p], o[2 * p + 1]);
     if constexpr (PAIRS == 2) {
-      *reinterpret_cast<f4*>(out + pair0 * 2) = *reinterpret_cast<const f4*>(o);
+      *reinterpret_cast<f4*>(out + off) = *reinterpret_cast<const f4*>(o);
     } else {
-      *reinterpret_cast<f2*>(out + pair0 * 2) = *reinterpret_cast<const f2*>(o);
+      *reinterpret_cast<f2*>(out + off) = *reinterpret_cast<const f2*>(o);
     }
   }
 }
@@ -61,11 +65,15 @@ template <int PAIRS>
 int launch_rope(const void* x, void* out, int seq_len, int hidden, int ref_quirk, hipStream_t st) {
   if (!x || !out || seq_len <= 0 || hidden <= 0) return CLN_ERR_BAD_ARG;
   if (hidden % (2 * PAIRS)) return CLN_ERR_UNSUPPORTED;
-  if (PAIRS == 2 && !(cln_aligned16(x) && cln_aligned16(out))) return CLN_ERR_BAD_ARG;
+  if (!cln_aligned(x, 8 * PAIRS) || !cln_aligned(out, 8 * PAIRS)) return CLN_ERR_BAD_ARG;
   const int half_hidden = hidden / 2;
-  const long long units = (long long)seq_len * half_hidden / PAIRS;
-  const int grid = cln_stream_grid(units, 256);
-  CLN_LAUNCH((rope_kernel<PAIRS>), dim3(grid), dim3(256), 0, st, (const float*)x, (float*)out, seq_len,
+  const int gx = (half_hidden / PAIRS + 255) / 256;
+  // ~4096 workgroups in flight at most; at least 16 rows per thread when the sequence allows (pow amortised)
+  int gy = 4096 / gx;
+  if (gy > (seq_len + 15) / 16) gy = (seq_len + 15) / 16;
+  if (gy < 1) gy = 1;
+  if (gy > 65535) gy = 65535;
+  CLN_LAUNCH((rope_kernel<PAIRS>), dim3(gx, gy), dim3(256), 0, st, (const float*)x, (float*)out, seq_len,
                      half_hidden, ref_quirk);
   return cln_check_launch();
 }

@@ -18,7 +18,8 @@ hg.init_cublas_handle()
 sizes = [int(x) for x in sys.argv[1:]] or [1024, 1536, 2048, 2560, 3072, 3584, 4096, 6144]
 #        tag, kind, layout, tile, bk, stages
 VARS = [("pp256 split", 8, 0, 1, 64, 4), ("pp256 unsplit", 11, 0, 1, 64, 1), ("pp192 unsplit", 11, 0, 1, 64, 2),
-        ("pp192 unsplit TN", 11, 1, 1, 64, 2),
+        ("pp192 unsplit TN", 11, 1, 1, 64, 2), ("pp256 dma-in-mma", 13, 0, 1, 64, 4), ("pp256 dma-in-mma TN", 13, 1, 1, 64, 4),
+        ("pp192 dma-in-mma", 13, 0, 1, 64, 2), ("pp192 dma-in-mma TN", 13, 1, 1, 64, 2), ("pp256 split TN", 8, 1, 1, 64, 4),
         ("ring 128x128 s3", 0, 0, 0, 64, 3), ("ring 64x128 s3", 0, 0, 6, 64, 3), ("ring 256x128 s2", 0, 0, 2, 64, 2),
         ("ring 128x256 s2", 0, 0, 3, 64, 2), ("ring 128x128 w8 s3", 0, 0, 5, 64, 3)]
 for S in sizes:

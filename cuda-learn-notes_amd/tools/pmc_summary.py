@@ -14,6 +14,17 @@ import os
 import sys
 
 
+def dynamic_lds(kernel_name):
+    """Dynamic LDS bytes the launcher asks for (csrc/*: Cfg::LDS_BYTES / GeoSplit::LDS_BYTES / Geo::LDS_BYTES)."""
+    table = (("hgemm_pp_kernel", 2 * (256 + 256) * 64 * 2), ("hgemm_pp32_kernel", 4 * (256 + 256) * 32 * 2),
+             ("fa2_fwd_dsplit_kernelILi64E", 2 * 2 * 128 * 128), ("fa2_fwd_dsplit_kernelILi128E", 8 * 32 * (256 + 16)),
+             ("fa2_fwd_dsplit_kernelILi256E", 8 * 32 * (512 + 16)), ("fa2_fwd_dsplit_kernelILi512E", 2 * 2 * 32 * 1024 + 8 * 4096))
+    for sub, b in table:
+        if sub in kernel_name:
+            return b
+    return None
+
+
 def main():
     sub, out = sys.argv[1], sys.argv[2]
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -26,8 +37,13 @@ def main():
                     continue
                 key = n[:120]
                 agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
-                meta[key] = {"vgpr": int(r["VGPR_Count"]), "agpr": int(r["Accum_VGPR_Count"]),
-                             "sgpr": int(r["SGPR_Count"]), "lds": int(r["LDS_Block_Size"]),
+                # rocprofv3 on gfx950 reports VGPR_Count in allocation units of 2 registers (108 for a 213-register
+                # kernel) and LDS_Block_Size WITHOUT the dynamic segment (0 for kernels whose LDS is all dynamic): the
+                # launch-side numbers are added from the table below (csrc Geo structs), the compiler's own from
+                # tools/kernel_resources.py
+                meta[key] = {"vgpr_rocprof_units_of_2": int(r["VGPR_Count"]), "vgpr_allocated": 2 * int(r["VGPR_Count"]),
+                             "agpr": int(r["Accum_VGPR_Count"]), "sgpr": int(r["SGPR_Count"]),
+                             "lds_static_bytes": int(r["LDS_Block_Size"]), "lds_dynamic_bytes": dynamic_lds(n),
                              "grid": int(r["Grid_Size"]), "wg": int(r["Workgroup_Size"])}
     res = {}
     for k, cs in agg.items():
