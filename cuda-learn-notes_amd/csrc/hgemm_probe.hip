@@ -3,6 +3,7 @@
 // forms (some ablations produce garbage by design; they exist to price one phase of the kernel).
 #include "hgemm_dispatch.h"
 #include "hgemm_mfma.cuh"
+#include "hgemm_w4.cuh"
 
 using namespace hgemm;
 
@@ -84,6 +85,28 @@ CLN_API int cln_hgemm_variant(int kind, int layout, int tile, int bk, int stages
                                          : launch_pp<NN, 2, 4, 0, 2, 192>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
     return layout == TN ? launch_pp<TN, 2, 4, 0, 2, 256>(a, b, c, M, N, K, swizzle, swizzle_stride, stream)
                         : launch_pp<NN, 2, 4, 0, 2, 256>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+  }
+  if (kind == 14) {  // one wave per SIMD, 128x128 wave tiles; stages = schedule variant (0..9), 100 + v = no-store probe
+#define W4_CASE(V)                                                                                         \
+  case V: return layout == TN ? launch_w4<TN, 2, V>(a, b, c, M, N, K, swizzle, swizzle_stride, stream)    \
+                              : launch_w4<NN, 2, V>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+    switch (stages) {
+      W4_CASE(0) W4_CASE(1) W4_CASE(2) W4_CASE(3) W4_CASE(4) W4_CASE(5) W4_CASE(6) W4_CASE(7) W4_CASE(8) W4_CASE(9)
+      case 104: return layout == TN ? launch_w4<TN, 1, 4>(a, b, c, M, N, K, swizzle, swizzle_stride, stream)
+                                    : launch_w4<NN, 1, 4>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+      W4_CASE(20) W4_CASE(36) W4_CASE(52)  // schedule 4 with MFMA orders 1..3
+      W4_CASE(26) W4_CASE(27) W4_CASE(28) W4_CASE(17) W4_CASE(25) W4_CASE(19) W4_CASE(22) W4_CASE(24) W4_CASE(41) W4_CASE(57) W4_CASE(13) W4_CASE(14)  // order 1 with schedules 10, 11, 12, 1, 9
+      case 120: return launch_w4<NN, 1, 20, 7>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);  // MFMA-only, orders 1..3
+      case 136: return launch_w4<NN, 1, 36, 7>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+      case 152: return launch_w4<NN, 1, 52, 7>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+      case 111: return launch_w4<NN, 1, 4, 1>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);  // no-store + ablations
+      case 112: return launch_w4<NN, 1, 4, 2>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+      case 113: return launch_w4<NN, 1, 4, 3>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+      case 114: return launch_w4<NN, 1, 4, 4>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+      case 117: return launch_w4<NN, 1, 4, 7>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+      default: return CLN_ERR_BAD_ARG;
+    }
+#undef W4_CASE
   }
   if (kind == 6) return launch_pp<NN, 1, 4>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);  // 4-slot no-store probe
   if (kind == 7) {  // ablations of the 4-slot no-store probe; `stages` = ABL bits (results are garbage by design)

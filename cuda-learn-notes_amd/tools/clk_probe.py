@@ -34,7 +34,11 @@ def smi():
         return "smi error %s" % e
 
 
-cands = [("rocblas TN", lambda: hg.hgemm_cublas_tensor_op_tn(a, bt, c)),
+w4 = lambda v, x=None, y=None, lay=0: (lambda: host.hgemm_variant(14, lay, 1, 64, v, x if x is not None else a, y if y is not None else (bt if lay else b), c, 1, 2048))
+cands = [("w4 v4 NN", w4(4)), ("w4 v4 snake", w4(20)), ("w4 v4 B-major", w4(36)), ("w4 v4 B-major snake", w4(52)),
+         ("w4 v4 TN", w4(4, lay=1)), ("w4 v4 TN snake", w4(20, lay=1)), ("w4 v4 TN B-major", w4(36, lay=1)), ("w4 v4 TN B-major snake", w4(52, lay=1)),
+         ("w4 mfma-only", w4(117)), ("w4 mfma-only snake", w4(120)), ("w4 mfma-only B-major", w4(136)), ("w4 mfma-only B-m snake", w4(152)),
+         ("rocblas TN", lambda: hg.hgemm_cublas_tensor_op_tn(a, bt, c)),
          ("rocblas NN", lambda: hg.hgemm_cublas_tensor_op_nn(a, b, c)),
          ("pp16 split NN", lambda: host.hgemm_variant(8, 0, 1, 64, 4, a, b, c, 1, 2048)),
          ("pp16 mfma-only", lambda: host.hgemm_variant(7, 0, 1, 64, 7, a, b, c, 1, 2048)),
@@ -59,4 +63,4 @@ for tag, fn in cands:
         n += 200
     dt = time.time() - t0
     th.join()
-    print("%-18s %7.1f TF sustained | %s" % (tag, 2.0 * S ** 3 * n / dt * 1e-12, res.get("smi")), flush=True)
+    print("%-24s %7.1f TF sustained | %s" % (tag, 2.0 * S ** 3 * n / dt * 1e-12, res.get("smi")), flush=True)
