@@ -122,13 +122,15 @@ def main():
 
     # ---- roofline of the dominant kernel: ONE timing source with `value` (the timed region above)
     achieved = flops / (ev_ms * 1e-3) * 1e-12
-    traffic, traffic_src = bu.pmc_value(profiles, "pmc_hgemm", "hbm_traffic_bytes_per_launch") if M == 4096 else (None, None)
-    busy, _ = bu.pmc_value(profiles, "pmc_hgemm", "mfma_busy_frac") if M == 4096 else (None, None)
+    kernel_desc = pkg.manifest.describe(bu.HEADLINE_HGEMM_NAME, (M, N, K), 2)
+    ksub = kernel_desc.split("<")[0] + "_kernel"  # device kernel family the PMC summary must have been taken on
+    traffic, traffic_src = bu.pmc_value(profiles, "pmc_hgemm", "hbm_traffic_bytes_per_launch", ksub) if M == 4096 else (None, None)
+    busy, _ = bu.pmc_value(profiles, "pmc_hgemm", "mfma_busy_frac", ksub) if M == 4096 else (None, None)
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": bu.PEAK_FP16_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(achieved / bu.PEAK_FP16_MFMA_TFLOPS, 4),
                 "traffic": round(traffic) if traffic else None, "traffic_source": traffic_src,
                 "mfma_busy": round(busy, 4) if busy else None,
-                "kernel": bu.HEADLINE_HGEMM_KERNEL, "avg_launch_ms": round(ev_ms, 5),
+                "kernel": kernel_desc, "avg_launch_ms": round(ev_ms, 5),
                 "timing": "HIP events on the launch stream around the %d timed steps (same region as value)" % args.steps,
                 "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": bu.hgemm_bytes(M, N, K)}
 

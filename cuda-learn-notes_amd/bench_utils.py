@@ -12,7 +12,7 @@ import torch
 
 PEAK_FP16_MFMA_TFLOPS = 2500.0  # dense fp16/bf16 MFMA, MI355X
 PEAK_HBM_GBPS = 8000.0          # HBM3E spec (6290 measured float4 copy)
-HEADLINE_HGEMM_KERNEL = "hgemm_pp_kernel<NN,256x256x64,4 slots,split DMA,LDS epilogue>"
+HEADLINE_HGEMM_NAME = "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem"  # what it runs: manifest.describe(name, dims, stages)
 
 
 def get_device_name():
@@ -196,9 +196,11 @@ def sdpa_rows(q, k, v, side_ms):
     return rows
 
 
-def pmc_value(profiles_dir: str, stem: str, key: str):
+def pmc_value(profiles_dir: str, stem: str, key: str, kernel_sub: str = ""):
     """`key` of the newest committed rocprofv3 PMC summary profiles/rNN_<stem>.json (written by tools/pmc_summary.py on
-    the GPU box: PMC counters cannot be collected from inside the timed process). -> (value | None, file name | None)"""
+    the GPU box: PMC counters cannot be collected from inside the timed process). `kernel_sub`: only entries whose
+    device-kernel name contains it count (a summary taken before the dispatcher changed kernels answers None, not a
+    stale number). -> (value | None, file name | None)"""
     import glob
     import json
     import os
@@ -207,7 +209,7 @@ def pmc_value(profiles_dir: str, stem: str, key: str):
         return None, None
     try:
         d = json.load(open(files[-1]))
-        vals = [e[key] for e in d.values() if isinstance(e, dict) and key in e]
+        vals = [e[key] for k, e in d.items() if isinstance(e, dict) and key in e and kernel_sub in k]
         return (vals[-1] if vals else None), os.path.basename(files[-1])
     except Exception:
         return None, None

@@ -10,6 +10,7 @@
 // cuda-learn-notes_amd/manifest.py (generated table in DESIGN.md).
 #include "hgemm_dispatch.h"
 #include "hgemm_mfma.cuh"
+#include "hgemm_w4.cuh"
 #include "hgemm_valu.cuh"
 #include <string.h>
 
@@ -66,14 +67,18 @@ int plan_tile(int plan) {
 }
 
 // Top rungs (reference warp4x4x2 family): for 256x256-tileable problems the `stages` knob selects a
-// distinct pipeline structure: 2 -> quadrant ping-pong over a 2 x 64-deep ring with split DMA,
+// distinct pipeline structure: 2 -> one-wave-per-SIMD kernel (hgemm_w4.cuh; K a multiple of 128 and >= 384, else the
+// quadrant ping-pong over a 2 x 64-deep ring with split DMA, which is also what an out-of-range `stages` gets),
 // 4 -> k-half ping-pong over a 4 x 32-deep ring, 3/5 -> plain multi-stage ring.
+constexpr int W4_PRODUCTION = 26;  // schedule 10 (one DMA piece per 8 MFMAs, running on into the next tile), boustrophedon MFMA order
+inline bool w4_ok(int K) { return K % 128 == 0 && K >= 384; }
 template <int LAYOUT>
 int best_dispatch(const void* a, const void* b, void* c, int M, int N, int K, int stages, int swizzle, int stride,
                   hipStream_t st) {
   const int plan = best_plan(M, N, K);
   if (plan == PLAN_PP192) return launch_pp<LAYOUT, 2, 4, 0, 0, 192>(a, b, c, M, N, K, swizzle, stride, st);
   if (plan == PLAN_PP256) {
+    if (stages == 2 && w4_ok(K)) return launch_w4<LAYOUT, 2, W4_PRODUCTION>(a, b, c, M, N, K, swizzle, stride, st);
     if (stages == 2 || stages < 2 || stages > 5) return launch_pp<LAYOUT, 2, 4, 0, 1>(a, b, c, M, N, K, swizzle, stride, st);
     if (stages == 4 && K % 32 == 0) return launch_pp32<LAYOUT, 2>(a, b, c, M, N, K, swizzle, stride, st);
   }
@@ -96,6 +101,8 @@ int describe_best(int layout, int M, int N, int K, int stages, char* buf, int le
   const char* l = layout == TN ? "TN" : "NN";
   if (plan == PLAN_PP192) return snprintf(buf, len, "hgemm_pp<192x256x64,8 waves,4 slots,LDS epilogue,%s>", l);
   if (plan == PLAN_PP256) {
+    if (stages == 2 && w4_ok(K))
+      return snprintf(buf, len, "hgemm_w4<256x256x64,4 waves,128x128 wave tiles,cross-tile LDS-DMA,LDS epilogue,%s>", l);
     if (stages == 2 || stages < 2 || stages > 5)
       return snprintf(buf, len, "hgemm_pp<256x256x64,8 waves,4 slots,split DMA,LDS epilogue,%s>", l);
     if (stages == 4 && K % 32 == 0) return snprintf(buf, len, "hgemm_pp32<256x256,BK=32 sub-tiles,4-deep ring,%s>", l);

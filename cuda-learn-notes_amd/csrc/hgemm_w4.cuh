@@ -7,12 +7,21 @@
 // in the AGPR half since no VALU instruction touches them inside the loop), both k-steps' fragments of A and B
 // (2 x 64 registers), and software-pipelines ONE instruction stream:
 //
-//   MFMA index n:   0 ........ 31 | 40 |  42 ........ 72  |  94  | 96 ........ 126 |
-//   k-step 0 (n<64)  read kk=1     B1    DMA(t+2), one      B2     read kk=0 of
-//   k-step 1 (n>=64) fragments           1-KiB piece per           tile t+1
-//                    of tile t           2 MFMAs
-//   B1 = lgkmcnt(0) + s_barrier: every wave has read all of tile t -> its ring buffer may be overwritten.
-//   B2 = vmcnt(16)  + s_barrier: every wave's pieces of tile t+1 have landed (those of t+2 stay in flight).
+//   production schedule (w4_sched(10)), MFMA index n within the 128 of K tile t:
+//     n = 1,3,..,31    read the k-step 1 fragments of tile t (the k-step 0 MFMAs n < 64 run meanwhile)
+//     n = 36       B1  lgkmcnt(0) + s_barrier: every wave has read all of tile t -> its ring buffer may be overwritten
+//     n = 38 + 8p      LDS-DMA piece p of tile t+2 into that buffer, one 1-KiB piece per 8 MFMAs; pieces 12..15 fall
+//                      past n = 127 and are issued by tile t+1's body at n = 6, 14, 22, 30 ("late" pieces)
+//     n = 102      B2  vmcnt(9) + s_barrier: every wave's pieces of tile t+1 have landed (9 of t+2 stay in flight)
+//     n = 103..118     read the k-step 0 fragments of tile t+1
+//   The MFMAs are inline asm with the accumulator tied to an AGPR tuple ("+a"): with the builtin hipcc gives C and D
+//   different registers and rotates the 64 tiles through ~370 v_accvgpr_mov/read/write per K tile. Inline asm is
+//   invisible to hipcc's hazard pass, so the zero-fill and the epilogue reads are fenced by hand (see below) and
+//   tests/test_no_spills.py checks the code object: no VALU/accvgpr write between the first and the last MFMA.
+//
+// Measured (profiles/r02_hgemm_w4_*.log): 4096^3 NN 1430-1470 TF vs 1340-1388 for the ping-pong kernel on the same box,
+// 8192^3 1517-1548 vs 1404-1428; the package sits at its ~1390 W cap either way (MFMAs alone 727 W/PF, LDS-DMA traffic
+// +143, fragment reads +71, C store +48), so what is left is energy per flop, not schedule.
 //
 // Versus the 128x64 wave tile: 32 fragment reads per 128 MFMAs instead of 48 (LDS bytes per flop -33 %), 2 barriers per
 // 128 MFMAs instead of 4 per 64, no slot in which a SIMD's matrix pipe waits for the partner wave's rendezvous.

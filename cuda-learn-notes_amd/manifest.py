@@ -68,12 +68,12 @@ _add("hgemm", "G6", "mfma_ring<128x128,BK by stages,NN>",
      "hgemm_mma_m16n8k16_mma2x4_warp4x4_stages", "hgemm_mma_m16n8k16_mma2x4_warp4x4_stages_dsmem")
 _add("hgemm", "G6", "mfma_ring<256x128,8 waves,NN>", "hgemm_wmma_m16n16k16_mma4x2_warp4x4_stages_dsmem")
 _add("hgemm", "G6", "mfma_ring<256x256,8 waves,NN>", "hgemm_wmma_m16n16k16_mma4x4_warp4x4_stages_dsmem")
-_add("hgemm", "G6", "best<NN>: tile shape by estimated CU utilisation x kernel efficiency (csrc/hgemm.hip best_plan): hgemm_pp<256x256x64> (stages 2) | hgemm_pp32<4x32 ring> (stages 4) | hgemm_pp<192x256x64> | mfma_ring<128x256> | <64x128> | <128x128> (see DISPATCH_EXAMPLES)",
+_add("hgemm", "G6", "best<NN>: tile shape by estimated CU utilisation x kernel efficiency (csrc/hgemm.hip best_plan): hgemm_w4<256x256x64, one wave per SIMD> (stages 2; hgemm_pp<256x256x64> when K is not a multiple of 128 or < 384) | hgemm_pp32<4x32 ring> (stages 4) | hgemm_pp<192x256x64> | mfma_ring<128x256> | <64x128> | <128x128> (see DISPATCH_EXAMPLES)",
      "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem", "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_x4",
      "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_rr",
      "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_swizzle")
 _add("hgemm", "G6", "mfma_ring<128x128,TN>", "hgemm_mma_m16n8k16_mma2x4_warp4x4_stages_dsmem_tn")
-_add("hgemm", "G6", "best<TN>: hgemm_pp / hgemm_pp32 / mfma_ring as for NN (see DISPATCH_EXAMPLES)", "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_tn_swizzle_x4")
+_add("hgemm", "G6", "best<TN>: hgemm_w4 / hgemm_pp / hgemm_pp32 / mfma_ring as for NN (see DISPATCH_EXAMPLES)", "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_tn_swizzle_x4")
 _add("hgemm", "G6", "mfma_ring<128x256,8 waves,TN>", "hgemm_mma_stages_block_swizzle_tn_cute")
 
 # ---------------------------------------------------------------- flash-attn (28 + 3)
@@ -270,18 +270,20 @@ _TQKV = "flash_attn_mma_stages_split_q_tiling_qkv"
 _IGN = " [stages ignored: one pipeline]"
 DISPATCH_EXAMPLES = [
     # HGEMM: BASELINE configs C2 (1024^3) and C3 (4096^3 / 8192^3) and the mid sizes
-    (_W4X2, (4096, 4096, 4096), 2, "hgemm_pp<256x256x64,8 waves,4 slots,split DMA,LDS epilogue,NN>"),
-    (_W4X2, (8192, 8192, 8192), 2, "hgemm_pp<256x256x64,8 waves,4 slots,split DMA,LDS epilogue,NN>"),
+    (_W4X2, (4096, 4096, 4096), 2, "hgemm_w4<256x256x64,4 waves,128x128 wave tiles,cross-tile LDS-DMA,LDS epilogue,NN>"),
+    (_W4X2, (4096, 4096, 4096), 0, "hgemm_pp<256x256x64,8 waves,4 slots,split DMA,LDS epilogue,NN>"),
+    (_W4X2, (4096, 4096, 320), 2, "hgemm_pp<256x256x64,8 waves,4 slots,split DMA,LDS epilogue,NN>"),
+    (_W4X2, (8192, 8192, 8192), 2, "hgemm_w4<256x256x64,4 waves,128x128 wave tiles,cross-tile LDS-DMA,LDS epilogue,NN>"),
     (_W4X2, (4096, 4096, 4096), 4, "hgemm_pp32<256x256,BK=32 sub-tiles,4-deep ring,NN>"),
     (_W4X2, (4096, 4096, 4096), 3, "mfma_ring<256x256x32,8 waves,stages=3,NN>"),
     (_W4X2, (3072, 3072, 3072), 2, "hgemm_pp<192x256x64,8 waves,4 slots,LDS epilogue,NN>"),
     (_W4X2, (6144, 6144, 6144), 2, "hgemm_pp<192x256x64,8 waves,4 slots,LDS epilogue,NN>"),
-    (_W4X2, (3584, 3584, 3584), 2, "hgemm_pp<256x256x64,8 waves,4 slots,split DMA,LDS epilogue,NN>"),
+    (_W4X2, (3584, 3584, 3584), 2, "hgemm_w4<256x256x64,4 waves,128x128 wave tiles,cross-tile LDS-DMA,LDS epilogue,NN>"),
     (_W4X2, (2560, 2560, 2560), 2, "mfma_ring<128x256x64,8 waves,stages=2,NN>"),
     (_W4X2, (1536, 1536, 1536), 2, "mfma_ring<64x128x64,4 waves,stages=2,NN>"),
     (_W4X2, (2048, 2048, 2048), 2, "mfma_ring<64x128x64,4 waves,stages=2,NN>"),
     (_W4X2, (1024, 1024, 1024), 2, "mfma_ring<64x128x64,4 waves,stages=2,NN>"),
-    (_W4X2 + "_tn_swizzle_x4", (4096, 4096, 4096), 2, "hgemm_pp<256x256x64,8 waves,4 slots,split DMA,LDS epilogue,TN>"),
+    (_W4X2 + "_tn_swizzle_x4", (4096, 4096, 4096), 2, "hgemm_w4<256x256x64,4 waves,128x128 wave tiles,cross-tile LDS-DMA,LDS epilogue,TN>"),
     ("hgemm_mma_m16n8k16_mma2x4_warp4x4_stages_dsmem", (4096, 4096, 4096), 3, "mfma_ring<128x128x64,4 waves,stages=3,NN>"),
     ("hgemm_mma_m16n8k16_mma2x4_warp4x4_stages_dsmem", (4096, 4096, 4096), 5, "mfma_ring<128x128x64,4 waves,stages=5,NN>"),
     ("hgemm_wmma_m16n16k16_mma4x4_warp4x4_stages_dsmem", (4096, 4096, 4096), 3, "mfma_ring<256x256x32,8 waves,stages=3,NN>"),

@@ -59,6 +59,61 @@ def report(src, keep=None):
     return parse(open(s).read()), s
 
 
+def _vregs(tok):
+    tok = tok.strip().rstrip(",")
+    m = re.match(r"([va])\[(\d+):(\d+)\]", tok)
+    if m:
+        return {(m.group(1), i) for i in range(int(m.group(2)), int(m.group(3)) + 1)}
+    m = re.match(r"([va])(\d+)$", tok)
+    return {(m.group(1), int(m.group(2)))} if m else set()
+
+
+def asm_mfma_stream_check(asm_text, mangled_name):
+    """Hand-checks for a kernel whose MFMAs are INLINE ASM (csrc/hgemm_w4.cuh): hipcc's hazard pass cannot see them, so
+    the wait states it would insert around them have to hold by construction. Returns a list of problems (empty = ok):
+      * no v_accvgpr_* and no VALU write of an MFMA operand between the first and the last MFMA (VALU write -> MFMA
+        read needs wait states; the accumulators must already sit in their AGPRs);
+      * an `s_nop 7` between the last accumulator zero-fill and the first MFMA, an `s_nop 15` between the last MFMA and
+        the first v_accvgpr_read of the epilogue;
+      * M0 (the LDS-DMA destination walks it across asm statements) is never saved / restored inside the stream, i.e.
+        the compiler found no use of its own for it there."""
+    m = re.search(r"^%s:" % re.escape(mangled_name), asm_text, re.M)
+    if not m:
+        return ["kernel not found: " + mangled_name]
+    body = asm_text[m.end():asm_text.index("s_endpgm", m.end())]
+    ins = [ln.split(";")[0].strip() for ln in body.split("\n")]
+    ins = [i for i in ins if i and not i.startswith(".") and not i.endswith(":")]
+    mf = [k for k, i in enumerate(ins) if i.startswith("v_mfma")]
+    if not mf:
+        return ["no MFMA in " + mangled_name]
+    first, last = mf[0], mf[-1]
+    problems = []
+    for k in range(first, last + 1):
+        i = ins[k]
+        if i.startswith("v_accvgpr"):
+            problems.append("accvgpr traffic inside the MFMA stream: " + i)
+        elif i.startswith("v_") and not i.startswith("v_mfma"):
+            dst = _vregs(i.split(None, 1)[1].split(",")[0])
+            for j in range(k + 1, min(k + 6, last + 1)):
+                if ins[j].startswith("v_mfma"):
+                    ops = set()
+                    for t in ins[j].split(None, 1)[1].split(", "):
+                        ops |= _vregs(t)
+                    if dst & ops:
+                        problems.append("VALU write %r feeds an MFMA %d instructions later" % (i, j - k))
+        if re.match(r"s_mov_b32 s\d+, m0", i):
+            problems.append("M0 saved inside the MFMA stream (somebody else uses it): " + i)
+    pre = ins[:first]
+    lastw = max([k for k, i in enumerate(pre) if i.startswith("v_accvgpr")] or [-1])
+    if not any(i.startswith("s_nop 7") for i in pre[lastw + 1:]):
+        problems.append("no s_nop 7 between the accumulator zero-fill and the first MFMA")
+    post = ins[last + 1:]
+    firstr = min([k for k, i in enumerate(post) if i.startswith("v_accvgpr_read")] or [len(post)])
+    if not any(i.startswith("s_nop 15") for i in post[:firstr]):
+        problems.append("no s_nop 15 between the last MFMA and the first v_accvgpr_read")
+    return problems
+
+
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     keep = None

@@ -16,7 +16,7 @@ import sys
 
 def dynamic_lds(kernel_name):
     """Dynamic LDS bytes the launcher asks for (csrc/*: Cfg::LDS_BYTES / GeoSplit::LDS_BYTES / Geo::LDS_BYTES)."""
-    table = (("hgemm_pp_kernel", 2 * (256 + 256) * 64 * 2), ("hgemm_pp32_kernel", 4 * (256 + 256) * 32 * 2),
+    table = (("hgemm_pp_kernel", 2 * (256 + 256) * 64 * 2), ("hgemm_w4_kernel", 2 * (256 + 256) * 64 * 2), ("hgemm_pp32_kernel", 4 * (256 + 256) * 32 * 2),
              ("fa2_fwd_dsplit_kernelILi64E", 2 * 2 * 128 * 128), ("fa2_fwd_dsplit_kernelILi128E", 8 * 32 * (256 + 16)),
              ("fa2_fwd_dsplit_kernelILi256E", 8 * 32 * (512 + 16)), ("fa2_fwd_dsplit_kernelILi512E", 2 * 2 * 32 * 1024 + 8 * 4096))
     for sub, b in table:

@@ -22,7 +22,7 @@ def test_every_run_time_dispatched_name_describes_itself(built):
             assert txt.startswith("fa2_fwd"), (e.name, txt)
         elif e.sig == "G6" and e.lib == "hgemm":
             txt = m.describe(e.name, (4096, 4096, 4096), 2)
-            assert txt.startswith(("hgemm_pp", "mfma_ring")), (e.name, txt)
+            assert txt.startswith(("hgemm_w4", "hgemm_pp", "mfma_ring")), (e.name, txt)
         elif e.sig == "G3" and e.lib == "hgemm":
             with pytest.raises(LookupError):
                 m.describe(e.name, (1024, 1024, 1024), 2)

@@ -241,3 +241,47 @@ def test_probe_kernels_stay_correct(built, dev, layout):
             c = torch.zeros(M, N, dtype=torch.half, device=dev)
             host.hgemm_variant(kind, layout, tile, bk, st, ad, bb, c, swizzle=1, swizzle_stride=512)
             assert torch.equal(c, base), (kind, tile, bk, st)
+
+
+@pytest.mark.parametrize("layout", [0, 1])
+def test_one_wave_per_simd_kernel(hg, built, dev, layout):
+    """hgemm_w4 (csrc/hgemm_w4.cuh, what the top rung runs at stages = 2 when K % 128 == 0 and K >= 384): smallest legal
+    K (two peeled tiles + one loop pair + two peeled tiles), odd pair counts, rectangular grids, every probe schedule incl.
+    the back-to-back-read ones that exposed the zero-fill hazard; bit-identical to the ping-pong kernel (same MFMA shape
+    and K order) and repeatable over launches."""
+    from cuda_learn_notes_amd import host
+    from cuda_learn_notes_amd.bench_utils import as_col_major
+    name = ("hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_tn_swizzle_x4" if layout
+            else "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem")
+    fn = getattr(hg, name)
+    via_name = 0
+    for (M, N, K) in ((256, 256, 384), (256, 512, 512), (768, 256, 640), (512, 768, 1152), (1024, 1024, 2048),
+                      (4096, 4096, 384), (4096, 3584, 896)):
+        runs_w4 = built.manifest.describe(name, (M, N, K), 2).startswith("hgemm_w4")  # the tile policy decides by M, N
+        via_name += runs_w4
+        a, b = seeded(170 + K, M, K), seeded(171 + K, K, N)
+        bb = (as_col_major(b) if layout else b).to(dev)
+        ad = a.to(dev)
+        base = torch.zeros(M, N, dtype=torch.half, device=dev)
+        host.hgemm_variant(8, layout, 1, 64, 4, ad, bb, base, swizzle=1, swizzle_stride=512)  # ping-pong kernel
+        check(base, a, b)
+        for rep in range(4 if runs_w4 else 0):
+            c = torch.zeros(M, N, dtype=torch.half, device=dev)
+            fn(ad, bb, c, 2, bool(rep & 1), 512)
+            assert torch.equal(c, base), (M, N, K, rep)
+        for var in (0, 1, 3, 4, 9, 13, 20, 25, 26, 27, 28):
+            c = torch.zeros(M, N, dtype=torch.half, device=dev)
+            host.hgemm_variant(14, layout, 1, 64, var, ad, bb, c, swizzle=1, swizzle_stride=512)
+            assert torch.equal(c, base), (M, N, K, var)
+    assert via_name >= 2
+    # K not a multiple of 128, or too short for the peeled structure: the ping-pong kernel answers, same result
+    for (M, N, K) in ((4096, 4096, 320), (4096, 4096, 256), (256, 256, 448)):
+        if M == 4096:
+            assert built.manifest.describe(name, (M, N, K), 2).startswith("hgemm_pp"), (M, N, K)
+        a, b = seeded(180 + K, M, K), seeded(181 + K, K, N)
+        bb = (as_col_major(b) if layout else b).to(dev)
+        c = torch.zeros(M, N, dtype=torch.half, device=dev)
+        fn(a.to(dev), bb, c, 2, True, 512)
+        check(c, a, b)
+        with pytest.raises(RuntimeError):
+            host.hgemm_variant(14, layout, 1, 64, 26, a.to(dev), bb, c, swizzle=1, swizzle_stride=512)

@@ -40,3 +40,17 @@ def test_production_attention_instantiations_are_in_the_report(tmp_path):
     for want in ("fa2_fwd_dsplit_kernel<512, 2, 1,", "fa2_fwd_dsplit_kernel<64, 1, 4,", "fa2_fwd_dsplit_kernel<256, 1, 1,",
                  "fa2_fwd_v2_kernel<128, 2, true", "fa2_fwd_splitkv_kernel<64>", "fa2_fwd_dwide_kernel<1024"):
         assert any(want in n for n in names), want
+
+
+def test_inline_asm_mfma_stream_of_the_one_wave_per_simd_hgemm(tmp_path):
+    """hgemm_w4_kernel issues its MFMAs from inline asm (AGPR-tied accumulators), which hides them from hipcc's hazard
+    pass: the wait states must hold by construction (a zero-fill sunk next to the first MFMA produced NaNs on the GPU
+    while this kernel was being written). Checked on the code object, both layouts, 512 registers, no spill."""
+    import kernel_resources as kr
+    kernels, s = kr.report(os.path.join(ROOT, "cuda-learn-notes_amd", "csrc", "hgemm.hip"), keep=str(tmp_path))
+    w4 = [k for k in kernels if "hgemm_w4_kernel" in k["demangled"]]
+    assert len(w4) == 2, [k["demangled"] for k in w4]
+    text = open(s).read()
+    for k in w4:
+        assert k["agpr"] == 256 and k["spill"] == 0 and k["scratch"] == 0, k
+        assert kr.asm_mfma_stream_check(text, k["name"]) == [], k["demangled"]
