@@ -210,7 +210,7 @@ def pmc_value(profiles_dir: str, stem: str, key: str, kernel_sub: str = ""):
     try:
         d = json.load(open(files[-1]))
         vals = [e[key] for k, e in d.items() if isinstance(e, dict) and key in e and kernel_sub in k]
-        return (vals[-1] if vals else None), os.path.basename(files[-1])
+        return (vals[-1], os.path.basename(files[-1])) if vals else (None, None)
     except Exception:
         return None, None
 

@@ -29,13 +29,15 @@ int check_args(const void* a, const void* b, const void* c, int M, int N, int K)
 // throughput for (M, N) on 256 CUs. score = eff x util x (1 + (1 - util) / 2):
 //   util = tiles / (rounds x slots)   -- slots = 256 workgroups in flight for the 8-wave kernels (one per CU), 512 for
 //                                        the 4-wave 64x128 / 128x128 rings (two per CU);
-//   eff  = measured rate at full occupancy relative to the 256x256 ping-pong kernel (4096^3, same box):
-//          ping-pong 256x256 1.00 | 192x256 0.97 | ring 128x256 0.84 | ring 64x128 0.58 | ring 128x128 0.56;
+//   eff  = measured rate at full occupancy relative to the one-wave-per-SIMD 256x256 kernel (same box):
+//          hgemm_w4 256x256 1.00 | 192x256 0.96 | 256x192 0.95 | 192x192 0.93 (all need K % 128 == 0, K >= 384) |
+//          ping-pong 256x256 0.94 | 192x256 0.91 | ring 128x256 0.79 | ring 64x128 0.545 | ring 128x128 0.53;
 //   the last factor: with CUs idle the busy ones clock higher (measured 1.2-1.3x at util 0.4-0.55).
-// It reproduces the measured winner at every size of profiles/r02_hgemm_midsize_probe.log (1024..6144): 64x128 below
-// 2048, 128x256 at 2560 (895 TF vs 613 for the round-1 policy and 840-884 for rocBLAS), 192x256 at 3072 / 6144
-// (968-980 vs 875, rocBLAS 970 / 1218 vs 1146, rocBLAS 1162), 256x256 at 3584 / 4096 / 8192.
-enum BestPlan { PLAN_PP256 = 0, PLAN_PP192, PLAN_R128x256, PLAN_R64x128, PLAN_R128 };
+// It reproduces the measured winner at every size of profiles/r02_hgemm_midsize_probe.log and
+// r02_hgemm_w4_shapes_probe.log (1024..8192): ring 64x128 up to 2048, w4 192x192 at 2304 / 3072 (890 / 1320 TF vs 769 /
+// 1066 for the previous policy, rocBLAS TN 894 / 1185), ring 128x256 at 2560, w4 192x256 at 4608 / 6144 (1356 / 1502 vs
+// 1146 / 1266, rocBLAS TN 1216 / 1388), w4 256x256 at 3584 / 4096 / 7680 / 8192.
+enum BestPlan { PLAN_PP256 = 0, PLAN_PP192, PLAN_R128x256, PLAN_R64x128, PLAN_R128, PLAN_W256, PLAN_W192x256, PLAN_W256x192, PLAN_W192 };
 int best_plan(int M, int N, int K) {
   auto score = [](long long tiles, int slots, double eff) {
     if (tiles <= 0) return 0.0;
@@ -48,12 +50,20 @@ int best_plan(int M, int N, int K) {
   auto offer = [&](int p, double sc) {
     if (sc > best) best = sc, plan = p;
   };
-  if (M % 128 == 0 && N % 128 == 0) offer(PLAN_R128, score((long long)(M / 128) * (N / 128), 512, 0.56));
-  if (M % 64 == 0 && N % 128 == 0) offer(PLAN_R64x128, score((long long)(M / 64) * (N / 128), 512, 0.58));
-  if (M % 128 == 0 && N % 256 == 0) offer(PLAN_R128x256, score((long long)(M / 128) * (N / 256), 256, 0.84));
+  // eff = measured rate at full occupancy relative to the one-wave-per-SIMD 256x256 kernel (round 2, same box:
+  // profiles/r02_hgemm_w4_shapes_probe.log, r02_hgemm_midsize_probe.log)
+  if (M % 128 == 0 && N % 128 == 0) offer(PLAN_R128, score((long long)(M / 128) * (N / 128), 512, 0.53));
+  if (M % 64 == 0 && N % 128 == 0) offer(PLAN_R64x128, score((long long)(M / 64) * (N / 128), 512, 0.545));
+  if (M % 128 == 0 && N % 256 == 0) offer(PLAN_R128x256, score((long long)(M / 128) * (N / 256), 256, 0.79));
   if (K % 64 == 0 && N % 256 == 0) {
-    if (M % 192 == 0) offer(PLAN_PP192, score((long long)(M / 192) * (N / 256), 256, 0.97));
-    if (M % 256 == 0) offer(PLAN_PP256, score((long long)(M / 256) * (N / 256), 256, 1.00));
+    if (M % 192 == 0) offer(PLAN_PP192, score((long long)(M / 192) * (N / 256), 256, 0.91));
+    if (M % 256 == 0) offer(PLAN_PP256, score((long long)(M / 256) * (N / 256), 256, 0.94));
+  }
+  if (w4_k_ok(K)) {
+    if (M % 192 == 0 && N % 192 == 0) offer(PLAN_W192, score((long long)(M / 192) * (N / 192), 256, 0.93));
+    if (M % 256 == 0 && N % 192 == 0) offer(PLAN_W256x192, score((long long)(M / 256) * (N / 192), 256, 0.95));
+    if (M % 192 == 0 && N % 256 == 0) offer(PLAN_W192x256, score((long long)(M / 192) * (N / 256), 256, 0.96));
+    if (M % 256 == 0 && N % 256 == 0) offer(PLAN_W256, score((long long)(M / 256) * (N / 256), 256, 1.00));
   }
   return plan;
 }
@@ -61,24 +71,29 @@ int plan_tile(int plan) {
   switch (plan) {
     case PLAN_R128x256: return T128x256;
     case PLAN_R64x128: return T64x128;
-    case PLAN_PP256: case PLAN_PP192: return T256;
+    case PLAN_PP256: case PLAN_PP192: case PLAN_W256: return T256;
     default: return T128;
   }
 }
 
-// Top rungs (reference warp4x4x2 family): for 256x256-tileable problems the `stages` knob selects a
-// distinct pipeline structure: 2 -> one-wave-per-SIMD kernel (hgemm_w4.cuh; K a multiple of 128 and >= 384, else the
-// quadrant ping-pong over a 2 x 64-deep ring with split DMA, which is also what an out-of-range `stages` gets),
-// 4 -> k-half ping-pong over a 4 x 32-deep ring, 3/5 -> plain multi-stage ring.
+// Top rungs (reference warp4x4x2 family): the tile shape comes from best_plan; where that is a 256x256 tile the
+// `stages` knob selects a distinct pipeline structure: 2 -> one-wave-per-SIMD kernel (hgemm_w4.cuh; K a multiple of
+// 128 and >= 384, else the quadrant ping-pong over a 2 x 64-deep ring with split DMA, which is also what an
+// out-of-range `stages` gets), 4 -> k-half ping-pong over a 4 x 32-deep ring, 3/5 -> plain multi-stage ring.
 constexpr int W4_PRODUCTION = 26;  // schedule 10 (one DMA piece per 8 MFMAs, running on into the next tile), boustrophedon MFMA order
-inline bool w4_ok(int K) { return K % 128 == 0 && K >= 384; }
 template <int LAYOUT>
 int best_dispatch(const void* a, const void* b, void* c, int M, int N, int K, int stages, int swizzle, int stride,
                   hipStream_t st) {
-  const int plan = best_plan(M, N, K);
+  int plan = best_plan(M, N, K);
+  if (plan == PLAN_W192) return launch_w4<LAYOUT, 2, W4_PRODUCTION, 0, 192, 192>(a, b, c, M, N, K, swizzle, stride, st);
+  if (plan == PLAN_W192x256) return launch_w4<LAYOUT, 2, W4_PRODUCTION, 0, 192, 256>(a, b, c, M, N, K, swizzle, stride, st);
+  if (plan == PLAN_W256x192) return launch_w4<LAYOUT, 2, W4_PRODUCTION, 0, 256, 192>(a, b, c, M, N, K, swizzle, stride, st);
+  if (plan == PLAN_W256) {
+    if (stages == 2) return launch_w4<LAYOUT, 2, W4_PRODUCTION>(a, b, c, M, N, K, swizzle, stride, st);
+    plan = PLAN_PP256;
+  }
   if (plan == PLAN_PP192) return launch_pp<LAYOUT, 2, 4, 0, 0, 192>(a, b, c, M, N, K, swizzle, stride, st);
   if (plan == PLAN_PP256) {
-    if (stages == 2 && w4_ok(K)) return launch_w4<LAYOUT, 2, W4_PRODUCTION>(a, b, c, M, N, K, swizzle, stride, st);
     if (stages == 2 || stages < 2 || stages > 5) return launch_pp<LAYOUT, 2, 4, 0, 1>(a, b, c, M, N, K, swizzle, stride, st);
     if (stages == 4 && K % 32 == 0) return launch_pp32<LAYOUT, 2>(a, b, c, M, N, K, swizzle, stride, st);
   }
@@ -97,12 +112,18 @@ int describe_ring(int tile, int layout, int M, int N, int K, int stages, char* b
   return snprintf(buf, len, "mfma_ring<%dx%dx%d,%d waves,stages=%d,%s>", BM, BN, BK, waves, stages, layout == TN ? "TN" : "NN");
 }
 int describe_best(int layout, int M, int N, int K, int stages, char* buf, int len) {
-  const int plan = best_plan(M, N, K);
+  int plan = best_plan(M, N, K);
   const char* l = layout == TN ? "TN" : "NN";
+  const char* w4 = "hgemm_w4<%sx64,4 waves,%s wave tiles,cross-tile LDS-DMA,LDS epilogue,%s>";
+  if (plan == PLAN_W192) return snprintf(buf, len, w4, "192x192", "96x96", l);
+  if (plan == PLAN_W192x256) return snprintf(buf, len, w4, "192x256", "96x128", l);
+  if (plan == PLAN_W256x192) return snprintf(buf, len, w4, "256x192", "128x96", l);
+  if (plan == PLAN_W256) {
+    if (stages == 2) return snprintf(buf, len, w4, "256x256", "128x128", l);
+    plan = PLAN_PP256;
+  }
   if (plan == PLAN_PP192) return snprintf(buf, len, "hgemm_pp<192x256x64,8 waves,4 slots,LDS epilogue,%s>", l);
   if (plan == PLAN_PP256) {
-    if (stages == 2 && w4_ok(K))
-      return snprintf(buf, len, "hgemm_w4<256x256x64,4 waves,128x128 wave tiles,cross-tile LDS-DMA,LDS epilogue,%s>", l);
     if (stages == 2 || stages < 2 || stages > 5)
       return snprintf(buf, len, "hgemm_pp<256x256x64,8 waves,4 slots,split DMA,LDS epilogue,%s>", l);
     if (stages == 4 && K % 32 == 0) return snprintf(buf, len, "hgemm_pp32<256x256,BK=32 sub-tiles,4-deep ring,%s>", l);

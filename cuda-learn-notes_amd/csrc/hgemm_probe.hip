@@ -86,19 +86,15 @@ CLN_API int cln_hgemm_variant(int kind, int layout, int tile, int bk, int stages
     return layout == TN ? launch_pp<TN, 2, 4, 0, 2, 256>(a, b, c, M, N, K, swizzle, swizzle_stride, stream)
                         : launch_pp<NN, 2, 4, 0, 2, 256>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
   }
-  if (kind == 14) {  // one wave per SIMD, 128x128 wave tiles; stages = schedule variant (0..9), 100 + v = no-store probe
+  if (kind == 14) {  // one wave per SIMD, 128x128 wave tiles; stages = schedule variant (+16: boustrophedon MFMA order), 100+ = no-store probes
 #define W4_CASE(V)                                                                                         \
   case V: return layout == TN ? launch_w4<TN, 2, V>(a, b, c, M, N, K, swizzle, swizzle_stride, stream)    \
                               : launch_w4<NN, 2, V>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
     switch (stages) {
-      W4_CASE(0) W4_CASE(1) W4_CASE(2) W4_CASE(3) W4_CASE(4) W4_CASE(5) W4_CASE(6) W4_CASE(7) W4_CASE(8) W4_CASE(9)
+      W4_CASE(0) W4_CASE(1) W4_CASE(3) W4_CASE(4) W4_CASE(9) W4_CASE(10) W4_CASE(13)
+      W4_CASE(20) W4_CASE(25) W4_CASE(26) W4_CASE(27) W4_CASE(28)
       case 104: return layout == TN ? launch_w4<TN, 1, 4>(a, b, c, M, N, K, swizzle, swizzle_stride, stream)
                                     : launch_w4<NN, 1, 4>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
-      W4_CASE(20) W4_CASE(36) W4_CASE(52)  // schedule 4 with MFMA orders 1..3
-      W4_CASE(26) W4_CASE(27) W4_CASE(28) W4_CASE(17) W4_CASE(25) W4_CASE(19) W4_CASE(22) W4_CASE(24) W4_CASE(41) W4_CASE(57) W4_CASE(13) W4_CASE(14)  // order 1 with schedules 10, 11, 12, 1, 9
-      case 120: return launch_w4<NN, 1, 20, 7>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);  // MFMA-only, orders 1..3
-      case 136: return launch_w4<NN, 1, 36, 7>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
-      case 152: return launch_w4<NN, 1, 52, 7>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
       case 111: return launch_w4<NN, 1, 4, 1>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);  // no-store + ablations
       case 112: return launch_w4<NN, 1, 4, 2>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
       case 113: return launch_w4<NN, 1, 4, 3>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
@@ -107,6 +103,16 @@ CLN_API int cln_hgemm_variant(int kind, int layout, int tile, int bk, int stages
       default: return CLN_ERR_BAD_ARG;
     }
 #undef W4_CASE
+  }
+  if (kind == 15) {  // one wave per SIMD on 192-row / 192-column tiles; tile = 0: 192x256, 1: 256x192, 2: 192x192
+#define W4_SHAPE(BM, BN)                                                                                              \
+  return layout == TN ? launch_w4<TN, 2, 26, 0, BM, BN>(a, b, c, M, N, K, swizzle, swizzle_stride, stream)           \
+                      : launch_w4<NN, 2, 26, 0, BM, BN>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+    if (tile == 0) { W4_SHAPE(192, 256) }
+    if (tile == 1) { W4_SHAPE(256, 192) }
+    if (tile == 2) { W4_SHAPE(192, 192) }
+#undef W4_SHAPE
+    return CLN_ERR_BAD_ARG;
   }
   if (kind == 6) return launch_pp<NN, 1, 4>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);  // 4-slot no-store probe
   if (kind == 7) {  // ablations of the 4-slot no-store probe; `stages` = ABL bits (results are garbage by design)

@@ -32,28 +32,37 @@
 
 namespace hgemm {
 
-// Epilogue through LDS for a 128-column wave tile: [64 rows][272 B] wave-private region, two passes of 64 rows; a lane
-// streams 16 bytes, one store instruction = 4 rows x 256 contiguous bytes.
+// Epilogue through LDS for a wave tile of FN x 16 columns (128 or 96): [64 rows][FN*32 + 16 B] wave-private region,
+// passes of up to 64 rows; a lane streams 16 bytes, one store instruction = 4 (5) rows x 256 (192) contiguous bytes.
 template <int FM, int FN>
 __device__ __forceinline__ void store_wide_tile_via_lds(half_t* Cmat, int N, int row0, int col0, int lane, char* wave_lds,
                                                         const f4 (&acc)[FM][FN]) {
-  static_assert(FN == 8 && FM % 4 == 0, "128-column wave tile, passes of 64 rows");
-  constexpr int RS = 272;
+  static_assert(FN == 8 || FN == 6, "128- or 96-column wave tile");
+  constexpr int RS = FN * 32 + 16;  // row stride in bytes
+  constexpr int LPR = FN * 2;       // 16-byte lanes per row
+  constexpr int RPI = 64 / LPR;     // whole rows per store instruction (4 or 5; lanes >= RPI*LPR idle)
 #pragma unroll
   for (int h0 = 0; h0 < FM; h0 += 4) {
+    constexpr int NF_FULL = 4;
+    const int nf = FM - h0 < NF_FULL ? FM - h0 : NF_FULL;  // 16-row fragments in this pass
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NF_FULL; ++i)
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
-        const f4 v = acc[h0 + i][j];
-        h4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-        *reinterpret_cast<h4*>(wave_lds + (i * 16 + (lane & 15)) * RS + (j * 16 + 4 * (lane >> 4)) * 2) = o;
+        if (i < nf) {
+          const f4 v = acc[(h0 + i) < FM ? (h0 + i) : 0][j];
+          h4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+          *reinterpret_cast<h4*>(wave_lds + (i * 16 + (lane & 15)) * RS + (j * 16 + 4 * (lane >> 4)) * 2) = o;
+        }
       }
+    const int rows = nf * 16;
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
-      const int r = it * 4 + (lane >> 4);
-      const u4 v = *reinterpret_cast<const u4*>(wave_lds + r * RS + (lane & 15) * 16);
-      *reinterpret_cast<u4*>(Cmat + (size_t)(row0 + h0 * 16 + r) * N + col0 + (lane & 15) * 8) = v;
+    for (int it = 0; it < (64 + RPI - 1) / RPI; ++it) {
+      const int r = it * RPI + lane / LPR;
+      if (it * RPI < rows && lane < RPI * LPR && r < rows) {
+        const u4 v = *reinterpret_cast<const u4*>(wave_lds + r * RS + (lane % LPR) * 16);
+        *reinterpret_cast<u4*>(Cmat + (size_t)(row0 + h0 * 16 + r) * N + col0 + (lane % LPR) * 8) = v;
+      }
     }
   }
 }
@@ -70,17 +79,17 @@ __device__ __forceinline__ void static_for(F&& f) {
   static_for_impl(std::make_integer_sequence<int, N>{}, f);
 }
 
-// Schedule positions (MFMA index within the 128 of one K tile); template so that variants can be probed.
+// Schedule positions (MFMA index within the NM = 2*FM*FN of one K tile); the numbered ones exist for the probe library.
 struct W4Sched {
   int r1_first, r1_step;  // k-step 1 fragment reads: op r at n = r1_first + r1_step * r
   int b1;                 // lgkmcnt(0) + barrier
-  int d_first, d_step;    // DMA piece p at n = d_first + d_step * p
+  int d_first, d_step;    // DMA piece p at n = d_first + d_step * p (positions >= NM: issued by the next tile's body)
   int b2;                 // vmcnt + barrier
   int r0_first, r0_step;  // next tile's k-step 0 fragment reads
 };
-constexpr W4Sched w4_sched(int var) {
+constexpr W4Sched w4_sched(int var) {  // 256x256 tile (NM = 128, 16 reads, 16 pieces)
   switch (var) {
-    case 1: return {1, 2, 36, 38, 4, 94, 96, 2};   // one DMA piece per 4 MFMAs (4 waves x 16 cycles of address path each)
+    case 1: return {1, 2, 36, 38, 4, 94, 96, 2};   // one DMA piece per 4 MFMAs
     case 2: return {1, 2, 40, 42, 3, 94, 96, 2};
     case 3: return {1, 1, 24, 26, 4, 94, 96, 2};   // k-step 1 reads back to back, earlier B1
     case 4: return {1, 2, 36, 38, 4, 102, 103, 1};
@@ -89,44 +98,96 @@ constexpr W4Sched w4_sched(int var) {
     case 7: return {1, 2, 36, 38, 4, 94, 95, 1};
     case 8: return {1, 1, 20, 22, 4, 94, 95, 1};
     case 9: return {1, 1, 20, 22, 5, 102, 103, 1};
-    case 10: return {1, 2, 36, 38, 8, 102, 103, 1};   // one piece per 8 MFMAs: the last five are issued by the next tile
+    case 10: return {1, 2, 36, 38, 8, 102, 103, 1};   // production: one piece per 8 MFMAs, the last four issued by the next tile
     case 11: return {1, 2, 36, 38, 7, 102, 103, 1};
     case 12: return {1, 2, 36, 40, 6, 102, 103, 1};
-    case 13: return {1, 1, 36, 38, 4, 102, 103, 1};   // debugging: back-to-back k-step 1 reads, late B1
-    case 14: return {1, 1, 20, 38, 4, 102, 103, 1};   // debugging: early B1, late DMA
-    case 15: return {1, 2, 36, 38, 4, 102, 103, 1};   // = 4
+    case 13: return {1, 1, 36, 38, 4, 102, 103, 1};
+    case 14: return {1, 1, 20, 38, 4, 102, 103, 1};
     default: return {1, 2, 40, 42, 2, 94, 96, 2};
   }
 }
+// Same shape of schedule for any wave tile: reads every other MFMA, B1 five MFMAs after the last read, the DMA from
+// there on with `d_step` MFMAs per piece, B2 ten MFMAs before the next tile's reads would run out of tile.
+constexpr W4Sched w4_sched_for(int FM, int FN, int d_step) {
+  const int NR = FM + FN, NM = 2 * FM * FN, b1 = 1 + 2 * (NR - 1) + 5, b2 = NM - NR - 10;
+  return {1, 2, b1, b1 + 2, d_step, b2, b2 + 1, 1};
+}
 
-template <int LAYOUT, int EPI = 2, int VAR = 0, int ABL = 0>
+// NN B image for BN = 192: 384-byte rows put consecutive k rows 32 banks apart, so the four even (odd) rows a 32-lane
+// group of ds_read_b64_tr_b16 touches share a bank half; they are spread over its four 8-bank quarters by XOR-ing the
+// 16-byte chunk index with 2 * (bit 1 of k | bit 3 of k << 1) -- bits 1..2 only, so a chunk never leaves its 128-byte
+// group (24 chunks per row are not a power of two).
+template <int BN>
+__device__ __forceinline__ int nswz_bn(int krow) {
+  if constexpr (BN == 192) return ((((krow >> 1) & 1) | (((krow >> 3) & 1) << 1)) << 1);
+  else return nswz(krow);
+}
+template <typename C, int NLOADS>
+struct NFillW {
+  unsigned voff[NLOADS];
+  __device__ __forceinline__ void init(int N, int wave, int lane) {
+    constexpr int LPR = C::BN / 8;  // 16-byte chunks per k row (32 or 24)
+#pragma unroll
+    for (int i = 0; i < NLOADS; ++i) {
+      const int L = (i * C::NW + wave) * 64 + lane;  // chunk index within the image, lane-linear
+      const int krow = L / LPR, c = L % LPR;
+      voff[i] = ((unsigned)krow * (unsigned)N + ((c ^ nswz_bn<C::BN>(krow)) << 3)) * 2u;
+    }
+  }
+};
+template <int BN>
+__device__ __forceinline__ h8 read_nfrag_w(const char* img, int n0w, int lane, int kk) {
+  const int i = lane & 15, g = lane >> 4;
+  const int q = (n0w >> 3) + ((i & 3) >> 1);
+  const int k_lo = kk * 32 + 8 * g + (i >> 2);
+  const int k_hi = k_lo + 4;
+  const char* p_lo = img + k_lo * (BN * 2) + ((q ^ nswz_bn<BN>(k_lo)) << 4) + ((i & 1) << 3);
+  const char* p_hi = img + k_hi * (BN * 2) + ((q ^ nswz_bn<BN>(k_hi)) << 4) + ((i & 1) << 3);
+  return h8_cat(lds_read_tr16(p_lo), lds_read_tr16(p_hi));
+}
+
+// Tile configuration without Cfg's BN in {128, 256} restriction.
+template <int BM_, int BN_, int LAYOUT_>
+struct W4Cfg {
+  static constexpr int BM = BM_, BN = BN_, BK = 64, NW = 4, LAYOUT = LAYOUT_;
+  static constexpr int WTM = BM / 2, WTN = BN / 2, FM = WTM / 16, FN = WTN / 16;
+  static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES, LDS_BYTES = 2 * STAGE_BYTES;
+  static constexpr int A_LOADS = FM, B_LOADS = FN, NP = FM + FN;  // 1-KiB DMA pieces per wave per K tile
+  static constexpr int NR = FM + FN, NM = 2 * FM * FN;            // fragment reads per k-step, MFMAs per K tile
+  static_assert((BM == 256 || BM == 192) && (BN == 256 || BN == 192), "wave tiles of 128 or 96 rows / columns");
+};
+
+// VAR: bits 0..3 = schedule number (256x256 only; other shapes take w4_sched_for), bit 4 = boustrophedon MFMA order
+// (B fragments walked back and forth, so only ONE operand changes between consecutive MFMAs: ~1 % less power).
+template <int LAYOUT, int EPI = 2, int VAR = 0, int ABL = 0, int BM = 256, int BN = 256>
 __global__ __launch_bounds__(256, 1) void hgemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ B,
                                                           half_t* __restrict__ Cmat, int M, int N, int K, int tiles_m,
                                                           int tiles_n, int swizzle, int band) {
-  using C = Cfg<256, 256, 64, 2, 2, 2, LAYOUT>;
-  static_assert(C::A_LOADS == 8 && C::B_LOADS == 8, "16 DMA pieces per wave per K tile");
-  constexpr W4Sched S = w4_sched(VAR & 15);
-  constexpr int ORDER = VAR >> 4;  // MFMA order inside a k-step: 0 A-fragment-major, 1 same with B walked boustrophedon, 2 B-major, 3 B-major boustrophedon
-  // pieces of tile t+2 already issued when B2 is reached: they stay in flight across it
-  // The DMA of tile t+2 starts after B1 of tile t (position d_first) and may run on into tile t+1 (positions >= 128 =
-  // "late" pieces, issued by tile t+1's body before its own B1 ... they only have to land before B2 of tile t+1).
-  static_assert(S.r0_first + 15 * S.r0_step < 128 && S.r1_first + 15 * S.r1_step < S.b1 && S.b1 < S.d_first &&
-                    S.b2 < S.r0_first && S.r0_first >= 64 && 15 * S.d_step < 128 && S.d_first + 15 * S.d_step - 128 < S.b2,
+  using C = W4Cfg<BM, BN, LAYOUT>;
+  constexpr int FM = C::FM, FN = C::FN, NR = C::NR, NP = C::NP, NM = C::NM;
+  constexpr W4Sched S = (BM == 256 && BN == 256) ? w4_sched(VAR & 15) : w4_sched_for(FM, FN, (BM == 192 && BN == 192) ? 4 : 5);
+  constexpr bool SNAKE = (VAR >> 4) & 1;
+  // The DMA of tile t+2 starts after B1 of tile t (position d_first) and may run on into tile t+1 (positions >= NM =
+  // "late" pieces, issued by tile t+1's body before its own B1; they only have to land before B2 of tile t+1).
+  static_assert(S.r0_first + (NR - 1) * S.r0_step < NM && S.r1_first + (NR - 1) * S.r1_step < S.b1 && S.b1 < S.d_first &&
+                    S.b2 < S.r0_first && S.r0_first >= NM / 2 && (NP - 1) * S.d_step < NM && S.d_first + (NP - 1) * S.d_step - NM < S.d_first &&
+                    S.d_first < NM && S.b2 >= S.d_first,
                 "schedule: reads drained before B1, DMA after B1 and landed before the next B2, late pieces before early ones");
-  constexpr int D_BEFORE_B2 = S.b2 < S.d_first ? 0 : ((S.b2 - S.d_first) / S.d_step + 1 > 16 ? 16 : (S.b2 - S.d_first) / S.d_step + 1);
-  constexpr int D_EARLY = (127 - S.d_first) / S.d_step + 1 > 16 ? 16 : (127 - S.d_first) / S.d_step + 1;  // pieces issued inside tile t
+  constexpr int D_EARLY = (NM - 1 - S.d_first) / S.d_step + 1 > NP ? NP : (NM - 1 - S.d_first) / S.d_step + 1;  // pieces issued inside tile t
+  // pieces of tile t+2 already issued when B2 is reached: they stay in flight across it
+  constexpr int D_BEFORE_B2 = (S.b2 - S.d_first) / S.d_step + 1 > D_EARLY ? D_EARLY : (S.b2 - S.d_first) / S.d_step + 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   int tm, tn;
   tile_coords(blockIdx.x, gridDim.x, tiles_m, tiles_n, swizzle, band, tm, tn);
-  const int m0 = tm * 256, n0 = tn * 256;
+  const int m0 = tm * BM, n0 = tn * BN;
 
-  KFill<C, 8> fa;
+  KFill<C, FM> fa;
   fa.init(K, wave, lane);
-  KFill<C, 8> fbt;
-  NFill<C, 8> fbn;
+  KFill<C, FN> fbt;
+  NFillW<C, FN> fbn;
   if constexpr (LAYOUT == TN) fbt.init(K, wave, lane);
   else fbn.init(N, wave, lane);
   const char* a_src = reinterpret_cast<const char*>(A + (size_t)m0 * K);
@@ -135,28 +196,22 @@ __global__ __launch_bounds__(256, 1) void hgemm_w4_kernel(const half_t* __restri
   const size_t a_step = 128;
   const size_t b_step = (LAYOUT == TN) ? (size_t)128 : (size_t)64 * N * 2;
   const unsigned lds0 = lds_addr_of(smem);
-  // piece p of the tile whose sources a_src / b_src currently point at
-  auto piece = [&](int p, unsigned img) {
-    if (p < 8) {
-      glds16_asm(a_src, fa.voff[p & 7], img + (unsigned)(p * 4 + wave) * 1024u);
-    } else {
-      const int q = p - 8;
-      if constexpr (LAYOUT == TN) glds16_asm(b_src, fbt.voff[q & 7], img + C::A_BYTES + (unsigned)(q * 4 + wave) * 1024u);
-      else glds16_asm(b_src, fbn.voff[q & 7], img + C::A_BYTES + (unsigned)(q * 4 + wave) * 1024u);
-    }
+  auto voff_of = [&](int p) -> unsigned {
+    return p < FM ? fa.voff[p < FM ? p : 0] : (LAYOUT == TN ? fbt.voff[(p - FM) < FN ? (p - FM) : 0] : fbn.voff[(p - FM) < FN ? (p - FM) : 0]);
   };
-  // In-loop form: M0 walks the 16 destinations of this wave (4 KiB apart, A image then B image) -- two instructions per
-  // piece instead of six. M0 is ours for the whole K loop: nothing else in it uses M0 (tests/test_no_spills.py checks
-  // the code object for foreign M0 writes).
+  // piece p (A pieces 0..FM-1, then B pieces) of the tile whose sources a_src / b_src currently point at; this wave's
+  // 16 destinations are 4 KiB apart (A image, then B image, both lane-linear in units of 4 waves x 1 KiB)
+  auto piece = [&](int p, unsigned img) { glds16_asm(p < FM ? a_src : b_src, voff_of(p), img + (unsigned)(p * 4 + wave) * 1024u); };
+  // In-loop form: M0 walks the destinations -- two instructions per piece instead of six. M0 is ours for the whole K
+  // loop: nothing else in it uses M0 (tests/test_no_spills.py checks the code object).
   const char* a_old = a_src;  // sources of the tile whose late pieces are still to be issued (one tile behind a_src)
   const char* b_old = b_src;
   auto piece_m0 = [&](int p, unsigned img, bool late, bool set_m0) {
-    const unsigned voff = p < 8 ? fa.voff[p & 7] : (LAYOUT == TN ? fbt.voff[(p - 8) & 7] : fbn.voff[(p - 8) & 7]);
-    const char* src = late ? (p < 8 ? a_old : b_old) : (p < 8 ? a_src : b_src);
-    img += (unsigned)p * 4096u;
+    const unsigned voff = voff_of(p);
+    const char* src = late ? (p < FM ? a_old : b_old) : (p < FM ? a_src : b_src);
     if (set_m0)
       asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\ts_add_u32 m0, m0, 0x1000"
-                   :: "v"(voff), "s"(src), "s"(img + (unsigned)wave * 1024u) : "memory", "scc");  // img already advanced to piece p
+                   :: "v"(voff), "s"(src), "s"(img + (unsigned)(p * 4 + wave) * 1024u) : "memory", "scc");
     else
       asm volatile("global_load_lds_dwordx4 %0, %1\n\ts_add_u32 m0, m0, 0x1000" :: "v"(voff), "s"(src) : "memory", "scc");
   };
@@ -167,33 +222,32 @@ __global__ __launch_bounds__(256, 1) void hgemm_w4_kernel(const half_t* __restri
     b_src += b_step;
   };
 
-  f4 acc[8][8];
+  f4 acc[FM][FN];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < FM; ++i)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < FN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
   // The MFMAs below are inline asm, invisible to hipcc's hazard pass: left alone it sinks each tile's zero-fill
   // (v_accvgpr_mov) to just before the tile's first MFMA, closer than the VALU-write -> MFMA-SrcC wait states allow (seen:
-  // NaNs from stale registers). Pin all 64 tiles into their AGPRs HERE, then pad.
+  // NaNs from stale registers). Pin all tiles into their AGPRs HERE, then pad.
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < FM; ++i)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) asm volatile("" : "+a"(acc[i][j]));
+    for (int j = 0; j < FN; ++j) asm volatile("" : "+a"(acc[i][j]));
   asm volatile("s_nop 7");
-  h8 af[2][8], bf[2][8];
+  h8 af[2][FM], bf[2][FN];
 
-  // fragment read op r of k-step kk: r = 0 -> A fragment 0, 1..8 -> B fragments 0..7, 9..15 -> A fragments 1..7
-  // (the MFMA order is A-fragment-major: the first eight MFMAs of a k-step need A0 and every B fragment).
+  // fragment read op r of k-step kk: r = 0 -> A fragment 0, 1..FN -> B fragments, FN+1.. -> A fragments 1..FM-1
+  // (the MFMA order is A-fragment-major: the first FN MFMAs of a k-step need A0 and every B fragment).
   auto read_op = [&](const char* img, int kk, int r) {
     const char* bimg = img + C::A_BYTES;
-    const bool is_a = (ORDER < 2) ? (r == 0 || r >= 9) : (r >= 1 && r <= 8);
-    if (is_a) {
-      const int i = (ORDER < 2) ? (r == 0 ? 0 : r - 8) : r - 1;
-      af[kk][i] = read_kfrag<64>(img, wm * 128 + i * 16 + (lane & 15), lane, kk);
+    if (r == 0 || r > FN) {
+      const int i = r == 0 ? 0 : r - FN;
+      af[kk][i] = read_kfrag<64>(img, wm * C::WTM + i * 16 + (lane & 15), lane, kk);
     } else {
-      const int j = (ORDER < 2) ? r - 1 : (r == 0 ? 0 : r - 8);
-      if constexpr (LAYOUT == TN) bf[kk][j] = read_kfrag<64>(bimg, wn * 128 + j * 16 + (lane & 15), lane, kk);
-      else bf[kk][j] = read_nfrag<256>(bimg, wn * 128 + j * 16, lane, kk);
+      const int j = r - 1;
+      if constexpr (LAYOUT == TN) bf[kk][j] = read_kfrag<64>(bimg, wn * C::WTN + j * 16 + (lane & 15), lane, kk);
+      else bf[kk][j] = read_nfrag_w<BN>(bimg, wn * C::WTN + j * 16, lane, kk);
     }
   };
 #define W4_PIN() __builtin_amdgcn_sched_barrier(0)
@@ -207,18 +261,18 @@ __global__ __launch_bounds__(256, 1) void hgemm_w4_kernel(const half_t* __restri
   // are still to be issued (into the other buffer); NEXT: tile t+1 exists (wait for it, read its k-step 0).
   auto tile = [&](auto dma_c, auto late_c, auto next_c, const char* img, const char* nimg, unsigned img_lds, unsigned nimg_lds) {
     constexpr bool DMA = decltype(dma_c)::value, LATE = decltype(late_c)::value, NEXT = decltype(next_c)::value;
-    static_for<128>([&](auto nc) {
+    static_for<NM>([&](auto nc) {
       constexpr int n = decltype(nc)::value;
-      constexpr int kk = n >> 6, hi = (n & 63) >> 3, lo0 = n & 7, lo = ((ORDER & 1) && (hi & 1)) ? 7 - lo0 : lo0;
-      constexpr int i = ORDER < 2 ? hi : lo, j = ORDER < 2 ? lo : hi;
-      // AGPR-tied accumulator: left to the builtin, hipcc gives C and D different registers and rotates the 64 tiles
+      constexpr int kk = n / (FM * FN), idx = n % (FM * FN), i = idx / FN, lo0 = idx % FN;
+      constexpr int j = (SNAKE && (i & 1)) ? FN - 1 - lo0 : lo0;
+      // AGPR-tied accumulator: left to the builtin, hipcc gives C and D different registers and rotates the tiles
       // through ~370 v_accvgpr_mov / read / write per K tile
       asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(bf[kk][j]), "v"(af[kk][i]));
-      constexpr bool R1 = n >= S.r1_first && (n - S.r1_first) % S.r1_step == 0 && (n - S.r1_first) / S.r1_step < 16;
-      constexpr bool DP = DMA && n >= S.d_first && (n - S.d_first) % S.d_step == 0 && (n - S.d_first) / S.d_step < 16;
-      constexpr int gl = n + 128;  // position of a late piece on the previous tile's clock
-      constexpr bool LP = LATE && (gl - S.d_first) % S.d_step == 0 && (gl - S.d_first) / S.d_step < 16 && (gl - S.d_first) / S.d_step >= D_EARLY;
-      constexpr bool R0 = NEXT && n >= S.r0_first && (n - S.r0_first) % S.r0_step == 0 && (n - S.r0_first) / S.r0_step < 16;
+      constexpr bool R1 = n >= S.r1_first && (n - S.r1_first) % S.r1_step == 0 && (n - S.r1_first) / S.r1_step < NR;
+      constexpr bool DP = DMA && n >= S.d_first && (n - S.d_first) % S.d_step == 0 && (n - S.d_first) / S.d_step < NP;
+      constexpr int gl = n + NM;  // position of a late piece on the previous tile's clock
+      constexpr bool LP = LATE && (gl - S.d_first) % S.d_step == 0 && (gl - S.d_first) / S.d_step < NP && (gl - S.d_first) / S.d_step >= D_EARLY;
+      constexpr bool R0 = NEXT && n >= S.r0_first && (n - S.r0_first) % S.r0_step == 0 && (n - S.r0_first) / S.r0_step < NR;
       // ABL (probe library only; results are garbage by design): 1 = no fragment reads, 2 = no DMA, 4 = no barriers
       if constexpr (R1 && !(ABL & 1)) read_op(img, 1, (n - S.r1_first) / S.r1_step);
       if constexpr (n == S.b1) {
@@ -241,15 +295,15 @@ __global__ __launch_bounds__(256, 1) void hgemm_w4_kernel(const half_t* __restri
   const int nt = K / 64;
   // prologue: tiles 0 and 1 in flight, tile 0 landed, its k-step 0 fragments in registers
 #pragma unroll
-  for (int p = 0; p < 16; ++p) piece(p, lds0);
+  for (int p = 0; p < NP; ++p) piece(p, lds0);
   advance();
 #pragma unroll
-  for (int p = 0; p < 16; ++p) piece(p, lds0 + C::STAGE_BYTES);
+  for (int p = 0; p < NP; ++p) piece(p, lds0 + C::STAGE_BYTES);
   advance();
-  wait_vmcnt<16>();
+  wait_vmcnt<NP>();
   W4_BARRIER();
 #pragma unroll
-  for (int r = 0; r < 16; ++r) read_op(smem, 0, r);
+  for (int r = 0; r < NR; ++r) read_op(smem, 0, r);
   W4_PIN();
 
   // nt even and >= 6 (launcher): two peeled tiles, a do-while over tile PAIRS (ring buffer = compile-time constant,
@@ -275,35 +329,35 @@ __global__ __launch_bounds__(256, 1) void hgemm_w4_kernel(const half_t* __restri
   // (asm volatile statements keep their order), so no read of an accumulator can be scheduled above it.
   asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < FM; ++i)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) asm volatile("" : "+a"(acc[i][j]));
+    for (int j = 0; j < FN; ++j) asm volatile("" : "+a"(acc[i][j]));
   if constexpr (EPI == 2) {
     // B1 of the last tile: every wave is past its last fragment read; no DMA is in flight
-    store_wide_tile_via_lds<8, 8>(Cmat, N, m0 + wm * 128, n0 + wn * 128, lane, smem + wave * (64 * 272), acc);
-  } else if constexpr (EPI == 0) {
-    store_tile<C>(Cmat, N, m0, n0, wm, wn, lane, acc);
-  } else {
+    store_wide_tile_via_lds<FM, FN>(Cmat, N, m0 + wm * C::WTM, n0 + wn * C::WTN, lane, smem + wave * (64 * (FN * 32 + 16)), acc);
+  } else {  // measurement-only variant: keep the accumulators live, store (almost) nothing
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < FM; ++i)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+      for (int j = 0; j < FN; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
     if (s == 123.456f) Cmat[(size_t)m0 * N + n0] = (half_t)s;
   }
 }
 
-template <int LAYOUT, int EPI = 2, int VAR = 0, int ABL = 0>
+inline bool w4_k_ok(int K) { return K % 128 == 0 && K >= 384; }
+
+template <int LAYOUT, int EPI = 2, int VAR = 0, int ABL = 0, int BM = 256, int BN = 256>
 int launch_w4(const void* a, const void* b, void* c, int M, int N, int K, int swizzle, int swizzle_stride,
               hipStream_t stream) {
-  using C = Cfg<256, 256, 64, 2, 2, 2, LAYOUT>;
-  if (M % 256 || N % 256 || K % 128 || K < 384) return CLN_ERR_UNSUPPORTED;
+  using C = W4Cfg<BM, BN, LAYOUT>;
+  if (M % BM || N % BN || !w4_k_ok(K)) return CLN_ERR_UNSUPPORTED;
   static cln_lds_attr lds_attr;  // per device, thread-safe (common.h)
-  if (cln_ensure_lds(lds_attr, reinterpret_cast<const void*>(&hgemm_w4_kernel<LAYOUT, EPI, VAR, ABL>), C::LDS_BYTES) != CLN_OK)
+  if (cln_ensure_lds(lds_attr, reinterpret_cast<const void*>(&hgemm_w4_kernel<LAYOUT, EPI, VAR, ABL, BM, BN>), C::LDS_BYTES) != CLN_OK)
     return CLN_ERR_LAUNCH;
-  const int tiles_m = M / 256, tiles_n = N / 256;
-  int band = (swizzle && swizzle_stride >= 256) ? swizzle_stride / 256 : tiles_n;
-  CLN_LAUNCH((hgemm_w4_kernel<LAYOUT, EPI, VAR, ABL>), dim3(tiles_m * tiles_n), dim3(256), C::LDS_BYTES, stream,
+  const int tiles_m = M / BM, tiles_n = N / BN;
+  int band = (swizzle && swizzle_stride >= BN) ? swizzle_stride / BN : tiles_n;
+  CLN_LAUNCH((hgemm_w4_kernel<LAYOUT, EPI, VAR, ABL, BM, BN>), dim3(tiles_m * tiles_n), dim3(256), C::LDS_BYTES, stream,
              (const half_t*)a, (const half_t*)b, (half_t*)c, M, N, K, tiles_m, tiles_n, swizzle ? 1 : 0, band);
   return cln_check_launch();
 }

@@ -276,8 +276,11 @@ DISPATCH_EXAMPLES = [
     (_W4X2, (8192, 8192, 8192), 2, "hgemm_w4<256x256x64,4 waves,128x128 wave tiles,cross-tile LDS-DMA,LDS epilogue,NN>"),
     (_W4X2, (4096, 4096, 4096), 4, "hgemm_pp32<256x256,BK=32 sub-tiles,4-deep ring,NN>"),
     (_W4X2, (4096, 4096, 4096), 3, "mfma_ring<256x256x32,8 waves,stages=3,NN>"),
-    (_W4X2, (3072, 3072, 3072), 2, "hgemm_pp<192x256x64,8 waves,4 slots,LDS epilogue,NN>"),
-    (_W4X2, (6144, 6144, 6144), 2, "hgemm_pp<192x256x64,8 waves,4 slots,LDS epilogue,NN>"),
+    (_W4X2, (3072, 3072, 3072), 2, "hgemm_w4<192x192x64,4 waves,96x96 wave tiles,cross-tile LDS-DMA,LDS epilogue,NN>"),
+    (_W4X2, (2304, 2304, 2304), 2, "hgemm_w4<192x192x64,4 waves,96x96 wave tiles,cross-tile LDS-DMA,LDS epilogue,NN>"),
+    (_W4X2, (3072, 3072, 3136), 2, "hgemm_pp<192x256x64,8 waves,4 slots,LDS epilogue,NN>"),
+    (_W4X2, (6144, 6144, 6144), 2, "hgemm_w4<192x256x64,4 waves,96x128 wave tiles,cross-tile LDS-DMA,LDS epilogue,NN>"),
+    (_W4X2, (4096, 6144, 4096), 2, "hgemm_w4<256x192x64,4 waves,128x96 wave tiles,cross-tile LDS-DMA,LDS epilogue,NN>"),
     (_W4X2, (3584, 3584, 3584), 2, "hgemm_w4<256x256x64,4 waves,128x128 wave tiles,cross-tile LDS-DMA,LDS epilogue,NN>"),
     (_W4X2, (2560, 2560, 2560), 2, "mfma_ring<128x256x64,8 waves,stages=2,NN>"),
     (_W4X2, (1536, 1536, 1536), 2, "mfma_ring<64x128x64,4 waves,stages=2,NN>"),

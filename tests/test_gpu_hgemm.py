@@ -269,7 +269,7 @@ def test_one_wave_per_simd_kernel(hg, built, dev, layout):
             c = torch.zeros(M, N, dtype=torch.half, device=dev)
             fn(ad, bb, c, 2, bool(rep & 1), 512)
             assert torch.equal(c, base), (M, N, K, rep)
-        for var in (0, 1, 3, 4, 9, 13, 20, 25, 26, 27, 28):
+        for var in (0, 1, 3, 4, 9, 10, 13, 20, 25, 26, 27, 28):
             c = torch.zeros(M, N, dtype=torch.half, device=dev)
             host.hgemm_variant(14, layout, 1, 64, var, ad, bb, c, swizzle=1, swizzle_stride=512)
             assert torch.equal(c, base), (M, N, K, var)
@@ -285,3 +285,54 @@ def test_one_wave_per_simd_kernel(hg, built, dev, layout):
         check(c, a, b)
         with pytest.raises(RuntimeError):
             host.hgemm_variant(14, layout, 1, 64, 26, a.to(dev), bb, c, swizzle=1, swizzle_stride=512)
+
+
+@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("tile,BM,BN", [(0, 192, 256), (1, 256, 192), (2, 192, 192)])
+def test_one_wave_per_simd_kernel_on_192_tiles(hg, built, dev, layout, tile, BM, BN):
+    """The 96-row / 96-column wave tiles of hgemm_w4 (what the tile policy picks at 2304 / 3072 / 4608 / 6144): grids of
+    one and several tiles, smallest and odd K-pair counts, the 384-byte-row NN image (its own bank swizzle), the
+    5-rows-per-store epilogue; against the fp32 oracle and bit-identical to the 128x128 ring kernel where that tiles."""
+    from cuda_learn_notes_amd import host
+    from cuda_learn_notes_amd.bench_utils import as_col_major
+    for (mt, nt_, K) in ((1, 1, 384), (2, 3, 640), (4, 2, 1152), (5, 5, 512)):
+        M, N = mt * BM, nt_ * BN
+        a, b = seeded(270 + K + tile, M, K), seeded(271 + K + tile, K, N)
+        bb = (as_col_major(b) if layout else b).to(dev)
+        ad = a.to(dev)
+        first = None
+        for rep in range(3):
+            c = torch.zeros(M, N, dtype=torch.half, device=dev)
+            host.hgemm_variant(15, layout, tile, 64, 2, ad, bb, c, swizzle=rep & 1, swizzle_stride=2 * BN)
+            if first is None:
+                check(c, a, b)
+                first = c
+            else:
+                assert torch.equal(c, first), (M, N, K, rep)
+        if M % 128 == 0 and N % 128 == 0:
+            ring = torch.zeros(M, N, dtype=torch.half, device=dev)
+            host.hgemm_variant(0, layout, 0, 64, 2, ad, bb, ring, swizzle=1, swizzle_stride=256)
+            assert torch.equal(first, ring), (M, N, K)
+    with pytest.raises(RuntimeError):  # not a multiple of the tile
+        c = torch.zeros(256, 256, dtype=torch.half, device=dev)
+        host.hgemm_variant(15, layout, 2, 64, 2, seeded(1, 256, 384).to(dev), seeded(2, 384, 256).to(dev), c, swizzle=1,
+                           swizzle_stride=256)
+
+
+@pytest.mark.parametrize("size", [2304, 3072, 4608])
+def test_policy_sizes_that_run_the_192_tiles(hg, built, dev, size):
+    """Through the reference names (NN and TN) at sizes where best_plan picks a 192 tile: sampled rows vs fp32."""
+    from cuda_learn_notes_amd.bench_utils import as_col_major
+    name = "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem"
+    assert "hgemm_w4<192x" in built.manifest.describe(name, (size, size, size), 2)
+    g = torch.Generator().manual_seed(size)
+    a = torch.randn(size, size, generator=g).half()
+    b = torch.randn(size, size, generator=g).half()
+    rows = torch.arange(0, size, max(1, size // 96))[:96]
+    truth = a[rows].float() @ b.float()
+    ad, bd = a.to(dev), b.to(dev)
+    for fn, bb in ((getattr(hg, name), bd), (getattr(hg, name + "_tn_swizzle_x4"), as_col_major(b).to(dev))):
+        c = torch.zeros(size, size, dtype=torch.half, device=dev)
+        fn(ad, bb, c, 2, True, 2048)
+        err = (c[rows.to(dev)].cpu().float() - truth).abs()
+        assert (err <= ATOL + RTOL * truth.abs()).all(), err.max().item()
