@@ -130,6 +130,8 @@ def main():
                 "unit": "TFLOP/s", "frac": round(achieved / bu.PEAK_FP16_MFMA_TFLOPS, 4),
                 "traffic": round(traffic) if traffic else None, "traffic_source": traffic_src,
                 "mfma_busy": round(busy, 4) if busy else None,
+                "mfma_busy_note": "SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE of the rocprofv3 counter pass, where the launch takes "
+                                  "more cycles than un-profiled (can read below frac); MFMA cycles per launch are fixed by the work",
                 "kernel": kernel_desc, "avg_launch_ms": round(ev_ms, 5),
                 "timing": "HIP events on the launch stream around the %d timed steps (same region as value)" % args.steps,
                 "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": bu.hgemm_bytes(M, N, K)}
