@@ -104,13 +104,15 @@ CLN_API int cln_hgemm_variant(int kind, int layout, int tile, int bk, int stages
     }
 #undef W4_CASE
   }
-  if (kind == 15) {  // one wave per SIMD on 192-row / 192-column tiles; tile = 0: 192x256, 1: 256x192, 2: 192x192
+  if (kind == 15) {  // one wave per SIMD on 192-row / 192-column tiles; tile = 0: 192x256, 1: 256x192, 2: 192x192, 3: 128x256, 4: 256x128
 #define W4_SHAPE(BM, BN)                                                                                              \
   return layout == TN ? launch_w4<TN, 2, 26, 0, BM, BN>(a, b, c, M, N, K, swizzle, swizzle_stride, stream)           \
                       : launch_w4<NN, 2, 26, 0, BM, BN>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
     if (tile == 0) { W4_SHAPE(192, 256) }
     if (tile == 1) { W4_SHAPE(256, 192) }
     if (tile == 2) { W4_SHAPE(192, 192) }
+    if (tile == 3) { W4_SHAPE(128, 256) }
+    if (tile == 4) { W4_SHAPE(256, 128) }
 #undef W4_SHAPE
     return CLN_ERR_BAD_ARG;
   }

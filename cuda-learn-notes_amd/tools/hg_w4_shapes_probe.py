@@ -16,7 +16,8 @@ dev = torch.device("cuda:0")
 hg = pkg.hgemm_lib()
 hg.init_cublas_handle()
 sizes = [int(x) for x in sys.argv[1:]] or [1536, 2304, 3072, 4608, 6144, 7680]
-SHAPES = {0: (192, 256), 1: (256, 192), 2: (192, 192)}
+SHAPES = {0: (192, 256), 1: (256, 192), 2: (192, 192), 3: (128, 256), 4: (256, 128)}
+ONLY = [int(x) for x in os.environ.get('W4_SHAPES', '0,1,2,3,4').split(',')]
 for S in sizes:
     torch.manual_seed(S)
     a = torch.randn(S, S, dtype=torch.half, device=dev)
@@ -37,7 +38,7 @@ for S in sizes:
     if S % 256 == 0:
         var += [("w4 256x256 NN", 14, 0, 1, 26), ("w4 256x256 TN", 14, 1, 1, 26)]
     for t, (bm, bn) in SHAPES.items():
-        if S % bm == 0 and S % bn == 0:
+        if S % bm == 0 and S % bn == 0 and t in ONLY:
             var += [("w4 %dx%d NN" % (bm, bn), 15, 0, t, 2), ("w4 %dx%d TN" % (bm, bn), 15, 1, t, 2)]
     for tag, kind, lay, tile, st in var:
         fn = lambda kind=kind, lay=lay, tile=tile, st=st: host.hgemm_variant(kind, lay, tile, 64, st, a, bt if lay else b, c, 1, stride)
