@@ -183,7 +183,7 @@ int fa2_describe(int family, bool vt, int B, int H, int N, int D, int stages, in
                                 "groups%s", D, p.bc, st);
     case K_DSPLIT:
       if (p.d_inst != D)
-        return snprintf(buf, len, "fa2_fwd_dsplit<D=%d,NSP=2,BC=32,PAD=%d> 8 waves, pairs split d%s", p.d_inst, D, st);
+        return snprintf(buf, len, "fa2_fwd_dsplit<D=%d,NSP=2,BC=32,LDS geometry of D=%d> 8 waves, pairs split the real d evenly%s", D, p.d_inst, st);
       return snprintf(buf, len, "fa2_fwd_dsplit<D=%d,NSP=%d,BC=%d%s> 8 waves, two groups one phase apart%s", D,
                       D == 512 ? 2 : 1, p.bc, D <= 128 ? ",pre-scaled Q" : "", st);
     case K_DWIDE:

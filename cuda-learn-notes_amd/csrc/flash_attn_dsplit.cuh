@@ -49,18 +49,22 @@ struct GeoSplit {
   static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
-// PAD (D = 512 only): the tensors have `dreal` < D columns (320 / 384); Q columns >= dreal are loaded as zeros, K/V
-// source chunks are clamped into the row (what lands in the padding is multiplied by those zeros / never stored), O is
-// stored for the real columns only. The MFMAs over the padding are wasted (25 % at 384), the structure is unchanged.
-template <int D, int NSP, int BCB, int OPT, int ABL = 0, bool PAD = false>
+// DREAL != 0 (D = 512 only): the tensors have DREAL < D columns (320 / 384). The LDS geometry stays that of D = 512
+// (1024-byte rows, one 512-byte half per wave of a pair), but the pair splits the REAL head dim evenly: wave `part` owns
+// columns [part * DREAL/2, (part + 1) * DREAL/2), which the DMA places at the start of its LDS half (the rest of the half
+// is never read), and every loop runs over DREAL/2 columns -- 12 / 10 k-steps and 6 / 5 output blocks per wave instead
+// of 16 / 8: no MFMA multiplies padding (round 1 padded Q with zeros: 25 % / 37 % of the MFMAs were wasted).
+template <int D, int NSP, int BCB, int OPT, int ABL = 0, int DREAL = 0>
 __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __restrict__ Q,
                                                                 const half_t* __restrict__ K,
                                                                 const half_t* __restrict__ V, half_t* __restrict__ O,
-                                                                int N, int n_qblk, int n_heads, float scale_log2e,
-                                                                int dreal) {
+                                                                int N, int n_qblk, int n_heads, float scale_log2e) {
   using G = GeoSplit<D, NSP, BCB>;
-  static_assert(!PAD || (D == 512 && NSP == 2), "padded head dims ride on the D = 512 instantiation");
-  const int DR = PAD ? dreal : D;  // columns per row in memory
+  constexpr bool PAD = DREAL != 0;
+  static_assert(!PAD || (D == 512 && NSP == 2 && DREAL % 64 == 0 && DREAL > 256 && DREAL < 512),
+                "head dims 320 / 384 ride on the D = 512 geometry");
+  constexpr int DR = PAD ? DREAL : D;            // columns per row in memory
+  constexpr int DHR = PAD ? DREAL / 2 : G::DH;   // columns this wave works on
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -96,8 +100,10 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
     const int piece = i * 4 + widx;
     unsigned voff = src_lane ^ ((unsigned)(((i * 4 * G::RPP) & 15) << 4) & kmask);
     const char* s;
-    if constexpr (PAD) {  // a piece is one LDS row (RPP = 1); the memory row is DR*2 bytes: clamp the chunk into it
-      voff = min(voff, (unsigned)(DR * 2 - 16));
+    if constexpr (PAD) {  // a piece is one 1024-byte LDS row (RPP = 1); voff >> 4 = the logical chunk X this lane's
+      // LDS position holds: half p = X >> 5, chunk cc = X & 31 of that half; real if cc < DHR/8 (else never read)
+      const unsigned X = voff >> 4, pp = X >> 5, cc = X & 31;
+      voff = cc < (unsigned)(DHR / 8) ? (pp * (unsigned)(DHR / 8) + cc) << 4 : 0u;
       s = src_h + (size_t)jt * (G::BC * DR * 2) + piece * (DR * 2);
     } else {
       s = src_h + (size_t)jt * G::TILE + piece * 1024;
@@ -106,14 +112,11 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
   };
 
   // ---- Q fragments: this wave's half of the head dim
-  h8 qf[G::DH / 16];
+  h8 qf[DHR / 16];
   {
-    const half_t* qp = Q + head + (size_t)(q_row0 + l31) * DR + part * G::DH + hi * 8;
+    const half_t* qp = Q + head + (size_t)(q_row0 + l31) * DR + part * DHR + hi * 8;
 #pragma unroll
-    for (int ks = 0; ks < G::DH / 16; ++ks) {
-      if (!PAD || part * G::DH + ks * 16 < DR) qf[ks] = *reinterpret_cast<const h8*>(qp + ks * 16);
-      else qf[ks] = h8{0, 0, 0, 0, 0, 0, 0, 0};  // DR is a multiple of 16: the predicate is wave-uniform
-    }
+    for (int ks = 0; ks < DHR / 16; ++ks) qf[ks] = *reinterpret_cast<const h8*>(qp + ks * 16);
   }
   // OPT_PRE (the VALU diet; the D = 64 kernel is VALU-bound: ~10 VALU instructions per MFMA, 49 VALU cycles against
   // 32 matrix cycles, profiles/r01_pmc_fa_v2_variants.json): Q is multiplied by log2(e)/sqrt(d) ONCE here and the S^T
@@ -122,9 +125,9 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
   // accumulator zeroing (2 of the ~5 VALU instructions per score). A rescale (rare) also shifts the pending scores.
   constexpr bool PRE = (OPT & OPT_PRE) != 0;
   static_assert(!PRE || NSP == 1, "OPT_PRE: one wave per row group");
-  f16v ot[G::DH / 32];
+  f16v ot[DHR / 32];
 #pragma unroll
-  for (int b = 0; b < G::DH / 32; ++b)
+  for (int b = 0; b < DHR / 32; ++b)
 #pragma unroll
     for (int r = 0; r < 16; ++r) ot[b][r] = 0.f;
   float m_run = PRE ? 0.f : -1.0e30f, l_run = 0.f;
@@ -141,11 +144,11 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
   if constexpr (PRE) {
     const half_t sc = (half_t)scale_log2e;
 #pragma unroll
-    for (int ks = 0; ks < G::DH / 16; ++ks) qf[ks] = qf[ks] * sc;
+    for (int ks = 0; ks < DHR / 16; ++ks) qf[ks] = qf[ks] * sc;
   }
   // ... and pin the fragments here: hipcc otherwise sinks the Q loads below the barrier and into the first KV iteration
 #pragma unroll
-  for (int ks = 0; ks < G::DH / 16; ++ks) asm volatile("" : "+v"(qf[ks]));
+  for (int ks = 0; ks < DHR / 16; ++ks) asm volatile("" : "+v"(qf[ks]));
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 
@@ -188,12 +191,14 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
       return *reinterpret_cast<const h8*>(smem + (kb_j ^ ((ks & 7) << 5)) + (ks >> 3) * 256 + (t % BCB) * 32 * G::ROW);
     };
     auto v_frag = [&](int idx) {  // idx = st * (DH/32) + b: rows 16*st + v_row and + 8 (same swizzle), block b
-      const int st = idx / (G::DH / 32), b = idx % (G::DH / 32);
-      if constexpr ((ABL & 64) != 0) return qf[idx % (G::DH / 16)];  // ablation: no V fragment reads
+      const int st = idx / (DHR / 32), b = idx % (DHR / 32);
+      if constexpr ((ABL & 64) != 0) return qf[idx % (DHR / 16)];  // ablation: no V fragment reads
       const char* vp = smem + (vb_j ^ ((b & 3) << 6)) + (16 * st) * G::ROW + (b >> 2) * 256;
       return h8_cat(lds_read_tr16(vp), lds_read_tr16(vp + 8 * G::ROW));
     };
-    constexpr int NK = G::DH / 16, NQK = BCB * NK, NPV = 2 * BCB * (G::DH / 32), NQK0 = NQK < NPV ? NQK : NPV;
+    constexpr int NK = DHR / 16, NQK = BCB * NK, NPV = 2 * BCB * (DHR / 32), NQK0 = NQK < NPV ? NQK : NPV;
+    constexpr int DSTEP = NQK / G::PPW >= 1 ? NQK / G::PPW : 1;  // QK^T MFMAs per DMA piece (12 / 10 MFMAs carry 8 pieces at 384 / 320)
+    static_assert(NQK >= G::PPW, "every DMA piece of the next tile needs an MFMA to ride on");
     // fragments in flight ahead of the MFMA that consumes them (the phase stamps of round 1 show the MFMA loops running
     // at 2-3x their matrix time: every MFMA waits for an LDS fragment read issued only a few MFMAs earlier)
     constexpr int PD0 = (OPT & OPT_PD16) ? 16 : (OPT & OPT_PD8) ? 8 : (OPT & OPT_KPRE) ? 4 : 1;
@@ -216,7 +221,7 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
         else if (PRE && t < BCB) s[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[t % PD], qf[0], minit, 0, 0, 0);  // chain starts at -m
         else s[t % BCB] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[t % PD], qf[t / BCB], s[t % BCB], 0, 0, 0);
         if (t + PD < NQK) kf[t % PD] = k_frag(t + PD);
-        if (!(ABL & 1) && (t % (NQK / G::PPW)) == NQK / G::PPW - 1) dma_piece(jn, (j + 1) & 1, t / (NQK / G::PPW));
+        if (!(ABL & 1) && (t % DSTEP) == DSTEP - 1 && t / DSTEP < G::PPW) dma_piece(jn, (j + 1) & 1, t / DSTEP);
         if (PD > 1 || (t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -272,7 +277,7 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
           asm volatile("" : "+v"(minit));
         }
 #pragma unroll
-        for (int b = 0; b < G::DH / 32; ++b)
+        for (int b = 0; b < DHR / 32; ++b)
 #pragma unroll
           for (int r = 0; r < 16; r += 4) {  // serialise the register round trips of the rescale
             float t0 = ot[b][r], t1 = ot[b][r + 1], t2 = ot[b][r + 2], t3 = ot[b][r + 3];
@@ -338,7 +343,7 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
       if (!(ABL & 8)) {
 #pragma unroll
         for (int idx = i0; idx < i1; ++idx) {
-          const int st = idx / (G::DH / 32), b = idx % (G::DH / 32);
+          const int st = idx / (DHR / 32), b = idx % (DHR / 32);
           ot[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[idx % PD], pf[st], ot[b], 0, 0, 0);
           if (idx + PD < NPV) vf[idx % PD] = v_frag(idx + PD);
           if (PD > 1 || (idx & 3) == 3) __builtin_amdgcn_sched_barrier(0);
@@ -380,7 +385,7 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
   // across the KV loop in a full register file, i.e. spilled (15 dwords at D = 512, 11 at D = 256)
   const int lane_e = cln_fresh_lane(), l31_e = lane_e & 31, hi_e = lane_e >> 5;
 #pragma unroll
-  for (int b = 0; b < G::DH / 32; ++b) {
+  for (int b = 0; b < DHR / 32; ++b) {
 #pragma unroll
     for (int rq = 0; rq < 4; ++rq) {
       h4 o;
@@ -390,14 +395,14 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
     }
     __builtin_amdgcn_sched_barrier(0);
   }
-  constexpr int LPR = G::DH / 8;
-  half_t* og = O + head + (size_t)q_row0 * DR + part * G::DH;
+  constexpr int LPR = DHR / 8;
+  half_t* og = O + head + (size_t)q_row0 * DR + part * DHR;
 #pragma unroll 4
   for (int it = 0; it < (32 * LPR) / 64; ++it) {
     const int idx = it * 64 + lane_e;
     const int row = idx / LPR, c = idx % LPR;
     const u4 v = *reinterpret_cast<const u4*>(ob + row * G::OS + c * 16);
-    if (!PAD || part * G::DH + c * 8 < DR) *reinterpret_cast<u4*>(og + (size_t)row * DR + c * 8) = v;
+    *reinterpret_cast<u4*>(og + (size_t)row * DR + c * 8) = v;
   }
   if constexpr ((ABL & 32) != 0) {  // probe only: block 0 overwrites the head of O with its 8 x 8 time stamps
     if (blockIdx.x == 0 && lane == 0) {
@@ -408,18 +413,17 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
   }
 }
 
-template <int D, int NSP, int BCB, int OPT, int ABL = 0, bool PAD = false>
-int launch_dsplit(const void* q, const void* k, const void* v, void* o, int B, int H, int N, hipStream_t stream,
-                  int dreal = D) {
+template <int D, int NSP, int BCB, int OPT, int ABL = 0, int DREAL = 0>
+int launch_dsplit(const void* q, const void* k, const void* v, void* o, int B, int H, int N, hipStream_t stream) {
   using G = GeoSplit<D, NSP, BCB>;
+  constexpr int dreal = DREAL ? DREAL : D;
   if (N % G::BR != 0) return CLN_ERR_UNSUPPORTED;
-  if (PAD ? (dreal % 64 != 0 || dreal <= D / 2 || dreal >= D) : dreal != D) return CLN_ERR_UNSUPPORTED;
   static cln_lds_attr lds_attr;  // per device, thread-safe (common.h)
-  if (cln_ensure_lds(lds_attr, reinterpret_cast<const void*>(&fa2_fwd_dsplit_kernel<D, NSP, BCB, OPT, ABL, PAD>), G::LDS_BYTES) != CLN_OK) return CLN_ERR_LAUNCH;
+  if (cln_ensure_lds(lds_attr, reinterpret_cast<const void*>(&fa2_fwd_dsplit_kernel<D, NSP, BCB, OPT, ABL, DREAL>), G::LDS_BYTES) != CLN_OK) return CLN_ERR_LAUNCH;
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)dreal);
   const int n_qblk = N / G::BR;
-  CLN_LAUNCH((fa2_fwd_dsplit_kernel<D, NSP, BCB, OPT, ABL, PAD>), dim3(n_qblk * B * H), dim3(G::NT), G::LDS_BYTES, stream,
-             (const half_t*)q, (const half_t*)k, (const half_t*)v, (half_t*)o, N, n_qblk, B * H, scale_log2e, dreal);
+  CLN_LAUNCH((fa2_fwd_dsplit_kernel<D, NSP, BCB, OPT, ABL, DREAL>), dim3(n_qblk * B * H), dim3(G::NT), G::LDS_BYTES, stream,
+             (const half_t*)q, (const half_t*)k, (const half_t*)v, (half_t*)o, N, n_qblk, B * H, scale_log2e);
   return cln_check_launch();
 }
 

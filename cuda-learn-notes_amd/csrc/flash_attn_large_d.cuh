@@ -5,7 +5,7 @@
 // O^T in registers and the partial S^T tiles are summed through LDS):
 //   512        pairs of waves, two 4-wave groups one phase apart, K/V double-buffered   (flash_attn_dsplit.cuh)
 //   768, 1024  triples / quads of waves, one K and one V tile in the 160 KiB LDS         (flash_attn_dwide.cuh)
-//   320, 384   the D = 512 kernel with the head dim padded in registers / LDS only (PAD); 640 likewise on D = 768
+//   320, 384   the D = 512 kernel's LDS geometry, every loop over the real head dim (DREAL; round 2); 640 padded on D = 768
 #pragma once
 #include "flash_attn.cuh"
 #include "flash_attn_bigd.cuh"
@@ -16,11 +16,11 @@ namespace fa {
 inline int launch_fa2_large_d(const void* q, const void* k, const void* v, void* o, int B, int H, int N, int D,
                               hipStream_t s) {
   switch (D) {
-    // D = 320 / 384 ride on the D = 512 kernel, D = 640 on the D = 768 kernel, with the missing columns padded in
-    // registers / LDS only (PAD): 585 / 695 / 593 TF at [1,16,4096,D] vs 368 / 418 / 217 for the round-1 kernel,
-    // (profiles/r01_fa_padded_dims.log); same N % 128 == 0 requirement as that kernel had
-    case 320: return fa2::launch_dsplit<512, 2, 1, fa2::OPT_DEFAULT, 0, true>(q, k, v, o, B, H, N, s, 320);
-    case 384: return fa2::launch_dsplit<512, 2, 1, fa2::OPT_DEFAULT, 0, true>(q, k, v, o, B, H, N, s, 384);
+    // D = 320 / 384: the D = 512 kernel's LDS geometry with the pair of waves splitting the REAL head dim evenly (no MFMA
+    // on padding): 745-817 / 793-876 TF at [1,16,4096,D] (profiles/r02_fa_native_320_384.log) vs 585 / 695 for the
+    // zero-padded round-1 form. D = 640 still rides padded on the D = 768 kernel (593 TF, profiles/r01_fa_padded_dims.log)
+    case 320: return fa2::launch_dsplit<512, 2, 1, fa2::OPT_DEFAULT, 0, 320>(q, k, v, o, B, H, N, s);
+    case 384: return fa2::launch_dsplit<512, 2, 1, fa2::OPT_DEFAULT, 0, 384>(q, k, v, o, B, H, N, s);
     // D = 512 (config C5): pairs of waves split the head dim, two 4-wave groups one phase apart
     // (flash_attn_dsplit.cuh): 990-1000 TF at [1,32,4096,512] vs 487 for the register-resident O-slice kernel
     // (flash_attn_bigd.cuh, still used for D = 768) and 411 for the v1 path (profiles/r01_fa_dsplit_probe.log)

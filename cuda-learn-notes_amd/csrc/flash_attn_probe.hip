@@ -123,7 +123,16 @@ CLN_API int cln_fa2_variant(int D, int nw, int vt, int opt, int abl, const void*
   if (D == 256 && abl == 302) return fa2::launch_dsplit<256, 1, 1, 15 | fa2::OPT_KPRE, 2>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 128 && abl == 301) return fa2::launch_dsplit<128, 1, 2, 15 | fa2::OPT_KPRE, 1>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 256 && abl == 301) return fa2::launch_dsplit<256, 1, 1, 15 | fa2::OPT_KPRE, 1>(q, k, v, o, B, H, N, (hipStream_t)stream);
-  if ((D == 384 || D == 320) && abl == 210) return fa2::launch_dsplit<512, 2, 1, 15, 0, true>(q, k, v, o, B, H, N, (hipStream_t)stream, D);
+  if (D == 384 && abl == 210) return fa2::launch_dsplit<512, 2, 1, 15, 0, 384>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 320 && abl == 210) return fa2::launch_dsplit<512, 2, 1, 15, 0, 320>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 384 && abl == 220) return fa2::launch_dsplit<512, 2, 1, 15 | fa2::OPT_KPRE, 0, 384>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 320 && abl == 220) return fa2::launch_dsplit<512, 2, 1, 15 | fa2::OPT_KPRE, 0, 320>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 384 && abl == 222) return fa2::launch_dsplit<512, 2, 1, fa2::OPT_DEFAULT | fa2::OPT_PD8, 0, 384>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 320 && abl == 222) return fa2::launch_dsplit<512, 2, 1, fa2::OPT_DEFAULT | fa2::OPT_PD8, 0, 320>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 384 && abl == 223) return fa2::launch_dsplit<512, 2, 1, fa2::OPT_DEFAULT | fa2::OPT_PD16, 0, 384>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 320 && abl == 223) return fa2::launch_dsplit<512, 2, 1, fa2::OPT_DEFAULT | fa2::OPT_PD16, 0, 320>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 384 && abl == 221) return fa2::launch_dsplit<512, 2, 1, 15 | fa2::OPT_PD8, 0, 384>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 320 && abl == 221) return fa2::launch_dsplit<512, 2, 1, 15 | fa2::OPT_PD8, 0, 320>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 640 && abl == 210) return fa2::launch_dwide<768, 15, true>(q, k, v, o, B, H, N, (hipStream_t)stream, D);
   if (D == 512 && abl == 211) return fa2::launch_dsplit<512, 2, 1, 15, 1>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 512 && abl == 212) return fa2::launch_dsplit<512, 2, 1, 15, 2>(q, k, v, o, B, H, N, (hipStream_t)stream);
