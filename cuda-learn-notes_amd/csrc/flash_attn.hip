@@ -16,6 +16,7 @@
 #include "flash_attn_splitkv.cuh"
 #include "flash_attn_v2.cuh"
 #include "flash_attn_rb.cuh"
+#include "flash_attn_w4.cuh"
 #include <string.h>
 
 namespace {
@@ -54,10 +55,11 @@ FaPlan fa2_plan(int family, bool vt, int B, int H, int N, int D, int stages, int
   if (small_d) {
     if (!vt && N % 256 == 0 && bh * (N / 256) >= 192) {
       // enough 256-row workgroups to occupy most of the chip:
-      //  D = 64 / 128: register-blocked kernel, 4 waves x 64 rows, one wave per SIMD (flash_attn_rb.cuh)
+      //  D = 64 / 128: ping-pong kernel (flash_attn_dsplit.cuh), or -- where W4_PRODUCTION_* says it measured faster --
+      //                the one-wave-per-SIMD kernel with the hand-placed stream (flash_attn_w4.cuh)
       //  D = 256: two-group ping-pong kernel, 8 waves x 32 rows (flash_attn_dsplit.cuh)
-      if (D == 64) return p.kind = fa2::RB_PRODUCTION_D64 ? K_RB : K_DSPLIT, p.d_inst = 64, p.nw = fa2::RB_PRODUCTION_D64 ? 4 : 8, p.bc = 128, p;
-      if (D == 128) return p.kind = fa2::RB_PRODUCTION_D128 ? K_RB : K_DSPLIT, p.d_inst = 128, p.nw = fa2::RB_PRODUCTION_D128 ? 4 : 8, p.bc = 64, p;
+      if (D == 64) return p.kind = fa2::W4_PRODUCTION_D64 ? K_RB : K_DSPLIT, p.d_inst = 64, p.nw = fa2::W4_PRODUCTION_D64 ? 4 : 8, p.bc = fa2::W4_PRODUCTION_D64 ? 64 : 128, p;
+      if (D == 128) return p.kind = fa2::W4_PRODUCTION_D128 ? K_RB : K_DSPLIT, p.d_inst = 128, p.nw = fa2::W4_PRODUCTION_D128 ? 4 : 8, p.bc = 64, p;
       if (D == 256) return p.kind = K_DSPLIT, p.d_inst = 256, p.nw = 8, p.bc = 32, p;
     }
     // v2 kernel: the largest of 8 / 4 / 2 waves (x 32 query rows) that N allows AND that still gives every one of the
@@ -132,8 +134,8 @@ int fa2_run(const FaPlan& p, const void* q, const void* k, const void* v, void* 
       return CLN_ERR_UNSUPPORTED;
     case K_RB:
       if constexpr (!VT) {
-        if (D == 64) return fa2::launch_rb<64, fa2::RB_BC_D64, fa2::RB_OPT_D64>(q, k, v, o, B, H, N, s);
-        if (D == 128) return fa2::launch_rb<128, fa2::RB_BC_D128, fa2::RB_OPT_D128>(q, k, v, o, B, H, N, s);
+        if (D == 64) return fa2::launch_fa_w4<64, fa2::W4_VAR_D64>(q, k, v, o, B, H, N, s);
+        if (D == 128) return fa2::launch_fa_w4<128, fa2::W4_VAR_D128>(q, k, v, o, B, H, N, s);
       }
       return CLN_ERR_UNSUPPORTED;
     case K_DSPLIT:
@@ -179,8 +181,8 @@ int fa2_describe(int family, bool vt, int B, int H, int N, int D, int stages, in
       return snprintf(buf, len, "fa2_fwd_v2<D=%d,NW=%d,BC=64,prefetch%s%s> %d waves x 32 rows%s", D, p.nw,
                       D <= 128 ? ",pre-scaled Q" : "", vts, p.nw, st);
     case K_RB:
-      return snprintf(buf, len, "fa2_fwd_rb<D=%d,BC=%d> 4 waves x 64 rows, 1 wave/SIMD, K/V fragments shared by 2 row "
-                                "groups%s", D, p.bc, st);
+      return snprintf(buf, len, "fa2_fwd_w4<D=%d,BC=%d,pre-scaled Q> 4 waves x 64 rows, 1 wave/SIMD, hand-placed stream, K/V "
+                                "fragments shared by 2 row groups%s", D, p.bc, st);
     case K_DSPLIT:
       if (p.d_inst != D)
         return snprintf(buf, len, "fa2_fwd_dsplit<D=%d,NSP=2,BC=32,LDS geometry of D=%d> 8 waves, pairs split the real d evenly%s", D, p.d_inst, st);

@@ -7,6 +7,7 @@
 #include "flash_attn_dwide.cuh"
 #include "flash_attn_v4.cuh"
 #include "flash_attn_rb.cuh"
+#include "flash_attn_w4.cuh"
 #include <type_traits>
 
 #define V3(DD, NWW, OPTT) \
@@ -36,6 +37,15 @@ CLN_API int cln_fa2_variant(int D, int nw, int vt, int opt, int abl, const void*
     RB(128, 410, 32, B0 | RB_ASMQK, 1) RB(128, 411, 32, B0 | RB_ASMQK, 2)
 #undef RB
   }
+  // one-wave-per-SIMD kernel with a hand-placed stream (flash_attn_w4.cuh): abl 600 + schedule variant, 610.. ablations
+#define FW4(DD, ABLN, VARR, ABLL) \
+  if (D == DD && abl == ABLN) return fa2::launch_fa_w4<DD, VARR, ABLL>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  FW4(64, 600, 0, 0) FW4(64, 601, 1, 0) FW4(64, 602, 2, 0) FW4(128, 600, 0, 0) FW4(128, 601, 1, 0) FW4(128, 602, 2, 0)
+  FW4(64, 632, 8, 32) FW4(64, 633, 0, 32 + 31) FW4(128, 632, 0, 32)
+  FW4(64, 608, 8, 0) FW4(64, 609, 9, 0) FW4(128, 608, 8, 0) FW4(128, 609, 9, 0)
+  FW4(64, 610, 0, 1) FW4(64, 611, 0, 2) FW4(64, 612, 0, 4) FW4(64, 613, 0, 8) FW4(64, 614, 0, 16) FW4(64, 615, 0, 31)
+  FW4(128, 610, 0, 1) FW4(128, 611, 0, 2) FW4(128, 612, 0, 4) FW4(128, 613, 0, 8) FW4(128, 614, 0, 16) FW4(128, 615, 0, 31)
+#undef FW4
   // ping-pong kernel with the VALU diet (OPT_PRE): abl 500.. 
   if (D == 64 && abl == 500) return fa2::launch_dsplit<64, 1, 4, 13 | fa2::OPT_STAGGER | fa2::OPT_PRE>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 64 && abl == 501) return fa2::launch_dsplit<64, 1, 4, 13 | fa2::OPT_PRE>(q, k, v, o, B, H, N, (hipStream_t)stream);

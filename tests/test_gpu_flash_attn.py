@@ -460,3 +460,24 @@ def test_probe_variants_match_production(fa, built, dev, oracle):
             o = torch.zeros(B, H, N, D, dtype=torch.half, device=dev)
             host.fa2_variant(var, q.to(dev), k.to(dev), v.to(dev), o)
             assert (o.cpu().double() - ref).abs().max().item() <= TOL, (D, var)
+
+
+@pytest.mark.parametrize("D,abl", [(64, 600), (64, 608), (64, 601), (128, 600), (128, 602)])
+def test_one_wave_per_simd_attention_probe(built, dev, oracle, D, abl):
+    """flash_attn_w4.cuh (probe library): hand-placed one-wave-per-SIMD stream; random data, the creeping-max / late
+    jump / early spike regimes (rescale decided in the PV phase, applied behind its last MFMA), several KV lengths."""
+    from cuda_learn_notes_amd import host
+    for (B, H, N) in ((1, 2, 256), (2, 3, 512), (1, 2, 1024)):
+        q, k, v = seeded(61 + N, B, H, N, D), seeded(62 + N, B, H, N, D), seeded(63 + N, B, H, N, D)
+        if N == 1024:
+            ramp = torch.linspace(0.2, 1.6, N).view(1, 1, N, 1)
+            k = (k.float() * ramp).half()
+            k[0, 0, 900] = q[0, 0, 5] * 3.0
+            k[0, 0, 70] = q[0, 0, 130] * 2.0
+            k[0, 1, 10] = q[0, 1, 300] * 5.0
+            k[0, H - 1, 1000] = q[0, H - 1, 1023] * 4.0
+        o = torch.zeros(B, H, N, D, dtype=torch.half, device=dev)
+        host.fa2_variant((4, 0, 0, abl), q.to(dev), k.to(dev), v.to(dev), o)
+        assert torch.isfinite(o).all()
+        ref = oracle.attention_fp64(q, k, v)
+        assert (o.cpu().double() - ref).abs().max().item() <= TOL_AMPLIFIED_KEYS, (B, H, N)
