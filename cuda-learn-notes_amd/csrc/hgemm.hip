@@ -34,10 +34,10 @@ int check_args(const void* a, const void* b, const void* c, int M, int N, int K)
 //          ping-pong 256x256 0.94 | 192x256 0.91 | ring 128x256 0.79 | ring 64x128 0.545 | ring 128x128 0.53;
 //   the last factor: with CUs idle the busy ones clock higher (measured 1.2-1.3x at util 0.4-0.55).
 // It reproduces the measured winner at every size of profiles/r02_hgemm_midsize_probe.log and
-// r02_hgemm_w4_shapes_probe.log (1024..8192): ring 64x128 up to 2048, w4 192x192 at 2304 / 3072 (890 / 1320 TF vs 769 /
+// r02_hgemm_w4_shapes_probe.log (1024..8192): ring 64x64 up to 1536, ring 64x128 at 1792 / 2048, w4 192x192 at 2304 / 3072 (890 / 1320 TF vs 769 /
 // 1066 for the previous policy, rocBLAS TN 894 / 1185), w4 128x256 at 2560 (1015 vs 910, rocBLAS TN 904-1006), w4 192x256 at 4608 / 6144 (1356 / 1502 vs
 // 1146 / 1266, rocBLAS TN 1216 / 1388), w4 256x256 at 3584 / 4096 / 7680 / 8192.
-enum BestPlan { PLAN_PP256 = 0, PLAN_PP192, PLAN_R128x256, PLAN_R64x128, PLAN_R128, PLAN_W256, PLAN_W192x256, PLAN_W256x192, PLAN_W192, PLAN_W128x256, PLAN_W256x128 };
+enum BestPlan { PLAN_PP256 = 0, PLAN_PP192, PLAN_R128x256, PLAN_R64x128, PLAN_R128, PLAN_W256, PLAN_W192x256, PLAN_W256x192, PLAN_W192, PLAN_W128x256, PLAN_W256x128, PLAN_R64x64 };
 int best_plan(int M, int N, int K) {
   auto score = [](long long tiles, int slots, double eff) {
     if (tiles <= 0) return 0.0;
@@ -45,6 +45,11 @@ int best_plan(int M, int N, int K) {
     const double util = (double)tiles / (double)(rounds * slots);
     return eff * util * (1.0 + 0.5 * (1.0 - util));
   };
+  // Small problems are latency-bound (launch ramp + one L2 round trip per K tile), not throughput-bound: up to 640
+  // tiles of 64x64 (1536^2) the smallest tile wins because it puts a workgroup on every CU (1024^3: 6.8 us vs 9.1 us for
+  // 64x128 on half the CUs and 8.4 / 10.0 us for rocBLAS TN / NN; profiles/r02_hgemm_small_probe.log); from 2048^2 on the
+  // throughput model below takes over.
+  if (M % 64 == 0 && N % 64 == 0 && K % 64 == 0 && (long long)(M / 64) * (N / 64) <= 640) return PLAN_R64x64;
   double best = -1.0;
   int plan = PLAN_R128;
   auto offer = [&](int p, double sc) {
@@ -73,6 +78,7 @@ int plan_tile(int plan) {
   switch (plan) {
     case PLAN_R128x256: return T128x256;
     case PLAN_R64x128: return T64x128;
+    case PLAN_R64x64: return T64x64;
     case PLAN_PP256: case PLAN_PP192: case PLAN_W256: return T256;
     default: return T128;
   }

@@ -2,7 +2,7 @@
 #pragma once
 #include "common.h"
 namespace hgemm {
-enum TileId { T128 = 0, T256 = 1, T256x128 = 2, T128x256 = 3, T256W4 = 4, T128W8 = 5, T64x128 = 6 };  // T256W4: 256x256 tile, 4 waves x 128x128
+enum TileId { T128 = 0, T256 = 1, T256x128 = 2, T128x256 = 3, T256W4 = 4, T128W8 = 5, T64x128 = 6, T64x64 = 7, T64x64W2 = 8 };  // T256W4: 256x256 tile, 4 waves x 128x128
 // stages in [2,5]; BK (64 or 32) is chosen so that stages * stage_bytes fits the 160 KiB LDS and
 // K % BK == 0. Returns CLN_ERR_UNSUPPORTED when M/N/K do not divide the tile.
 int ring_dispatch_nn(int tile, const void* a, const void* b, void* c, int M, int N, int K, int stages, int swizzle,
@@ -35,6 +35,8 @@ inline void tile_dims(int tile, int& BM, int& BN, int& waves) {
     case T256W4: BM = 256, BN = 256, waves = 4; break;
     case T128W8: BM = 128, BN = 128, waves = 8; break;
     case T64x128: BM = 64, BN = 128, waves = 4; break;
+    case T64x64: BM = 64, BN = 64, waves = 4; break;
+    case T64x64W2: BM = 64, BN = 64, waves = 2; break;
     default: BM = 128, BN = 128, waves = 4; break;
   }
 }

@@ -43,6 +43,15 @@ __device__ __forceinline__ int kswz(int row) {
 }
 // N-contiguous image of B for the NN layout ([BK][BN] halves, BN in {128,256}).
 __device__ __forceinline__ int nswz(int krow) { return ((krow & 3) << 1) | (((krow >> 3) & 1) << 3); }
+// Rows that are an ODD multiple of 128 bytes (BN = 64, 192) put consecutive k rows 32 banks apart, so the four even
+// (odd) rows a 32-lane group of ds_read_b64_tr_b16 touches share a bank half; they are spread over its four 8-bank
+// quarters by XOR-ing the chunk index with 2 * (bit 1 of k | bit 3 of k << 1) -- bits 1..2 only, so a chunk never
+// leaves its 128-byte group (8 or 24 chunks per row).
+template <int BN>
+__device__ __forceinline__ int nswz_bn(int krow) {
+  if constexpr (BN == 192 || BN == 64) return ((((krow >> 1) & 1) | (((krow >> 3) & 1) << 1)) << 1);
+  else return nswz(krow);
+}
 
 // Counted wait: leaves N vector-memory ops (LDS-DMA pieces) in flight. vmcnt is a 6-bit field.
 template <int N>
@@ -88,7 +97,7 @@ struct Cfg {
   static constexpr int LDS_BYTES = STAGES * STAGE_BYTES;
   static_assert(BK == 32 || BK == 64, "BK");
   static_assert(A_BYTES % (1024 * NW) == 0 && B_BYTES % (1024 * NW) == 0, "tile must split evenly over waves");
-  static_assert(LAYOUT == TN || BN == 128 || BN == 256, "NN image swizzle derived for BN in {128,256}");
+  static_assert(LAYOUT == TN || BN == 64 || BN == 128 || BN == 256, "NN image swizzle derived for BN in {64,128,256}");
   static_assert(WTM % 16 == 0 && WTN % 16 == 0, "wave tile");
 };
 
@@ -139,7 +148,7 @@ struct NFill {
       const int t = i * C::NW + wave;
       const int krow = t * RPI + lane / LPR;
       const int c = lane % LPR;
-      voff[i] = ((unsigned)krow * (unsigned)N + ((c ^ nswz(krow)) << 3)) * 2u;
+      voff[i] = ((unsigned)krow * (unsigned)N + ((c ^ nswz_bn<C::BN>(krow)) << 3)) * 2u;
     }
   }
 };
@@ -175,8 +184,8 @@ __device__ __forceinline__ h8 read_nfrag(const char* img, int n0w, int lane, int
   const int q = (n0w >> 3) + ((i & 3) >> 1);
   const int k_lo = kk * 32 + 8 * g + (i >> 2);
   const int k_hi = k_lo + 4;
-  const char* p_lo = img + k_lo * (BN * 2) + ((q ^ nswz(k_lo)) << 4) + ((i & 1) << 3);
-  const char* p_hi = img + k_hi * (BN * 2) + ((q ^ nswz(k_hi)) << 4) + ((i & 1) << 3);
+  const char* p_lo = img + k_lo * (BN * 2) + ((q ^ nswz_bn<BN>(k_lo)) << 4) + ((i & 1) << 3);
+  const char* p_hi = img + k_hi * (BN * 2) + ((q ^ nswz_bn<BN>(k_hi)) << 4) + ((i & 1) << 3);
   return h8_cat(lds_read_tr16(p_lo), lds_read_tr16(p_hi));
 }
 

@@ -113,15 +113,8 @@ constexpr W4Sched w4_sched_for(int FM, int FN, int d_step) {
   return {1, 2, b1, b1 + 2, d_step, b2, b2 + 1, 1};
 }
 
-// NN B image for BN = 192: 384-byte rows put consecutive k rows 32 banks apart, so the four even (odd) rows a 32-lane
-// group of ds_read_b64_tr_b16 touches share a bank half; they are spread over its four 8-bank quarters by XOR-ing the
-// 16-byte chunk index with 2 * (bit 1 of k | bit 3 of k << 1) -- bits 1..2 only, so a chunk never leaves its 128-byte
-// group (24 chunks per row are not a power of two).
-template <int BN>
-__device__ __forceinline__ int nswz_bn(int krow) {
-  if constexpr (BN == 192) return ((((krow >> 1) & 1) | (((krow >> 3) & 1) << 1)) << 1);
-  else return nswz(krow);
-}
+// NN B image for BN = 192: its chunk swizzle is nswz_bn<192> (hgemm_mfma.cuh); the fill below maps lanes to (k row, chunk)
+// for rows that are not a power-of-two number of chunks.
 template <typename C, int NLOADS>
 struct NFillW {
   unsigned voff[NLOADS];

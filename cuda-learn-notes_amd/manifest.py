@@ -68,7 +68,7 @@ _add("hgemm", "G6", "mfma_ring<128x128,BK by stages,NN>",
      "hgemm_mma_m16n8k16_mma2x4_warp4x4_stages", "hgemm_mma_m16n8k16_mma2x4_warp4x4_stages_dsmem")
 _add("hgemm", "G6", "mfma_ring<256x128,8 waves,NN>", "hgemm_wmma_m16n16k16_mma4x2_warp4x4_stages_dsmem")
 _add("hgemm", "G6", "mfma_ring<256x256,8 waves,NN>", "hgemm_wmma_m16n16k16_mma4x4_warp4x4_stages_dsmem")
-_add("hgemm", "G6", "best<NN>: tile shape by estimated CU utilisation x kernel efficiency (csrc/hgemm.hip best_plan): hgemm_w4<256x256x64, one wave per SIMD> (stages 2; hgemm_pp<256x256x64> when K is not a multiple of 128 or < 384) | hgemm_pp32<4x32 ring> (stages 4) | hgemm_pp<192x256x64> | mfma_ring<128x256> | <64x128> | <128x128> (see DISPATCH_EXAMPLES)",
+_add("hgemm", "G6", "best<NN>: tile shape by estimated CU utilisation x kernel efficiency (csrc/hgemm.hip best_plan): hgemm_w4<256x256x64, one wave per SIMD> (stages 2; hgemm_pp<256x256x64> when K is not a multiple of 128 or < 384) | hgemm_pp32<4x32 ring> (stages 4) | hgemm_pp<192x256x64> | mfma_ring<128x256> | <64x128> | <64x64> (small problems) | <128x128> (see DISPATCH_EXAMPLES)",
      "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem", "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_x4",
      "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_rr",
      "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_swizzle")
@@ -284,9 +284,10 @@ DISPATCH_EXAMPLES = [
     (_W4X2, (3584, 3584, 3584), 2, "hgemm_w4<256x256x64,4 waves,128x128 wave tiles,cross-tile LDS-DMA,LDS epilogue,NN>"),
     (_W4X2, (2560, 2560, 2560), 2, "hgemm_w4<128x256x64,4 waves,64x128 wave tiles,cross-tile LDS-DMA,LDS epilogue,NN>"),
     (_W4X2, (2560, 2560, 2624), 2, "mfma_ring<128x256x64,8 waves,stages=2,NN>"),
-    (_W4X2, (1536, 1536, 1536), 2, "mfma_ring<64x128x64,4 waves,stages=2,NN>"),
+    (_W4X2, (1536, 1536, 1536), 2, "mfma_ring<64x64x64,4 waves,stages=2,NN>"),
+    (_W4X2, (1792, 1792, 1792), 2, "mfma_ring<64x128x64,4 waves,stages=2,NN>"),
     (_W4X2, (2048, 2048, 2048), 2, "mfma_ring<64x128x64,4 waves,stages=2,NN>"),
-    (_W4X2, (1024, 1024, 1024), 2, "mfma_ring<64x128x64,4 waves,stages=2,NN>"),
+    (_W4X2, (1024, 1024, 1024), 2, "mfma_ring<64x64x64,4 waves,stages=2,NN>"),
     (_W4X2 + "_tn_swizzle_x4", (4096, 4096, 4096), 2, "hgemm_w4<256x256x64,4 waves,128x128 wave tiles,cross-tile LDS-DMA,LDS epilogue,TN>"),
     ("hgemm_mma_m16n8k16_mma2x4_warp4x4_stages_dsmem", (4096, 4096, 4096), 3, "mfma_ring<128x128x64,4 waves,stages=3,NN>"),
     ("hgemm_mma_m16n8k16_mma2x4_warp4x4_stages_dsmem", (4096, 4096, 4096), 5, "mfma_ring<128x128x64,4 waves,stages=5,NN>"),

@@ -88,13 +88,14 @@ def test_tn_functions(hg, dev, built, name, stages, swizzle):
 
 
 @pytest.mark.parametrize("layout", [0, 1])
-@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 6, 7, 8])
 @pytest.mark.parametrize("bk,stages", [(64, 2), (64, 3), (64, 5), (32, 2), (32, 3), (32, 4), (32, 5)])
 def test_every_ring_instantiation(built, dev, layout, tile, bk, stages):
-    """Each (tile, BK, stages, layout) template instantiation, incl. K tiles fewer than stages."""
+    """Each (tile, BK, stages, layout) template instantiation, incl. K tiles fewer than stages (tiles 6 / 7 / 8 = 64x128,
+    64x64 on four and on two waves: the small-problem tiles; 64-column NN images have their own bank swizzle)."""
     from cuda_learn_notes_amd import host
     from cuda_learn_notes_amd.bench_utils import as_col_major
-    lds = stages * {0: 256, 1: 512, 2: 384, 3: 384}[tile] * bk * 2
+    lds = stages * {0: 256, 1: 512, 2: 384, 3: 384, 6: 192, 7: 128, 8: 128}[tile] * bk * 2
     if lds > 160 * 1024:
         pytest.skip("does not fit LDS")
     for K in (bk, 3 * bk, 9 * bk):
