@@ -145,6 +145,16 @@ int describe_best(int layout, int M, int N, int K, int stages, char* buf, int le
 
 using C1S_128_NN = Cfg<128, 128, 32, 2, 2, 1, NN>;
 using C1S_64x128_NN = Cfg<64, 128, 32, 1, 2, 1, NN>;
+using C1S_64_NN = Cfg<64, 64, 64, 2, 2, 1, NN>;
+// The 1-stage rungs (register-staged, two barriers per K tile, no overlap -- config C2's "naive 1-stage MFMA tile"): every K
+// tile exposes a full global-load latency, so a small problem wants (a) a workgroup on every CU and (b) fewer, deeper K
+// tiles: below 256 tiles of 128x128 the 64x64x64 form of the same kernel runs (1024^3: 64 -> 256 workgroups, 32 -> 16 K
+// tiles).
+inline int launch_1stage_128_or_64(const void* a, const void* b, void* c, int M, int N, int K, hipStream_t stream) {
+  if ((long long)(M / 128) * (N / 128) < 256 && M % 64 == 0 && N % 64 == 0 && K % 64 == 0)
+    return launch_1stage<C1S_64_NN>(a, b, c, M, N, K, stream);
+  return launch_1stage<C1S_128_NN>(a, b, c, M, N, K, stream);
+}
 
 }  // namespace
 
@@ -188,8 +198,8 @@ CLN_G3(hgemm_t_16x8_sliced_k32_f16x8_pack_dbuf_async,
 CLN_G3(hgemm_wmma_m16n16k16_naive, launch_naive<NN>(a, b, c, M, N, K, stream))
 CLN_G3(hgemm_mma_m16n8k16_naive, launch_naive<NN>(a, b, c, M, N, K, stream))
 CLN_G3(hgemm_wmma_m16n16k16_mma4x2, launch_1stage<C1S_64x128_NN>(a, b, c, M, N, K, stream))
-CLN_G3(hgemm_wmma_m16n16k16_mma4x2_warp2x4, launch_1stage<C1S_128_NN>(a, b, c, M, N, K, stream))
-CLN_G3(hgemm_mma_m16n8k16_mma2x4_warp4x4, launch_1stage<C1S_128_NN>(a, b, c, M, N, K, stream))
+CLN_G3(hgemm_wmma_m16n16k16_mma4x2_warp2x4, launch_1stage_128_or_64(a, b, c, M, N, K, stream))
+CLN_G3(hgemm_mma_m16n8k16_mma2x4_warp4x4, launch_1stage_128_or_64(a, b, c, M, N, K, stream))
 CLN_G3(hgemm_wmma_m16n16k16_mma4x2_warp2x4_dbuf_async,
        ring_exact_nn(T128, (K % 64 == 0) ? 64 : 32, 2, a, b, c, M, N, K, 0, 1, stream))
 CLN_G3(hgemm_wmma_m32n8k16_mma2x4_warp2x4_dbuf_async,

@@ -59,7 +59,7 @@ _add("hgemm_vendor", "G3", "rocblas_gemm_ex f16/f32-acc TN", "hgemm_cublas_tenso
 _add("hgemm", "G3", "mfma_naive<NN> 1 wave/16x16 tile, mfma_16x16x16",
      "hgemm_wmma_m16n16k16_naive", "hgemm_mma_m16n8k16_naive")
 _add("hgemm", "G3", "mfma_1stage<64x128x32,2 waves,NN>", "hgemm_wmma_m16n16k16_mma4x2")
-_add("hgemm", "G3", "mfma_1stage<128x128x32,4 waves,NN>",
+_add("hgemm", "G3", "mfma_1stage<128x128x32,4 waves,NN>; below 256 tiles of 128x128 (e.g. config C2, 1024^3): mfma_1stage<64x64x64,4 waves,NN>",
      "hgemm_wmma_m16n16k16_mma4x2_warp2x4", "hgemm_mma_m16n8k16_mma2x4_warp4x4")
 _add("hgemm", "G3", "mfma_ring<128x128,BK=64|32,stages=2,NN>", "hgemm_wmma_m16n16k16_mma4x2_warp2x4_dbuf_async")
 _add("hgemm", "G3", "mfma_ring<128x128,BK=32,stages=2,NN>", "hgemm_wmma_m32n8k16_mma2x4_warp2x4_dbuf_async")

@@ -25,6 +25,7 @@ for S in [int(x) for x in sys.argv[1:]] or [512, 1024, 1536, 2048]:
     stride = bu.make_block_swizzle_stride(S, S)
     top = hg.hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem
     cands = [("rocblas NN", lambda: hg.hgemm_cublas_tensor_op_nn(a, b, c)), ("rocblas TN", lambda: hg.hgemm_cublas_tensor_op_tn(a, bt, c))]
+    cands.append(("1-stage rung (config C2 name) mma2x4_warp4x4", lambda: hg.hgemm_mma_m16n8k16_mma2x4_warp4x4(a, b, c)))
     for st in (2, 3, 4, 5):
         cands.append(("top rung stages=%d %s" % (st, pkg.manifest.describe(top.__name__, (S, S, S), st)[:30]), lambda st=st: top(a, b, c, st, True, stride)))
     #            tag, tile, bk, stages  (ring_exact: tile 0 = 128x128, 6 = 64x128)
