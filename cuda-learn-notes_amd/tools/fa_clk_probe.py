@@ -19,7 +19,8 @@ def smi():
         return "smi error %s" % e
 
 
-for (B, H, N, D) in ((4, 8, 2048, 64), (4, 8, 2048, 128), (2, 32, 4096, 128)):
+ABLATE = os.environ.get("FA_CLK_ABLATE")  # energy ablations of the shipped C4 kernel (probe variants 520..527)
+for (B, H, N, D) in (((4, 8, 2048, 64),) if ABLATE else ((4, 8, 2048, 64), (4, 8, 2048, 128), (2, 32, 4096, 128))):
     q, k, v = (torch.randn(B, H, N, D, dtype=torch.half, device=dev) for _ in range(3))
     z = torch.zeros_like(q)
     o = torch.zeros_like(q)
@@ -29,6 +30,10 @@ for (B, H, N, D) in ((4, 8, 2048, 64), (4, 8, 2048, 128), (2, 32, 4096, 128)):
              ("w4 %d" % (608 if D == 64 else 600), lambda: host.fa2_variant((4, 0, 0, 608 if D == 64 else 600), q, k, v, o)),
              ("w4 skeleton 615", lambda: host.fa2_variant((4, 0, 0, 615), q, k, v, o)),
              ("w4 skeleton zeros", lambda: host.fa2_variant((4, 0, 0, 615), z, z, z, o))]
+    if ABLATE:
+        names = {500: "shipped (variant 500)", 520: "no DMA", 521: "no exp", 522: "no fragment reads", 523: "no PV MFMA", 524: "no QK MFMA",
+                 525: "no MFMA", 526: "no exp, no fragment reads", 527: "no exp, no reads, no DMA"}
+        cands = [(names[a], lambda a=a: host.fa2_variant((8, 0, 0, a), q, k, v, o)) for a in (500, 520, 521, 522, 523, 524, 525, 526, 527)]
     for tag, fn in cands:
         res = {}
 
@@ -46,4 +51,4 @@ for (B, H, N, D) in ((4, 8, 2048, 64), (4, 8, 2048, 128), (2, 32, 4096, 128)):
             n += 200
         dt = time.time() - t0
         th.join()
-        print("%s %-20s %7.1f TF sustained | %s" % ((B, H, N, D), tag, fl * n / dt * 1e-12, res.get("smi")), flush=True)
+        print("%s %-28s %7.1f TF sustained | %s" % ((B, H, N, D), tag, fl * n / dt * 1e-12, res.get("smi")), flush=True)
