@@ -17,12 +17,13 @@
 #include "flash_attn_v2.cuh"
 #include "flash_attn_rb.cuh"
 #include "flash_attn_w4.cuh"
+#include "flash_attn_dsplit2.cuh"
 #include <string.h>
 
 namespace {
 
 enum FaFamily { FAM_SPLIT_KV = 0, FAM_SPLIT_Q = 1 };
-enum FaKind { K_NONE = 0, K_SPLITKV, K_LOAD_THEN_COMPUTE, K_V2, K_DSPLIT, K_DWIDE, K_RB };
+enum FaKind { K_NONE = 0, K_SPLITKV, K_LOAD_THEN_COMPUTE, K_V2, K_DSPLIT, K_DWIDE, K_RB, K_DSPLIT64R };
 
 struct FaPlan {
   int rc = CLN_OK;     // CLN_ERR_* when the shape is not supported
@@ -53,6 +54,13 @@ FaPlan fa2_plan(int family, bool vt, int B, int H, int N, int D, int stages, int
   }
   p.stages_honoured = stages != 1;
   if (small_d) {
+    if (!vt && D == 64 && N % 512 == 0) {
+      // >= 512 query rows per CU, in (nearly) whole rounds of 256 workgroups: the ping-pong kernel with 64 rows per wave
+      // (flash_attn_dsplit2.cuh; every K / V fragment feeds two MFMAs): [1,48,8192,64] 1008 -> 1047-1068 TF,
+      // [2,32,4096,64] 967 -> 1020, [1,16,16384,64] 980 -> 1058 (profiles/r02_fa_64rows_probe.log)
+      const long long wgs = bh * (N / 512), rounds = (wgs + 255) / 256;
+      if (wgs >= 256 && wgs * 100 >= rounds * 256 * 88) return p.kind = K_DSPLIT64R, p.d_inst = 64, p.nw = 8, p.bc = 64, p;
+    }
     if (!vt && N % 256 == 0 && bh * (N / 256) >= 192) {
       // enough 256-row workgroups to occupy most of the chip:
       //  D = 64 / 128: ping-pong kernel (flash_attn_dsplit.cuh), or -- where W4_PRODUCTION_* says it measured faster --
@@ -132,6 +140,9 @@ int fa2_run(const FaPlan& p, const void* q, const void* k, const void* v, void* 
       }
 #undef FA_V2
       return CLN_ERR_UNSUPPORTED;
+    case K_DSPLIT64R:
+      if constexpr (!VT) return fa2::launch_dsplit2<4>(q, k, v, o, B, H, N, s);
+      return CLN_ERR_UNSUPPORTED;
     case K_RB:
       if constexpr (!VT) {
         if (D == 64) return fa2::launch_fa_w4<64, fa2::W4_VAR_D64>(q, k, v, o, B, H, N, s);
@@ -180,6 +191,9 @@ int fa2_describe(int family, bool vt, int B, int H, int N, int D, int stages, in
     case K_V2:
       return snprintf(buf, len, "fa2_fwd_v2<D=%d,NW=%d,BC=64,prefetch%s%s> %d waves x 32 rows%s", D, p.nw,
                       D <= 128 ? ",pre-scaled Q" : "", vts, p.nw, st);
+    case K_DSPLIT64R:
+      return snprintf(buf, len, "fa2_fwd_dsplit2<D=64,BC=64,pre-scaled Q> 8 waves x 64 rows, two groups one phase apart, K/V "
+                                "fragments shared by 2 row groups%s", st);
     case K_RB:
       return snprintf(buf, len, "fa2_fwd_w4<D=%d,BC=%d,pre-scaled Q> 4 waves x 64 rows, 1 wave/SIMD, hand-placed stream, K/V "
                                 "fragments shared by 2 row groups%s", D, p.bc, st);

@@ -8,6 +8,7 @@
 #include "flash_attn_v4.cuh"
 #include "flash_attn_rb.cuh"
 #include "flash_attn_w4.cuh"
+#include "flash_attn_dsplit2.cuh"
 #include <type_traits>
 
 #define V3(DD, NWW, OPTT) \
@@ -37,6 +38,11 @@ CLN_API int cln_fa2_variant(int D, int nw, int vt, int opt, int abl, const void*
     RB(128, 410, 32, B0 | RB_ASMQK, 1) RB(128, 411, 32, B0 | RB_ASMQK, 2)
 #undef RB
   }
+  // ping-pong kernel with 64 rows per wave (flash_attn_dsplit2.cuh): abl 700.. = fragment prefetch depth
+  if (D == 64 && abl == 700) return fa2::launch_dsplit2<4>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 64 && abl == 701) return fa2::launch_dsplit2<2>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 64 && abl == 702) return fa2::launch_dsplit2<8>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 64 && abl == 703) return fa2::launch_dsplit2<1>(q, k, v, o, B, H, N, (hipStream_t)stream);
   // one-wave-per-SIMD kernel with a hand-placed stream (flash_attn_w4.cuh): abl 600 + schedule variant, 610.. ablations
 #define FW4(DD, ABLN, VARR, ABLL) \
   if (D == DD && abl == ABLN) return fa2::launch_fa_w4<DD, VARR, ABLL>(q, k, v, o, B, H, N, (hipStream_t)stream);

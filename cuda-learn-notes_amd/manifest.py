@@ -298,6 +298,8 @@ DISPATCH_EXAMPLES = [
      "fa2_fwd_splitkv<D=64> 4 waves share 32 rows, 128-key tiles split over the waves, cross-wave max via LDS" + _IGN),
     (_SQKV, (4, 8, 2048, 64), 1, "fa2_fwd<D=64,BC=64,load-then-compute> 4 waves x 32 rows"),
     (_SQKV, (4, 8, 2048, 64), 2, "fa2_fwd_dsplit<D=64,NSP=1,BC=128,pre-scaled Q> 8 waves, two groups one phase apart"),
+    (_SQKV, (1, 48, 8192, 64), 2, "fa2_fwd_dsplit2<D=64,BC=64,pre-scaled Q> 8 waves x 64 rows, two groups one phase apart, K/V fragments shared by 2 row groups"),
+    (_SQKV, (2, 24, 4096, 64), 2, "fa2_fwd_dsplit<D=64,NSP=1,BC=128,pre-scaled Q> 8 waves, two groups one phase apart"),
     (_SQKV, (4, 8, 2048, 128), 2, "fa2_fwd_dsplit<D=128,NSP=1,BC=64,pre-scaled Q> 8 waves, two groups one phase apart"),
     (_SQKV, (2, 32, 4096, 256), 2, "fa2_fwd_dsplit<D=256,NSP=1,BC=32> 8 waves, two groups one phase apart"),
     (_SQKV, (2, 8, 2048, 64), 2, "fa2_fwd_v2<D=64,NW=4,BC=64,prefetch,pre-scaled Q> 4 waves x 32 rows"),

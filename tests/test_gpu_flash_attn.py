@@ -481,3 +481,28 @@ def test_one_wave_per_simd_attention_probe(built, dev, oracle, D, abl):
         assert torch.isfinite(o).all()
         ref = oracle.attention_fp64(q, k, v)
         assert (o.cpu().double() - ref).abs().max().item() <= TOL_AMPLIFIED_KEYS, (B, H, N)
+
+
+def test_pingpong_kernel_with_64_rows_per_wave(fa, built, dev, oracle):
+    """flash_attn_dsplit2.cuh (D = 64, >= 256 workgroups of 512 rows in whole rounds): the planner must pick it for these
+    shapes; random data plus the creeping-max / late-jump / early-spike regimes (rescale of BOTH row groups of a wave,
+    only one of which grows), sampled heads against the fp64 oracle, and bit-repeatability."""
+    name = "flash_attn_mma_stages_split_q_shared_qkv"
+    for (B, H, N) in ((1, 256, 512), (2, 64, 1024)):
+        assert built.manifest.describe(name, (B, H, N, 64), 2).startswith("fa2_fwd_dsplit2"), (B, H, N)
+        q, k, v = seeded(71 + N, B, H, N, 64), seeded(72 + N, B, H, N, 64), seeded(73 + N, B, H, N, 64)
+        if N == 1024:
+            ramp = torch.linspace(0.2, 1.6, N).view(1, 1, N, 1)
+            k = (k.float() * ramp).half()
+            k[0, 0, 900] = q[0, 0, 5] * 3.0      # row 5 (group 0 of wave 0) jumps late; its partner group does not
+            k[0, 0, 70] = q[0, 0, 40] * 2.0      # row 40 (group 1 of wave 0)
+            k[0, 1, 10] = q[0, 1, 300] * 5.0     # early spike: everything later ~ -inf
+            k[1, H - 1, 1000] = q[1, H - 1, 1023] * 4.0
+        o = run(fa, built, name, q, k, v, 2, dev)
+        o2 = run(fa, built, name, q, k, v, 2, dev)
+        assert torch.isfinite(o).all() and torch.equal(o, o2)
+        for (b, h) in ((0, 0), (0, 1), (B - 1, H - 1), (0, H // 2)):
+            ref = oracle.attention_fp64(q[b:b + 1, h:h + 1], k[b:b + 1, h:h + 1], v[b:b + 1, h:h + 1])
+            assert (o[b:b + 1, h:h + 1].double() - ref).abs().max().item() <= TOL_AMPLIFIED_KEYS, (B, H, N, b, h)
+    # a grid that does not fill whole rounds keeps the 32-row kernel
+    assert built.manifest.describe(name, (2, 24, 4096, 64), 2).startswith("fa2_fwd_dsplit<D=64")
