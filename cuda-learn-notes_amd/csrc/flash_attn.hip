@@ -15,7 +15,6 @@
 #include "flash_attn_large_d.cuh"
 #include "flash_attn_splitkv.cuh"
 #include "flash_attn_v2.cuh"
-#include "flash_attn_rb.cuh"
 #include "flash_attn_w4.cuh"
 #include "flash_attn_dsplit2.cuh"
 #include <string.h>
