@@ -30,14 +30,14 @@ int check_args(const void* a, const void* b, const void* c, int M, int N, int K)
 //   util = tiles / (rounds x slots)   -- slots = 256 workgroups in flight for the 8-wave kernels (one per CU), 512 for
 //                                        the 4-wave 64x128 / 128x128 rings (two per CU);
 //   eff  = measured rate at full occupancy relative to the one-wave-per-SIMD 256x256 kernel (same box):
-//          hgemm_w4 256x256 1.00 | 192x256 0.96 | 256x192 0.95 | 192x192 0.93 | 128x256 0.82 | 256x128 0.81 (all need K % 128 == 0, K >= 384) |
+//          hgemm_w4 256x256 1.00 | 192x256 0.96 | 256x192 0.95 | 192x192 0.93 | 128x256 0.82 | 256x128 0.81 | 160x160 0.88 (all need K % 128 == 0, K >= 384) |
 //          ping-pong 256x256 0.94 | 192x256 0.91 | ring 128x256 0.79 | ring 64x128 0.545 | ring 128x128 0.53;
 //   the last factor: with CUs idle the busy ones clock higher (measured 1.2-1.3x at util 0.4-0.55).
 // It reproduces the measured winner at every size of profiles/r02_hgemm_midsize_probe.log and
 // r02_hgemm_w4_shapes_probe.log (1024..8192): ring 64x64 up to 1536, ring 64x128 at 1792 / 2048, w4 192x192 at 2304 / 3072 (890 / 1320 TF vs 769 /
-// 1066 for the previous policy, rocBLAS TN 894 / 1185), w4 128x256 at 2560 (1015 vs 910, rocBLAS TN 904-1006), w4 192x256 at 4608 / 6144 (1356 / 1502 vs
+// 1066 for the previous policy, rocBLAS TN 894 / 1185), w4 160x160 at 2560 / 3200 (1065-1126 / 1080 TF vs 1015-1039 for 128x256 and 857 for the 64x128 ring; rocBLAS TN 900-1006 / 915), w4 192x256 at 4608 / 6144 (1356 / 1502 vs
 // 1146 / 1266, rocBLAS TN 1216 / 1388), w4 256x256 at 3584 / 4096 / 7680 / 8192.
-enum BestPlan { PLAN_PP256 = 0, PLAN_PP192, PLAN_R128x256, PLAN_R64x128, PLAN_R128, PLAN_W256, PLAN_W192x256, PLAN_W256x192, PLAN_W192, PLAN_W128x256, PLAN_W256x128, PLAN_R64x64 };
+enum BestPlan { PLAN_PP256 = 0, PLAN_PP192, PLAN_R128x256, PLAN_R64x128, PLAN_R128, PLAN_W256, PLAN_W192x256, PLAN_W256x192, PLAN_W192, PLAN_W128x256, PLAN_W256x128, PLAN_R64x64, PLAN_W160 };
 int best_plan(int M, int N, int K) {
   auto score = [](long long tiles, int slots, double eff) {
     if (tiles <= 0) return 0.0;
@@ -57,6 +57,7 @@ int best_plan(int M, int N, int K) {
   };
   // eff = measured rate at full occupancy relative to the one-wave-per-SIMD 256x256 kernel (round 2, same box:
   // profiles/r02_hgemm_w4_shapes_probe.log, r02_hgemm_midsize_probe.log)
+  if (M % 64 == 0 && N % 64 == 0 && K % 64 == 0) offer(PLAN_R64x64, score((long long)(M / 64) * (N / 64), 1024, 0.44));
   if (M % 128 == 0 && N % 128 == 0) offer(PLAN_R128, score((long long)(M / 128) * (N / 128), 512, 0.53));
   if (M % 64 == 0 && N % 128 == 0) offer(PLAN_R64x128, score((long long)(M / 64) * (N / 128), 512, 0.545));
   if (M % 128 == 0 && N % 256 == 0) offer(PLAN_R128x256, score((long long)(M / 128) * (N / 256), 256, 0.79));
@@ -65,6 +66,7 @@ int best_plan(int M, int N, int K) {
     if (M % 256 == 0) offer(PLAN_PP256, score((long long)(M / 256) * (N / 256), 256, 0.94));
   }
   if (w4_k_ok(K)) {
+    if (M % 160 == 0 && N % 160 == 0) offer(PLAN_W160, score((long long)(M / 160) * (N / 160), 256, 0.88));
     if (M % 256 == 0 && N % 128 == 0) offer(PLAN_W256x128, score((long long)(M / 256) * (N / 128), 256, 0.81));
     if (M % 128 == 0 && N % 256 == 0) offer(PLAN_W128x256, score((long long)(M / 128) * (N / 256), 256, 0.82));
     if (M % 192 == 0 && N % 192 == 0) offer(PLAN_W192, score((long long)(M / 192) * (N / 192), 256, 0.93));
@@ -96,6 +98,7 @@ int best_dispatch(const void* a, const void* b, void* c, int M, int N, int K, in
   if (plan == PLAN_W192) return launch_w4<LAYOUT, 2, W4_PRODUCTION, 0, 192, 192>(a, b, c, M, N, K, swizzle, stride, st);
   if (plan == PLAN_W192x256) return launch_w4<LAYOUT, 2, W4_PRODUCTION, 0, 192, 256>(a, b, c, M, N, K, swizzle, stride, st);
   if (plan == PLAN_W256x192) return launch_w4<LAYOUT, 2, W4_PRODUCTION, 0, 256, 192>(a, b, c, M, N, K, swizzle, stride, st);
+  if (plan == PLAN_W160) return launch_w4<LAYOUT, 2, W4_PRODUCTION, 0, 160, 160>(a, b, c, M, N, K, swizzle, stride, st);
   if (plan == PLAN_W128x256) return launch_w4<LAYOUT, 2, W4_PRODUCTION, 0, 128, 256>(a, b, c, M, N, K, swizzle, stride, st);
   if (plan == PLAN_W256x128) return launch_w4<LAYOUT, 2, W4_PRODUCTION, 0, 256, 128>(a, b, c, M, N, K, swizzle, stride, st);
   if (plan == PLAN_W256) {
@@ -128,6 +131,7 @@ int describe_best(int layout, int M, int N, int K, int stages, char* buf, int le
   if (plan == PLAN_W192) return snprintf(buf, len, w4, "192x192", "96x96", l);
   if (plan == PLAN_W192x256) return snprintf(buf, len, w4, "192x256", "96x128", l);
   if (plan == PLAN_W256x192) return snprintf(buf, len, w4, "256x192", "128x96", l);
+  if (plan == PLAN_W160) return snprintf(buf, len, w4, "160x160", "80x80", l);
   if (plan == PLAN_W128x256) return snprintf(buf, len, w4, "128x256", "64x128", l);
   if (plan == PLAN_W256x128) return snprintf(buf, len, w4, "256x128", "128x64", l);
   if (plan == PLAN_W256) {

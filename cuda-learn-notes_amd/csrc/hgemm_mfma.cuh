@@ -50,6 +50,9 @@ __device__ __forceinline__ int nswz(int krow) { return ((krow & 3) << 1) | (((kr
 template <int BN>
 __device__ __forceinline__ int nswz_bn(int krow) {
   if constexpr (BN == 192 || BN == 64) return ((((krow >> 1) & 1) | (((krow >> 3) & 1) << 1)) << 1);
+  // 320-byte rows (BN = 160): consecutive k rows are 16 banks apart, so rows r and r + 8 of a 32-lane group land on the same
+  // 16-bank slot (each uses 8 of them): move the second to the other half of the slot
+  else if constexpr (BN == 160) return ((krow >> 3) & 1) << 1;
   else return nswz(krow);
 }
 

@@ -113,6 +113,7 @@ CLN_API int cln_hgemm_variant(int kind, int layout, int tile, int bk, int stages
     if (tile == 2) { W4_SHAPE(192, 192) }
     if (tile == 3) { W4_SHAPE(128, 256) }
     if (tile == 4) { W4_SHAPE(256, 128) }
+    if (tile == 5) { W4_SHAPE(160, 160) }
 #undef W4_SHAPE
     return CLN_ERR_BAD_ARG;
   }

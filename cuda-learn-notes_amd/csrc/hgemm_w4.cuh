@@ -37,7 +37,7 @@ namespace hgemm {
 template <int FM, int FN>
 __device__ __forceinline__ void store_wide_tile_via_lds(half_t* Cmat, int N, int row0, int col0, int lane, char* wave_lds,
                                                         const f4 (&acc)[FM][FN]) {
-  static_assert(FN == 8 || FN == 6 || FN == 4, "128-, 96- or 64-column wave tile");
+  static_assert(FN == 8 || FN == 6 || FN == 5 || FN == 4, "128-, 96-, 80- or 64-column wave tile");
   constexpr int RS = FN * 32 + 16;  // row stride in bytes
   constexpr int LPR = FN * 2;       // 16-byte lanes per row
   constexpr int RPI = 64 / LPR;     // whole rows per store instruction (4 or 5; lanes >= RPI*LPR idle)
@@ -147,8 +147,9 @@ struct W4Cfg {
   static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES, LDS_BYTES = 2 * STAGE_BYTES;
   static constexpr int A_LOADS = FM, B_LOADS = FN, NP = FM + FN;  // 1-KiB DMA pieces per wave per K tile
   static constexpr int NR = FM + FN, NM = 2 * FM * FN;            // fragment reads per k-step, MFMAs per K tile
-  static_assert((BM == 256 || BM == 192 || BM == 128) && (BN == 256 || BN == 192 || BN == 128) && BM + BN >= 384,
-                "wave tiles of 128, 96 or 64 rows / columns; at least 64 MFMAs per K tile to hang the schedule on");
+  static_assert(((BM == 256 || BM == 192 || BM == 128) && (BN == 256 || BN == 192 || BN == 128) && BM + BN >= 384) ||
+                    (BM == 160 && BN == 160),
+                "wave tiles of 128, 96, 80 or 64 rows / columns; enough MFMAs per K tile to hang the schedule on");
 };
 
 // VAR: bits 0..3 = schedule number (256x256 only; other shapes take w4_sched_for), bit 4 = boustrophedon MFMA order
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(256, 1) void hgemm_w4_kernel(const half_t* __restri
                                                           int tiles_n, int swizzle, int band) {
   using C = W4Cfg<BM, BN, LAYOUT>;
   constexpr int FM = C::FM, FN = C::FN, NR = C::NR, NP = C::NP, NM = C::NM;
-  constexpr W4Sched S = (BM == 256 && BN == 256) ? w4_sched(VAR & 15) : w4_sched_for(FM, FN, (BM == 128 || BN == 128) ? 2 : (BM == 192 && BN == 192) ? 4 : 5);
+  constexpr W4Sched S = (BM == 256 && BN == 256) ? w4_sched(VAR & 15) : w4_sched_for(FM, FN, (BM == 128 || BN == 128 || BM == 160) ? 2 : (BM == 192 && BN == 192) ? 4 : 5);
   constexpr bool SNAKE = (VAR >> 4) & 1;
   // The DMA of tile t+2 starts after B1 of tile t (position d_first) and may run on into tile t+1 (positions >= NM =
   // "late" pieces, issued by tile t+1's body before its own B1; they only have to land before B2 of tile t+1).

@@ -282,7 +282,10 @@ DISPATCH_EXAMPLES = [
     (_W4X2, (6144, 6144, 6144), 2, "hgemm_w4<192x256x64,4 waves,96x128 wave tiles,cross-tile LDS-DMA,LDS epilogue,NN>"),
     (_W4X2, (4096, 6144, 4096), 2, "hgemm_w4<256x192x64,4 waves,128x96 wave tiles,cross-tile LDS-DMA,LDS epilogue,NN>"),
     (_W4X2, (3584, 3584, 3584), 2, "hgemm_w4<256x256x64,4 waves,128x128 wave tiles,cross-tile LDS-DMA,LDS epilogue,NN>"),
-    (_W4X2, (2560, 2560, 2560), 2, "hgemm_w4<128x256x64,4 waves,64x128 wave tiles,cross-tile LDS-DMA,LDS epilogue,NN>"),
+    (_W4X2, (2560, 2560, 2560), 2, "hgemm_w4<160x160x64,4 waves,80x80 wave tiles,cross-tile LDS-DMA,LDS epilogue,NN>"),
+    (_W4X2, (2816, 2816, 2816), 2, "hgemm_w4<128x256x64,4 waves,64x128 wave tiles,cross-tile LDS-DMA,LDS epilogue,NN>"),
+    (_W4X2, (3200, 3200, 3200), 2, "hgemm_w4<160x160x64,4 waves,80x80 wave tiles,cross-tile LDS-DMA,LDS epilogue,NN>"),
+    (_W4X2, (4800, 4800, 4800), 2, "mfma_ring<64x64x64,4 waves,stages=2,NN>"),
     (_W4X2, (2560, 2560, 2624), 2, "mfma_ring<128x256x64,8 waves,stages=2,NN>"),
     (_W4X2, (1536, 1536, 1536), 2, "mfma_ring<64x64x64,4 waves,stages=2,NN>"),
     (_W4X2, (1792, 1792, 1792), 2, "mfma_ring<64x128x64,4 waves,stages=2,NN>"),

@@ -16,8 +16,8 @@ dev = torch.device("cuda:0")
 hg = pkg.hgemm_lib()
 hg.init_cublas_handle()
 sizes = [int(x) for x in sys.argv[1:]] or [1536, 2304, 3072, 4608, 6144, 7680]
-SHAPES = {0: (192, 256), 1: (256, 192), 2: (192, 192), 3: (128, 256), 4: (256, 128)}
-ONLY = [int(x) for x in os.environ.get('W4_SHAPES', '0,1,2,3,4').split(',')]
+SHAPES = {0: (192, 256), 1: (256, 192), 2: (192, 192), 3: (128, 256), 4: (256, 128), 5: (160, 160)}
+ONLY = [int(x) for x in os.environ.get('W4_SHAPES', '0,1,2,3,4,5').split(',')]
 for S in sizes:
     torch.manual_seed(S)
     a = torch.randn(S, S, dtype=torch.half, device=dev)
@@ -31,9 +31,15 @@ for S in sizes:
     stride = bu.make_block_swizzle_stride(S, S)
     shipped = hg.hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem
     shipped_tn = hg.hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_tn_swizzle_x4
+    try:
+        what = pkg.manifest.describe(shipped.__name__, (S, S, S), 2)
+    except ValueError:
+        what = "(unsupported)"
     cands = [("rocblas NN", lambda: hg.hgemm_cublas_tensor_op_nn(a, b, c)), ("rocblas TN", lambda: hg.hgemm_cublas_tensor_op_tn(a, bt, c)),
-             ("shipped NN " + pkg.manifest.describe(shipped.__name__, (S, S, S), 2)[:22], lambda: shipped(a, b, c, 2, True, stride)),
+             ("shipped NN " + what[:22], lambda: shipped(a, b, c, 2, True, stride)),
              ("shipped TN", lambda: shipped_tn(a, bt, c, 2, True, stride))]
+    if what == "(unsupported)":
+        cands = cands[:2]
     var = []
     if S % 256 == 0:
         var += [("w4 256x256 NN", 14, 0, 1, 26), ("w4 256x256 TN", 14, 1, 1, 26)]

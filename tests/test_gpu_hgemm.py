@@ -289,7 +289,7 @@ def test_one_wave_per_simd_kernel(hg, built, dev, layout):
 
 
 @pytest.mark.parametrize("layout", [0, 1])
-@pytest.mark.parametrize("tile,BM,BN", [(0, 192, 256), (1, 256, 192), (2, 192, 192), (3, 128, 256), (4, 256, 128)])
+@pytest.mark.parametrize("tile,BM,BN", [(0, 192, 256), (1, 256, 192), (2, 192, 192), (3, 128, 256), (4, 256, 128), (5, 160, 160)])
 def test_one_wave_per_simd_kernel_on_192_tiles(hg, built, dev, layout, tile, BM, BN):
     """The 96-row / 96-column wave tiles of hgemm_w4 (what the tile policy picks at 2304 / 3072 / 4608 / 6144): grids of
     one and several tiles, smallest and odd K-pair counts, the 384-byte-row NN image (its own bank swizzle), the
@@ -320,12 +320,12 @@ def test_one_wave_per_simd_kernel_on_192_tiles(hg, built, dev, layout, tile, BM,
                            swizzle_stride=256)
 
 
-@pytest.mark.parametrize("size", [2304, 2560, 3072, 4608])
+@pytest.mark.parametrize("size", [2304, 2560, 2816, 3072, 3200, 4608])
 def test_policy_sizes_that_run_the_192_tiles(hg, built, dev, size):
     """Through the reference names (NN and TN) at sizes where best_plan picks a 192 tile: sampled rows vs fp32."""
     from cuda_learn_notes_amd.bench_utils import as_col_major
     name = "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem"
-    assert built.manifest.describe(name, (size, size, size), 2).startswith(("hgemm_w4<192x", "hgemm_w4<128x"))
+    assert built.manifest.describe(name, (size, size, size), 2).startswith(("hgemm_w4<192x", "hgemm_w4<128x", "hgemm_w4<160x"))
     g = torch.Generator().manual_seed(size)
     a = torch.randn(size, size, generator=g).half()
     b = torch.randn(size, size, generator=g).half()
