@@ -66,6 +66,10 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
   constexpr int DR = PAD ? DREAL : D;            // columns per row in memory
   constexpr int DHR = PAD ? DREAL / 2 : G::DH;   // columns this wave works on
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  // ABL & 128 (probe only): s_memrealtime (100 MHz, chip-wide) at kernel entry, after the prologue, at the start of
+  // tiles 1 2 3 4 8 16, after the KV loop and after the O stores -- every wave writes them over the head of its O rows
+  unsigned long long life[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if constexpr ((ABL & 128) != 0) life[0] = __builtin_amdgcn_s_memrealtime();
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hi = lane >> 5;
@@ -178,8 +182,17 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
     if constexpr ((ABL & 32) != 0)
       if (j == 16) stamp[i] = __builtin_amdgcn_s_memtime();
   };
+  if constexpr ((ABL & 128) != 0) life[1] = __builtin_amdgcn_s_memrealtime();
   for (int j = 0; j < T; ++j) {
     mark(j, 0);
+    if constexpr ((ABL & 128) != 0) {
+      if (j == 1) life[2] = __builtin_amdgcn_s_memrealtime();
+      if (j == 2) life[3] = __builtin_amdgcn_s_memrealtime();
+      if (j == 3) life[4] = __builtin_amdgcn_s_memrealtime();
+      if (j == 4) life[5] = __builtin_amdgcn_s_memrealtime();
+      if (j == 8) life[6] = __builtin_amdgcn_s_memrealtime();
+      if (j == T - 1) life[7] = __builtin_amdgcn_s_memrealtime();
+    }
     const char* kb = smem + (j & 1) * G::STAGE;
     const char* vb = kb + G::TILE;
     // ================= phase A: partial S^T = K[:, half] Q[:, half]^T; fetch this group's operand of tile j+1
@@ -373,6 +386,7 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
     asm volatile("" ::: "memory");
   }
 
+  if constexpr ((ABL & 128) != 0) life[8] = __builtin_amdgcn_s_memrealtime();
   // ---- epilogue: O = O^T / l, staged through LDS (wave-private rows)
   float l_tot;
   {
@@ -403,6 +417,19 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
     const int row = idx / LPR, c = idx % LPR;
     const u4 v = *reinterpret_cast<const u4*>(ob + row * G::OS + c * 16);
     *reinterpret_cast<u4*>(og + (size_t)row * DR + c * 8) = v;
+  }
+  if constexpr ((ABL & 128) != 0) {
+    life[9] = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // the O stores have been acknowledged
+    life[10] = __builtin_amdgcn_s_memrealtime();
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(hwid));
+    life[11] = hwid;
+    if (lane == 0) {
+      unsigned long long* dbg = reinterpret_cast<unsigned long long*>(og);
+#pragma unroll
+      for (int i = 0; i < 12; ++i) dbg[i] = life[i];
+    }
   }
   if constexpr ((ABL & 32) != 0) {  // probe only: block 0 overwrites the head of O with its 8 x 8 time stamps
     if (blockIdx.x == 0 && lane == 0) {

@@ -15,6 +15,11 @@
 //     exponentials between its halves (the split softmax of the 32-row kernel);
 //   * Q pre-multiplied by log2(e)/sqrt(d), accumulators started at -m through the MFMA C operand (OPT_PRE), deferred
 //     running max; K tiles fetched by group 0, V tiles by group 1 (LDS-DMA, 2 pieces per wave and tile), double-buffered.
+// KVS = true (round 2, for shapes with only 256 rows per CU such as config C4): the workgroup owns 256 query rows and the
+// two groups split the KEYS instead -- group 0 walks the first half of the KV tiles, group 1 the second half, each through
+// its own double-buffered K+V ring (4 DMA pieces per wave and tile), still one phase apart. Wave (g, w) and wave (1-g, w)
+// hold partial (O^T, m, l) of the same 64 rows; they are merged once at the end through LDS (each wave exports the 32-row
+// group it does not finalise, imports its partner's half of the one it does): O = O_0 2^(m_0-m) + O_1 2^(m_1-m).
 #pragma once
 #include "flash_attn_dsplit.cuh"
 
@@ -25,6 +30,9 @@ struct GeoSplit2 {
   static constexpr int ROW = D * 2, TILE = BC * ROW, STAGE = 2 * TILE, RING = 2 * STAGE;
   static constexpr int OS = D * 2 + 16, EPI = NW * 64 * OS;
   static constexpr int LDS_BYTES = RING > EPI ? RING : EPI;
+  // KVS: one ring per group; exchange area = per wave 34 floats per lane (32 O^T values, m, l of the exported row group)
+  static constexpr int XCH_WAVE = 34 * 64 * 4, XCH = NW * XCH_WAVE;
+  static constexpr int LDS_BYTES_KVS = 2 * RING > XCH ? 2 * RING : XCH;
   static constexpr int PPW = TILE / 1024 / 4;  // DMA pieces per wave per tile (4 waves fill one operand)
   static constexpr int RPP = 1024 / ROW, CPR = ROW / 16;
   static constexpr int NK = D / 16, NDB = D / 32, NQK = BCB * NK, NPV = 2 * BCB * NDB;
@@ -33,7 +41,7 @@ struct GeoSplit2 {
   static __device__ __forceinline__ int swz_v(int row) { return ((row >> 1) & 1) << 2; }
 };
 
-template <int PD = 4>
+template <int PD = 4, bool KVS = false>
 __global__ __launch_bounds__(512, 2) void fa2_fwd_dsplit2_kernel(const half_t* __restrict__ Q, const half_t* __restrict__ K,
                                                                  const half_t* __restrict__ V, half_t* __restrict__ O,
                                                                  int N, int n_qblk, int n_heads, float scale_log2e) {
@@ -58,7 +66,7 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_dsplit2_kernel(const half_t* _
     }
   }
   const size_t head = (size_t)head_i * N * D;
-  const int q_row0 = qb * G::BR + wave * 64;
+  const int q_row0 = KVS ? qb * (G::BR / 2) + widx * 64 : qb * G::BR + wave * 64;
   const unsigned lds0 = hgemm::lds_addr_of(smem);
 
   // ---- LDS-DMA: wave widx of group 0 fills the 1-KiB pieces i*4 + widx of the K tile, group 1 those of the V tile
@@ -67,13 +75,26 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_dsplit2_kernel(const half_t* _
   const int lr = lane / G::CPR, lc = lane % G::CPR, rlow = widx * G::RPP + lr;
   const unsigned src_lane = (unsigned)(lr * G::ROW) + (grp == 0 ? (unsigned)((lc ^ G::swz_k(rlow)) << 4) : (unsigned)((lc ^ G::swz_v(rlow)) << 4));
   const unsigned kmask = grp == 0 ? 0xFFu : 0u;
+  // KVS: every wave fetches K pieces (i = 0, 1) and V pieces (i = 2, 3) of its own group's tile
+  const char* src_k = reinterpret_cast<const char*>(K + head);
+  const char* src_v = reinterpret_cast<const char*>(V + head);
+  const unsigned src_lane_k = (unsigned)(lr * G::ROW) + (unsigned)((lc ^ G::swz_k(rlow)) << 4);
+  const unsigned src_lane_v = (unsigned)(lr * G::ROW) + (unsigned)((lc ^ G::swz_v(rlow)) << 4);
+  constexpr int PPW = KVS ? 2 * G::PPW : G::PPW;
+  const int gring = KVS ? grp * G::RING : 0;  // byte offset of this group's ring
   auto dma_piece = [&](int jt, int slot, int i) __attribute__((always_inline)) {
-    const int piece = i * 4 + widx;
     // K rows piece*RPP + lr: (row >> 1) & 7 = ((i*4*RPP >> 1) & 7) ^ ... -- the piece part of the row only touches
     // bits >= 3 of (row >> 1) when RPP = 8 (i*32 rows): swz_k(row) = swz_k(rlow) for every i, no per-piece term
-    const unsigned voff = src_lane ^ ((unsigned)((((i * 4 * G::RPP) >> 1) & 7) << 4) & kmask);
-    const char* s = src_h + (size_t)jt * G::TILE + piece * 1024;
-    hgemm::glds16_asm(s, voff, lds0 + slot * G::STAGE + grp * G::TILE + piece * 1024);
+    if constexpr (KVS) {
+      const int op = i >> 1, piece = (i & 1) * 4 + widx;
+      const char* s = (op ? src_v : src_k) + (size_t)jt * G::TILE + piece * 1024;
+      hgemm::glds16_asm(s, op ? src_lane_v : src_lane_k, lds0 + gring + slot * G::STAGE + op * G::TILE + piece * 1024);
+    } else {
+      const int piece = i * 4 + widx;
+      const unsigned voff = src_lane ^ ((unsigned)((((i * 4 * G::RPP) >> 1) & 7) << 4) & kmask);
+      const char* s = src_h + (size_t)jt * G::TILE + piece * 1024;
+      hgemm::glds16_asm(s, voff, lds0 + slot * G::STAGE + grp * G::TILE + piece * 1024);
+    }
   };
 
   // ---- Q fragments of both row groups, pre-scaled
@@ -100,10 +121,11 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_dsplit2_kernel(const half_t* _
     asm volatile("" : "+v"(minit[g]));
   }
 
-  const int T = N / G::BC;
+  const int T = KVS ? N / G::BC / 2 : N / G::BC;  // tiles this group walks
+  const int jt0 = KVS ? grp * T : 0;              // its first tile
   __builtin_assume(T > 0);
 #pragma unroll
-  for (int i = 0; i < G::PPW; ++i) dma_piece(0, 0, i);
+  for (int i = 0; i < PPW; ++i) dma_piece(jt0, 0, i);
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), compiler-visible: also retires the Q loads
   {
     const half_t sc = (half_t)scale_log2e;
@@ -131,7 +153,7 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_dsplit2_kernel(const half_t* _
 
   for (int j = 0; j < T; ++j) {
     const int jn = j + 1 < T ? j + 1 : T - 1;  // past the end: refill a dead slot with the last tile (branch-free)
-    const int kb_j = kbase + (j & 1) * G::STAGE, vb_j = vbase + (j & 1) * G::STAGE + G::TILE;
+    const int kb_j = kbase + gring + (j & 1) * G::STAGE, vb_j = vbase + gring + (j & 1) * G::STAGE + G::TILE;
     auto k_frag = [&](int t) __attribute__((always_inline)) {  // keys (t % BCB)*32 + l31, k-step t / BCB
       const int ks = t / BCB;
       return *reinterpret_cast<const h8*>(smem + (kb_j ^ ((ks & 7) << 5)) + (t % BCB) * 32 * G::ROW);
@@ -155,7 +177,7 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_dsplit2_kernel(const half_t* _
           else s[g][t % BCB] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[t % PD], qf[g][t / BCB], s[g][t % BCB], 0, 0, 0);
         }
         if (t + PD < NQK) kf[t % PD] = k_frag(t + PD);
-        if ((t % (NQK / G::PPW)) == NQK / G::PPW - 1) dma_piece(jn, (j + 1) & 1, t / (NQK / G::PPW));
+        if ((t % (NQK / PPW)) == NQK / PPW - 1) dma_piece(jt0 + jn, (j + 1) & 1, t / (NQK / PPW));
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -254,46 +276,80 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_dsplit2_kernel(const half_t* _
 
   // ---- epilogue: O = O^T / l, staged through LDS (wave-private rows)
   const int lane_e = cln_fresh_lane(), l31_e = lane_e & 31, hi_e = lane_e >> 5;
-#pragma unroll
-  for (int g = 0; g < 2; ++g) {
+  auto finish_group = [&](auto gc, f16v (&og_t)[NDB], float l_part, char* ob, int row0) __attribute__((always_inline)) {
     float l_tot;
     {
-      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run[g]), __float_as_uint(l_run[g]), false, false);
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_part), __float_as_uint(l_part), false, false);
       l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
     }
     const float inv = 1.0f / l_tot;
-    char* ob = smem + (wave * 2 + g) * (32 * G::OS);
 #pragma unroll
     for (int b = 0; b < NDB; ++b) {
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) {
         h4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (half_t)(ot[g][b][rq * 4 + e] * inv);
+        for (int e = 0; e < 4; ++e) o[e] = (half_t)(og_t[b][rq * 4 + e] * inv);
         *reinterpret_cast<h4*>(ob + l31_e * G::OS + (b * 32 + rq * 8 + hi_e * 4) * 2) = o;
       }
       __builtin_amdgcn_sched_barrier(0);
     }
     constexpr int LPR = D / 8;
-    half_t* og = O + head + (size_t)(q_row0 + g * 32) * D;
+    half_t* og = O + head + (size_t)row0 * D;
 #pragma unroll 4
     for (int it = 0; it < (32 * LPR) / 64; ++it) {
       const int idx = it * 64 + lane_e;
       const int row = idx / LPR, c = idx % LPR;
       *reinterpret_cast<u4*>(og + (size_t)row * D + c * 8) = *reinterpret_cast<const u4*>(ob + row * G::OS + c * 16);
     }
+  };
+  if constexpr (!KVS) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g) finish_group(std::integral_constant<int, 0>{}, ot[g], l_run[g], smem + (wave * 2 + g) * (32 * G::OS), q_row0 + g * 32);
+  } else {
+    // merge the two key halves: wave (grp, widx) finalises row group `grp`, exports the other one to its partner
+    auto merge = [&](auto goc) __attribute__((always_inline)) {
+      constexpr int GO = decltype(goc)::value, GX = 1 - GO;
+      float* xw = reinterpret_cast<float*>(smem + wave * G::XCH_WAVE) + lane_e;
+#pragma unroll
+      for (int b = 0; b < NDB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xw[(b * 16 + r) * 64] = ot[GX][b][r];
+      xw[32 * 64] = m_run[GX];
+      xw[33 * 64] = l_run[GX];
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const float* xr = reinterpret_cast<const float*>(smem + (wave ^ 4) * G::XCH_WAVE) + lane_e;
+      const float m_p = xr[32 * 64], l_p = xr[33 * 64];
+      const float m = fmaxf(m_run[GO], m_p);
+      const float sa = __builtin_amdgcn_exp2f(m_run[GO] - m), sb = __builtin_amdgcn_exp2f(m_p - m);
+#pragma unroll
+      for (int b = 0; b < NDB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[GO][b][r] = ot[GO][b][r] * sa + xr[(b * 16 + r) * 64] * sb;
+      const float l_part = l_run[GO] * sa + l_p * sb;
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_s_barrier();  // every wave has read its partner's export: the area becomes the staging buffer
+      asm volatile("" ::: "memory");
+      finish_group(goc, ot[GO], l_part, smem + wave * (32 * G::OS), q_row0 + GO * 32);
+    };
+    if (grp == 0) merge(std::integral_constant<int, 0>{});
+    else merge(std::integral_constant<int, 1>{});
   }
 }
 
-template <int PD = 4>
+template <int PD = 4, bool KVS = false>
 int launch_dsplit2(const void* q, const void* k, const void* v, void* o, int B, int H, int N, hipStream_t stream) {
   using G = GeoSplit2;
-  if (N % G::BR != 0) return CLN_ERR_UNSUPPORTED;
+  constexpr int BRW = KVS ? G::BR / 2 : G::BR;  // query rows per workgroup
+  constexpr int LDS = KVS ? G::LDS_BYTES_KVS : G::LDS_BYTES;
+  if (N % BRW != 0 || (KVS && N % (2 * G::BC) != 0)) return CLN_ERR_UNSUPPORTED;
   static cln_lds_attr lds_attr;  // per device, thread-safe (common.h)
-  if (cln_ensure_lds(lds_attr, reinterpret_cast<const void*>(&fa2_fwd_dsplit2_kernel<PD>), G::LDS_BYTES) != CLN_OK) return CLN_ERR_LAUNCH;
+  if (cln_ensure_lds(lds_attr, reinterpret_cast<const void*>(&fa2_fwd_dsplit2_kernel<PD, KVS>), LDS) != CLN_OK) return CLN_ERR_LAUNCH;
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)G::D);
-  const int n_qblk = N / G::BR;
-  CLN_LAUNCH((fa2_fwd_dsplit2_kernel<PD>), dim3(n_qblk * B * H), dim3(G::NT), G::LDS_BYTES, stream,
+  const int n_qblk = N / BRW;
+  CLN_LAUNCH((fa2_fwd_dsplit2_kernel<PD, KVS>), dim3(n_qblk * B * H), dim3(G::NT), LDS, stream,
              (const half_t*)q, (const half_t*)k, (const half_t*)v, (half_t*)o, N, n_qblk, B * H, scale_log2e);
   return cln_check_launch();
 }

@@ -43,6 +43,9 @@ CLN_API int cln_fa2_variant(int D, int nw, int vt, int opt, int abl, const void*
   if (D == 64 && abl == 701) return fa2::launch_dsplit2<2>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 64 && abl == 702) return fa2::launch_dsplit2<8>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 64 && abl == 703) return fa2::launch_dsplit2<1>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  // 710.. = the key-split form (256 rows per workgroup, the two groups walk one half of the KV tiles each)
+  if (D == 64 && abl == 710) return fa2::launch_dsplit2<4, true>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 64 && abl == 711) return fa2::launch_dsplit2<2, true>(q, k, v, o, B, H, N, (hipStream_t)stream);
   // one-wave-per-SIMD kernel with a hand-placed stream (flash_attn_w4.cuh): abl 600 + schedule variant, 610.. ablations
 #define FW4(DD, ABLN, VARR, ABLL) \
   if (D == DD && abl == ABLN) return fa2::launch_fa_w4<DD, VARR, ABLL>(q, k, v, o, B, H, N, (hipStream_t)stream);
@@ -66,6 +69,7 @@ CLN_API int cln_fa2_variant(int D, int nw, int vt, int opt, int abl, const void*
 #define PPA(ABLN, ABLL) \
   if (D == 64 && abl == ABLN) return fa2::launch_dsplit<64, 1, 4, 13 | fa2::OPT_STAGGER | fa2::OPT_PRE, ABLL>(q, k, v, o, B, H, N, (hipStream_t)stream);
   PPA(520, 1) PPA(521, 2) PPA(522, 64) PPA(523, 8) PPA(524, 16) PPA(525, 24) PPA(526, 2 | 64) PPA(527, 1 | 2 | 64)  // energy ablations of the shipped C4 kernel
+  PPA(528, 128)  // life stamps of every wave
 #undef PPA
   if (D == 64 && abl == 510) return fa2::launch_dsplit<64, 1, 4, 13 | fa2::OPT_PRE | fa2::OPT_PD16>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 64 && abl == 511) return fa2::launch_dsplit<64, 1, 2, 13 | fa2::OPT_STAGGER | fa2::OPT_PRE | fa2::OPT_PD8>(q, k, v, o, B, H, N, (hipStream_t)stream);

@@ -483,6 +483,26 @@ def test_one_wave_per_simd_attention_probe(built, dev, oracle, D, abl):
         assert (o.cpu().double() - ref).abs().max().item() <= TOL_AMPLIFIED_KEYS, (B, H, N)
 
 
+@pytest.mark.parametrize("abl", [710, 711])
+def test_key_split_attention_probe(built, dev, oracle, abl):
+    """flash_attn_dsplit2.cuh KVS = true (probe library): the two wave groups walk one half of the KV tiles each and merge
+    (O^T, m, l) through LDS. Random data; a dominant key only in the FIRST half, only in the SECOND half (the merge then
+    scales one partner by ~2^-large), in both; several KV lengths incl. the minimum (one tile per group)."""
+    from cuda_learn_notes_amd import host
+    for (B, H, N) in ((1, 2, 256), (2, 3, 512), (1, 2, 1024), (1, 1, 2048)):
+        q, k, v = seeded(81 + N, B, H, N, 64), seeded(82 + N, B, H, N, 64), seeded(83 + N, B, H, N, 64)
+        if N >= 512:
+            k[0, 0, 10] = q[0, 0, 5] * 4.0           # first half only: row 5 (group 0's row group of wave 0)
+            k[0, 0, N - 7] = q[0, 0, 40] * 4.0       # second half only: row 40 (row group 1 of wave 0)
+            k[0, H - 1, 3] = q[0, H - 1, 200] * 3.0  # both halves, different strength
+            k[0, H - 1, N // 2 + 3] = q[0, H - 1, 200] * 5.0
+        o = torch.zeros(B, H, N, 64, dtype=torch.half, device=dev)
+        host.fa2_variant((8, 0, 0, abl), q.to(dev), k.to(dev), v.to(dev), o)
+        assert torch.isfinite(o).all()
+        ref = oracle.attention_fp64(q, k, v)
+        assert (o.cpu().double() - ref).abs().max().item() <= TOL_AMPLIFIED_KEYS, (B, H, N)
+
+
 def test_pingpong_kernel_with_64_rows_per_wave(fa, built, dev, oracle):
     """flash_attn_dsplit2.cuh (D = 64, >= 256 workgroups of 512 rows in whole rounds): the planner must pick it for these
     shapes; random data plus the creeping-max / late-jump / early-spike regimes (rescale of BOTH row groups of a wave,
