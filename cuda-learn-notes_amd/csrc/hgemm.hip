@@ -124,18 +124,21 @@ int describe_ring(int tile, int layout, int M, int N, int K, int stages, char* b
   if (K % BK) return CLN_ERR_UNSUPPORTED;
   return snprintf(buf, len, "mfma_ring<%dx%dx%d,%d waves,stages=%d,%s>", BM, BN, BK, waves, stages, layout == TN ? "TN" : "NN");
 }
+int describe_w4(int BM, int BN, int layout, char* buf, int len) {
+  return snprintf(buf, len, "hgemm_w4<%dx%dx64,4 waves,%dx%d wave tiles,cross-tile LDS-DMA,LDS epilogue,%s>", BM, BN, BM / 2,
+                  BN / 2, layout == TN ? "TN" : "NN");
+}
 int describe_best(int layout, int M, int N, int K, int stages, char* buf, int len) {
   int plan = best_plan(M, N, K);
   const char* l = layout == TN ? "TN" : "NN";
-  const char* w4 = "hgemm_w4<%sx64,4 waves,%s wave tiles,cross-tile LDS-DMA,LDS epilogue,%s>";
-  if (plan == PLAN_W192) return snprintf(buf, len, w4, "192x192", "96x96", l);
-  if (plan == PLAN_W192x256) return snprintf(buf, len, w4, "192x256", "96x128", l);
-  if (plan == PLAN_W256x192) return snprintf(buf, len, w4, "256x192", "128x96", l);
-  if (plan == PLAN_W160) return snprintf(buf, len, w4, "160x160", "80x80", l);
-  if (plan == PLAN_W128x256) return snprintf(buf, len, w4, "128x256", "64x128", l);
-  if (plan == PLAN_W256x128) return snprintf(buf, len, w4, "256x128", "128x64", l);
+  if (plan == PLAN_W192) return describe_w4(192, 192, layout, buf, len);
+  if (plan == PLAN_W192x256) return describe_w4(192, 256, layout, buf, len);
+  if (plan == PLAN_W256x192) return describe_w4(256, 192, layout, buf, len);
+  if (plan == PLAN_W160) return describe_w4(160, 160, layout, buf, len);
+  if (plan == PLAN_W128x256) return describe_w4(128, 256, layout, buf, len);
+  if (plan == PLAN_W256x128) return describe_w4(256, 128, layout, buf, len);
   if (plan == PLAN_W256) {
-    if (stages == 2) return snprintf(buf, len, w4, "256x256", "128x128", l);
+    if (stages == 2) return describe_w4(256, 256, layout, buf, len);
     plan = PLAN_PP256;
   }
   if (plan == PLAN_PP192) return snprintf(buf, len, "hgemm_pp<192x256x64,8 waves,4 slots,LDS epilogue,%s>", l);
@@ -197,6 +200,22 @@ CLN_G3(hgemm_t_16x8_sliced_k32_f16x8_pack_dbuf, (launch_valu_tile<32, 16, true, 
 CLN_G3(hgemm_t_16x8_sliced_k32_f16x8_pack_dbuf_async,
        (launch_valu_tile<32, 16, true, true>(a, b, c, M, N, K, stream)))
 
+// Rungs whose NAME fixes the block tile (reference: 256x256 `mma4x4_warp4x4`, 256x128 `mma4x2_warp4x4`, CuTe 128x256):
+// at stages = 2 they run the one-wave-per-SIMD kernel of that tile when the shape allows it (K % 128 == 0, K >= 384),
+// the multi-stage ring of the same tile otherwise (other stage counts, other K).
+template <int LAYOUT, int BM, int BN>
+static bool fixed_tile_runs_w4(int M, int N, int K, int stages) {
+  return stages == 2 && M % BM == 0 && N % BN == 0 && w4_k_ok(K);
+}
+template <int LAYOUT, int BM, int BN>
+static int fixed_tile_dispatch(int ring_tile, const void* a, const void* b, void* c, int M, int N, int K, int stages,
+                               int swizzle, int swizzle_stride, hipStream_t stream) {
+  if (fixed_tile_runs_w4<LAYOUT, BM, BN>(M, N, K, stages))
+    return launch_w4<LAYOUT, 2, W4_PRODUCTION, 0, BM, BN>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+  if constexpr (LAYOUT == TN) return ring_dispatch_tn(ring_tile, a, b, c, M, N, K, stages, swizzle, swizzle_stride, stream);
+  else return ring_dispatch_nn(ring_tile, a, b, c, M, N, K, stages, swizzle, swizzle_stride, stream);
+}
+
 // ---- matrix-core rungs, no `stages` argument ----------------------------------------------------
 // reference kernels/hgemm/wmma/hgemm_wmma.cu:594-758, kernels/hgemm/mma/basic/hgemm_mma.cu:270-336
 CLN_G3(hgemm_wmma_m16n16k16_naive, launch_naive<NN>(a, b, c, M, N, K, stream))
@@ -216,9 +235,9 @@ CLN_G6(hgemm_wmma_m16n16k16_mma4x2_warp2x4_stages,
 CLN_G6(hgemm_wmma_m16n16k16_mma4x2_warp2x4_stages_dsmem,
        ring_dispatch_nn(T128, a, b, c, M, N, K, stages, swizzle, swizzle_stride, stream))
 CLN_G6(hgemm_wmma_m16n16k16_mma4x2_warp4x4_stages_dsmem,
-       ring_dispatch_nn(T256x128, a, b, c, M, N, K, stages, swizzle, swizzle_stride, stream))
+       (fixed_tile_dispatch<NN, 256, 128>(T256x128, a, b, c, M, N, K, stages, swizzle, swizzle_stride, stream)))
 CLN_G6(hgemm_wmma_m16n16k16_mma4x4_warp4x4_stages_dsmem,
-       ring_dispatch_nn(T256, a, b, c, M, N, K, stages, swizzle, swizzle_stride, stream))
+       (fixed_tile_dispatch<NN, 256, 256>(T256, a, b, c, M, N, K, stages, swizzle, swizzle_stride, stream)))
 // reference kernels/hgemm/mma/basic/hgemm_mma_stage.cu:2124-2717, mma/swizzle/hgemm_mma_stage_swizzle.cu:757
 CLN_G6(hgemm_mma_m16n8k16_mma2x4_warp4x4_stages,
        ring_dispatch_nn(T128, a, b, c, M, N, K, stages, swizzle, swizzle_stride, stream))
@@ -239,19 +258,19 @@ CLN_G6(hgemm_mma_m16n8k16_mma2x4_warp4x4_stages_dsmem_tn,
 CLN_G6(hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_tn_swizzle_x4,
        best_dispatch<TN>(a, b, c, M, N, K, stages, swizzle, swizzle_stride, stream))
 CLN_G6(hgemm_mma_stages_block_swizzle_tn_cute,
-       ring_dispatch_tn((N % 256 == 0) ? T128x256 : T128, a, b, c, M, N, K, stages, swizzle, swizzle_stride,
-                        stream))
+       ((N % 256 == 0) ? fixed_tile_dispatch<TN, 128, 256>(T128x256, a, b, c, M, N, K, stages, swizzle, swizzle_stride, stream)
+                       : ring_dispatch_tn(T128, a, b, c, M, N, K, stages, swizzle, swizzle_stride, stream)))
 
 // describe hook of this library group (see cln_describe in describe.hip): the kernel a G6 name runs for (M, N, K,
 // stages); CLN_ERR_BAD_ARG when `name` is not one of the run-time dispatched HGEMM names (every other HGEMM name is
 // one fixed kernel: manifest.py `impl`).
 int cln_hgemm_describe(const char* name, int M, int N, int K, int stages, char* buf, int len) {
-  struct Row { const char* name; int kind; int tile; int layout; };  // kind 0: ring_dispatch(tile), 1: best_dispatch
+  struct Row { const char* name; int kind; int tile; int layout; };  // kind 0: ring_dispatch(tile), 1: best_dispatch, 2: fixed_tile_dispatch
   static const Row rows[] = {
       {"hgemm_wmma_m16n16k16_mma4x2_warp2x4_stages", 0, T128, NN},
       {"hgemm_wmma_m16n16k16_mma4x2_warp2x4_stages_dsmem", 0, T128, NN},
-      {"hgemm_wmma_m16n16k16_mma4x2_warp4x4_stages_dsmem", 0, T256x128, NN},
-      {"hgemm_wmma_m16n16k16_mma4x4_warp4x4_stages_dsmem", 0, T256, NN},
+      {"hgemm_wmma_m16n16k16_mma4x2_warp4x4_stages_dsmem", 2, T256x128, NN},
+      {"hgemm_wmma_m16n16k16_mma4x4_warp4x4_stages_dsmem", 2, T256, NN},
       {"hgemm_mma_m16n8k16_mma2x4_warp4x4_stages", 0, T128, NN},
       {"hgemm_mma_m16n8k16_mma2x4_warp4x4_stages_dsmem", 0, T128, NN},
       {"hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem", 1, 0, NN},
@@ -260,13 +279,19 @@ int cln_hgemm_describe(const char* name, int M, int N, int K, int stages, char* 
       {"hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_swizzle", 1, 0, NN},
       {"hgemm_mma_m16n8k16_mma2x4_warp4x4_stages_dsmem_tn", 0, T128, TN},
       {"hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_tn_swizzle_x4", 1, 0, TN},
-      {"hgemm_mma_stages_block_swizzle_tn_cute", 0, -1, TN},
+      {"hgemm_mma_stages_block_swizzle_tn_cute", 2, -1, TN},
   };
   if (M <= 0 || N <= 0 || K <= 0) return CLN_ERR_BAD_ARG;
   for (const Row& r : rows) {
     if (strcmp(r.name, name) != 0) continue;
     if (r.kind == 1) return describe_best(r.layout, M, N, K, stages, buf, len);
     const int tile = r.tile >= 0 ? r.tile : ((N % 256 == 0) ? T128x256 : T128);
+    if (r.kind == 2 && tile != T128) {
+      int BM, BN, waves;
+      tile_dims(tile, BM, BN, waves);
+      if (stages == 2 && M % BM == 0 && N % BN == 0 && w4_k_ok(K))
+        return describe_w4(BM, BN, r.layout, buf, len);
+    }
     return describe_ring(tile, r.layout, M, N, K, stages, buf, len);
   }
   return CLN_ERR_BAD_ARG;

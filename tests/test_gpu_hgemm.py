@@ -320,6 +320,38 @@ def test_one_wave_per_simd_kernel_on_192_tiles(hg, built, dev, layout, tile, BM,
                            swizzle_stride=256)
 
 
+@pytest.mark.parametrize("name,layout,BM,BN", [
+    ("hgemm_wmma_m16n16k16_mma4x4_warp4x4_stages_dsmem", 0, 256, 256),
+    ("hgemm_wmma_m16n16k16_mma4x2_warp4x4_stages_dsmem", 0, 256, 128),
+    ("hgemm_mma_stages_block_swizzle_tn_cute", 1, 128, 256)])
+def test_fixed_tile_rungs_on_the_one_wave_per_simd_kernel(hg, built, dev, name, layout, BM, BN):
+    """The rungs whose name fixes the block tile (reference 256x256 / 256x128 WMMA stage kernels, the CuTe 128x256 TN
+    kernel) run hgemm_w4 of THAT tile at stages = 2 when K % 128 == 0 and K >= 384, the ring of the same tile otherwise;
+    both answers against the fp32 oracle, and identical to each other (same MFMA shape and K order)."""
+    from cuda_learn_notes_amd.bench_utils import as_col_major
+    fn = getattr(hg, name)
+    for (mt, nt_, K) in ((1, 1, 384), (3, 2, 640), (2, 5, 1152)):
+        M, N = mt * BM, nt_ * BN
+        assert built.manifest.describe(name, (M, N, K), 2).startswith("hgemm_w4<%dx%dx64" % (BM, BN)), (M, N, K)
+        assert built.manifest.describe(name, (M, N, K), 3).startswith("mfma_ring<%dx%d" % (BM, BN)), (M, N, K)
+        a, b = seeded(370 + K, M, K), seeded(371 + K, K, N)
+        bb = (as_col_major(b) if layout else b).to(dev)
+        ad = a.to(dev)
+        c2 = torch.zeros(M, N, dtype=torch.half, device=dev)
+        fn(ad, bb, c2, 2, True, 2 * BN)
+        check(c2, a, b)
+        c3 = torch.zeros(M, N, dtype=torch.half, device=dev)
+        fn(ad, bb, c3, 3, False, 0)
+        assert torch.equal(c2, c3), (M, N, K)
+    # K outside the kernel's structure: the ring answers at stages = 2 as well
+    M, N, K = BM, BN, 320
+    assert built.manifest.describe(name, (M, N, K), 2).startswith("mfma_ring<"), (M, N, K)
+    a, b = seeded(380, M, K), seeded(381, K, N)
+    c = torch.zeros(M, N, dtype=torch.half, device=dev)
+    fn(a.to(dev), (as_col_major(b) if layout else b).to(dev), c, 2, False, 0)
+    check(c, a, b)
+
+
 @pytest.mark.parametrize("size", [2304, 2560, 2816, 3072, 3200, 4608])
 def test_policy_sizes_that_run_the_192_tiles(hg, built, dev, size):
     """Through the reference names (NN and TN) at sizes where best_plan picks a 192 tile: sampled rows vs fp32."""
