@@ -30,7 +30,7 @@ int check_args(const void* a, const void* b, const void* c, int M, int N, int K)
 //   util = tiles / (rounds x slots)   -- slots = 256 workgroups in flight for the 8-wave kernels (one per CU), 512 for
 //                                        the 4-wave 64x128 / 128x128 rings (two per CU);
 //   eff  = measured rate at full occupancy relative to the one-wave-per-SIMD 256x256 kernel (same box):
-//          hgemm_w4 256x256 1.00 | 192x256 0.96 | 256x192 0.95 | 192x192 0.93 | 128x256 0.82 | 256x128 0.81 | 160x160 0.88 (all need K % 128 == 0, K >= 384) |
+//          hgemm_w4 256x256 1.00 | 192x256 0.96 | 256x192 0.95 | 192x192 0.93 | 128x256 0.82 | 256x128 0.81 | 160x160 0.88 (all need K % 64 == 0 and >= 6 K tiles, >= 7 when their number is odd) |
 //          ping-pong 256x256 0.94 | 192x256 0.91 | ring 128x256 0.79 | ring 64x128 0.545 | ring 128x128 0.53;
 //   the last factor: with CUs idle the busy ones clock higher (measured 1.2-1.3x at util 0.4-0.55).
 // It reproduces the measured winner at every size of profiles/r02_hgemm_midsize_probe.log and
@@ -201,7 +201,7 @@ CLN_G3(hgemm_t_16x8_sliced_k32_f16x8_pack_dbuf_async,
        (launch_valu_tile<32, 16, true, true>(a, b, c, M, N, K, stream)))
 
 // Rungs whose NAME fixes the block tile (reference: 256x256 `mma4x4_warp4x4`, 256x128 `mma4x2_warp4x4`, CuTe 128x256):
-// at stages = 2 they run the one-wave-per-SIMD kernel of that tile when the shape allows it (K % 128 == 0, K >= 384),
+// at stages = 2 they run the one-wave-per-SIMD kernel of that tile when the shape allows it (w4_k_ok: K % 64 == 0, >= 6 K tiles, >= 7 when odd),
 // the multi-stage ring of the same tile otherwise (other stage counts, other K).
 template <int LAYOUT, int BM, int BN>
 static bool fixed_tile_runs_w4(int M, int N, int K, int stages) {

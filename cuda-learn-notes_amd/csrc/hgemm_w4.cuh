@@ -154,7 +154,8 @@ struct W4Cfg {
 
 // VAR: bits 0..3 = schedule number (256x256 only; other shapes take w4_sched_for), bit 4 = boustrophedon MFMA order
 // (B fragments walked back and forth, so only ONE operand changes between consecutive MFMAs: ~1 % less power).
-template <int LAYOUT, int EPI = 2, int VAR = 0, int ABL = 0, int BM = 256, int BN = 256>
+// ODD: K / 64 is odd (>= 7): one more whole tile between the loop over tile pairs and the two closing tiles.
+template <int LAYOUT, int EPI = 2, int VAR = 0, int ABL = 0, int BM = 256, int BN = 256, bool ODD = false>
 __global__ __launch_bounds__(256, 1) void hgemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ B,
                                                           half_t* __restrict__ Cmat, int M, int N, int K, int tiles_m,
                                                           int tiles_n, int swizzle, int band) {
@@ -301,8 +302,9 @@ __global__ __launch_bounds__(256, 1) void hgemm_w4_kernel(const half_t* __restri
   for (int r = 0; r < NR; ++r) read_op(smem, 0, r);
   W4_PIN();
 
-  // nt even and >= 6 (launcher): two peeled tiles, a do-while over tile PAIRS (ring buffer = compile-time constant,
-  // every LDS address loop-invariant), two peeled tiles; no control-flow merge that would need accumulator copies.
+  // nt even and >= 6, or (ODD) odd and >= 7 (launcher): two peeled tiles, a do-while over tile PAIRS (ring buffer =
+  // compile-time constant, every LDS address loop-invariant), [ODD: one more whole tile,] two closing tiles; no
+  // control-flow merge that would need accumulator copies.
   const char* img0 = smem;
   const char* img1 = smem + C::STAGE_BYTES;
   const unsigned lds1 = lds0 + C::STAGE_BYTES;
@@ -315,9 +317,15 @@ __global__ __launch_bounds__(256, 1) void hgemm_w4_kernel(const half_t* __restri
     tile(Y, Y, Y, img0, img1, lds0, lds1);
     tile(Y, Y, Y, img1, img0, lds1, lds0);
     t += 2;
-  } while (t + 2 < nt);
-  tile(NO, Y, Y, img0, img1, lds0, lds1);
-  tile(NO, NO, NO, img1, img0, lds1, lds0);
+  } while (t + (ODD ? 3 : 2) < nt);
+  if constexpr (ODD) {
+    tile(Y, Y, Y, img0, img1, lds0, lds1);
+    tile(NO, Y, Y, img1, img0, lds1, lds0);
+    tile(NO, NO, NO, img0, img1, lds0, lds1);
+  } else {
+    tile(NO, Y, Y, img0, img1, lds0, lds1);
+    tile(NO, NO, NO, img1, img0, lds1, lds0);
+  }
 #undef W4_PIN
 #undef W4_BARRIER
   // Last MFMA results -> v_accvgpr_read: same blindness of the hazard pass. Pad, then re-define every tile AFTER the pad
@@ -340,18 +348,32 @@ __global__ __launch_bounds__(256, 1) void hgemm_w4_kernel(const half_t* __restri
   }
 }
 
-inline bool w4_k_ok(int K) { return K % 128 == 0 && K >= 384; }
+// K the kernel's peeled structure covers: whole 64-wide tiles, >= 6 of them when their number is even, >= 7 when odd
+inline bool w4_k_ok(int K) { return K % 64 == 0 && K >= ((K / 64) & 1 ? 448 : 384); }
 
 template <int LAYOUT, int EPI = 2, int VAR = 0, int ABL = 0, int BM = 256, int BN = 256>
 int launch_w4(const void* a, const void* b, void* c, int M, int N, int K, int swizzle, int swizzle_stride,
               hipStream_t stream) {
   using C = W4Cfg<BM, BN, LAYOUT>;
-  if (M % BM || N % BN || !w4_k_ok(K)) return CLN_ERR_UNSUPPORTED;
+  // the odd-tile-count form exists for the production schedule only (the probe variants keep K % 128 == 0)
+  constexpr bool HAS_ODD = ABL == 0 && EPI == 2 && (VAR == 26 || BM != 256 || BN != 256);
+  const bool odd = (K / 64) & 1;
+  if (M % BM || N % BN || !w4_k_ok(K) || (odd && !HAS_ODD)) return CLN_ERR_UNSUPPORTED;
+  const int tiles_m = M / BM, tiles_n = N / BN;
+  int band = (swizzle && swizzle_stride >= BN) ? swizzle_stride / BN : tiles_n;
+  if constexpr (HAS_ODD) {
+    if (odd) {
+      static cln_lds_attr lds_attr_odd;  // per device, thread-safe (common.h)
+      if (cln_ensure_lds(lds_attr_odd, reinterpret_cast<const void*>(&hgemm_w4_kernel<LAYOUT, EPI, VAR, ABL, BM, BN, true>), C::LDS_BYTES) != CLN_OK)
+        return CLN_ERR_LAUNCH;
+      CLN_LAUNCH((hgemm_w4_kernel<LAYOUT, EPI, VAR, ABL, BM, BN, true>), dim3(tiles_m * tiles_n), dim3(256), C::LDS_BYTES, stream,
+                 (const half_t*)a, (const half_t*)b, (half_t*)c, M, N, K, tiles_m, tiles_n, swizzle ? 1 : 0, band);
+      return cln_check_launch();
+    }
+  }
   static cln_lds_attr lds_attr;  // per device, thread-safe (common.h)
   if (cln_ensure_lds(lds_attr, reinterpret_cast<const void*>(&hgemm_w4_kernel<LAYOUT, EPI, VAR, ABL, BM, BN>), C::LDS_BYTES) != CLN_OK)
     return CLN_ERR_LAUNCH;
-  const int tiles_m = M / BM, tiles_n = N / BN;
-  int band = (swizzle && swizzle_stride >= BN) ? swizzle_stride / BN : tiles_n;
   CLN_LAUNCH((hgemm_w4_kernel<LAYOUT, EPI, VAR, ABL, BM, BN>), dim3(tiles_m * tiles_n), dim3(256), C::LDS_BYTES, stream,
              (const half_t*)a, (const half_t*)b, (half_t*)c, M, N, K, tiles_m, tiles_n, swizzle ? 1 : 0, band);
   return cln_check_launch();

@@ -66,15 +66,15 @@ _add("hgemm", "G3", "mfma_ring<128x128,BK=32,stages=2,NN>", "hgemm_wmma_m32n8k16
 _add("hgemm", "G6", "mfma_ring<128x128,BK by stages,NN>",
      "hgemm_wmma_m16n16k16_mma4x2_warp2x4_stages", "hgemm_wmma_m16n16k16_mma4x2_warp2x4_stages_dsmem",
      "hgemm_mma_m16n8k16_mma2x4_warp4x4_stages", "hgemm_mma_m16n8k16_mma2x4_warp4x4_stages_dsmem")
-_add("hgemm", "G6", "hgemm_w4<256x128> at stages=2 (K % 128 == 0, K >= 384) | mfma_ring<256x128,8 waves,NN>", "hgemm_wmma_m16n16k16_mma4x2_warp4x4_stages_dsmem")
-_add("hgemm", "G6", "hgemm_w4<256x256> at stages=2 (K % 128 == 0, K >= 384) | mfma_ring<256x256,8 waves,NN>", "hgemm_wmma_m16n16k16_mma4x4_warp4x4_stages_dsmem")
+_add("hgemm", "G6", "hgemm_w4<256x128> at stages=2 (K % 64 == 0, K >= 384 / 448 for an even / odd K / 64) | mfma_ring<256x128,8 waves,NN>", "hgemm_wmma_m16n16k16_mma4x2_warp4x4_stages_dsmem")
+_add("hgemm", "G6", "hgemm_w4<256x256> at stages=2 (K % 64 == 0, K >= 384 / 448 for an even / odd K / 64) | mfma_ring<256x256,8 waves,NN>", "hgemm_wmma_m16n16k16_mma4x4_warp4x4_stages_dsmem")
 _add("hgemm", "G6", "best<NN>: tile shape by estimated CU utilisation x kernel efficiency (csrc/hgemm.hip best_plan): hgemm_w4<256x256x64, one wave per SIMD> (stages 2; hgemm_pp<256x256x64> when K is not a multiple of 128 or < 384) | hgemm_pp32<4x32 ring> (stages 4) | hgemm_pp<192x256x64> | mfma_ring<128x256> | <64x128> | <64x64> (small problems) | <128x128> (see DISPATCH_EXAMPLES)",
      "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem", "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_x4",
      "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_rr",
      "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_swizzle")
 _add("hgemm", "G6", "mfma_ring<128x128,TN>", "hgemm_mma_m16n8k16_mma2x4_warp4x4_stages_dsmem_tn")
 _add("hgemm", "G6", "best<TN>: hgemm_w4 / hgemm_pp / hgemm_pp32 / mfma_ring as for NN (see DISPATCH_EXAMPLES)", "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_tn_swizzle_x4")
-_add("hgemm", "G6", "hgemm_w4<128x256> at stages=2 (K % 128 == 0, K >= 384) | mfma_ring<128x256,8 waves,TN>", "hgemm_mma_stages_block_swizzle_tn_cute")
+_add("hgemm", "G6", "hgemm_w4<128x256> at stages=2 (K % 64 == 0, K >= 384 / 448 for an even / odd K / 64) | mfma_ring<128x256,8 waves,TN>", "hgemm_mma_stages_block_swizzle_tn_cute")
 
 # ---------------------------------------------------------------- flash-attn (28 + 3)
 _FA_PLAIN = [
@@ -278,15 +278,18 @@ DISPATCH_EXAMPLES = [
     (_W4X2, (4096, 4096, 4096), 3, "mfma_ring<256x256x32,8 waves,stages=3,NN>"),
     (_W4X2, (3072, 3072, 3072), 2, "hgemm_w4<192x192x64,4 waves,96x96 wave tiles,cross-tile LDS-DMA,LDS epilogue,NN>"),
     (_W4X2, (2304, 2304, 2304), 2, "hgemm_w4<192x192x64,4 waves,96x96 wave tiles,cross-tile LDS-DMA,LDS epilogue,NN>"),
-    (_W4X2, (3072, 3072, 3136), 2, "hgemm_pp<192x256x64,8 waves,4 slots,LDS epilogue,NN>"),
+    (_W4X2, (3072, 3072, 3136), 2, "hgemm_w4<192x192x64,4 waves,96x96 wave tiles,cross-tile LDS-DMA,LDS epilogue,NN>"),
+    (_W4X2, (3072, 3072, 320), 2, "hgemm_pp<192x256x64,8 waves,4 slots,LDS epilogue,NN>"),
     (_W4X2, (6144, 6144, 6144), 2, "hgemm_w4<192x256x64,4 waves,96x128 wave tiles,cross-tile LDS-DMA,LDS epilogue,NN>"),
     (_W4X2, (4096, 6144, 4096), 2, "hgemm_w4<256x192x64,4 waves,128x96 wave tiles,cross-tile LDS-DMA,LDS epilogue,NN>"),
     (_W4X2, (3584, 3584, 3584), 2, "hgemm_w4<256x256x64,4 waves,128x128 wave tiles,cross-tile LDS-DMA,LDS epilogue,NN>"),
     (_W4X2, (2560, 2560, 2560), 2, "hgemm_w4<160x160x64,4 waves,80x80 wave tiles,cross-tile LDS-DMA,LDS epilogue,NN>"),
     (_W4X2, (2816, 2816, 2816), 2, "hgemm_w4<128x256x64,4 waves,64x128 wave tiles,cross-tile LDS-DMA,LDS epilogue,NN>"),
     (_W4X2, (3200, 3200, 3200), 2, "hgemm_w4<160x160x64,4 waves,80x80 wave tiles,cross-tile LDS-DMA,LDS epilogue,NN>"),
-    (_W4X2, (4800, 4800, 4800), 2, "mfma_ring<64x64x64,4 waves,stages=2,NN>"),
-    (_W4X2, (2560, 2560, 2624), 2, "mfma_ring<128x256x64,8 waves,stages=2,NN>"),
+    (_W4X2, (4800, 4800, 4800), 2, "hgemm_w4<192x192x64,4 waves,96x96 wave tiles,cross-tile LDS-DMA,LDS epilogue,NN>"),
+    (_W4X2, (4800, 4800, 320), 2, "mfma_ring<64x64x64,4 waves,stages=2,NN>"),
+    (_W4X2, (2560, 2560, 2624), 2, "hgemm_w4<160x160x64,4 waves,80x80 wave tiles,cross-tile LDS-DMA,LDS epilogue,NN>"),
+    (_W4X2, (2560, 2560, 320), 2, "mfma_ring<128x256x64,8 waves,stages=2,NN>"),
     (_W4X2, (1536, 1536, 1536), 2, "mfma_ring<64x64x64,4 waves,stages=2,NN>"),
     (_W4X2, (1792, 1792, 1792), 2, "mfma_ring<64x128x64,4 waves,stages=2,NN>"),
     (_W4X2, (2048, 2048, 2048), 2, "mfma_ring<64x128x64,4 waves,stages=2,NN>"),
@@ -297,7 +300,8 @@ DISPATCH_EXAMPLES = [
     ("hgemm_wmma_m16n16k16_mma4x4_warp4x4_stages_dsmem", (4096, 4096, 4096), 3, "mfma_ring<256x256x32,8 waves,stages=3,NN>"),
     ("hgemm_mma_stages_block_swizzle_tn_cute", (4096, 4096, 4096), 2, "hgemm_w4<128x256x64,4 waves,64x128 wave tiles,cross-tile LDS-DMA,LDS epilogue,TN>"),
     ("hgemm_mma_stages_block_swizzle_tn_cute", (4096, 4096, 4096), 3, "mfma_ring<128x256x64,8 waves,stages=3,TN>"),
-    ("hgemm_mma_stages_block_swizzle_tn_cute", (4096, 4096, 4160), 2, "mfma_ring<128x256x64,8 waves,stages=2,TN>"),
+    ("hgemm_mma_stages_block_swizzle_tn_cute", (4096, 4096, 4160), 2, "hgemm_w4<128x256x64,4 waves,64x128 wave tiles,cross-tile LDS-DMA,LDS epilogue,TN>"),
+    ("hgemm_mma_stages_block_swizzle_tn_cute", (4096, 4096, 320), 2, "mfma_ring<128x256x64,8 waves,stages=2,TN>"),
     ("hgemm_wmma_m16n16k16_mma4x4_warp4x4_stages_dsmem", (4096, 4096, 4096), 2, "hgemm_w4<256x256x64,4 waves,128x128 wave tiles,cross-tile LDS-DMA,LDS epilogue,NN>"),
     ("hgemm_wmma_m16n16k16_mma4x2_warp4x4_stages_dsmem", (4096, 4096, 4096), 2, "hgemm_w4<256x128x64,4 waves,128x64 wave tiles,cross-tile LDS-DMA,LDS epilogue,NN>"),
     ("hgemm_wmma_m16n16k16_mma4x2_warp4x4_stages_dsmem", (4096, 4096, 256), 2, "mfma_ring<256x128x64,8 waves,stages=2,NN>"),

@@ -246,7 +246,7 @@ def test_probe_kernels_stay_correct(built, dev, layout):
 
 @pytest.mark.parametrize("layout", [0, 1])
 def test_one_wave_per_simd_kernel(hg, built, dev, layout):
-    """hgemm_w4 (csrc/hgemm_w4.cuh, what the top rung runs at stages = 2 when K % 128 == 0 and K >= 384): smallest legal
+    """hgemm_w4 (csrc/hgemm_w4.cuh, what the top rung runs at stages = 2 when K % 64 == 0 and K >= 384; 448 when K / 64 is odd): smallest legal
     K (two peeled tiles + one loop pair + two peeled tiles), odd pair counts, rectangular grids, every probe schedule incl.
     the back-to-back-read ones that exposed the zero-fill hazard; bit-identical to the ping-pong kernel (same MFMA shape
     and K order) and repeatable over launches."""
@@ -257,7 +257,7 @@ def test_one_wave_per_simd_kernel(hg, built, dev, layout):
     fn = getattr(hg, name)
     via_name = 0
     for (M, N, K) in ((256, 256, 384), (256, 512, 512), (768, 256, 640), (512, 768, 1152), (1024, 1024, 2048),
-                      (4096, 4096, 384), (4096, 3584, 896)):
+                      (4096, 4096, 384), (4096, 3584, 896), (256, 256, 448), (512, 256, 576), (4096, 4096, 704)):  # last three: odd K / 64
         runs_w4 = built.manifest.describe(name, (M, N, K), 2).startswith("hgemm_w4")  # the tile policy decides by M, N
         via_name += runs_w4
         a, b = seeded(170 + K, M, K), seeded(171 + K, K, N)
@@ -270,13 +270,14 @@ def test_one_wave_per_simd_kernel(hg, built, dev, layout):
             c = torch.zeros(M, N, dtype=torch.half, device=dev)
             fn(ad, bb, c, 2, bool(rep & 1), 512)
             assert torch.equal(c, base), (M, N, K, rep)
-        for var in (0, 1, 3, 4, 9, 10, 13, 20, 25, 26, 27, 28):
+        for var in ((26,) if (K // 64) & 1 else (0, 1, 3, 4, 9, 10, 13, 20, 25, 26, 27, 28)):  # odd tile counts: production schedule only
             c = torch.zeros(M, N, dtype=torch.half, device=dev)
             host.hgemm_variant(14, layout, 1, 64, var, ad, bb, c, swizzle=1, swizzle_stride=512)
             assert torch.equal(c, base), (M, N, K, var)
     assert via_name >= 2
-    # K not a multiple of 128, or too short for the peeled structure: the ping-pong kernel answers, same result
-    for (M, N, K) in ((4096, 4096, 320), (4096, 4096, 256), (256, 256, 448)):
+    # K too short for the peeled structure (< 6 tiles, or 5 = odd and < 7), or not a multiple of 64: the ping-pong kernel
+    # answers, same result
+    for (M, N, K) in ((4096, 4096, 320), (4096, 4096, 256), (256, 256, 352)):
         if M == 4096:
             assert built.manifest.describe(name, (M, N, K), 2).startswith("hgemm_pp"), (M, N, K)
         a, b = seeded(180 + K, M, K), seeded(181 + K, K, N)
@@ -296,7 +297,7 @@ def test_one_wave_per_simd_kernel_on_192_tiles(hg, built, dev, layout, tile, BM,
     5-rows-per-store epilogue; against the fp32 oracle and bit-identical to the 128x128 ring kernel where that tiles."""
     from cuda_learn_notes_amd import host
     from cuda_learn_notes_amd.bench_utils import as_col_major
-    for (mt, nt_, K) in ((1, 1, 384), (2, 3, 640), (4, 2, 1152), (5, 5, 512)):
+    for (mt, nt_, K) in ((1, 1, 384), (2, 3, 640), (4, 2, 1152), (5, 5, 512), (1, 2, 448), (3, 1, 704)):
         M, N = mt * BM, nt_ * BN
         a, b = seeded(270 + K + tile, M, K), seeded(271 + K + tile, K, N)
         bb = (as_col_major(b) if layout else b).to(dev)
@@ -326,11 +327,11 @@ def test_one_wave_per_simd_kernel_on_192_tiles(hg, built, dev, layout, tile, BM,
     ("hgemm_mma_stages_block_swizzle_tn_cute", 1, 128, 256)])
 def test_fixed_tile_rungs_on_the_one_wave_per_simd_kernel(hg, built, dev, name, layout, BM, BN):
     """The rungs whose name fixes the block tile (reference 256x256 / 256x128 WMMA stage kernels, the CuTe 128x256 TN
-    kernel) run hgemm_w4 of THAT tile at stages = 2 when K % 128 == 0 and K >= 384, the ring of the same tile otherwise;
+    kernel) run hgemm_w4 of THAT tile at stages = 2 when K has >= 6 (even) / >= 7 (odd) whole 64-wide tiles, the ring of the same tile otherwise;
     both answers against the fp32 oracle, and identical to each other (same MFMA shape and K order)."""
     from cuda_learn_notes_amd.bench_utils import as_col_major
     fn = getattr(hg, name)
-    for (mt, nt_, K) in ((1, 1, 384), (3, 2, 640), (2, 5, 1152)):
+    for (mt, nt_, K) in ((1, 1, 384), (3, 2, 640), (2, 5, 1152), (2, 1, 448), (1, 3, 832)):
         M, N = mt * BM, nt_ * BN
         assert built.manifest.describe(name, (M, N, K), 2).startswith("hgemm_w4<%dx%dx64" % (BM, BN)), (M, N, K)
         assert built.manifest.describe(name, (M, N, K), 3).startswith("mfma_ring<%dx%d" % (BM, BN)), (M, N, K)
