@@ -135,6 +135,20 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
 #pragma unroll
     for (int r = 0; r < 16; ++r) ot[b][r] = 0.f;
   float m_run = PRE ? 0.f : -1.0e30f, l_run = 0.f;
+  // OPT_SUMM: the row sums ride on the matrix pipe -- one more MFMA per 16-key step with an all-ones A operand:
+  // lacc[m][n] = sum_k P^T[k][n] for every m, i.e. each lane's 16 registers all hold the sum of ITS query row (no
+  // per-score v_add, no cross-half exchange at the end). +25 % MFMAs at D = 64 for -42 VALU instructions per tile.
+  constexpr bool SUMM = (OPT & OPT_SUMM) != 0;
+  static_assert(!SUMM || (PRE && NSP == 1), "OPT_SUMM: on the pre-scaled single-wave-per-row-group kernel");
+  f16v lacc;
+  h8 ones;
+  if constexpr (SUMM) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lacc[r] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (half_t)1.0f;
+    asm volatile("" : "+v"(ones));
+  }
   f16v minit;  // OPT_PRE: -m in all 16 registers (opaque to hipcc: otherwise the splat is re-materialised per tile)
 #pragma unroll
   for (int r = 0; r < 16; ++r) minit[r] = 0.f;
@@ -280,6 +294,10 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
         const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);
         m_run = m_new;
         l_run *= alpha;
+        if constexpr (SUMM) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) lacc[r] *= alpha;
+        }
         if constexpr (PRE) {  // the pending scores were accumulated from the old -m
 #pragma unroll
           for (int kb2 = 0; kb2 < BCB; ++kb2)
@@ -311,11 +329,11 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
           const float x1 = PRE ? s[kb2][r + 1] : fmaf(s[kb2][r + 1], scale_log2e, nm);
           const float a0 = (ABL & 2) ? s[kb2][r] : __builtin_amdgcn_exp2f(x0);
           const float a1 = (ABL & 2) ? s[kb2][r + 1] : __builtin_amdgcn_exp2f(x1);
-          psum += a0 + a1;
+          if constexpr (!SUMM) psum += a0 + a1;
           const h2 a = __builtin_convertvector(f2{a0, a1}, h2);
           pf[u][e] = a[0], pf[u][e + 1] = a[1];
         }
-      l_run += psum;
+      if constexpr (!SUMM) l_run += psum;
     };
     if constexpr (SPLIT) {
       valu_prio(true);
@@ -358,6 +376,8 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
         for (int idx = i0; idx < i1; ++idx) {
           const int st = idx / (DHR / 32), b = idx % (DHR / 32);
           ot[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[idx % PD], pf[st], ot[b], 0, 0, 0);
+          if constexpr (SUMM)
+            if (b == DHR / 32 - 1) lacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf[st], lacc, 0, 0, 0);
           if (idx + PD < NPV) vf[idx % PD] = v_frag(idx + PD);
           if (PD > 1 || (idx & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
@@ -389,7 +409,9 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
   if constexpr ((ABL & 128) != 0) life[8] = __builtin_amdgcn_s_memrealtime();
   // ---- epilogue: O = O^T / l, staged through LDS (wave-private rows)
   float l_tot;
-  {
+  if constexpr (SUMM) {
+    l_tot = lacc[0];
+  } else {
     const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
     l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
   }

@@ -70,6 +70,10 @@ CLN_API int cln_fa2_variant(int D, int nw, int vt, int opt, int abl, const void*
   if (D == 64 && abl == ABLN) return fa2::launch_dsplit<64, 1, 4, 13 | fa2::OPT_STAGGER | fa2::OPT_PRE, ABLL>(q, k, v, o, B, H, N, (hipStream_t)stream);
   PPA(520, 1) PPA(521, 2) PPA(522, 64) PPA(523, 8) PPA(524, 16) PPA(525, 24) PPA(526, 2 | 64) PPA(527, 1 | 2 | 64)  // energy ablations of the shipped C4 kernel
   PPA(528, 128)  // life stamps of every wave
+  // 530.. = row sums on the matrix pipe (OPT_SUMM)
+  if (D == 64 && abl == 530) return fa2::launch_dsplit<64, 1, 4, 13 | fa2::OPT_STAGGER | fa2::OPT_PRE | fa2::OPT_SUMM>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 64 && abl == 531) return fa2::launch_dsplit<64, 1, 2, 13 | fa2::OPT_STAGGER | fa2::OPT_PRE | fa2::OPT_SUMM>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 128 && abl == 530) return fa2::launch_dsplit<128, 1, 2, 15 | fa2::OPT_PRE | fa2::OPT_SUMM>(q, k, v, o, B, H, N, (hipStream_t)stream);
 #undef PPA
   if (D == 64 && abl == 510) return fa2::launch_dsplit<64, 1, 4, 13 | fa2::OPT_PRE | fa2::OPT_PD16>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 64 && abl == 511) return fa2::launch_dsplit<64, 1, 2, 13 | fa2::OPT_STAGGER | fa2::OPT_PRE | fa2::OPT_PD8>(q, k, v, o, B, H, N, (hipStream_t)stream);
