@@ -17,12 +17,13 @@
 #include "flash_attn_v2.cuh"
 #include "flash_attn_w4.cuh"
 #include "flash_attn_dsplit2.cuh"
+#include "flash_attn_m16.cuh"
 #include <string.h>
 
 namespace {
 
 enum FaFamily { FAM_SPLIT_KV = 0, FAM_SPLIT_Q = 1 };
-enum FaKind { K_NONE = 0, K_SPLITKV, K_LOAD_THEN_COMPUTE, K_V2, K_DSPLIT, K_DWIDE, K_RB, K_DSPLIT64R };
+enum FaKind { K_NONE = 0, K_SPLITKV, K_LOAD_THEN_COMPUTE, K_V2, K_DSPLIT, K_DWIDE, K_RB, K_DSPLIT64R, K_M16 };
 
 struct FaPlan {
   int rc = CLN_OK;     // CLN_ERR_* when the shape is not supported
@@ -62,11 +63,13 @@ FaPlan fa2_plan(int family, bool vt, int B, int H, int N, int D, int stages, int
     }
     if (!vt && N % 256 == 0 && bh * (N / 256) >= 192) {
       // enough 256-row workgroups to occupy most of the chip:
-      //  D = 64 / 128: ping-pong kernel (flash_attn_dsplit.cuh), or -- where W4_PRODUCTION_* says it measured faster --
-      //                the one-wave-per-SIMD kernel with the hand-placed stream (flash_attn_w4.cuh)
+      //  D = 64 / 128: ping-pong kernel on 16x16x32 MFMAs (flash_attn_m16.cuh: the energy-cheaper matrix shape, +3.5-5 %
+      //                at D = 64 and +5.5-6.5 % at D = 128 over the 32x32x16 form of flash_attn_dsplit.cuh,
+      //                profiles/r02_fa_m16_probe.log), or -- where W4_PRODUCTION_* says it measured faster -- the
+      //                one-wave-per-SIMD kernel with the hand-placed stream (flash_attn_w4.cuh)
       //  D = 256: two-group ping-pong kernel, 8 waves x 32 rows (flash_attn_dsplit.cuh)
-      if (D == 64) return p.kind = fa2::W4_PRODUCTION_D64 ? K_RB : K_DSPLIT, p.d_inst = 64, p.nw = fa2::W4_PRODUCTION_D64 ? 4 : 8, p.bc = fa2::W4_PRODUCTION_D64 ? 64 : 128, p;
-      if (D == 128) return p.kind = fa2::W4_PRODUCTION_D128 ? K_RB : K_DSPLIT, p.d_inst = 128, p.nw = fa2::W4_PRODUCTION_D128 ? 4 : 8, p.bc = 64, p;
+      if (D == 64) return p.kind = fa2::W4_PRODUCTION_D64 ? K_RB : K_M16, p.d_inst = 64, p.nw = fa2::W4_PRODUCTION_D64 ? 4 : 8, p.bc = fa2::W4_PRODUCTION_D64 ? 64 : 128, p;
+      if (D == 128) return p.kind = fa2::W4_PRODUCTION_D128 ? K_RB : K_M16, p.d_inst = 128, p.nw = fa2::W4_PRODUCTION_D128 ? 4 : 8, p.bc = fa2::W4_PRODUCTION_D128 ? 64 : 128, p;
       if (D == 256) return p.kind = K_DSPLIT, p.d_inst = 256, p.nw = 8, p.bc = 32, p;
     }
     // v2 kernel: the largest of 8 / 4 / 2 waves (x 32 query rows) that N allows AND that still gives every one of the
@@ -148,13 +151,15 @@ int fa2_run(const FaPlan& p, const void* q, const void* k, const void* v, void* 
         if (D == 128) return fa2::launch_fa_w4<128, fa2::W4_VAR_D128>(q, k, v, o, B, H, N, s);
       }
       return CLN_ERR_UNSUPPORTED;
+    case K_M16:
+      if constexpr (!VT) {
+        if (D == 64) return fa2::launch_m16<64, 32, 128, 8>(q, k, v, o, B, H, N, s);
+        if (D == 128) return fa2::launch_m16<128, 32, 128, 4>(q, k, v, o, B, H, N, s);  // 128-key tiles: +3 % over 64
+      }
+      return CLN_ERR_UNSUPPORTED;
     case K_DSPLIT:
       if constexpr (!VT) {
-        // D = 64 (config C4): 128-key tiles, half of the exponentials moved into the QK^T phase (OPT_STAGGER).
-        // OPT_PRE (Q pre-scaled, accumulators started at -m: 2 of ~5 VALU instructions per score gone): +6-8 % at
-        // D = 64 (834 vs 787 TF at C4, 981 vs 904 at [1,48,8192,64]), +3-4 % at D = 128 (profiles/r02_fa_probe_pre.log)
-        if (D == 64) return fa2::launch_dsplit<64, 1, 4, 13 | fa2::OPT_STAGGER | fa2::OPT_PRE>(q, k, v, o, B, H, N, s);
-        if (D == 128) return fa2::launch_dsplit<128, 1, 2, fa2::OPT_DEFAULT | fa2::OPT_KPRE | fa2::OPT_PRE>(q, k, v, o, B, H, N, s);
+        // (the D = 64 / 128 forms of this kernel -- 32x32x16 MFMAs -- are in the probe library: variants 500 of kind 8)
         if (D == 256) return fa2::launch_dsplit<256, 1, 1, fa2::OPT_DEFAULT | fa2::OPT_KPRE>(q, k, v, o, B, H, N, s);
         return fa::launch_fa2_large_d(q, k, v, o, B, H, N, D, s);
       }
@@ -196,11 +201,13 @@ int fa2_describe(int family, bool vt, int B, int H, int N, int D, int stages, in
     case K_RB:
       return snprintf(buf, len, "fa2_fwd_w4<D=%d,BC=%d,pre-scaled Q> 4 waves x 64 rows, 1 wave/SIMD, hand-placed stream, K/V "
                                 "fragments shared by 2 row groups%s", D, p.bc, st);
+    case K_M16:
+      return snprintf(buf, len, "fa2_fwd_m16<D=%d,BC=%d,16x16x32 MFMA,pre-scaled Q> 8 waves x 32 rows, two groups one phase apart%s", D, p.bc, st);
     case K_DSPLIT:
       if (p.d_inst != D)
         return snprintf(buf, len, "fa2_fwd_dsplit<D=%d,NSP=2,BC=32,LDS geometry of D=%d> 8 waves, pairs split the real d evenly%s", D, p.d_inst, st);
-      return snprintf(buf, len, "fa2_fwd_dsplit<D=%d,NSP=%d,BC=%d%s> 8 waves, two groups one phase apart%s", D,
-                      D == 512 ? 2 : 1, p.bc, D <= 128 ? ",pre-scaled Q" : "", st);
+      return snprintf(buf, len, "fa2_fwd_dsplit<D=%d,NSP=%d,BC=%d> 8 waves, two groups one phase apart%s", D,
+                      D == 512 ? 2 : 1, p.bc, st);
     case K_DWIDE:
       if (p.d_inst != D)
         return snprintf(buf, len, "fa2_fwd_dwide<D=%d,PAD=%d> %d waves split d%s", p.d_inst, D, p.nw, st);

@@ -9,6 +9,7 @@
 #include "flash_attn_rb.cuh"
 #include "flash_attn_w4.cuh"
 #include "flash_attn_dsplit2.cuh"
+#include "flash_attn_m16.cuh"
 #include <type_traits>
 
 #define V3(DD, NWW, OPTT) \
@@ -70,6 +71,16 @@ CLN_API int cln_fa2_variant(int D, int nw, int vt, int opt, int abl, const void*
   if (D == 64 && abl == ABLN) return fa2::launch_dsplit<64, 1, 4, 13 | fa2::OPT_STAGGER | fa2::OPT_PRE, ABLL>(q, k, v, o, B, H, N, (hipStream_t)stream);
   PPA(520, 1) PPA(521, 2) PPA(522, 64) PPA(523, 8) PPA(524, 16) PPA(525, 24) PPA(526, 2 | 64) PPA(527, 1 | 2 | 64)  // energy ablations of the shipped C4 kernel
   PPA(528, 128)  // life stamps of every wave
+  // 540.. = the ping-pong kernel on 16x16x32 MFMAs (flash_attn_m16.cuh): fragment prefetch depth 4 / 2 / 8;
+  // 545.. = 64 query rows per wave (512-row workgroups, 64-key tiles); D = 128: 540 / 542 (32 rows, 64-key tiles)
+  if (D == 64 && abl == 540) return fa2::launch_m16<64, 32, 128, 4>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 64 && abl == 541) return fa2::launch_m16<64, 32, 128, 2>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 64 && abl == 542) return fa2::launch_m16<64, 32, 128, 8>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 64 && abl == 545) return fa2::launch_m16<64, 64, 64, 4>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 64 && abl == 546) return fa2::launch_m16<64, 64, 64, 8>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 128 && abl == 540) return fa2::launch_m16<128, 32, 64, 4>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 128 && abl == 542) return fa2::launch_m16<128, 32, 64, 8>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 128 && abl == 543) return fa2::launch_m16<128, 32, 128, 4>(q, k, v, o, B, H, N, (hipStream_t)stream);
   // 530.. = row sums on the matrix pipe (OPT_SUMM)
   if (D == 64 && abl == 530) return fa2::launch_dsplit<64, 1, 4, 13 | fa2::OPT_STAGGER | fa2::OPT_PRE | fa2::OPT_SUMM>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 64 && abl == 531) return fa2::launch_dsplit<64, 1, 2, 13 | fa2::OPT_STAGGER | fa2::OPT_PRE | fa2::OPT_SUMM>(q, k, v, o, B, H, N, (hipStream_t)stream);

@@ -40,7 +40,7 @@ for (B, H, N, D) in SHAPES:
     for abl in ABLS:
         cands.append(("w4 %d" % abl, lambda abl=abl: host.fa2_variant((4, 0, 0, abl), q, k, v, o)))
     for abl in [int(x) for x in os.environ.get("FA_PP2", "").split(",") if x]:
-        if abl < 600 or (D == 64 and N % (256 if abl >= 710 else 512) == 0):  # 5xx: variants of the shipped ping-pong kernel
+        if (abl < 600 and (abl not in (545, 546) or (D == 64 and N % 512 == 0))) or (abl >= 600 and D == 64 and N % (256 if abl >= 710 else 512) == 0):  # 5xx: variants of the shipped ping-pong kernel
             cands.append(("pp64rows %d" % abl, lambda abl=abl: host.fa2_variant((8, 0, 0, abl), q, k, v, o)))
     ok = {}
     for tag, fn in cands:
