@@ -34,6 +34,9 @@ def parse():
     p.add_argument("--stages", type=int, default=2)
     p.add_argument("--prewarm", type=float, default=0.6, help="seconds of untimed back-to-back launches before warmup")
     p.add_argument("--no-extras", action="store_true", help="skip FA2 / rocBLAS / CPU baseline side measurements")
+    p.add_argument("--launch", choices=["graph", "eager"], default="eager",
+                   help="how the K timed steps reach the GPU: K eager launches from Python (default: host enqueue 9.5 us per step against a "
+                        "94 us kernel) or one hipGraph holding the K launches (measured slower: +26 us per kernel node, 1141 vs 1442 TF)")
     return p.parse_args()
 
 
@@ -101,16 +104,42 @@ def main():
     # of a launch burst run on a higher (un-sustained) or lower (ramping) clock -- a 20-step run read 12-14 % low in
     # round 1. After >= 0.5 s of back-to-back launches the 20-step and the 500-step numbers agree.
     bu.prewarm(step, args.prewarm)
+    settle_hist = bu.settle(step, max(20, min(args.steps, 200)))
+    # --launch graph: the K timed steps as ONE hipGraph (K kernel nodes, captured from the same Python calls). Measured
+    # in round 2 (profiles/r02_bench_launch_modes.log): the graph costs +26 us per kernel node (1141 vs 1442 TF at 20
+    # steps) while eager enqueue takes 9.5 us of host time per 94 us kernel, so eager is the default.
+    graph, launch_mode = None, "eager"
+    if args.launch == "graph":
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                for _ in range(args.steps):
+                    step()
+            torch.cuda.synchronize()
+            launch_mode = "hipGraph of %d kernel launches" % args.steps
+        except Exception as e:  # noqa: BLE001 -- capture not available: measure eagerly and say so
+            graph, launch_mode = None, "eager (graph capture failed: %s)" % str(e)[:80]
+            torch.cuda.synchronize()
+
+    def run_steps():
+        if graph is not None:
+            graph.replay()
+        else:
+            for _ in range(args.steps):
+                step()
+
     for _ in range(args.warmup):
         step()
+    if graph is not None:
+        graph.replay()  # untimed: first replay uploads the graph
     barrier()
     stream = torch.cuda.current_stream()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record(stream)
-    for _ in range(args.steps):
-        step()
+    run_steps()
     ev1.record(stream)
+    t_enq = time.perf_counter() - t0  # host time to hand the K steps to the GPU
     barrier()
     elapsed = time.perf_counter() - t0
     elapsed = bu.max_over_ranks(elapsed, dist, None)
@@ -144,7 +173,9 @@ def main():
         "config": {"workload": "HGEMM fp16 NN M=N=K=%d, stages=%d, block swizzle stride %d (BASELINE config C3)"
                                % (M, args.stages, stride),
                    "kernel": "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem", "parallelism": "replicas x%d" % world,
-                   "prewarm_s": args.prewarm},
+                   "prewarm_s": args.prewarm, "launch": launch_mode,
+                   "settle_ms_per_step": [round(x, 5) for x in settle_hist],
+                   "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 5)},
         "pct_of_fp16_mfma_peak": round(100.0 * achieved / bu.PEAK_FP16_MFMA_TFLOPS, 2),
         "roofline": roofline,
     }
