@@ -40,7 +40,7 @@ def parse():
     return p.parse_args()
 
 
-def fa_roofline(kern, shape, pmc_file, dev, bu, profiles):
+def fa_roofline(kern, shape, pmc_file, dev, bu, profiles, kernel_desc=""):
     """roofline object of one FlashAttention-2 forward config: algorithmic flops (4 B H N^2 D) / mean launch
     duration from HIP events over `iters` back-to-back launches on the launch stream (after a time-based pre-warm)."""
     B_, H_, N_, D = shape
@@ -52,8 +52,9 @@ def fa_roofline(kern, shape, pmc_file, dev, bu, profiles):
     ms = min(bu.time_region_events(fn, iters), bu.time_region_events(fn, iters))
     flops = bu.mha_flops_conventional(B_, H_, N_, D)
     ach = flops / (ms * 1e-3) * 1e-12
-    busy, src = bu.pmc_value(profiles, pmc_file, "mfma_busy_frac")
-    traffic, _ = bu.pmc_value(profiles, pmc_file, "hbm_traffic_bytes_per_launch")
+    ksub = kernel_desc.split("<")[0] + "_kernel" if kernel_desc else ""  # counters must come from THIS kernel family
+    busy, src = bu.pmc_value(profiles, pmc_file, "mfma_busy_frac", ksub)
+    traffic, _ = bu.pmc_value(profiles, pmc_file, "hbm_traffic_bytes_per_launch", ksub)
     return {"bound": "mfma", "achieved": round(ach, 2), "peak": bu.PEAK_FP16_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / bu.PEAK_FP16_MFMA_TFLOPS, 4), "traffic": round(traffic) if traffic else None,
             "mfma_busy": round(busy, 4) if busy else None, "pmc_source": src, "shape": [B_, H_, N_, D],
@@ -210,8 +211,9 @@ def main():
             for key, kern, shape, pmc in (("roofline_fa2_c4_d64", sq, (4, 8, 2048, 64), "pmc_fa_d64"),
                                           ("roofline_fa2_d128", sq, (4, 8, 2048, 128), "pmc_fa_d128"),
                                           ("roofline_fa2_c5_d512", tq, (1, 32, 4096, 512), "pmc_fa_d512")):
-                r, (q, k, v, o) = fa_roofline(kern, shape, pmc, dev, bu, profiles)
-                r["kernel"] = pkg.manifest.describe(kern.__name__, shape, 2)
+                desc = pkg.manifest.describe(kern.__name__, shape, 2)
+                r, (q, k, v, o) = fa_roofline(kern, shape, pmc, dev, bu, profiles, desc)
+                r["kernel"] = desc
                 # the FlashAttention-2-ROCm row available on the box is torch SDPA (the `flash_attn` package is not in
                 # the image): each backend forced in turn, so the row says WHICH implementation it is
                 r["torch_sdpa"] = bu.sdpa_rows(q, k, v, side_ms)

@@ -298,4 +298,292 @@ int launch_m16(const void* q, const void* k, const void* v, void* o, int B, int 
   return cln_check_launch();
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Head dim 512 (config C5) on 16x16x32 MFMAs: the d-split PAIR form of flash_attn_dsplit.cuh (NSP = 2) in the lane layout
+// above. A pair of waves (wave, wave ^ 1) owns 32 query rows, each holds one 256-column half of d: Q 64 + O^T 128
+// registers, a partial S^T over its half, the partials swapped through LDS (4 KiB each way), both run the same softmax on
+// the (commutative, hence bit-identical) sum and each accumulates its own 256 output columns. 128 query rows per
+// workgroup, 32-key tiles, 1024-byte rows: every row starts at bank 0, so the K image is chunk ^ (row & 15) and the V
+// image chunk ^ ((row & 15) << 1) (16 rows x 32 bytes of one transposing read = all 64 banks twice); a DMA piece is ONE
+// row (row = 4*i + widx), so both swizzles carry a per-piece term. Q is pre-scaled; the wave with part = 0 starts its
+// partial at -m through the MFMA C operand, so the exchanged sum is already relative to the running max.
+// PROBE ONLY (variants 540 / 541 of kind 8, tested, not dispatched): +3.2 % at config C5 (1025 vs 994 TF), but rounding
+// Q * log2(e)/sqrt(512) to fp16 raises the max-abs-error from 1.0e-4 to 3.1e-4 at C5 (3.6e-4 -> 9.7e-4 at [2,3,256,512]);
+// a form that scales the exchanged sum in fp32 instead measured +0.8 % only and was dropped (profiles/r02_fa_m16_pair_probe.log).
+struct GeoM16Pair {
+  static constexpr int D = 512, DH = 256, BC = 32, NW = 8, BR = 128, NT = 512;
+  static constexpr int ROW = D * 2, TILE = BC * ROW, STAGE = 2 * TILE, RING = 2 * STAGE, SX = NW * 4096;
+  static constexpr int OS = DH * 2 + 16, EPI = NW * 32 * OS;
+  static constexpr int LDS_BYTES = RING + SX > EPI ? RING + SX : EPI;
+  static constexpr int PPW = TILE / 1024 / 4;
+  static constexpr int NKB = BC / 16, NKS = DH / 32, NQB = 2, NDB = DH / 16, NQK = NKB * NKS, NPV = NDB;
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+  static __device__ __forceinline__ int swz_k(int row) { return row & 15; }
+  static __device__ __forceinline__ int swz_v(int row) { return (row & 15) << 1; }
+};
+
+template <int PD = 2>
+__global__ __launch_bounds__(512, 2) void fa2_fwd_m16_pair_kernel(const half_t* __restrict__ Q, const half_t* __restrict__ K,
+                                                                  const half_t* __restrict__ V, half_t* __restrict__ O,
+                                                                  int N, int n_qblk, int n_heads, float scale_log2e) {
+  using G = GeoM16Pair;
+  constexpr int D = G::D, DH = G::DH, NKB = G::NKB, NKS = G::NKS, NQB = G::NQB, NDB = G::NDB, NQK = G::NQK, NPV = G::NPV;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15, g4 = lane >> 4;
+  const int grp = wave >> 2, widx = wave & 3;
+  const int part = widx & 1, rg = grp * 2 + (widx >> 1);
+
+  int head_i, qb_i;
+  {
+    const int bid = blockIdx.x;
+    if ((n_heads & 7) == 0) {
+      const int xcd = bid & 7, k = bid >> 3;
+      head_i = (k / n_qblk) * 8 + xcd;
+      qb_i = k - (k / n_qblk) * n_qblk;
+    } else {
+      head_i = bid / n_qblk;
+      qb_i = bid - head_i * n_qblk;
+    }
+  }
+  const size_t head = (size_t)head_i * N * D;
+  const int q_row0 = qb_i * G::BR + rg * 32;
+  const unsigned lds0 = hgemm::lds_addr_of(smem);
+
+  // ---- LDS-DMA: a piece = row 4*i + widx (1 KiB), lane = chunk position; source chunk = position ^ swizzle(row), and
+  // swizzle(4*i + widx) = swizzle(widx) ^ swizzle(4*i) (disjoint bits)
+  const char* src_h = reinterpret_cast<const char*>((grp == 0 ? K : V) + head);
+  const unsigned src_lane = (unsigned)((lane ^ (grp == 0 ? G::swz_k(widx) : G::swz_v(widx))) << 4);
+  auto dma_piece = [&](int jt, int slot, int i) __attribute__((always_inline)) {
+    const int piece = i * 4 + widx;
+    const unsigned voff = src_lane ^ (unsigned)((grp == 0 ? G::swz_k(4 * i) : G::swz_v(4 * i)) << 4);
+    const char* s = src_h + (size_t)jt * G::TILE + piece * 1024;
+    hgemm::glds16_asm(s, voff, lds0 + slot * G::STAGE + grp * G::TILE + piece * 1024);
+  };
+
+  // ---- Q fragments of this wave's half of d, pre-scaled
+  h8 qf[NQB][NKS];
+#pragma unroll
+  for (int qb = 0; qb < NQB; ++qb) {
+    const half_t* qp = Q + head + (size_t)(q_row0 + qb * 16 + i16) * D + part * DH + g4 * 8;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) qf[qb][ks] = *reinterpret_cast<const h8*>(qp + ks * 32);
+  }
+  f4 ot[NDB][NQB];
+#pragma unroll
+  for (int b = 0; b < NDB; ++b)
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) ot[b][qb] = f4{0.f, 0.f, 0.f, 0.f};
+  float m_run[NQB], l_run[NQB];
+  f4 minit[NQB];
+#pragma unroll
+  for (int qb = 0; qb < NQB; ++qb) {
+    m_run[qb] = 0.f, l_run[qb] = 0.f;
+    minit[qb] = f4{0.f, 0.f, 0.f, 0.f};
+    asm volatile("" : "+v"(minit[qb]));
+  }
+
+  const int T = N / G::BC;
+  __builtin_assume(T > 0);
+#pragma unroll
+  for (int i = 0; i < G::PPW; ++i) dma_piece(0, 0, i);
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  {
+    const half_t sc = (half_t)scale_log2e;
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb)
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) qf[qb][ks] = qf[qb][ks] * sc;
+  }
+#pragma unroll
+  for (int qb = 0; qb < NQB; ++qb)
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+v"(qf[qb][ks]));
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  // K fragment (kb, ks): row 16*kb + i16, logical chunk part*32 + 4*ks + g4; V^T fragment (db): rows 4*g4 + (i16 >> 2)
+  // and + 16, logical chunk part*32 + 2*db + ((i16 & 3) >> 1), 8-byte half i16 & 1
+  const int kbase = i16 * G::ROW + ((g4 ^ G::swz_k(i16)) << 4) + part * 512;
+  const int v_row = 4 * g4 + (i16 >> 2);
+  const int vbase = v_row * G::ROW + (((((i16 & 3) >> 1)) ^ G::swz_v(v_row)) << 4) + ((i16 & 1) << 3) + part * 512;
+  char* sx_mine = smem + G::RING + wave * 4096 + lane * 16;
+  const char* sx_peer = smem + G::RING + (wave ^ 1) * 4096 + lane * 16;
+  const bool lead = part == 0;  // this wave's partial starts at -m
+
+  if (grp == 1) {
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+
+  for (int j = 0; j < T; ++j) {
+    const int jn = j + 1 < T ? j + 1 : T - 1;
+    const int kb_j = kbase + (j & 1) * G::STAGE, vb_j = vbase + (j & 1) * G::STAGE + G::TILE;
+    auto k_frag = [&](int t) __attribute__((always_inline)) {  // t = kb * NKS + ks
+      const int kb = t / NKS, ks = t % NKS;
+      return *reinterpret_cast<const h8*>(smem + (kb_j ^ (ks << 6)) + kb * 16 * G::ROW);
+    };
+    auto v_frag = [&](int db) __attribute__((always_inline)) {
+      const char* vp = smem + (vb_j ^ (db << 5));
+      return h8_cat(lds_read_tr16(vp), lds_read_tr16(vp + 16 * G::ROW));
+    };
+    // ================= phase A: partial S^T over this wave's half of d
+    f4 s[NKB][NQB];
+    {
+      h8 kf[PD];
+#pragma unroll
+      for (int i = 0; i < PD; ++i) kf[i] = k_frag(i);
+      constexpr int DSTEP = NQK / G::PPW;
+#pragma unroll
+      for (int t = 0; t < NQK; ++t) {
+        const int kb = t / NKS, ks = t % NKS;
+#pragma unroll
+        for (int qb = 0; qb < NQB; ++qb) {
+          if (ks == 0) {
+            const f4 c0 = lead ? minit[qb] : f4{0.f, 0.f, 0.f, 0.f};
+            s[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[t % PD], qf[qb][0], c0, 0, 0, 0);
+          } else {
+            s[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[t % PD], qf[qb][ks], s[kb][qb], 0, 0, 0);
+          }
+        }
+        if (t + PD < NQK) kf[t % PD] = k_frag(t + PD);
+        if ((t % DSTEP) == DSTEP - 1) dma_piece(jn, (j + 1) & 1, t / DSTEP);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int qb = 0; qb < NQB; ++qb) *reinterpret_cast<f4*>(sx_mine + (kb * NQB + qb) * 1024) = s[kb][qb];
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the partial is in LDS before the barrier
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    // ================= phase B: S = own + partner's partial, softmax, O^T[half] += V[:, half]^T P^T
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int qb = 0; qb < NQB; ++qb) {
+        const f4 pp = *reinterpret_cast<const f4*>(sx_peer + (kb * NQB + qb) * 1024);
+        s[kb][qb] += pp;
+      }
+    h8 vf[PD];
+#pragma unroll
+    for (int i = 0; i < PD; ++i) vf[i] = v_frag(i);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      float d[NQB];
+      bool grow = false;
+#pragma unroll
+      for (int qb = 0; qb < NQB; ++qb) {
+        float mx = s[0][qb][0];
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kb][qb][r]);
+        const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+        mx = fmaxf(__uint_as_float(s16[0]), __uint_as_float(s16[1]));
+        const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+        d[qb] = fmaxf(__uint_as_float(s32[0]), __uint_as_float(s32[1]));
+        grow |= d[qb] > 8.0f;
+      }
+      const bool first = j == 0;
+      if (first || __builtin_amdgcn_ballot_w64(grow) != 0) {
+#pragma unroll
+        for (int qb = 0; qb < NQB; ++qb) {
+          const float delta = first ? d[qb] : fmaxf(d[qb], 0.f);
+          const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-delta);
+          m_run[qb] += delta;
+          l_run[qb] *= alpha;
+#pragma unroll
+          for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[kb][qb][r] -= delta;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) minit[qb][r] = -m_run[qb];
+          asm volatile("" : "+v"(minit[qb]));
+#pragma unroll
+          for (int b = 0; b < NDB; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ot[b][qb][r] *= alpha;
+        }
+      }
+    }
+    h8 pf[NQB];  // the one 32-key step: k-slot 8*g4 + e <-> key 16*(e >> 2) + 4*g4 + (e & 3)
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) {
+      float psum = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {
+        const int kb = e >> 2, r = e & 3;
+        const float a0 = __builtin_amdgcn_exp2f(s[kb][qb][r]);
+        const float a1 = __builtin_amdgcn_exp2f(s[kb][qb][r + 1]);
+        psum += a0 + a1;
+        const h2 a = __builtin_convertvector(f2{a0, a1}, h2);
+        pf[qb][e] = a[0], pf[qb][e + 1] = a[1];
+      }
+      l_run[qb] += psum;
+    }
+#pragma unroll
+    for (int db = 0; db < NPV; ++db) {
+#pragma unroll
+      for (int qb = 0; qb < NQB; ++qb) ot[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[db % PD], pf[qb], ot[db][qb], 0, 0, 0);
+      if (db + PD < NPV) vf[db % PD] = v_frag(db + PD);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    hgemm::wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+  if (grp == 0) {
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+
+  // ---- epilogue: this wave's 256 output columns of its 32 rows, staged through LDS (wave-private rows)
+  const int lane_e = cln_fresh_lane(), i16_e = lane_e & 15, g4_e = lane_e >> 4;
+  char* ob = smem + wave * (32 * G::OS);
+#pragma unroll
+  for (int qb = 0; qb < NQB; ++qb) {
+    float l_tot = l_run[qb];
+    {
+      const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(l_tot), __float_as_uint(l_tot), false, false);
+      l_tot = __uint_as_float(s16[0]) + __uint_as_float(s16[1]);
+      const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_tot), __float_as_uint(l_tot), false, false);
+      l_tot = __uint_as_float(s32[0]) + __uint_as_float(s32[1]);
+    }
+    const float inv = 1.0f / l_tot;
+#pragma unroll
+    for (int b = 0; b < NDB; ++b) {
+      h4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (half_t)(ot[b][qb][e] * inv);
+      *reinterpret_cast<h4*>(ob + (qb * 16 + i16_e) * G::OS + (b * 16 + g4_e * 4) * 2) = o;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  constexpr int LPR = DH / 8;
+  half_t* og = O + head + (size_t)q_row0 * D + part * DH;
+#pragma unroll 4
+  for (int it = 0; it < (32 * LPR) / 64; ++it) {
+    const int idx = it * 64 + lane_e;
+    const int row = idx / LPR, c = idx % LPR;
+    *reinterpret_cast<u4*>(og + (size_t)row * D + c * 8) = *reinterpret_cast<const u4*>(ob + row * G::OS + c * 16);
+  }
+}
+
+template <int PD = 2>
+int launch_m16_pair(const void* q, const void* k, const void* v, void* o, int B, int H, int N, hipStream_t stream) {
+  using G = GeoM16Pair;
+  if (N % G::BR != 0) return CLN_ERR_UNSUPPORTED;
+  static cln_lds_attr lds_attr;  // per device, thread-safe (common.h)
+  if (cln_ensure_lds(lds_attr, reinterpret_cast<const void*>(&fa2_fwd_m16_pair_kernel<PD>), G::LDS_BYTES) != CLN_OK) return CLN_ERR_LAUNCH;
+  const float scale_log2e = 1.4426950408889634f / sqrtf((float)G::D);
+  const int n_qblk = N / G::BR;
+  CLN_LAUNCH((fa2_fwd_m16_pair_kernel<PD>), dim3(n_qblk * B * H), dim3(G::NT), G::LDS_BYTES, stream,
+             (const half_t*)q, (const half_t*)k, (const half_t*)v, (half_t*)o, N, n_qblk, B * H, scale_log2e);
+  return cln_check_launch();
+}
+
 }  // namespace fa2

@@ -110,3 +110,48 @@ def test_p_operand_key_order_matches_the_score_registers():
         kb, r = 2 * u + (e >> 2), e & 3
         key = 16 * kb + 4 * g4 + r
         assert key == 32 * u + (4 * g4 + e if e < 4 else 16 + 4 * g4 + (e - 4))
+
+
+# ---- the d-split pair form at D = 512 (GeoM16Pair): 1024-byte rows, a DMA piece is ONE row, swizzles with a per-piece term
+def pair_image(operand):
+    sw = (lambda row: row & 15) if operand == "K" else (lambda row: (row & 15) << 1)
+    img = {}
+    for i, widx, lane in itertools.product(range(8), range(4), range(64)):
+        row = 4 * i + widx
+        src_chunk = lane ^ sw(widx) ^ sw(4 * i)  # what dma_piece computes: src_lane ^ swizzle(4*i)
+        assert src_chunk == lane ^ sw(row) and 0 <= src_chunk < 64
+        img[(row, lane)] = src_chunk
+    assert len(img) == 32 * 64
+    return img
+
+
+def test_pair_form_k_reads():
+    img = pair_image("K")
+    for part, kb, ks, g4 in itertools.product(range(2), range(2), range(8), range(4)):
+        banks = []
+        for i16 in range(16):
+            kbase = i16 * 1024 + ((g4 ^ (i16 & 15)) << 4) + part * 512
+            addr = (kbase ^ (ks << 6)) + kb * 16 * 1024
+            row, pos = addr // 1024, (addr % 1024) // 16
+            assert row == 16 * kb + i16
+            assert img[(row, pos)] == part * 32 + 4 * ks + g4  # d = 256*part + 32*ks + 8*g4
+            banks += banks_of(addr, 16)
+        assert len(set(banks)) == 64
+
+
+def test_pair_form_v_reads():
+    img = pair_image("V")
+    for part, db, half in itertools.product(range(2), range(16), range(2)):
+        bank_load = [0] * 64
+        for lane in range(64):
+            i16, g4 = lane & 15, lane >> 4
+            v_row = 4 * g4 + (i16 >> 2)
+            vbase = v_row * 1024 + ((((i16 & 3) >> 1) ^ ((v_row & 15) << 1)) << 4) + ((i16 & 1) << 3) + part * 512
+            addr = (vbase ^ (db << 5)) + half * 16 * 1024
+            row, pos, within = addr // 1024, (addr % 1024) // 16, addr % 16
+            assert row == 16 * half + 4 * g4 + (i16 >> 2)
+            d0 = img[(row, pos)] * 8 + within // 2
+            assert d0 == 256 * part + 16 * db + 4 * (i16 & 3)
+            for b in banks_of(addr, 8):
+                bank_load[b] += 1
+        assert max(bank_load) == 2 and min(bank_load) == 2
