@@ -483,6 +483,24 @@ def test_one_wave_per_simd_attention_probe(built, dev, oracle, D, abl):
         assert (o.cpu().double() - ref).abs().max().item() <= TOL_AMPLIFIED_KEYS, (B, H, N)
 
 
+@pytest.mark.parametrize("D,abl,N", [(64, 540, 256), (64, 541, 512), (64, 545, 512), (64, 546, 1024), (128, 540, 256),
+                                     (128, 542, 512), (128, 543, 512), (512, 540, 128), (512, 541, 256)])
+def test_attention_on_16x16x32_mfma_probe_forms(built, dev, oracle, D, abl, N):
+    """flash_attn_m16.cuh forms that are NOT behind a name (the dispatched ones run in every other test of this file):
+    other prefetch depths, 64 query rows per wave, 64-key tiles at D = 128, and the D = 512 pair kernel. Random data plus a
+    late dominant key (rescale of ONE of the query blocks a lane holds) and an early spike; fp64 oracle."""
+    from cuda_learn_notes_amd import host
+    for (B, H) in ((1, 2), (2, 3)):
+        q, k, v = seeded(91 + N + D, B, H, N, D), seeded(92 + N + D, B, H, N, D), seeded(93 + N + D, B, H, N, D)
+        k[0, 0, N - 3] = q[0, 0, 5] * (3.0 if D <= 128 else 1.5)    # row 5: query block 0 of wave 0 jumps in the last tile
+        k[0, H - 1, 2] = q[0, H - 1, 20] * (4.0 if D <= 128 else 2.0)  # row 20 (query block 1): everything later ~ -inf
+        o = torch.zeros(B, H, N, D, dtype=torch.half, device=dev)
+        host.fa2_variant((8, 0, 0, abl), q.to(dev), k.to(dev), v.to(dev), o)
+        assert torch.isfinite(o).all()
+        ref = oracle.attention_fp64(q, k, v)
+        assert (o.cpu().double() - ref).abs().max().item() <= TOL_AMPLIFIED_KEYS, (B, H, N, D, abl)
+
+
 @pytest.mark.parametrize("abl", [710, 711])
 def test_key_split_attention_probe(built, dev, oracle, abl):
     """flash_attn_dsplit2.cuh KVS = true (probe library): the two wave groups walk one half of the KV tiles each and merge
