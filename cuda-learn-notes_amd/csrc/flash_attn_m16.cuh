@@ -310,9 +310,13 @@ int launch_m16(const void* q, const void* k, const void* v, void* o, int B, int 
 // PROBE ONLY (variants 540 / 541 of kind 8, tested, not dispatched): +3.2 % at config C5 (1025 vs 994 TF), but rounding
 // Q * log2(e)/sqrt(512) to fp16 raises the max-abs-error from 1.0e-4 to 3.1e-4 at C5 (3.6e-4 -> 9.7e-4 at [2,3,256,512]);
 // a form that scales the exchanged sum in fp32 instead measured +0.8 % only and was dropped (profiles/r02_fa_m16_pair_probe.log).
+// PAIR = false: the same kernel for head dim 256 -- ONE wave per 32 query rows holds the whole d (still Q 64 + O^T 128
+// registers), no exchange, 256 query rows per workgroup, 512-byte rows (a DMA piece is two rows: row = 8*i + 2*widx + lr).
+template <bool PAIR>
 struct GeoM16Pair {
-  static constexpr int D = 512, DH = 256, BC = 32, NW = 8, BR = 128, NT = 512;
-  static constexpr int ROW = D * 2, TILE = BC * ROW, STAGE = 2 * TILE, RING = 2 * STAGE, SX = NW * 4096;
+  static constexpr int D = PAIR ? 512 : 256, DH = 256, BC = 32, NW = 8, BR = PAIR ? 128 : 256, NT = 512;
+  static constexpr int ROW = D * 2, TILE = BC * ROW, STAGE = 2 * TILE, RING = 2 * STAGE, SX = PAIR ? NW * 4096 : 0;
+  static constexpr int RPP = 1024 / ROW, CPR = ROW / 16;  // rows per 1-KiB DMA piece, 16-byte chunks per row
   static constexpr int OS = DH * 2 + 16, EPI = NW * 32 * OS;
   static constexpr int LDS_BYTES = RING + SX > EPI ? RING + SX : EPI;
   static constexpr int PPW = TILE / 1024 / 4;
@@ -322,18 +326,18 @@ struct GeoM16Pair {
   static __device__ __forceinline__ int swz_v(int row) { return (row & 15) << 1; }
 };
 
-template <int PD = 2>
+template <int PD = 2, bool PAIR = true>
 __global__ __launch_bounds__(512, 2) void fa2_fwd_m16_pair_kernel(const half_t* __restrict__ Q, const half_t* __restrict__ K,
                                                                   const half_t* __restrict__ V, half_t* __restrict__ O,
                                                                   int N, int n_qblk, int n_heads, float scale_log2e) {
-  using G = GeoM16Pair;
+  using G = GeoM16Pair<PAIR>;
   constexpr int D = G::D, DH = G::DH, NKB = G::NKB, NKS = G::NKS, NQB = G::NQB, NDB = G::NDB, NQK = G::NQK, NPV = G::NPV;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i16 = lane & 15, g4 = lane >> 4;
   const int grp = wave >> 2, widx = wave & 3;
-  const int part = widx & 1, rg = grp * 2 + (widx >> 1);
+  const int part = PAIR ? widx & 1 : 0, rg = PAIR ? grp * 2 + (widx >> 1) : wave;
 
   int head_i, qb_i;
   {
@@ -351,13 +355,14 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16_pair_kernel(const half_t* 
   const int q_row0 = qb_i * G::BR + rg * 32;
   const unsigned lds0 = hgemm::lds_addr_of(smem);
 
-  // ---- LDS-DMA: a piece = row 4*i + widx (1 KiB), lane = chunk position; source chunk = position ^ swizzle(row), and
-  // swizzle(4*i + widx) = swizzle(widx) ^ swizzle(4*i) (disjoint bits)
+  // ---- LDS-DMA: a piece = RPP rows (1 KiB): row = (4*i + widx)*RPP + lr, lane = lr*CPR + chunk position; source chunk =
+  // position ^ swizzle(row), and swizzle(row) = swizzle(widx*RPP + lr) ^ swizzle(4*i*RPP) (disjoint bits)
   const char* src_h = reinterpret_cast<const char*>((grp == 0 ? K : V) + head);
-  const unsigned src_lane = (unsigned)((lane ^ (grp == 0 ? G::swz_k(widx) : G::swz_v(widx))) << 4);
+  const int lr = lane / G::CPR, lc = lane % G::CPR, rlow = widx * G::RPP + lr;
+  const unsigned src_lane = (unsigned)(lr * G::ROW) + (unsigned)((lc ^ (grp == 0 ? G::swz_k(rlow) : G::swz_v(rlow))) << 4);
   auto dma_piece = [&](int jt, int slot, int i) __attribute__((always_inline)) {
     const int piece = i * 4 + widx;
-    const unsigned voff = src_lane ^ (unsigned)((grp == 0 ? G::swz_k(4 * i) : G::swz_v(4 * i)) << 4);
+    const unsigned voff = src_lane ^ (unsigned)((grp == 0 ? G::swz_k(4 * i * G::RPP) : G::swz_v(4 * i * G::RPP)) << 4);
     const char* s = src_h + (size_t)jt * G::TILE + piece * 1024;
     hgemm::glds16_asm(s, voff, lds0 + slot * G::STAGE + grp * G::TILE + piece * 1024);
   };
@@ -410,7 +415,7 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16_pair_kernel(const half_t* 
   const int vbase = v_row * G::ROW + (((((i16 & 3) >> 1)) ^ G::swz_v(v_row)) << 4) + ((i16 & 1) << 3) + part * 512;
   char* sx_mine = smem + G::RING + wave * 4096 + lane * 16;
   const char* sx_peer = smem + G::RING + (wave ^ 1) * 4096 + lane * 16;
-  const bool lead = part == 0;  // this wave's partial starts at -m
+  const bool lead = part == 0;  // this wave's partial starts at -m (PAIR = false: every wave)
 
   if (grp == 1) {
     __builtin_amdgcn_s_barrier();
@@ -452,6 +457,7 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16_pair_kernel(const half_t* 
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    if constexpr (PAIR)
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
@@ -461,6 +467,7 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16_pair_kernel(const half_t* 
     asm volatile("" ::: "memory");
 
     // ================= phase B: S = own + partner's partial, softmax, O^T[half] += V[:, half]^T P^T
+    if constexpr (PAIR)
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
@@ -573,15 +580,15 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16_pair_kernel(const half_t* 
   }
 }
 
-template <int PD = 2>
+template <int PD = 2, bool PAIR = true>
 int launch_m16_pair(const void* q, const void* k, const void* v, void* o, int B, int H, int N, hipStream_t stream) {
-  using G = GeoM16Pair;
+  using G = GeoM16Pair<PAIR>;
   if (N % G::BR != 0) return CLN_ERR_UNSUPPORTED;
   static cln_lds_attr lds_attr;  // per device, thread-safe (common.h)
-  if (cln_ensure_lds(lds_attr, reinterpret_cast<const void*>(&fa2_fwd_m16_pair_kernel<PD>), G::LDS_BYTES) != CLN_OK) return CLN_ERR_LAUNCH;
+  if (cln_ensure_lds(lds_attr, reinterpret_cast<const void*>(&fa2_fwd_m16_pair_kernel<PD, PAIR>), G::LDS_BYTES) != CLN_OK) return CLN_ERR_LAUNCH;
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)G::D);
   const int n_qblk = N / G::BR;
-  CLN_LAUNCH((fa2_fwd_m16_pair_kernel<PD>), dim3(n_qblk * B * H), dim3(G::NT), G::LDS_BYTES, stream,
+  CLN_LAUNCH((fa2_fwd_m16_pair_kernel<PD, PAIR>), dim3(n_qblk * B * H), dim3(G::NT), G::LDS_BYTES, stream,
              (const half_t*)q, (const half_t*)k, (const half_t*)v, (half_t*)o, N, n_qblk, B * H, scale_log2e);
   return cln_check_launch();
 }

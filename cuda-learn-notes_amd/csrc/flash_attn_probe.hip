@@ -83,6 +83,8 @@ CLN_API int cln_fa2_variant(int D, int nw, int vt, int opt, int abl, const void*
   if (D == 128 && abl == 543) return fa2::launch_m16<128, 32, 128, 4>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 512 && abl == 540) return fa2::launch_m16_pair<2>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 512 && abl == 541) return fa2::launch_m16_pair<1>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 256 && abl == 540) return fa2::launch_m16_pair<2, false>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 256 && abl == 541) return fa2::launch_m16_pair<1, false>(q, k, v, o, B, H, N, (hipStream_t)stream);
   // 530.. = row sums on the matrix pipe (OPT_SUMM)
   if (D == 64 && abl == 530) return fa2::launch_dsplit<64, 1, 4, 13 | fa2::OPT_STAGGER | fa2::OPT_PRE | fa2::OPT_SUMM>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 64 && abl == 531) return fa2::launch_dsplit<64, 1, 2, 13 | fa2::OPT_STAGGER | fa2::OPT_PRE | fa2::OPT_SUMM>(q, k, v, o, B, H, N, (hipStream_t)stream);

@@ -484,10 +484,11 @@ def test_one_wave_per_simd_attention_probe(built, dev, oracle, D, abl):
 
 
 @pytest.mark.parametrize("D,abl,N", [(64, 540, 256), (64, 541, 512), (64, 545, 512), (64, 546, 1024), (128, 540, 256),
-                                     (128, 542, 512), (128, 543, 512), (512, 540, 128), (512, 541, 256)])
+                                     (128, 542, 512), (128, 543, 512), (512, 540, 128), (512, 541, 256), (256, 540, 256),
+                                     (256, 541, 512)])
 def test_attention_on_16x16x32_mfma_probe_forms(built, dev, oracle, D, abl, N):
     """flash_attn_m16.cuh forms that are NOT behind a name (the dispatched ones run in every other test of this file):
-    other prefetch depths, 64 query rows per wave, 64-key tiles at D = 128, and the D = 512 pair kernel. Random data plus a
+    other prefetch depths, 64 query rows per wave, 64-key tiles at D = 128, the D = 512 pair kernel and its D = 256 form. Random data plus a
     late dominant key (rescale of ONE of the query blocks a lane holds) and an early spike; fp64 oracle."""
     from cuda_learn_notes_amd import host
     for (B, H) in ((1, 2), (2, 3)):

@@ -113,15 +113,21 @@ def test_p_operand_key_order_matches_the_score_registers():
 
 
 # ---- the d-split pair form at D = 512 (GeoM16Pair): 1024-byte rows, a DMA piece is ONE row, swizzles with a per-piece term
-def pair_image(operand):
+def pair_image(operand, rowbytes=1024):
+    """rowbytes 1024: the D = 512 pair form; 512: the same kernel at D = 256 (PAIR = false, a piece is two rows)."""
     sw = (lambda row: row & 15) if operand == "K" else (lambda row: (row & 15) << 1)
+    rpp, cpr = 1024 // rowbytes, rowbytes // 16
+    ppw = 32 * rowbytes // 1024 // 4
     img = {}
-    for i, widx, lane in itertools.product(range(8), range(4), range(64)):
-        row = 4 * i + widx
-        src_chunk = lane ^ sw(widx) ^ sw(4 * i)  # what dma_piece computes: src_lane ^ swizzle(4*i)
-        assert src_chunk == lane ^ sw(row) and 0 <= src_chunk < 64
-        img[(row, lane)] = src_chunk
-    assert len(img) == 32 * 64
+    for i, widx, lane in itertools.product(range(ppw), range(4), range(64)):
+        lr, lc = lane // cpr, lane % cpr
+        row = (4 * i + widx) * rpp + lr
+        src_chunk = lc ^ sw(widx * rpp + lr) ^ sw(4 * i * rpp)  # what dma_piece computes: src_lane ^ swizzle(4*i*RPP)
+        assert src_chunk == lc ^ sw(row) and 0 <= src_chunk < cpr
+        dst = (4 * i + widx) * 1024 + lane * 16
+        assert dst // rowbytes == row and (dst % rowbytes) // 16 == lc
+        img[(row, lc)] = src_chunk
+    assert len(img) == 32 * cpr
     return img
 
 
@@ -152,6 +158,32 @@ def test_pair_form_v_reads():
             assert row == 16 * half + 4 * g4 + (i16 >> 2)
             d0 = img[(row, pos)] * 8 + within // 2
             assert d0 == 256 * part + 16 * db + 4 * (i16 & 3)
+            for b in banks_of(addr, 8):
+                bank_load[b] += 1
+        assert max(bank_load) == 2 and min(bank_load) == 2
+
+
+def test_d256_form_reads():
+    """PAIR = false (D = 256): 512-byte rows, whole d in one wave (no part offset)."""
+    imgk, imgv = pair_image("K", 512), pair_image("V", 512)
+    for kb, ks, g4 in itertools.product(range(2), range(8), range(4)):
+        banks = []
+        for i16 in range(16):
+            addr = ((i16 * 512 + ((g4 ^ (i16 & 15)) << 4)) ^ (ks << 6)) + kb * 16 * 512
+            row, pos = addr // 512, (addr % 512) // 16
+            assert row == 16 * kb + i16 and imgk[(row, pos)] == 4 * ks + g4
+            banks += banks_of(addr, 16)
+        assert len(set(banks)) == 64
+    for db, half in itertools.product(range(16), range(2)):
+        bank_load = [0] * 64
+        for lane in range(64):
+            i16, g4 = lane & 15, lane >> 4
+            v_row = 4 * g4 + (i16 >> 2)
+            vbase = v_row * 512 + ((((i16 & 3) >> 1) ^ ((v_row & 15) << 1)) << 4) + ((i16 & 1) << 3)
+            addr = (vbase ^ (db << 5)) + half * 16 * 512
+            row, pos, within = addr // 512, (addr % 512) // 16, addr % 16
+            assert row == 16 * half + 4 * g4 + (i16 >> 2)
+            assert imgv[(row, pos)] * 8 + within // 2 == 16 * db + 4 * (i16 & 3)
             for b in banks_of(addr, 8):
                 bank_load[b] += 1
         assert max(bank_load) == 2 and min(bank_load) == 2
