@@ -70,7 +70,10 @@ FaPlan fa2_plan(int family, bool vt, int B, int H, int N, int D, int stages, int
       //  D = 256: two-group ping-pong kernel, 8 waves x 32 rows (flash_attn_dsplit.cuh)
       if (D == 64) return p.kind = fa2::W4_PRODUCTION_D64 ? K_RB : K_M16, p.d_inst = 64, p.nw = fa2::W4_PRODUCTION_D64 ? 4 : 8, p.bc = fa2::W4_PRODUCTION_D64 ? 64 : 128, p;
       if (D == 128) return p.kind = fa2::W4_PRODUCTION_D128 ? K_RB : K_M16, p.d_inst = 128, p.nw = fa2::W4_PRODUCTION_D128 ? 4 : 8, p.bc = fa2::W4_PRODUCTION_D128 ? 64 : 128, p;
-      if (D == 256) return p.kind = K_DSPLIT, p.d_inst = 256, p.nw = 8, p.bc = 32, p;
+      // D = 256: the same 16x16x32 layout, one wave per 32 rows holding the whole d, scores scaled in fp32 (max-abs-error
+      // identical to the 32x32x16 kernel it replaces): [4,8,2048,256] 1057 -> 1125 TF, [2,32,4096,256] 1132 -> 1183
+      // (profiles/r02_fa_m16_d256_probe.log, variant 544)
+      if (D == 256) return p.kind = K_M16, p.d_inst = 256, p.nw = 8, p.bc = 32, p;
     }
     // v2 kernel: the largest of 8 / 4 / 2 waves (x 32 query rows) that N allows AND that still gives every one of the
     // 256 CUs a workgroup (measured [2,8,2048,64]: 534 TF with 4 waves x 256 workgroups vs 413 TF with 8 x 128)
@@ -155,12 +158,13 @@ int fa2_run(const FaPlan& p, const void* q, const void* k, const void* v, void* 
       if constexpr (!VT) {
         if (D == 64) return fa2::launch_m16<64, 32, 128, 8>(q, k, v, o, B, H, N, s);
         if (D == 128) return fa2::launch_m16<128, 32, 128, 4>(q, k, v, o, B, H, N, s);  // 128-key tiles: +3 % over 64
+        if (D == 256) return fa2::launch_m16_pair<2, false, false>(q, k, v, o, B, H, N, s);
       }
       return CLN_ERR_UNSUPPORTED;
     case K_DSPLIT:
       if constexpr (!VT) {
         // (the D = 64 / 128 forms of this kernel -- 32x32x16 MFMAs -- are in the probe library: variants 500 of kind 8)
-        if (D == 256) return fa2::launch_dsplit<256, 1, 1, fa2::OPT_DEFAULT | fa2::OPT_KPRE>(q, k, v, o, B, H, N, s);
+        // (D = 256 moved to the 16x16x32 kernel; its 32x32x16 form is probe variant 220 of kind 8)
         return fa::launch_fa2_large_d(q, k, v, o, B, H, N, D, s);
       }
       return CLN_ERR_UNSUPPORTED;
@@ -202,7 +206,8 @@ int fa2_describe(int family, bool vt, int B, int H, int N, int D, int stages, in
       return snprintf(buf, len, "fa2_fwd_w4<D=%d,BC=%d,pre-scaled Q> 4 waves x 64 rows, 1 wave/SIMD, hand-placed stream, K/V "
                                 "fragments shared by 2 row groups%s", D, p.bc, st);
     case K_M16:
-      return snprintf(buf, len, "fa2_fwd_m16<D=%d,BC=%d,16x16x32 MFMA,pre-scaled Q> 8 waves x 32 rows, two groups one phase apart%s", D, p.bc, st);
+      return snprintf(buf, len, "fa2_fwd_m16<D=%d,BC=%d,16x16x32 MFMA%s> 8 waves x 32 rows, two groups one phase apart%s", D, p.bc,
+                      D <= 128 ? ",pre-scaled Q" : "", st);
     case K_DSPLIT:
       if (p.d_inst != D)
         return snprintf(buf, len, "fa2_fwd_dsplit<D=%d,NSP=2,BC=32,LDS geometry of D=%d> 8 waves, pairs split the real d evenly%s", D, p.d_inst, st);

@@ -326,7 +326,9 @@ struct GeoM16Pair {
   static __device__ __forceinline__ int swz_v(int row) { return (row & 15) << 1; }
 };
 
-template <int PD = 2, bool PAIR = true>
+// PRE = false: Q stays as loaded; the (summed) scores are scaled and made relative to the running max in fp32, one v_fma per
+// score (16 per lane and tile) -- the accuracy of the 32x32x16 kernels at these head dims.
+template <int PD = 2, bool PAIR = true, bool PRE = true>
 __global__ __launch_bounds__(512, 2) void fa2_fwd_m16_pair_kernel(const half_t* __restrict__ Q, const half_t* __restrict__ K,
                                                                   const half_t* __restrict__ V, half_t* __restrict__ O,
                                                                   int N, int n_qblk, int n_heads, float scale_log2e) {
@@ -394,7 +396,7 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16_pair_kernel(const half_t* 
 #pragma unroll
   for (int i = 0; i < G::PPW; ++i) dma_piece(0, 0, i);
   __builtin_amdgcn_s_waitcnt(0x0F70);
-  {
+  if constexpr (PRE) {
     const half_t sc = (half_t)scale_log2e;
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb)
@@ -415,7 +417,7 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16_pair_kernel(const half_t* 
   const int vbase = v_row * G::ROW + (((((i16 & 3) >> 1)) ^ G::swz_v(v_row)) << 4) + ((i16 & 1) << 3) + part * 512;
   char* sx_mine = smem + G::RING + wave * 4096 + lane * 16;
   const char* sx_peer = smem + G::RING + (wave ^ 1) * 4096 + lane * 16;
-  const bool lead = part == 0;  // this wave's partial starts at -m (PAIR = false: every wave)
+  const bool lead = PRE && part == 0;  // this wave's partial starts at -m (PAIR = false: every wave)
 
   if (grp == 1) {
     __builtin_amdgcn_s_barrier();
@@ -475,6 +477,13 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16_pair_kernel(const half_t* 
         const f4 pp = *reinterpret_cast<const f4*>(sx_peer + (kb * NQB + qb) * 1024);
         s[kb][qb] += pp;
       }
+    if constexpr (!PRE)
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int qb = 0; qb < NQB; ++qb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[kb][qb][r] = fmaf(s[kb][qb][r], scale_log2e, -m_run[qb]);  // log2 domain, relative
     h8 vf[PD];
 #pragma unroll
     for (int i = 0; i < PD; ++i) vf[i] = v_frag(i);
@@ -580,15 +589,15 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16_pair_kernel(const half_t* 
   }
 }
 
-template <int PD = 2, bool PAIR = true>
+template <int PD = 2, bool PAIR = true, bool PRE = true>
 int launch_m16_pair(const void* q, const void* k, const void* v, void* o, int B, int H, int N, hipStream_t stream) {
   using G = GeoM16Pair<PAIR>;
   if (N % G::BR != 0) return CLN_ERR_UNSUPPORTED;
   static cln_lds_attr lds_attr;  // per device, thread-safe (common.h)
-  if (cln_ensure_lds(lds_attr, reinterpret_cast<const void*>(&fa2_fwd_m16_pair_kernel<PD, PAIR>), G::LDS_BYTES) != CLN_OK) return CLN_ERR_LAUNCH;
+  if (cln_ensure_lds(lds_attr, reinterpret_cast<const void*>(&fa2_fwd_m16_pair_kernel<PD, PAIR, PRE>), G::LDS_BYTES) != CLN_OK) return CLN_ERR_LAUNCH;
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)G::D);
   const int n_qblk = N / G::BR;
-  CLN_LAUNCH((fa2_fwd_m16_pair_kernel<PD, PAIR>), dim3(n_qblk * B * H), dim3(G::NT), G::LDS_BYTES, stream,
+  CLN_LAUNCH((fa2_fwd_m16_pair_kernel<PD, PAIR, PRE>), dim3(n_qblk * B * H), dim3(G::NT), G::LDS_BYTES, stream,
              (const half_t*)q, (const half_t*)k, (const half_t*)v, (half_t*)o, N, n_qblk, B * H, scale_log2e);
   return cln_check_launch();
 }

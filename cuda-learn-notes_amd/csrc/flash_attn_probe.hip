@@ -85,6 +85,9 @@ CLN_API int cln_fa2_variant(int D, int nw, int vt, int opt, int abl, const void*
   if (D == 512 && abl == 541) return fa2::launch_m16_pair<1>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 256 && abl == 540) return fa2::launch_m16_pair<2, false>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 256 && abl == 541) return fa2::launch_m16_pair<1, false>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  // 544 = scores scaled in fp32 (Q not pre-scaled)
+  if (D == 256 && abl == 544) return fa2::launch_m16_pair<2, false, false>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 512 && abl == 544) return fa2::launch_m16_pair<2, true, false>(q, k, v, o, B, H, N, (hipStream_t)stream);
   // 530.. = row sums on the matrix pipe (OPT_SUMM)
   if (D == 64 && abl == 530) return fa2::launch_dsplit<64, 1, 4, 13 | fa2::OPT_STAGGER | fa2::OPT_PRE | fa2::OPT_SUMM>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 64 && abl == 531) return fa2::launch_dsplit<64, 1, 2, 13 | fa2::OPT_STAGGER | fa2::OPT_PRE | fa2::OPT_SUMM>(q, k, v, o, B, H, N, (hipStream_t)stream);

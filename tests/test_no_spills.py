@@ -37,7 +37,7 @@ def test_production_attention_instantiations_are_in_the_report(tmp_path):
     import kernel_resources as kr
     kernels, _ = kr.report(os.path.join(ROOT, "cuda-learn-notes_amd", "csrc", "flash_attn.hip"), keep=str(tmp_path))
     names = [k["demangled"] for k in kernels]
-    for want in ("fa2_fwd_dsplit_kernel<512, 2, 1,", "fa2_fwd_m16_kernel<64, 32, 128, 8>", "fa2_fwd_m16_kernel<128, 32, 128, 4>", "fa2_fwd_dsplit_kernel<256, 1, 1,",
+    for want in ("fa2_fwd_dsplit_kernel<512, 2, 1,", "fa2_fwd_m16_kernel<64, 32, 128, 8>", "fa2_fwd_m16_kernel<128, 32, 128, 4>", "fa2_fwd_m16_pair_kernel<2, false, false>",
                  "fa2_fwd_v2_kernel<128, 2, true", "fa2_fwd_splitkv_kernel<64>", "fa2_fwd_dwide_kernel<1024", "fa2_fwd_dsplit2_kernel<4, false>"):
         assert any(want in n for n in names), want
 
