@@ -151,17 +151,20 @@ def prewarm(fn, seconds: float):
         torch.cuda.synchronize()
 
 
-def settle(fn, batch: int, tol: float = 0.03, max_seconds: float = 3.0):
+def settle(fn, batch: int, tol: float = 0.03, max_seconds: float = 3.0, min_seconds: float = 0.2):
     """Untimed steady-state check after the time-based pre-warm: event-timed batches of `batch` back-to-back launches
-    until two consecutive batches agree within `tol` and the last one is within `tol` of the fastest seen (or
-    `max_seconds` pass). On some boxes the first launch bursts of a process run at ~2/3 of the sustained rate for a
-    while (a 20-step region read 955 instead of 1430-1460 TF once in round 2). Returns the ms-per-launch history."""
+    until the last THREE batches agree within `tol`, the last one is within `tol` of the fastest seen and at least
+    `min_seconds` have been observed (or `max_seconds` pass). On some boxes the launch bursts of a process run at ~2/3 of
+    the sustained rate for a while (a 20-step region read 955 instead of 1430-1460 TF once in round 2, directly after the
+    full GPU suite). Returns the ms-per-launch history; a plateau that outlasts `max_seconds` is reported as it is."""
     hist = []
     t0 = time.time()
     while time.time() - t0 < max_seconds:
         hist.append(time_region_events(fn, batch))
-        if len(hist) >= 2 and abs(hist[-1] - hist[-2]) <= tol * hist[-2] and hist[-1] <= (1.0 + tol) * min(hist):
-            break
+        if len(hist) >= 3 and time.time() - t0 >= min_seconds:
+            last = hist[-3:]
+            if max(last) <= (1.0 + tol) * min(last) and hist[-1] <= (1.0 + tol) * min(hist):
+                break
     return hist
 
 

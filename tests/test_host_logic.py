@@ -50,3 +50,30 @@ def test_block_swizzle_policy_and_tflops_model(built):
     assert bu.make_block_swizzle_stride(256, 256) == 1
     assert abs(bu.hgemm_flops(4096, 4096, 4096) - 137438953472) < 1
     assert abs(bu.get_mha_tflops(4, 8, 2048, 64, 1.0) - 0.035026501632) < 1e-12
+
+
+def test_bench_steady_state_check_stops_when_the_rate_settles(built, monkeypatch):
+    """bench_utils.settle (the untimed check between the pre-warm and the timed region of bench.py): event-timed batches
+    until the last three agree within tol and the last is within tol of the fastest; a slow plateau of two batches does
+    not count as settled."""
+    from cuda_learn_notes_amd import bench_utils as bu
+    seq = iter([0.142, 0.139, 0.120, 0.096, 0.0945, 0.0950, 0.0947, 0.0946])  # a slow start that recovers (ms per launch)
+    calls = []
+    monkeypatch.setattr(bu, "time_region_events", lambda fn, n, stream=None: (calls.append(n), next(seq))[1])
+    hist = bu.settle(lambda: None, 20, tol=0.03, max_seconds=5.0, min_seconds=0.0)
+    assert hist == [0.142, 0.139, 0.120, 0.096, 0.0945, 0.0950]
+    assert all(n == 20 for n in calls)
+
+
+def test_bench_steady_state_check_is_bounded(built, monkeypatch):
+    from cuda_learn_notes_amd import bench_utils as bu
+    t = [0.0]
+
+    def timed(fn, n, stream=None):
+        t[0] += 1.0  # every batch "takes" a second and is 10 % slower than the one before: never settles
+        return 0.1 * 1.1 ** t[0]
+
+    monkeypatch.setattr(bu, "time_region_events", timed)
+    monkeypatch.setattr(bu.time, "time", lambda: t[0])
+    hist = bu.settle(lambda: None, 20, tol=0.001, max_seconds=4.0)
+    assert len(hist) == 4
