@@ -175,7 +175,8 @@ def main():
                                % (M, args.stages, stride),
                    "kernel": "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem", "parallelism": "replicas x%d" % world,
                    "prewarm_s": args.prewarm, "launch": launch_mode,
-                   "settle_ms_per_step": [round(x, 5) for x in settle_hist],
+                   "settle_batches": len(settle_hist),  # untimed steady-state check: first and last three batches
+                   "settle_ms_per_step": [round(x, 5) for x in (settle_hist if len(settle_hist) <= 6 else settle_hist[:3] + settle_hist[-3:])],
                    "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 5)},
         "pct_of_fp16_mfma_peak": round(100.0 * achieved / bu.PEAK_FP16_MFMA_TFLOPS, 2),
         "roofline": roofline,
