@@ -54,3 +54,25 @@ def test_inline_asm_mfma_stream_of_the_one_wave_per_simd_hgemm(tmp_path):
     for k in w4:
         assert k["agpr"] in (256, 192, 144, 128, 100) and k["spill"] == 0 and k["scratch"] == 0, k
         assert kr.asm_mfma_stream_check(text, k["name"]) == [], k["demangled"]
+
+
+def test_production_attention_kernels_use_the_16x16x32_matrix_shape(tmp_path):
+    """attention sits at the package power cap and v_mfma_f32_16x16x32_f16 is the energy-cheaper shape, so the
+    kernels behind D = 64 / 128 / 256 must issue ONLY that MFMA; per KV tile and wave the D = 64 kernel's loop holds 64 of
+    them (32 for S^T = K Q^T, 32 for O^T += V^T P^T) and 64 exponentials (32 rows x 128 keys / 64 lanes)."""
+    import re
+    import kernel_resources as kr
+    kernels, s = kr.report(os.path.join(ROOT, "cuda-learn-notes_amd", "csrc", "flash_attn.hip"), keep=str(tmp_path))
+    text = open(s).read()
+    for want in ("fa2_fwd_m16_kernel<64, 32, 128, 8>", "fa2_fwd_m16_kernel<128, 32, 128, 4>", "fa2_fwd_m16_pair_kernel<2, false, false>"):
+        k = [k for k in kernels if want in k["demangled"]]
+        assert len(k) == 1, want
+        body = text[text.index("\n" + k[0]["name"] + ":"):]
+        body = body[:body.index("s_endpgm")]
+        shapes = set(re.findall(r"v_mfma_f32_(\w+?)_f16", body))
+        assert shapes == {"16x16x32"}, (want, shapes)
+        if want.startswith("fa2_fwd_m16_kernel<64"):
+            # hipcc peels the first KV tile: two tile bodies, each 32 + 32 MFMAs and 64 exponentials (+ 2 in the rare
+            # rescale branch of the loop)
+            assert body.count("v_mfma_f32_16x16x32_f16") == 128 and 128 <= body.count("v_exp_f32") <= 132, \
+                (body.count("v_mfma_f32_16x16x32_f16"), body.count("v_exp_f32"))
