@@ -40,3 +40,40 @@ def test_stages_knob_selects_a_different_flash_attn_kernel(built):
     assert m.describe("flash_attn_mma_stages_split_kv", (4, 8, 2048, 64), 2).startswith("fa2_fwd_splitkv")
     with pytest.raises(ValueError):
         m.describe("flash_attn_mma_stages_split_q", (1, 1, 256, 256), 2)  # head dim above this name's limit
+
+
+def test_hgemm_tile_policy_invariants_over_a_grid_of_shapes(built):
+    """csrc/hgemm.hip best_plan, through cln_describe (host only): every M, N, K that are multiples of 64 (K >= 64) get a
+    kernel; the tile the text names divides M and N; the one-wave-per-SIMD kernel is only named when K has >= 6 whole
+    64-wide tiles (>= 7 when their number is odd) and stages = 2 for the 256x256 form; NN and TN names agree on the tile."""
+    import re
+    m = built.manifest
+    nn = "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem"
+    tn = "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_tn_swizzle_x4"
+    sizes = [64, 128, 192, 256, 320, 384, 512, 640, 960, 1024, 1280, 1536, 1600, 1920, 2048, 2240, 2560, 3072, 3200, 4096, 4160, 4800]
+    ks = [64, 128, 320, 384, 448, 512, 576, 1024, 4096, 4160]
+    seen = set()
+    for M in sizes:
+        for N in sizes[::2] + [M]:
+            for K in ks:
+                for stages in (2, 3):
+                    t = m.describe(nn, (M, N, K), stages)
+                    fam, bm, bn = re.match(r"(\w+)<(\d+)x(\d+)", t).groups()
+                    bm, bn = int(bm), int(bn)
+                    assert M % bm == 0 and N % bn == 0, (M, N, K, t)
+                    seen.add((fam, bm, bn))
+                    if fam == "hgemm_w4":
+                        nt = K // 64
+                        assert K % 64 == 0 and nt >= (7 if nt & 1 else 6), (M, N, K, t)
+                        assert not (bm == 256 and bn == 256 and stages != 2), (M, N, K, stages, t)
+                    t2 = m.describe(tn, (M, N, K), stages)
+                    assert t2.endswith("TN>") and t2[:t2.rindex(",")] == t[:t.rindex(",")], (t, t2)
+    # the policy actually uses its repertoire on this grid
+    for want in (("hgemm_w4", 256, 256), ("hgemm_w4", 160, 160), ("hgemm_w4", 192, 192), ("hgemm_w4", 128, 256),
+                 ("mfma_ring", 64, 64), ("hgemm_pp", 256, 256)):
+        assert want in seen, (want, sorted(seen))
+    # a shape no tile divides is refused, not mis-tiled
+    with pytest.raises(ValueError):
+        m.describe(nn, (4096, 4096, 4096 + 16), 2)
+    with pytest.raises(ValueError):
+        m.describe(nn, (4096 + 32, 4096, 4096), 2)
