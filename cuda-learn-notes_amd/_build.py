@@ -24,14 +24,16 @@ LIBDIR = os.path.join(PKG_DIR, "lib")
 ARCH = "gfx950"
 KERNEL_SOURCES = [
     "elementwise.hip", "activation.hip", "blas1.hip", "indexing.hip", "reduce.hip", "softmax.hip", "norm.hip", "rope.hip",
-    "sgemm.hip", "hgemm.hip", "hgemm_ring_nn.hip", "hgemm_ring_tn.hip", "flash_attn.hip", "describe.hip",
+    "sgemm.hip", "hgemm.hip", "hgemm_ring_nn.hip", "hgemm_ring_tn.hip", "flash_attn.hip", "flash_attn_m16x.hip", "describe.hip",
 ]
-VENDOR_SOURCES = ["hgemm_vendor.hip"]
+VENDOR_SOURCES = ["hgemm_vendor.hip", "hgemm_vendor_lt.hip"]
 # test-only library; it re-links the two ring compile units for the explicit (tile, BK, stages) hook
-PROBE_SOURCES = ["hgemm_probe.hip", "flash_attn_probe.hip"]
+PROBE_SOURCES = ["hgemm_probe.hip", "flash_attn_probe.hip", "flash_attn_m16x_probe.hip"]
 PROBE_SHARED = ["hgemm_ring_nn.hip", "hgemm_ring_tn.hip"]
 CFLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-ffp-contract=fast",
           "-I" + CSRC]
+# per-file additions (the reason is stated at the top of each file)
+EXTRA_FLAGS = {"flash_attn_m16x.hip": ["-fno-slp-vectorize"], "flash_attn_m16x_probe.hip": ["-fno-slp-vectorize"]}
 
 
 def hipcc():
@@ -50,6 +52,7 @@ def _deps_digest():
                 h.update(fn.encode())
                 h.update(f.read())
     h.update(" ".join(CFLAGS).encode())
+    h.update(repr(sorted(EXTRA_FLAGS.items())).encode())
     return h.hexdigest()
 
 
@@ -60,7 +63,7 @@ def _compile_one(src, hdr_digest, verbose):
         digest = hashlib.sha256(f.read() + hdr_digest.encode()).hexdigest()
     if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == digest:
         return obj, False
-    cmd = [hipcc()] + CFLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+    cmd = [hipcc()] + CFLAGS + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -97,7 +100,7 @@ def build(verbose=False, force=False):
     if force or not os.path.exists(main_so) or any(objs[s][1] for s in KERNEL_SOURCES):
         _link([objs[s][0] for s in KERNEL_SOURCES], main_so, [], verbose)
     if force or not os.path.exists(vend_so) or any(objs[s][1] for s in VENDOR_SOURCES):
-        _link([objs[s][0] for s in VENDOR_SOURCES], vend_so, ["-L/opt/rocm/lib", "-lrocblas"], verbose)
+        _link([objs[s][0] for s in VENDOR_SOURCES], vend_so, ["-L/opt/rocm/lib", "-lrocblas", "-lhipblaslt"], verbose)
     if force or not os.path.exists(probe_so) or any(objs[s][1] for s in PROBE_SOURCES + PROBE_SHARED):
         _link([objs[s][0] for s in PROBE_SOURCES + PROBE_SHARED], probe_so, [], verbose)
     return main_so, vend_so, probe_so

@@ -15,15 +15,15 @@
 #include "flash_attn_large_d.cuh"
 #include "flash_attn_splitkv.cuh"
 #include "flash_attn_v2.cuh"
-#include "flash_attn_w4.cuh"
 #include "flash_attn_dsplit2.cuh"
 #include "flash_attn_m16.cuh"
+#include "flash_attn_m16x_api.h"
 #include <string.h>
 
 namespace {
 
 enum FaFamily { FAM_SPLIT_KV = 0, FAM_SPLIT_Q = 1 };
-enum FaKind { K_NONE = 0, K_SPLITKV, K_LOAD_THEN_COMPUTE, K_V2, K_DSPLIT, K_DWIDE, K_RB, K_DSPLIT64R, K_M16 };
+enum FaKind { K_NONE = 0, K_SPLITKV, K_LOAD_THEN_COMPUTE, K_V2, K_DSPLIT, K_DWIDE, K_DSPLIT64R, K_M16 };
 
 struct FaPlan {
   int rc = CLN_OK;     // CLN_ERR_* when the shape is not supported
@@ -37,18 +37,19 @@ struct FaPlan {
 FaPlan fa2_plan(int family, bool vt, int B, int H, int N, int D, int stages, int max_d) {
   FaPlan p;
   if (B <= 0 || H <= 0 || N <= 0 || D <= 0) return p.rc = CLN_ERR_BAD_ARG, p;
-  if ((long long)B * H * (long long)(N / 32 + 1) > 0x7fffffffLL) return p.rc = CLN_ERR_UNSUPPORTED, p;  // grid size
+  if ((long long)B * H * (long long)(N / 32 + 1) > 0x7fffffffLL) return p.rc = CLN_ERR_UNSUPPORTED, p;  // grid size (x)
   if (D > max_d) return p.rc = CLN_ERR_UNSUPPORTED, p;  // "headdim not support!"
   const long long bh = (long long)B * H;
   if (family == FAM_SPLIT_KV) {
     // the split-KV rung: its own kernel (flash_attn_splitkv.cuh); it has no cross-tile prefetch to switch off
     if ((D != 32 && D != 64 && D != 96 && D != 128) || N % 32 != 0) return p.rc = CLN_ERR_UNSUPPORTED, p;
+    if (bh > 65535) return p.rc = CLN_ERR_UNSUPPORTED, p;  // this kernel carries B*H in gridDim.y
     p.kind = K_SPLITKV, p.d_inst = D, p.nw = 4, p.bc = 128, p.stages_honoured = false;
     return p;
   }
   const bool small_d = D == 32 || D == 64 || D == 96 || D == 128 || D == 256;
   // ---- stages = 1: load-then-compute (flash_attn.cuh with PREFETCH = false): 4 waves x 32 rows, 64-key tiles
-  if (stages == 1 && small_d && N % 128 == 0) {
+  if (stages == 1 && small_d && N % 128 == 0 && bh <= 65535) {  // (B*H in gridDim.y)
     p.kind = K_LOAD_THEN_COMPUTE, p.d_inst = D, p.nw = 4, p.bc = 64;
     return p;
   }
@@ -63,13 +64,14 @@ FaPlan fa2_plan(int family, bool vt, int B, int H, int N, int D, int stages, int
     }
     if (!vt && N % 256 == 0 && bh * (N / 256) >= 192) {
       // enough 256-row workgroups to occupy most of the chip:
-      //  D = 64 / 128: ping-pong kernel on 16x16x32 MFMAs (flash_attn_m16.cuh: the energy-cheaper matrix shape, +3.5-5 %
-      //                at D = 64 and +5.5-6.5 % at D = 128 over the 32x32x16 form of flash_attn_dsplit.cuh,
-      //                profiles/r02_fa_m16_probe.log), or -- where W4_PRODUCTION_* says it measured faster -- the
-      //                one-wave-per-SIMD kernel with the hand-placed stream (flash_attn_w4.cuh)
-      //  D = 256: two-group ping-pong kernel, 8 waves x 32 rows (flash_attn_dsplit.cuh)
-      if (D == 64) return p.kind = fa2::W4_PRODUCTION_D64 ? K_RB : K_M16, p.d_inst = 64, p.nw = fa2::W4_PRODUCTION_D64 ? 4 : 8, p.bc = fa2::W4_PRODUCTION_D64 ? 64 : 128, p;
-      if (D == 128) return p.kind = fa2::W4_PRODUCTION_D128 ? K_RB : K_M16, p.d_inst = 128, p.nw = fa2::W4_PRODUCTION_D128 ? 4 : 8, p.bc = fa2::W4_PRODUCTION_D128 ? 64 : 128, p;
+      //  D = 64 / 128: ping-pong kernel on 16x16x32 MFMAs (the energy-cheaper matrix shape, +3.5-5 % at D = 64 and
+      //                +5.5-6.5 % at D = 128 over the 32x32x16 form of flash_attn_dsplit.cuh, profiles/r02_fa_m16_probe.log)
+      //                with the sum-checked optimistic softmax, phase-A priority and the split prologue of round 3
+      //                (flash_attn_m16x.cuh: +1-2.5 % over flash_attn_m16.cuh, profiles/r03_fa_m16x_probe.log). (The one-wave-per-SIMD kernel flash_attn_w4.cuh measured parity at
+      //                best and lives in the probe library only.)
+      //  D = 256: two-group ping-pong kernel, 8 waves x 32 rows
+      if (D == 64) return p.kind = K_M16, p.d_inst = 64, p.nw = 8, p.bc = 128, p;
+      if (D == 128) return p.kind = K_M16, p.d_inst = 128, p.nw = 8, p.bc = 128, p;
       // D = 256: the same 16x16x32 layout, one wave per 32 rows holding the whole d, scores scaled in fp32 (max-abs-error
       // identical to the 32x32x16 kernel it replaces): [4,8,2048,256] 1057 -> 1125 TF, [2,32,4096,256] 1132 -> 1183
       // (profiles/r02_fa_m16_d256_probe.log, variant 544)
@@ -91,8 +93,15 @@ FaPlan fa2_plan(int family, bool vt, int B, int H, int N, int D, int stages, int
     return p.kind = K_V2, p.d_inst = D, p.nw = nw, p.bc = 64, p;
   }
   if (vt) return p.rc = CLN_ERR_UNSUPPORTED, p;
-  // ---- head dims above 256 ("fine-grained tiling" rungs, flash_attn_large_d.cuh); one pipeline each
-  p.stages_honoured = false;
+  // ---- head dims above 256 ("fine-grained tiling" rungs, flash_attn_large_d.cuh). The reference's tiling kernels template
+  // on kStage 1 / 2 (flash_attn_mma_tiling_qkv.cu:63, :189-223): stages = 1 runs the load-then-compute kernel here too
+  // (flash_attn.cuh with PREFETCH = false: whole K rows of a tile in LDS, the OUTPUT head dim sliced over blockIdx.z, S
+  // recomputed per slice -- the slow, structurally simple rung); stages = 2 the d-split / d-wide pipelines.
+  if (stages == 1 && N % 128 == 0 && bh <= 65535 && (D == 320 || D == 384 || D == 512 || D == 640 || D == 768 || D == 1024)) {
+    p.kind = K_LOAD_THEN_COMPUTE, p.d_inst = D, p.nw = 4, p.bc = D <= 512 ? 64 : 32;
+    return p;
+  }
+  p.stages_honoured = stages != 1;
   switch (D) {
     case 320: case 384: case 512:
       if (N % 128 != 0) return p.rc = CLN_ERR_UNSUPPORTED, p;
@@ -129,6 +138,16 @@ int fa2_run(const FaPlan& p, const void* q, const void* k, const void* v, void* 
         case 128: return fa::launch_fa2<128, 128, 64, VT, false>(q, k, v, o, B, H, N, s);
         case 256: return fa::launch_fa2<256, 256, 64, VT, false>(q, k, v, o, B, H, N, s);
       }
+      if constexpr (!VT) {  // head dims above 256: output head dim sliced over blockIdx.z (DV), S recomputed per slice
+        switch (D) {
+          case 320: return fa::launch_fa2<320, 160, 64, false, false>(q, k, v, o, B, H, N, s);
+          case 384: return fa::launch_fa2<384, 192, 64, false, false>(q, k, v, o, B, H, N, s);
+          case 512: return fa::launch_fa2<512, 256, 64, false, false>(q, k, v, o, B, H, N, s);
+          case 640: return fa::launch_fa2<640, 320, 32, false, false>(q, k, v, o, B, H, N, s);
+          case 768: return fa::launch_fa2<768, 192, 32, false, false>(q, k, v, o, B, H, N, s);
+          case 1024: return fa::launch_fa2<1024, 256, 32, false, false>(q, k, v, o, B, H, N, s);
+        }
+      }
       return CLN_ERR_UNSUPPORTED;
     case K_V2:
 #define FA_V2(DD, OPTT)                                                                                \
@@ -148,16 +167,9 @@ int fa2_run(const FaPlan& p, const void* q, const void* k, const void* v, void* 
     case K_DSPLIT64R:
       if constexpr (!VT) return fa2::launch_dsplit2<4>(q, k, v, o, B, H, N, s);
       return CLN_ERR_UNSUPPORTED;
-    case K_RB:
-      if constexpr (!VT) {
-        if (D == 64) return fa2::launch_fa_w4<64, fa2::W4_VAR_D64>(q, k, v, o, B, H, N, s);
-        if (D == 128) return fa2::launch_fa_w4<128, fa2::W4_VAR_D128>(q, k, v, o, B, H, N, s);
-      }
-      return CLN_ERR_UNSUPPORTED;
     case K_M16:
       if constexpr (!VT) {
-        if (D == 64) return fa2::launch_m16<64, 32, 128, 8>(q, k, v, o, B, H, N, s);
-        if (D == 128) return fa2::launch_m16<128, 32, 128, 4>(q, k, v, o, B, H, N, s);  // 128-key tiles: +3 % over 64
+        if (D == 64 || D == 128) return fa2::m16x_run(D, q, k, v, o, B, H, N, s);  // 128-key tiles; own compile unit
         if (D == 256) return fa2::launch_m16_pair<2, false, false>(q, k, v, o, B, H, N, s);
       }
       return CLN_ERR_UNSUPPORTED;
@@ -195,6 +207,11 @@ int fa2_describe(int family, bool vt, int B, int H, int N, int D, int stages, in
       return snprintf(buf, len, "fa2_fwd_splitkv<D=%d> 4 waves share 32 rows, 128-key tiles split over the waves, "
                                 "cross-wave max via LDS%s", D, st);
     case K_LOAD_THEN_COMPUTE:
+      if (D > 256) {
+        const int dv = D == 320 ? 160 : D == 384 ? 192 : D == 640 ? 320 : D == 768 ? 192 : 256;
+        return snprintf(buf, len, "fa2_fwd<D=%d,DV=%d,BC=%d,load-then-compute> 4 waves x 32 rows, output head dim sliced over %d "
+                                  "workgroups", D, dv, p.bc, D / dv);
+      }
       return snprintf(buf, len, "fa2_fwd<D=%d,BC=64,load-then-compute%s> 4 waves x 32 rows", D, vts);
     case K_V2:
       return snprintf(buf, len, "fa2_fwd_v2<D=%d,NW=%d,BC=64,prefetch%s%s> %d waves x 32 rows%s", D, p.nw,
@@ -202,12 +219,11 @@ int fa2_describe(int family, bool vt, int B, int H, int N, int D, int stages, in
     case K_DSPLIT64R:
       return snprintf(buf, len, "fa2_fwd_dsplit2<D=64,BC=64,pre-scaled Q> 8 waves x 64 rows, two groups one phase apart, K/V "
                                 "fragments shared by 2 row groups%s", st);
-    case K_RB:
-      return snprintf(buf, len, "fa2_fwd_w4<D=%d,BC=%d,pre-scaled Q> 4 waves x 64 rows, 1 wave/SIMD, hand-placed stream, K/V "
-                                "fragments shared by 2 row groups%s", D, p.bc, st);
     case K_M16:
-      return snprintf(buf, len, "fa2_fwd_m16<D=%d,BC=%d,16x16x32 MFMA%s> 8 waves x 32 rows, two groups one phase apart%s", D, p.bc,
-                      D <= 128 ? ",pre-scaled Q" : "", st);
+      if (D <= 128)
+        return snprintf(buf, len, "fa2_fwd_m16x<D=%d,BC=%d,16x16x32 MFMA,pre-scaled Q,sum-checked softmax> 8 waves x 32 rows, two groups "
+                                  "one phase apart%s", D, p.bc, st);
+      return snprintf(buf, len, "fa2_fwd_m16<D=%d,BC=%d,16x16x32 MFMA> 8 waves x 32 rows, two groups one phase apart%s", D, p.bc, st);
     case K_DSPLIT:
       if (p.d_inst != D)
         return snprintf(buf, len, "fa2_fwd_dsplit<D=%d,NSP=2,BC=32,LDS geometry of D=%d> 8 waves, pairs split the real d evenly%s", D, p.d_inst, st);

@@ -1,0 +1,335 @@
+// FlashAttention-2 forward, head dims 64 / 128: the 16x16x32 ping-pong kernel of flash_attn_m16.cuh with a SUM-CHECKED
+// OPTIMISTIC softmax (round 3). Reference rung: kernels/flash-attn/mma/basic/flash_attn_mma_share_qkv.cu:66.
+//
+// What changes against flash_attn_m16.cuh, and why. That kernel computes, per KV tile, the row maximum of all scores
+// (a serial v_max3 chain + two cross-lane swaps, ~40 of its ~190 VALU instructions per wave and tile), decides whether
+// the running reference m must move, and only then starts the exponentials: inside a wave the QK^T MFMAs, the maximum
+// and the exponentials are strictly serial. But the maximum is only ever USED to keep P = 2^(s - m) inside fp16
+// (the reference m is deferred anyway: it moves only when a row grew by more than 2^8). So:
+//   * the S^T accumulators start at -m (as before) and every 16-key block is exponentiated AS SOON AS its MFMA chain
+//     has finished, relative to the current reference, while the MFMAs of the next key block run -- no maximum first;
+//   * the row sums that the softmax needs anyway are the overflow check: if the per-lane partial sum of a tile is
+//     <= 2^15, every P of it is <= 2^15 and fits fp16; inf / NaN fail the comparison too. One compare per query block
+//     and tile replaces the max chain;
+//   * only when a lane fails the check (or on tile 0, which has no reference yet) the wave takes the COLD path: the true
+//     row maxima of the tile, the standard rescale of O / l / the pending scores, and the exponentials again.
+//   * the exponentials of the last NDEF key blocks are issued in phase B under the PV MFMAs (their scores are checked
+//     directly against 14 at the end of phase A: 4 v_max3 per block instead of a sum that does not exist yet).
+// fp16 has the same relative precision from 2^-14 to 2^15 and O / l accumulate in fp32, so a reference that lags the true
+// maximum by up to 15 binades costs nothing (the deferred form already allowed 8); the reference never moves down, and
+// tile 0 adopts its true maximum, so the largest P of a row is always >= 1.
+// Phase A (QK^T + exponentials) is now VALU-dense and phase B (PV) MFMA-only: with OX & 1 the wave raises its priority
+// in phase A so its VALU instructions win the issue arbitration against the partner's MFMAs (the matrix pipe needs one
+// issue slot per 16 cycles).
+#pragma once
+#include "flash_attn_m16.cuh"
+
+namespace fa2 {
+
+enum : int { M16X_PRIO = 1, M16X_PRIO_B = 2, M16X_SPLIT_PROLOGUE = 4 };
+
+template <int D_, int RPW_, int BC_, int PD = 4, int NDEF = 1, int OX = 0>
+__global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __restrict__ Q, const half_t* __restrict__ K,
+                                                              const half_t* __restrict__ V, half_t* __restrict__ O,
+                                                              int N, int n_qblk, int n_heads, float scale_log2e) {
+  using G = GeoM16<D_, RPW_, BC_>;
+  constexpr int D = G::D, NKB = G::NKB, NKS = G::NKS, NQB = G::NQB, NU = G::NU, NDB = G::NDB, NQK = G::NQK, NPV = G::NPV;
+  constexpr int NOPT = NKB - NDEF;            // key blocks exponentiated in phase A
+  constexpr int NPAIR = NQB * 2;              // (query block, register pair) items of one key block
+  constexpr int PER_STEP = (NPAIR + NKS - 1) / NKS;
+  constexpr int DSTEPS = (NOPT / 2) * NDB;    // PV steps before the first P^T k-step that contains a deferred block
+  constexpr int DRATE = (NDEF * NPAIR + DSTEPS - 1) / DSTEPS;
+  static_assert(NDEF >= 1 && NOPT >= 2, "at least one P^T k-step must be complete at the end of phase A");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15, g4 = lane >> 4;
+  const int grp = wave >> 2, widx = wave & 3;
+
+  int head_i, qb_i;
+  {
+    const int bid = blockIdx.x;
+    if ((n_heads & 7) == 0) {  // heads pinned to XCDs: a head's K/V stays in one L2
+      const int xcd = bid & 7, k = bid >> 3;
+      head_i = (k / n_qblk) * 8 + xcd;
+      qb_i = k - (k / n_qblk) * n_qblk;
+    } else {
+      head_i = bid / n_qblk;
+      qb_i = bid - head_i * n_qblk;
+    }
+  }
+  const size_t head = (size_t)head_i * N * D;
+  const int q_row0 = qb_i * G::BR + wave * G::RPW;
+  const unsigned lds0 = hgemm::lds_addr_of(smem);
+
+  const char* src_h = reinterpret_cast<const char*>((grp == 0 ? K : V) + head);
+  const int lr = lane / G::CPR, lc = lane % G::CPR;
+  const int sw_src = grp == 0 ? G::swz_k(widx * G::RPP + lr) : G::swz_v(widx * G::RPP + lr);
+  const unsigned src_lane = (unsigned)(lr * G::ROW) + (unsigned)((lc ^ sw_src) << 4);
+  auto dma_piece = [&](int jt, int slot, int i) __attribute__((always_inline)) {
+    const int piece = i * 4 + widx;
+    const char* s = src_h + (size_t)jt * G::TILE + piece * 1024;
+    hgemm::glds16_asm(s, src_lane, lds0 + slot * G::STAGE + grp * G::TILE + piece * 1024);
+  };
+
+  h8 qf[NQB][NKS];
+  const int T = N / G::BC;
+  __builtin_assume(T > 0);
+  if constexpr ((OX & M16X_SPLIT_PROLOGUE) != 0) {
+    // tile 0's pieces first (group 0: K, needed by the first MFMA; group 1: V, needed one phase later), then Q
+#pragma unroll
+    for (int i = 0; i < G::PPW; ++i) dma_piece(0, 0, i);
+  }
+#pragma unroll
+  for (int qb = 0; qb < NQB; ++qb) {
+    const half_t* qp = Q + head + (size_t)(q_row0 + qb * 16 + i16) * D + g4 * 8;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) qf[qb][ks] = *reinterpret_cast<const h8*>(qp + ks * 32);
+  }
+  f4 ot[NDB][NQB];
+#pragma unroll
+  for (int b = 0; b < NDB; ++b)
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) ot[b][qb] = f4{0.f, 0.f, 0.f, 0.f};
+  float m_run[NQB], l_run[NQB];
+  f4 minit[NQB];
+#pragma unroll
+  for (int qb = 0; qb < NQB; ++qb) {
+    m_run[qb] = 0.f, l_run[qb] = 0.f;
+    minit[qb] = f4{0.f, 0.f, 0.f, 0.f};
+    asm volatile("" : "+v"(minit[qb]));
+  }
+  if constexpr ((OX & M16X_SPLIT_PROLOGUE) == 0) {
+#pragma unroll
+    for (int i = 0; i < G::PPW; ++i) dma_piece(0, 0, i);
+  }
+  auto scale_q = [&]() __attribute__((always_inline)) {
+    const half_t sc = (half_t)scale_log2e;
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb)
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        qf[qb][ks] = qf[qb][ks] * sc;
+        asm volatile("" : "+v"(qf[qb][ks]));
+      }
+  };
+  if constexpr ((OX & M16X_SPLIT_PROLOGUE) != 0) {
+    // group 0 needs K tile 0 (its own pieces) and its Q rows; group 1's V pieces and Q rows are not needed before the
+    // second barrier, so group 1 does not hold up the first one
+    if (grp == 0) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      scale_q();
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (grp == 1) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      scale_q();
+    }
+  } else {
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), compiler-visible: also retires the Q loads
+    scale_q();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+
+  const int kbase = i16 * G::ROW + ((g4 ^ G::swz_k(i16)) << 4);
+  const int v_row = 4 * g4 + (i16 >> 2);
+  const int vbase = v_row * G::ROW + (((((i16 & 3) >> 1)) ^ G::swz_v(v_row)) << 4) + ((i16 & 1) << 3);
+
+  if (grp == 1) {  // group 1 runs one phase behind group 0
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+
+  for (int j = 0; j < T; ++j) {
+    const int jn = j + 1 < T ? j + 1 : T - 1;
+    const int kb_j = kbase + (j & 1) * G::STAGE, vb_j = vbase + (j & 1) * G::STAGE + G::TILE;
+    auto k_frag = [&](int t) __attribute__((always_inline)) {
+      const int kb = t / NKS, ks = t % NKS;
+      return *reinterpret_cast<const h8*>(smem + (kb_j ^ (ks << 6)) + kb * 16 * G::ROW);
+    };
+    auto v_frag = [&](int idx) __attribute__((always_inline)) {
+      const int u = idx / NDB, db = idx % NDB;
+      const char* vp = smem + (vb_j ^ (db << 5)) + (32 * u) * G::ROW;
+      return h8_cat(lds_read_tr16(vp), lds_read_tr16(vp + 16 * G::ROW));
+    };
+    f4 s[NKB][NQB];
+    h8 pf[NU][NQB];
+    float psum[NQB];
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) psum[qb] = 0.f;
+    // item it of key block kb: query block it >> 1, registers (it & 1) * 2, + 1 -> k-slots of P^T step kb >> 1
+    auto exp_item = [&](int kb, int it, float (&acc)[NQB]) __attribute__((always_inline)) {
+      const int qb = it >> 1, r = (it & 1) * 2;
+      const float a0 = __builtin_amdgcn_exp2f(s[kb][qb][r]);
+      const float a1 = __builtin_amdgcn_exp2f(s[kb][qb][r + 1]);
+      acc[qb] += a0 + a1;
+      const h2 a = __builtin_convertvector(f2{a0, a1}, h2);
+      // an input-only empty asm is a chained node of the instruction selector: the item stays in the step it was
+      // written in (without it hipcc sinks every exponential below the last MFMA of the phase)
+      asm volatile("" ::"v"(a), "v"(acc[qb]));
+      const int u = kb >> 1, e = (kb & 1) * 4 + r;
+      pf[u][qb][e] = a[0], pf[u][qb][e + 1] = a[1];
+    };
+
+    // ================= phase A: S^T = K Q^T, block kb - 1 exponentiated behind the MFMAs of block kb
+    if constexpr ((OX & M16X_PRIO) != 0) __builtin_amdgcn_s_setprio(1);
+    if constexpr ((OX & M16X_PRIO_B) != 0) __builtin_amdgcn_s_setprio(0);
+    {
+      h8 kf[PD];
+#pragma unroll
+      for (int i = 0; i < PD; ++i) kf[i] = k_frag(i);
+      constexpr int DSTEP = NQK / G::PPW;
+#pragma unroll
+      for (int t = 0; t < NQK; ++t) {
+        const int kb = t / NKS, ks = t % NKS;
+#pragma unroll
+        for (int qb = 0; qb < NQB; ++qb) {
+          if (ks == 0) s[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[t % PD], qf[qb][0], minit[qb], 0, 0, 0);  // chain starts at -m
+          else s[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[t % PD], qf[qb][ks], s[kb][qb], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // the MFMAs of the step first: the VALU slice runs in their shadow
+        if (t + PD < NQK) kf[t % PD] = k_frag(t + PD);
+        if ((t % DSTEP) == DSTEP - 1) dma_piece(jn, (j + 1) & 1, t / DSTEP);
+        if (kb >= 1 && kb - 1 < NOPT) {
+#pragma unroll
+          for (int it = ks * PER_STEP; it < (ks + 1) * PER_STEP && it < NPAIR; ++it) exp_item(kb - 1, it, psum);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    {
+      // ---- the check: partial sums of the optimistic blocks, raw scores of the deferred ones
+      bool bad = false;
+#pragma unroll
+      for (int qb = 0; qb < NQB; ++qb) {
+        bad |= !(psum[qb] <= 32768.0f);
+        float mx = s[NOPT][qb][0];
+#pragma unroll
+        for (int kb = NOPT; kb < NKB; ++kb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kb][qb][r]);
+        bad |= mx > 14.0f;
+      }
+      const bool first = j == 0;  // tile 0 has no reference yet: it adopts its true maximum
+      if (first || __builtin_amdgcn_ballot_w64(bad) != 0) {
+        // ---- cold path: true row maxima, standard rescale, the optimistic blocks again
+#pragma unroll
+        for (int qb = 0; qb < NQB; ++qb) {
+          float mx = s[0][qb][0];
+#pragma unroll
+          for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kb][qb][r]);
+          const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+          mx = fmaxf(__uint_as_float(s16[0]), __uint_as_float(s16[1]));
+          const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+          const float d = fmaxf(__uint_as_float(s32[0]), __uint_as_float(s32[1]));  // relative to the running reference
+          const float delta = first ? d : fmaxf(d, 0.f);
+          const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-delta);
+          m_run[qb] += delta;
+          l_run[qb] *= alpha;
+#pragma unroll
+          for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[kb][qb][r] -= delta;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) minit[qb][r] = -m_run[qb];
+          asm volatile("" : "+v"(minit[qb]));
+#pragma unroll
+          for (int b = 0; b < NDB; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ot[b][qb][r] *= alpha;
+          psum[qb] = 0.f;
+        }
+#pragma unroll
+        for (int kb = 0; kb < NOPT; ++kb)
+#pragma unroll
+          for (int it = 0; it < NPAIR; ++it) exp_item(kb, it, psum);
+      }
+#pragma unroll
+      for (int qb = 0; qb < NQB; ++qb) l_run[qb] += psum[qb];
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    // ================= phase B: O^T += V^T P^T; the deferred key blocks are exponentiated under its first MFMAs
+    if constexpr ((OX & M16X_PRIO) != 0) __builtin_amdgcn_s_setprio(0);
+    if constexpr ((OX & M16X_PRIO_B) != 0) __builtin_amdgcn_s_setprio(1);
+    float psum_d[NQB];
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) psum_d[qb] = 0.f;
+    h8 vf[PD];
+#pragma unroll
+    for (int i = 0; i < PD; ++i) vf[i] = v_frag(i);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int idx = 0; idx < NPV; ++idx) {
+      const int u = idx / NDB, b = idx % NDB;
+#pragma unroll
+      for (int qb = 0; qb < NQB; ++qb) ot[b][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[idx % PD], pf[u][qb], ot[b][qb], 0, 0, 0);
+      if (idx + PD < NPV) vf[idx % PD] = v_frag(idx + PD);
+      // deferred items at DRATE per step: all of them are done before the first P^T step that holds a deferred block
+#pragma unroll
+      for (int it = idx * DRATE; it < (idx + 1) * DRATE && it < NDEF * NPAIR; ++it) exp_item(NOPT + it / NPAIR, it % NPAIR, psum_d);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) l_run[qb] += psum_d[qb];
+    hgemm::wait_vmcnt<0>();  // own DMA pieces of tile j+1 landed
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+  if (grp == 0) {
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+
+  // ---- epilogue: O = O^T / l, staged through LDS (wave-private rows). Lane (query 16*qb + i16) holds d = 16*b + 4*g4 .. +3.
+  const int lane_e = cln_fresh_lane(), i16_e = lane_e & 15, g4_e = lane_e >> 4;
+  char* ob = smem + wave * (G::RPW * G::OS);
+#pragma unroll
+  for (int qb = 0; qb < NQB; ++qb) {
+    float l_tot = l_run[qb];
+    {
+      const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(l_tot), __float_as_uint(l_tot), false, false);
+      l_tot = __uint_as_float(s16[0]) + __uint_as_float(s16[1]);
+      const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_tot), __float_as_uint(l_tot), false, false);
+      l_tot = __uint_as_float(s32[0]) + __uint_as_float(s32[1]);
+    }
+    const float inv = 1.0f / l_tot;
+#pragma unroll
+    for (int b = 0; b < NDB; ++b) {
+      h4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (half_t)(ot[b][qb][e] * inv);
+      *reinterpret_cast<h4*>(ob + (qb * 16 + i16_e) * G::OS + (b * 16 + g4_e * 4) * 2) = o;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  constexpr int LPR = D / 8;
+  half_t* og = O + head + (size_t)q_row0 * D;
+#pragma unroll 4
+  for (int it = 0; it < (G::RPW * LPR) / 64; ++it) {
+    const int idx = it * 64 + lane_e;
+    const int row = idx / LPR, c = idx % LPR;
+    *reinterpret_cast<u4*>(og + (size_t)row * D + c * 8) = *reinterpret_cast<const u4*>(ob + row * G::OS + c * 16);
+  }
+}
+
+template <int D_, int RPW_, int BC_, int PD = 4, int NDEF = 1, int OX = 0>
+int launch_m16x(const void* q, const void* k, const void* v, void* o, int B, int H, int N, hipStream_t stream) {
+  using G = GeoM16<D_, RPW_, BC_>;
+  if (N % G::BR != 0) return CLN_ERR_UNSUPPORTED;
+  static cln_lds_attr lds_attr;  // per device, thread-safe (common.h)
+  if (cln_ensure_lds(lds_attr, reinterpret_cast<const void*>(&fa2_fwd_m16x_kernel<D_, RPW_, BC_, PD, NDEF, OX>), G::LDS_BYTES) != CLN_OK) return CLN_ERR_LAUNCH;
+  const float scale_log2e = 1.4426950408889634f / sqrtf((float)G::D);
+  const int n_qblk = N / G::BR;
+  CLN_LAUNCH((fa2_fwd_m16x_kernel<D_, RPW_, BC_, PD, NDEF, OX>), dim3(n_qblk * B * H), dim3(G::NT), G::LDS_BYTES, stream,
+             (const half_t*)q, (const half_t*)k, (const half_t*)v, (half_t*)o, N, n_qblk, B * H, scale_log2e);
+  return cln_check_launch();
+}
+
+}  // namespace fa2

@@ -1,0 +1,19 @@
+// Compile unit of the sum-checked optimistic-softmax attention kernels (flash_attn_m16x.cuh). It is built with
+// -fno-slp-vectorize (see _build.py EXTRA_FLAGS): hipcc's SLP pass pairs the per-score f32 row-sum adds of neighbouring
+// steps into v_pk_add_f32, which drags the exponentials of a whole phase behind its last MFMA and is slower than two
+// plain adds beside MFMAs (MI355X_MICROARCH.md, per-instruction constants). Linked into the product library
+// (and, as a dependency of nothing else, not into the probe library, which has its own unit flash_attn_m16x_probe.hip).
+#include "flash_attn_m16x.cuh"
+#include "flash_attn_m16x_api.h"
+
+namespace fa2 {
+
+// The dispatched forms (fa2_plan, flash_attn.hip): NDEF = 4 (half of the exponentials under the PV MFMAs), phase-A priority,
+// split prologue -- the best of profiles/r03_fa_m16x_probe.log at both head dims.
+int m16x_run(int D, const void* q, const void* k, const void* v, void* o, int B, int H, int N, hipStream_t s) {
+  if (D == 64) return launch_m16x<64, 32, 128, 8, 4, M16X_PRIO | M16X_SPLIT_PROLOGUE>(q, k, v, o, B, H, N, s);
+  if (D == 128) return launch_m16x<128, 32, 128, 4, 4, M16X_PRIO | M16X_SPLIT_PROLOGUE>(q, k, v, o, B, H, N, s);
+  return CLN_ERR_UNSUPPORTED;
+}
+
+}  // namespace fa2

@@ -1,0 +1,28 @@
+// TEST-ONLY compile unit: the probe variants of the sum-checked optimistic-softmax attention kernels
+// (flash_attn_m16x.cuh; NDEF / priority / prologue forms measured in profiles/r03_fa_m16x_probe.log). Built, like
+// flash_attn_m16x.hip, with
+// -fno-slp-vectorize (see _build.py EXTRA_FLAGS): hipcc's SLP pass pairs the per-score f32 row-sum adds of neighbouring
+// steps into v_pk_add_f32, which drags the exponentials of a whole phase behind its last MFMA and is slower than two
+// plain adds beside MFMAs (MI355X_MICROARCH.md, per-instruction constants). Linked into the probe library only.
+#include "flash_attn_m16x.cuh"
+#include "flash_attn_m16x_api.h"
+
+namespace fa2 {
+
+// code = 16 * (NDEF - 1) + OX for the 32-rows-per-wave forms; 96 + ...: fragment prefetch depth 4 instead of 8 (D = 64);
+// 120 + 16 * (NDEF - 1) + OX: 64 rows per wave (D = 64, 64-key tiles)
+int m16x_probe_run(int D, int code, const void* q, const void* k, const void* v, void* o, int B, int H, int N, hipStream_t s) {
+#define MX(DD, CODE, RPWW, BCC, PDD, NDEFF, OXX) \
+  if (D == DD && code == CODE) return launch_m16x<DD, RPWW, BCC, PDD, NDEFF, OXX>(q, k, v, o, B, H, N, s);
+  MX(64, 5, 32, 128, 8, 1, 5) MX(64, 21, 32, 128, 8, 2, 5) MX(64, 33, 32, 128, 8, 3, 1) MX(64, 37, 32, 128, 8, 3, 5) MX(64, 38, 32, 128, 8, 3, 6)
+  MX(64, 48, 32, 128, 8, 4, 0) MX(64, 49, 32, 128, 8, 4, 1) MX(64, 53, 32, 128, 8, 4, 5) MX(64, 54, 32, 128, 8, 4, 6) MX(64, 52, 32, 128, 8, 4, 4)
+  MX(64, 69, 32, 128, 8, 5, 5) MX(64, 85, 32, 128, 8, 6, 5)
+  MX(64, 101, 32, 128, 4, 4, 5)
+  MX(64, 120, 64, 64, 4, 1, 0) MX(64, 125, 64, 64, 4, 1, 5) MX(64, 141, 64, 64, 4, 2, 5)
+  MX(128, 5, 32, 128, 4, 1, 5) MX(128, 21, 32, 128, 4, 2, 5) MX(128, 49, 32, 128, 4, 4, 1) MX(128, 53, 32, 128, 4, 4, 5) MX(128, 54, 32, 128, 4, 4, 6)
+  MX(128, 85, 32, 128, 4, 6, 5)
+#undef MX
+  return CLN_ERR_UNSUPPORTED;
+}
+
+}  // namespace fa2

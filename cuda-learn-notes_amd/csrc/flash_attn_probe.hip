@@ -10,6 +10,7 @@
 #include "flash_attn_w4.cuh"
 #include "flash_attn_dsplit2.cuh"
 #include "flash_attn_m16.cuh"
+#include "flash_attn_m16x_api.h"
 #include <type_traits>
 
 #define V3(DD, NWW, OPTT) \
@@ -88,6 +89,9 @@ CLN_API int cln_fa2_variant(int D, int nw, int vt, int opt, int abl, const void*
   // 544 = scores scaled in fp32 (Q not pre-scaled)
   if (D == 256 && abl == 544) return fa2::launch_m16_pair<2, false, false>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 512 && abl == 544) return fa2::launch_m16_pair<2, true, false>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  // 800.. = the sum-checked optimistic softmax form (flash_attn_m16x.cuh, its own compile unit): abl = 800 + code,
+  //         code = 16 * (NDEF - 1) + OX (OX: 1 = phase-A priority, 4 = split prologue); 860.. = prefetch depth 4; 880.. = 64 rows per wave
+  if (abl >= 800 && abl < 1000) return fa2::m16x_probe_run(D, abl - 800, q, k, v, o, B, H, N, (hipStream_t)stream);
   // 530.. = row sums on the matrix pipe (OPT_SUMM)
   if (D == 64 && abl == 530) return fa2::launch_dsplit<64, 1, 4, 13 | fa2::OPT_STAGGER | fa2::OPT_PRE | fa2::OPT_SUMM>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 64 && abl == 531) return fa2::launch_dsplit<64, 1, 2, 13 | fa2::OPT_STAGGER | fa2::OPT_PRE | fa2::OPT_SUMM>(q, k, v, o, B, H, N, (hipStream_t)stream);

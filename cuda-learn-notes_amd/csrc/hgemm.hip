@@ -48,8 +48,9 @@ int best_plan(int M, int N, int K) {
   // Small problems are latency-bound (launch ramp + one L2 round trip per K tile), not throughput-bound: up to 640
   // tiles of 64x64 (1536^2) the smallest tile wins because it puts a workgroup on every CU (1024^3: 6.8 us vs 9.1 us for
   // 64x128 on half the CUs and 8.4 / 10.0 us for rocBLAS TN / NN; profiles/r02_hgemm_small_probe.log); from 2048^2 on the
-  // throughput model below takes over.
-  if (M % 64 == 0 && N % 64 == 0 && K % 64 == 0 && (long long)(M / 64) * (N / 64) <= 640) return PLAN_R64x64;
+  // throughput model below takes over. The shortcut is for SHORT K only (measured up to 1536): a skinny, K-heavy problem
+  // (1600^2 x 16384) is throughput-bound and goes through the model (where the 160x160 form scores 0.88 against 0.44).
+  if (M % 64 == 0 && N % 64 == 0 && K % 64 == 0 && K <= 2048 && (long long)(M / 64) * (N / 64) <= 640) return PLAN_R64x64;
   double best = -1.0;
   int plan = PLAN_R128;
   auto offer = [&](int p, double sc) {
@@ -87,9 +88,11 @@ int plan_tile(int plan) {
 }
 
 // Top rungs (reference warp4x4x2 family): the tile shape comes from best_plan; where that is a 256x256 tile the
-// `stages` knob selects a distinct pipeline structure: 2 -> one-wave-per-SIMD kernel (hgemm_w4.cuh; K a multiple of
-// 128 and >= 384, else the quadrant ping-pong over a 2 x 64-deep ring with split DMA, which is also what an
-// out-of-range `stages` gets), 4 -> k-half ping-pong over a 4 x 32-deep ring, 3/5 -> plain multi-stage ring.
+// `stages` knob selects a distinct pipeline structure: 2 -> one-wave-per-SIMD kernel (hgemm_w4.cuh; best_plan offers it
+// when w4_k_ok(K): whole 64-wide K tiles, >= 6 of them, >= 7 when their number is odd -- otherwise the quadrant
+// ping-pong over a 2 x 64-deep ring with split DMA, which is also what an out-of-range `stages` gets), 4 -> k-half
+// ping-pong over a 4 x 32-deep ring, 3/5 -> plain multi-stage ring. The other hgemm_w4 tile forms (192 / 160 / 128-wide)
+// have ONE pipeline: `stages` is ignored there and cln_describe says so.
 constexpr int W4_PRODUCTION = 26;  // schedule 10 (one DMA piece per 8 MFMAs, running on into the next tile), boustrophedon MFMA order
 template <int LAYOUT>
 int best_dispatch(const void* a, const void* b, void* c, int M, int N, int K, int stages, int swizzle, int stride,
@@ -124,19 +127,19 @@ int describe_ring(int tile, int layout, int M, int N, int K, int stages, char* b
   if (K % BK) return CLN_ERR_UNSUPPORTED;
   return snprintf(buf, len, "mfma_ring<%dx%dx%d,%d waves,stages=%d,%s>", BM, BN, BK, waves, stages, layout == TN ? "TN" : "NN");
 }
-int describe_w4(int BM, int BN, int layout, char* buf, int len) {
-  return snprintf(buf, len, "hgemm_w4<%dx%dx64,4 waves,%dx%d wave tiles,cross-tile LDS-DMA,LDS epilogue,%s>", BM, BN, BM / 2,
-                  BN / 2, layout == TN ? "TN" : "NN");
+int describe_w4(int BM, int BN, int layout, char* buf, int len, bool stages_ignored = false) {
+  return snprintf(buf, len, "hgemm_w4<%dx%dx64,4 waves,%dx%d wave tiles,cross-tile LDS-DMA,LDS epilogue,%s>%s", BM, BN, BM / 2,
+                  BN / 2, layout == TN ? "TN" : "NN", stages_ignored ? " [stages ignored: one pipeline]" : "");
 }
 int describe_best(int layout, int M, int N, int K, int stages, char* buf, int len) {
   int plan = best_plan(M, N, K);
   const char* l = layout == TN ? "TN" : "NN";
-  if (plan == PLAN_W192) return describe_w4(192, 192, layout, buf, len);
-  if (plan == PLAN_W192x256) return describe_w4(192, 256, layout, buf, len);
-  if (plan == PLAN_W256x192) return describe_w4(256, 192, layout, buf, len);
-  if (plan == PLAN_W160) return describe_w4(160, 160, layout, buf, len);
-  if (plan == PLAN_W128x256) return describe_w4(128, 256, layout, buf, len);
-  if (plan == PLAN_W256x128) return describe_w4(256, 128, layout, buf, len);
+  if (plan == PLAN_W192) return describe_w4(192, 192, layout, buf, len, stages != 2);
+  if (plan == PLAN_W192x256) return describe_w4(192, 256, layout, buf, len, stages != 2);
+  if (plan == PLAN_W256x192) return describe_w4(256, 192, layout, buf, len, stages != 2);
+  if (plan == PLAN_W160) return describe_w4(160, 160, layout, buf, len, stages != 2);
+  if (plan == PLAN_W128x256) return describe_w4(128, 256, layout, buf, len, stages != 2);
+  if (plan == PLAN_W256x128) return describe_w4(256, 128, layout, buf, len, stages != 2);
   if (plan == PLAN_W256) {
     if (stages == 2) return describe_w4(256, 256, layout, buf, len);
     plan = PLAN_PP256;

@@ -56,6 +56,9 @@ _add("hgemm_vendor", "H0", "rocblas_create_handle", "init_cublas_handle")
 _add("hgemm_vendor", "H0", "rocblas_destroy_handle", "destroy_cublas_handle")
 _add("hgemm_vendor", "G3", "rocblas_gemm_ex f16/f32-acc NN", "hgemm_cublas_tensor_op_nn")
 _add("hgemm_vendor", "G3", "rocblas_gemm_ex f16/f32-acc TN", "hgemm_cublas_tensor_op_tn")
+# second vendor comparison row (NOT a reference name, hence the cln_ prefix): hipBLASLt, csrc/hgemm_vendor_lt.hip
+_add("hgemm_vendor_lt", "G3", "hipblasLtMatmul f16/f32-acc NN, heuristic's top algorithm", "cln_hgemm_hipblaslt_nn")
+_add("hgemm_vendor_lt", "G3", "hipblasLtMatmul f16/f32-acc TN, heuristic's top algorithm", "cln_hgemm_hipblaslt_tn")
 _add("hgemm", "G3", "mfma_naive<NN> 1 wave/16x16 tile, mfma_16x16x16",
      "hgemm_wmma_m16n16k16_naive", "hgemm_mma_m16n8k16_naive")
 _add("hgemm", "G3", "mfma_1stage<64x128x32,2 waves,NN>", "hgemm_wmma_m16n16k16_mma4x2")
@@ -99,7 +102,7 @@ _FA_VT = [
     "flash_attn_mma_stages_split_q_tiling_qk_swizzle_qkv",
 ]
 _FA_SPLIT_Q_IMPL = ("planner fa2_plan(shape, stages) [csrc/flash_attn.hip]: stages=1 -> fa2_fwd<load-then-compute>; "
-                    "stages=2 -> fa2_fwd_m16<D=64|128|256> (>=192 workgroups of 256 rows) | fa2_fwd_dsplit2<D=64> (>=256 workgroups of 512 rows) | fa2_fwd_v2<D<=256, 8|4|2 waves> | "
+                    "stages=2 -> fa2_fwd_m16x<D=64|128> / fa2_fwd_m16<D=256> (>=192 workgroups of 256 rows) | fa2_fwd_dsplit2<D=64> (>=256 workgroups of 512 rows) | fa2_fwd_v2<D<=256, 8|4|2 waves> | "
                     "fa2_fwd_dsplit<512; 320 / 384 on its LDS geometry with the real d split evenly> | fa2_fwd_dwide<768 (+PAD 640), 1024>; mfma_32x32x16 (m16: 16x16x32), f32 acc "
                     "(see DISPATCH_EXAMPLES)")
 _add("flash_attn", "FA", "fa2_fwd_splitkv<D<=128>: 4 waves share 32 query rows, KV tile split over the waves, cross-wave "
@@ -231,7 +234,7 @@ assert len(BY_NAME) == len(ENTRIES), "duplicate exported name"
 SO_OF_LIB = {
     "hgemm": "libcln_amd.so", "flash_attn": "libcln_amd.so", "elementwise": "libcln_amd.so",
     "reduce": "libcln_amd.so", "softmax": "libcln_amd.so", "layer_norm": "libcln_amd.so",
-    "rms_norm": "libcln_amd.so", "rope": "libcln_amd.so", "hgemm_vendor": "libcln_amd_vendor.so",
+    "rms_norm": "libcln_amd.so", "rope": "libcln_amd.so", "hgemm_vendor": "libcln_amd_vendor.so", "hgemm_vendor_lt": "libcln_amd_vendor.so",
     "histogram": "libcln_amd.so", "embedding": "libcln_amd.so", "activation": "libcln_amd.so",
     "sgemm": "libcln_amd.so", "sgemm_vendor": "libcln_amd_vendor.so",
     "dot_product": "libcln_amd.so", "sgemv": "libcln_amd.so", "hgemv": "libcln_amd.so", "mat_transpose": "libcln_amd.so",
@@ -309,21 +312,25 @@ DISPATCH_EXAMPLES = [
     ("flash_attn_mma_stages_split_kv", (4, 8, 2048, 64), 2,
      "fa2_fwd_splitkv<D=64> 4 waves share 32 rows, 128-key tiles split over the waves, cross-wave max via LDS" + _IGN),
     (_SQKV, (4, 8, 2048, 64), 1, "fa2_fwd<D=64,BC=64,load-then-compute> 4 waves x 32 rows"),
-    (_SQKV, (4, 8, 2048, 64), 2, "fa2_fwd_m16<D=64,BC=128,16x16x32 MFMA,pre-scaled Q> 8 waves x 32 rows, two groups one phase apart"),
+    (_SQKV, (4, 8, 2048, 64), 2, "fa2_fwd_m16x<D=64,BC=128,16x16x32 MFMA,pre-scaled Q,sum-checked softmax> 8 waves x 32 rows, two groups one phase apart"),
     (_SQKV, (1, 48, 8192, 64), 2, "fa2_fwd_dsplit2<D=64,BC=64,pre-scaled Q> 8 waves x 64 rows, two groups one phase apart, K/V fragments shared by 2 row groups"),
-    (_SQKV, (2, 24, 4096, 64), 2, "fa2_fwd_m16<D=64,BC=128,16x16x32 MFMA,pre-scaled Q> 8 waves x 32 rows, two groups one phase apart"),
-    (_SQKV, (4, 8, 2048, 128), 2, "fa2_fwd_m16<D=128,BC=128,16x16x32 MFMA,pre-scaled Q> 8 waves x 32 rows, two groups one phase apart"),
+    (_SQKV, (2, 24, 4096, 64), 2, "fa2_fwd_m16x<D=64,BC=128,16x16x32 MFMA,pre-scaled Q,sum-checked softmax> 8 waves x 32 rows, two groups one phase apart"),
+    (_SQKV, (4, 8, 2048, 128), 2, "fa2_fwd_m16x<D=128,BC=128,16x16x32 MFMA,pre-scaled Q,sum-checked softmax> 8 waves x 32 rows, two groups one phase apart"),
     (_SQKV, (2, 32, 4096, 256), 2, "fa2_fwd_m16<D=256,BC=32,16x16x32 MFMA> 8 waves x 32 rows, two groups one phase apart"),
     (_SQKV, (2, 8, 2048, 64), 2, "fa2_fwd_v2<D=64,NW=4,BC=64,prefetch,pre-scaled Q> 4 waves x 32 rows"),
     (_SQKV, (1, 2, 256, 64), 2, "fa2_fwd_v2<D=64,NW=2,BC=64,prefetch,pre-scaled Q> 2 waves x 32 rows"),
     (_SQKV, (1, 2, 192, 64), 1, "fa2_fwd_v2<D=64,NW=2,BC=64,prefetch,pre-scaled Q> 2 waves x 32 rows" + _IGN),
     (_SQKV + "_swizzle_qkv", (4, 8, 2048, 128), 2, "fa2_fwd_v2<D=128,NW=8,BC=64,prefetch,pre-scaled Q,V^T> 8 waves x 32 rows"),
     (_SQKV + "_swizzle_qkv", (4, 8, 2048, 128), 1, "fa2_fwd<D=128,BC=64,load-then-compute,V^T> 4 waves x 32 rows"),
-    (_TQKV, (1, 32, 4096, 512), 2, "fa2_fwd_dsplit<D=512,NSP=2,BC=32> 8 waves, two groups one phase apart" + _IGN),
-    (_TQKV, (1, 16, 4096, 384), 2, "fa2_fwd_dsplit<D=384,NSP=2,BC=32,LDS geometry of D=512> 8 waves, pairs split the real d evenly" + _IGN),
-    (_TQKV, (1, 16, 4096, 320), 2, "fa2_fwd_dsplit<D=320,NSP=2,BC=32,LDS geometry of D=512> 8 waves, pairs split the real d evenly" + _IGN),
-    (_TQKV, (1, 16, 4096, 640), 2, "fa2_fwd_dwide<D=768,PAD=640> 6 waves split d" + _IGN),
-    (_TQKV, (1, 16, 4096, 1024), 2, "fa2_fwd_dwide<D=1024> 8 waves split d" + _IGN),
+    (_TQKV, (1, 32, 4096, 512), 2, "fa2_fwd_dsplit<D=512,NSP=2,BC=32> 8 waves, two groups one phase apart"),
+    (_TQKV, (1, 16, 4096, 384), 2, "fa2_fwd_dsplit<D=384,NSP=2,BC=32,LDS geometry of D=512> 8 waves, pairs split the real d evenly"),
+    (_TQKV, (1, 16, 4096, 320), 2, "fa2_fwd_dsplit<D=320,NSP=2,BC=32,LDS geometry of D=512> 8 waves, pairs split the real d evenly"),
+    (_TQKV, (1, 16, 4096, 640), 2, "fa2_fwd_dwide<D=768,PAD=640> 6 waves split d"),
+    (_TQKV, (1, 16, 4096, 1024), 2, "fa2_fwd_dwide<D=1024> 8 waves split d"),
+    # stages = 1 above D = 256: the load-then-compute kernel with the output head dim sliced over blockIdx.z
+    (_TQKV, (1, 32, 4096, 512), 1, "fa2_fwd<D=512,DV=256,BC=64,load-then-compute> 4 waves x 32 rows, output head dim sliced over 2 workgroups"),
+    (_TQKV, (1, 16, 4096, 1024), 1, "fa2_fwd<D=1024,DV=256,BC=32,load-then-compute> 4 waves x 32 rows, output head dim sliced over 4 workgroups"),
+    (_TQKV, (1, 16, 4160, 768), 1, "fa2_fwd_dwide<D=768> 6 waves split d" + _IGN),  # N % 128 != 0: the load-then-compute kernel does not tile it
 ]
 
 

@@ -42,6 +42,8 @@ GROUPS = [
               " * (`void f(torch::Tensor a, b, c[, int stages, bool swizzle, int swizzle_stride])`)."),
     ("hgemm_vendor", "Vendor row (libcln_amd_vendor.so, rocBLAS): reference kernels/hgemm/cublas/hgemm_cublas.cu:15-84,\n"
                      " * bindings :222-261 (init/destroy handle are process-global as in the reference)."),
+    ("hgemm_vendor_lt", "Second vendor row (libcln_amd_vendor.so, hipBLASLt; csrc/hgemm_vendor_lt.hip). NOT reference names (hence cln_):\n"
+                        " * BASELINE.md's C3 target reads \"rocBLAS/hipBLASLt\"; the reference's own vendor row is cuBLAS (hgemm_cublas.cu:15-84)."),
     ("flash_attn", "FlashAttention-2 forward, fp16 [B,H,N,D]; *_swizzle_qkv of share_kv/share_qkv/tiling_qk take V as [B,H,D,N].\n"
                    " * Replaces reference kernels/flash-attn/pybind/flash_attn.cc:182-215\n"
                    " * (`void f(torch::Tensor Q, K, V, O, int stages)`)."),

@@ -35,7 +35,14 @@ def test_stages_knob_selects_a_different_flash_attn_kernel(built):
     n = "flash_attn_mma_stages_split_q_shared_qkv"
     one, two = m.describe(n, (4, 8, 2048, 64), 1), m.describe(n, (4, 8, 2048, 64), 2)
     assert "load-then-compute" in one and "load-then-compute" not in two
-    assert "stages ignored" in m.describe("flash_attn_mma_stages_split_q_tiling_qkv", (1, 32, 4096, 512), 1)
+    # above D = 256 too (reference kStage of the tiling kernels, flash_attn_mma_tiling_qkv.cu:63, :189-223): config C5
+    tq = "flash_attn_mma_stages_split_q_tiling_qkv"
+    one5, two5 = m.describe(tq, (1, 32, 4096, 512), 1), m.describe(tq, (1, 32, 4096, 512), 2)
+    assert "load-then-compute" in one5 and two5.startswith("fa2_fwd_dsplit<D=512") and "stages ignored" not in two5
+    for D in (320, 384, 640, 768, 1024):
+        assert "load-then-compute" in m.describe(tq, (1, 16, 4096, D), 1), D
+    # where the load-then-compute kernel does not tile N, the one pipeline serves both stage counts and says so
+    assert "stages ignored" in m.describe(tq, (1, 16, 4160, 768), 1)
     # the split-KV rung is its own kernel, not an alias of the split-Q dispatcher
     assert m.describe("flash_attn_mma_stages_split_kv", (4, 8, 2048, 64), 2).startswith("fa2_fwd_splitkv")
     with pytest.raises(ValueError):
@@ -66,8 +73,10 @@ def test_hgemm_tile_policy_invariants_over_a_grid_of_shapes(built):
                         nt = K // 64
                         assert K % 64 == 0 and nt >= (7 if nt & 1 else 6), (M, N, K, t)
                         assert not (bm == 256 and bn == 256 and stages != 2), (M, N, K, stages, t)
+                        if (bm, bn) != (256, 256):  # the other tile forms have one pipeline and say so
+                            assert ("stages ignored" in t) == (stages != 2), (M, N, K, stages, t)
                     t2 = m.describe(tn, (M, N, K), stages)
-                    assert t2.endswith("TN>") and t2[:t2.rindex(",")] == t[:t.rindex(",")], (t, t2)
+                    assert t2.replace(",TN>", ",NN>") == t and ",TN>" in t2, (t, t2)
     # the policy actually uses its repertoire on this grid
     for want in (("hgemm_w4", 256, 256), ("hgemm_w4", 160, 160), ("hgemm_w4", 192, 192), ("hgemm_w4", 128, 256),
                  ("mfma_ring", 64, 64), ("hgemm_pp", 256, 256)):
@@ -84,7 +93,7 @@ def test_flash_attn_planner_invariants_over_a_grid_of_shapes(built):
     row / key granularity divides N (a launcher would otherwise refuse at run time what describe promised)."""
     m = built.manifest
     tq, sq = "flash_attn_mma_stages_split_q_tiling_qkv", "flash_attn_mma_stages_split_q_shared_qkv"
-    rows_per_wg = {"fa2_fwd_m16": 256, "fa2_fwd_dsplit2": 512, "fa2_fwd_dsplit": 128, "fa2_fwd_dwide": 64, "fa2_fwd_v2": 64}
+    rows_per_wg = {"fa2_fwd_m16": 256, "fa2_fwd_m16x": 256, "fa2_fwd_dsplit2": 512, "fa2_fwd_dsplit": 128, "fa2_fwd_dwide": 64, "fa2_fwd_v2": 64}
     fam_seen = set()
     for D in (32, 64, 96, 128, 256, 320, 384, 512, 640, 768, 1024):
         for (B, H) in ((1, 1), (1, 8), (4, 8), (1, 48), (2, 96), (1, 256)):
@@ -98,14 +107,14 @@ def test_flash_attn_planner_invariants_over_a_grid_of_shapes(built):
                 assert N % rows_per_wg[fam] == 0 or fam == "fa2_fwd_v2", (B, H, N, D, t)
                 wgs256 = B * H * (N // 256) if N % 256 == 0 else 0
                 if D in (64, 128, 256) and wgs256 >= 192 and not (D == 64 and t.startswith("fa2_fwd_dsplit2")):
-                    assert fam == "fa2_fwd_m16" and "16x16x32" in t, (B, H, N, D, t)
+                    assert fam == ("fa2_fwd_m16" if D == 256 else "fa2_fwd_m16x") and "16x16x32" in t, (B, H, N, D, t)
                 if D in (320, 384, 512):
                     assert fam == "fa2_fwd_dsplit", t
                 if D in (640, 768, 1024):
                     assert fam == "fa2_fwd_dwide", t
                 if D <= 256:  # the shared-QKV name (max head dim 256) plans the same kernel
                     assert m.describe(sq, (B, H, N, D), 2) == t
-    for want in (("fa2_fwd_m16", 64), ("fa2_fwd_m16", 128), ("fa2_fwd_m16", 256), ("fa2_fwd_dsplit2", 64), ("fa2_fwd_v2", 32),
+    for want in (("fa2_fwd_m16x", 64), ("fa2_fwd_m16x", 128), ("fa2_fwd_m16", 256), ("fa2_fwd_dsplit2", 64), ("fa2_fwd_v2", 32),
                  ("fa2_fwd_dsplit", 512), ("fa2_fwd_dwide", 1024)):
         assert want in fam_seen, (want, sorted(fam_seen))
     with pytest.raises(ValueError):  # "headdim not support!" of the shared-QKV rung (MAX_HEADDIM_CFG: 256)

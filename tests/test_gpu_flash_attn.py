@@ -544,4 +544,4 @@ def test_pingpong_kernel_with_64_rows_per_wave(fa, built, dev, oracle):
             ref = oracle.attention_fp64(q[b:b + 1, h:h + 1], k[b:b + 1, h:h + 1], v[b:b + 1, h:h + 1])
             assert (o[b:b + 1, h:h + 1].double() - ref).abs().max().item() <= TOL_AMPLIFIED_KEYS, (B, H, N, b, h)
     # a grid that does not fill whole rounds keeps the 32-row kernel
-    assert built.manifest.describe(name, (2, 24, 4096, 64), 2).startswith("fa2_fwd_m16<D=64")
+    assert built.manifest.describe(name, (2, 24, 4096, 64), 2).startswith("fa2_fwd_m16x<D=64")

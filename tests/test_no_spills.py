@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.join(ROOT, "cuda-learn-notes_amd", "tools"))
 # no reference name dispatches it (csrc/hgemm.hip best_tile / the CLN_G6 table)
 PROBE_ONLY = ("hgemm::Cfg<256, 256, 32, 2, 2,", "hgemm::Cfg<256, 256, 64, 2, 2,")
 
-SOURCES = ["flash_attn.hip", "hgemm.hip", "hgemm_ring_nn.hip", "hgemm_ring_tn.hip", "sgemm.hip", "softmax.hip", "norm.hip",
+SOURCES = ["flash_attn.hip", "flash_attn_m16x.hip", "hgemm.hip", "hgemm_ring_nn.hip", "hgemm_ring_tn.hip", "sgemm.hip", "softmax.hip", "norm.hip",
            "reduce.hip", "elementwise.hip", "rope.hip", "activation.hip", "blas1.hip", "indexing.hip"]
 
 
@@ -36,8 +36,10 @@ def test_production_attention_instantiations_are_in_the_report(tmp_path):
     when an instantiation is renamed)."""
     import kernel_resources as kr
     kernels, _ = kr.report(os.path.join(ROOT, "cuda-learn-notes_amd", "csrc", "flash_attn.hip"), keep=str(tmp_path))
-    names = [k["demangled"] for k in kernels]
-    for want in ("fa2_fwd_dsplit_kernel<512, 2, 1,", "fa2_fwd_m16_kernel<64, 32, 128, 8>", "fa2_fwd_m16_kernel<128, 32, 128, 4>", "fa2_fwd_m16_pair_kernel<2, false, false>",
+    kernels_x, _ = kr.report(os.path.join(ROOT, "cuda-learn-notes_amd", "csrc", "flash_attn_m16x.hip"), keep=str(tmp_path))
+    names = [k["demangled"] for k in kernels + kernels_x]
+    assert len(kernels_x) == 2, [k["demangled"] for k in kernels_x]  # the product unit holds the two dispatched forms only
+    for want in ("fa2_fwd_dsplit_kernel<512, 2, 1,", "fa2_fwd_m16x_kernel<64, 32, 128, 8, 4, 5>", "fa2_fwd_m16x_kernel<128, 32, 128, 4, 4, 5>", "fa2_fwd_m16_pair_kernel<2, false, false>",
                  "fa2_fwd_v2_kernel<128, 2, true", "fa2_fwd_splitkv_kernel<64>", "fa2_fwd_dwide_kernel<1024", "fa2_fwd_dsplit2_kernel<4, false>"):
         assert any(want in n for n in names), want
 
@@ -63,16 +65,20 @@ def test_production_attention_kernels_use_the_16x16x32_matrix_shape(tmp_path):
     import re
     import kernel_resources as kr
     kernels, s = kr.report(os.path.join(ROOT, "cuda-learn-notes_amd", "csrc", "flash_attn.hip"), keep=str(tmp_path))
-    text = open(s).read()
-    for want in ("fa2_fwd_m16_kernel<64, 32, 128, 8>", "fa2_fwd_m16_kernel<128, 32, 128, 4>", "fa2_fwd_m16_pair_kernel<2, false, false>"):
-        k = [k for k in kernels if want in k["demangled"]]
+    kernels_x, sx = kr.report(os.path.join(ROOT, "cuda-learn-notes_amd", "csrc", "flash_attn_m16x.hip"), keep=str(tmp_path))
+    text = open(s).read() + open(sx).read()
+    for want in ("fa2_fwd_m16x_kernel<64, 32, 128, 8, 4, 5>", "fa2_fwd_m16x_kernel<128, 32, 128, 4, 4, 5>", "fa2_fwd_m16_pair_kernel<2, false, false>"):
+        k = [k for k in kernels + kernels_x if want in k["demangled"]]
         assert len(k) == 1, want
         body = text[text.index("\n" + k[0]["name"] + ":"):]
         body = body[:body.index("s_endpgm")]
         shapes = set(re.findall(r"v_mfma_f32_(\w+?)_f16", body))
         assert shapes == {"16x16x32"}, (want, shapes)
-        if want.startswith("fa2_fwd_m16_kernel<64"):
-            # hipcc peels the first KV tile: two tile bodies, each 32 + 32 MFMAs and 64 exponentials (+ 2 in the rare
-            # rescale branch of the loop)
-            assert body.count("v_mfma_f32_16x16x32_f16") == 128 and 128 <= body.count("v_exp_f32") <= 132, \
-                (body.count("v_mfma_f32_16x16x32_f16"), body.count("v_exp_f32"))
+        if want.startswith("fa2_fwd_m16x_kernel<64"):
+            # one tile body in the KV loop: 32 + 32 MFMAs and 64 exponentials per wave (32 rows x 128 keys / 64 lanes);
+            # the cold (rescale) block repeats the 32 optimistic ones of phase A and holds no MFMA. The sum-checked
+            # softmax has no row-maximum chain on the hot path: the v_max3 of the kernel sit in the cold block and in the
+            # check of the deferred key blocks (4 per block and query block)
+            assert body.count("v_mfma_f32_16x16x32_f16") == 64, body.count("v_mfma_f32_16x16x32_f16")
+            assert 96 <= body.count("v_exp_f32") <= 100, body.count("v_exp_f32")
+            assert "v_pk_add_f32" not in body  # -fno-slp-vectorize on this unit (see flash_attn_m16x.hip)
