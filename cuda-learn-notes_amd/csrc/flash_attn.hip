@@ -23,7 +23,7 @@
 namespace {
 
 enum FaFamily { FAM_SPLIT_KV = 0, FAM_SPLIT_Q = 1 };
-enum FaKind { K_NONE = 0, K_SPLITKV, K_LOAD_THEN_COMPUTE, K_V2, K_DSPLIT, K_DWIDE, K_DSPLIT64R, K_M16 };
+enum FaKind { K_NONE = 0, K_SPLITKV, K_LOAD_THEN_COMPUTE, K_V2, K_DSPLIT, K_DRING, K_DSPLIT64R, K_M16 };
 
 struct FaPlan {
   int rc = CLN_OK;     // CLN_ERR_* when the shape is not supported
@@ -108,10 +108,10 @@ FaPlan fa2_plan(int family, bool vt, int B, int H, int N, int D, int stages, int
       return p.kind = K_DSPLIT, p.d_inst = 512, p.nw = 8, p.bc = 32, p;
     case 640: case 768:
       if (N % 64 != 0) return p.rc = CLN_ERR_UNSUPPORTED, p;
-      return p.kind = K_DWIDE, p.d_inst = 768, p.nw = 6, p.bc = 32, p;
+      return p.kind = K_DRING, p.d_inst = D, p.nw = 8, p.bc = 16, p;
     case 1024:
       if (N % 64 != 0) return p.rc = CLN_ERR_UNSUPPORTED, p;
-      return p.kind = K_DWIDE, p.d_inst = 1024, p.nw = 8, p.bc = 32, p;
+      return p.kind = K_DRING, p.d_inst = 1024, p.nw = 8, p.bc = 16, p;
     default: return p.rc = CLN_ERR_UNSUPPORTED, p;
   }
 }
@@ -150,16 +150,19 @@ int fa2_run(const FaPlan& p, const void* q, const void* k, const void* v, void* 
       }
       return CLN_ERR_UNSUPPORTED;
     case K_V2:
-#define FA_V2(DD, OPTT)                                                                                \
+#define FA_V2(DD, OPTT, HAS8)                                                                          \
   case DD:                                                                                             \
-    if (p.nw == 8) return fa2::launch_v2<DD, 8, VT, OPTT>(q, k, v, o, B, H, N, s);                     \
+    if (p.nw == 8) {                                                                                   \
+      if constexpr (HAS8 || VT) return fa2::launch_v2<DD, 8, VT, OPTT>(q, k, v, o, B, H, N, s);       \
+      else return CLN_ERR_UNSUPPORTED; /* the plan never names it: these shapes run fa2_fwd_m16x */   \
+    }                                                                                                  \
     if (p.nw == 4) return fa2::launch_v2<DD, 4, VT, OPTT>(q, k, v, o, B, H, N, s);                     \
     return fa2::launch_v2<DD, 2, VT, OPTT>(q, k, v, o, B, H, N, s);
       switch (D) {
-        FA_V2(32, 13 | fa2::OPT_PRE)
-        FA_V2(64, 13 | fa2::OPT_PRE)
-        FA_V2(96, 15 | fa2::OPT_PRE)
-        FA_V2(128, 15 | fa2::OPT_PRE)
+        FA_V2(32, 13 | fa2::OPT_PRE, true)
+        FA_V2(64, 13 | fa2::OPT_PRE, false)
+        FA_V2(96, 15 | fa2::OPT_PRE, true)
+        FA_V2(128, 15 | fa2::OPT_PRE, false)
         case 256: return fa2::launch_v2<256, 4, VT, 15>(q, k, v, o, B, H, N, s);
       }
 #undef FA_V2
@@ -180,7 +183,7 @@ int fa2_run(const FaPlan& p, const void* q, const void* k, const void* v, void* 
         return fa::launch_fa2_large_d(q, k, v, o, B, H, N, D, s);
       }
       return CLN_ERR_UNSUPPORTED;
-    case K_DWIDE:
+    case K_DRING:
       if constexpr (!VT) return fa::launch_fa2_large_d(q, k, v, o, B, H, N, D, s);
       return CLN_ERR_UNSUPPORTED;
     default: return CLN_ERR_UNSUPPORTED;
@@ -229,10 +232,9 @@ int fa2_describe(int family, bool vt, int B, int H, int N, int D, int stages, in
         return snprintf(buf, len, "fa2_fwd_dsplit<D=%d,NSP=2,BC=32,LDS geometry of D=%d> 8 waves, pairs split the real d evenly%s", D, p.d_inst, st);
       return snprintf(buf, len, "fa2_fwd_dsplit<D=%d,NSP=%d,BC=%d> 8 waves, two groups one phase apart%s", D,
                       D == 512 ? 2 : 1, p.bc, st);
-    case K_DWIDE:
-      if (p.d_inst != D)
-        return snprintf(buf, len, "fa2_fwd_dwide<D=%d,PAD=%d> %d waves split d%s", p.d_inst, D, p.nw, st);
-      return snprintf(buf, len, "fa2_fwd_dwide<D=%d> %d waves split d%s", D, p.nw, st);
+    case K_DRING:
+      return snprintf(buf, len, "fa2_fwd_dring<D=%d,BC=16,2-slot K/V rings%s> 8 waves, 4 split d (%d columns each), 64 rows%s", D,
+                      D == 1024 ? ",row groups one phase apart" : "", D / 4, st);
     default: return CLN_ERR_UNSUPPORTED;
   }
 }

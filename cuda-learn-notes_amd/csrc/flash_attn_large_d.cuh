@@ -4,13 +4,15 @@
 // the head dim is split across the waves of a query-row group instead (each wave keeps its 256 columns of Q and of
 // O^T in registers and the partial S^T tiles are summed through LDS):
 //   512        pairs of waves, two 4-wave groups one phase apart, K/V double-buffered   (flash_attn_dsplit.cuh)
-//   768, 1024  triples / quads of waves, one K and one V tile in the 160 KiB LDS         (flash_attn_dwide.cuh)
-//   320, 384   the D = 512 kernel's LDS geometry, every loop over the real head dim (DREAL; round 2); 640 padded on D = 768
+//   640, 768, 1024  quads of waves (D / 4 columns each), K / V through two-slot rings of 16-key tiles (flash_attn_dring.cuh,
+//              round 3; its predecessor flash_attn_dwide.cuh -- one 32-key K tile and one V tile, no prefetch, D = 640 padded
+//              to 768 -- lives on in the probe library)
+//   320, 384   the D = 512 kernel's LDS geometry, every loop over the real head dim (DREAL; round 2)
 #pragma once
 #include "flash_attn.cuh"
 #include "flash_attn_bigd.cuh"
 #include "flash_attn_dsplit.cuh"
-#include "flash_attn_dwide.cuh"
+#include "flash_attn_dring.cuh"
 
 namespace fa {
 inline int launch_fa2_large_d(const void* q, const void* k, const void* v, void* o, int B, int H, int N, int D,
@@ -18,18 +20,19 @@ inline int launch_fa2_large_d(const void* q, const void* k, const void* v, void*
   switch (D) {
     // D = 320 / 384: the D = 512 kernel's LDS geometry with the pair of waves splitting the REAL head dim evenly (no MFMA
     // on padding): 745-817 / 793-876 TF at [1,16,4096,D] (profiles/r02_fa_native_320_384.log) vs 585 / 695 for the
-    // zero-padded round-1 form. D = 640 still rides padded on the D = 768 kernel (593 TF, profiles/r01_fa_padded_dims.log)
+    // zero-padded round-1 form.
     case 320: return fa2::launch_dsplit<512, 2, 1, fa2::OPT_DEFAULT, 0, 320>(q, k, v, o, B, H, N, s);
     case 384: return fa2::launch_dsplit<512, 2, 1, fa2::OPT_DEFAULT, 0, 384>(q, k, v, o, B, H, N, s);
     // D = 512 (config C5): pairs of waves split the head dim, two 4-wave groups one phase apart
     // (flash_attn_dsplit.cuh): 990-1000 TF at [1,32,4096,512] vs 487 for the register-resident O-slice kernel
     // (flash_attn_bigd.cuh, still used for D = 768) and 411 for the v1 path (profiles/r01_fa_dsplit_probe.log)
     case 512: return fa2::launch_dsplit<512, 2, 1, fa2::OPT_DEFAULT>(q, k, v, o, B, H, N, s);
-    case 640: return fa2::launch_dwide<768, fa2::OPT_DEFAULT, true>(q, k, v, o, B, H, N, s, 640);
-    // D = 768 / 1024: three / four waves split the head dim of a 32-row group (flash_attn_dwide.cuh): 675-690 TF
-    // at [1,16,4096,768] (big-D kernel 223-295), 706-776 TF at D = 1024 (v1 path 100-131, below torch SDPA)
-    case 768: return fa2::launch_dwide<768, fa2::OPT_DEFAULT>(q, k, v, o, B, H, N, s);
-    case 1024: return fa2::launch_dwide<1024, fa2::OPT_DEFAULT>(q, k, v, o, B, H, N, s);
+    // D = 640 / 768 / 1024 (flash_attn_dring.cuh): [1,16,4096,D] 604 -> 649 / 684 -> 703 / 691 -> 780 TF, [1,8,8192,1024] 657 -> 804
+    // over the d-wide kernel (profiles/r03_fa_dring_probe.log); the two row groups run one phase apart at D = 1024 only
+    // (lock-step measured 1-4 % faster at 640 / 768)
+    case 640: return fa2::launch_dring<640, fa2::OPT_DEFAULT, false>(q, k, v, o, B, H, N, s);
+    case 768: return fa2::launch_dring<768, fa2::OPT_DEFAULT, false>(q, k, v, o, B, H, N, s);
+    case 1024: return fa2::launch_dring<1024, fa2::OPT_DEFAULT, true>(q, k, v, o, B, H, N, s);
     default: return CLN_ERR_UNSUPPORTED;
   }
 }

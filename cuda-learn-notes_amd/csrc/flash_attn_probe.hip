@@ -11,6 +11,7 @@
 #include "flash_attn_dsplit2.cuh"
 #include "flash_attn_m16.cuh"
 #include "flash_attn_m16x_api.h"
+#include "flash_attn_dring.cuh"
 #include <type_traits>
 
 #define V3(DD, NWW, OPTT) \
@@ -92,6 +93,13 @@ CLN_API int cln_fa2_variant(int D, int nw, int vt, int opt, int abl, const void*
   // 800.. = the sum-checked optimistic softmax form (flash_attn_m16x.cuh, its own compile unit): abl = 800 + code,
   //         code = 16 * (NDEF - 1) + OX (OX: 1 = phase-A priority, 4 = split prologue); 860.. = prefetch depth 4; 880.. = 64 rows per wave
   if (abl >= 800 && abl < 1000) return fa2::m16x_probe_run(D, abl - 800, q, k, v, o, B, H, N, (hipStream_t)stream);
+  // 1000 = the ring kernel for head dims 640 / 768 / 1024 (flash_attn_dring.cuh), row groups one phase apart; 1001 = lock-step
+  if (D == 640 && abl == 1000) return fa2::launch_dring<640, fa2::OPT_DEFAULT>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 768 && abl == 1000) return fa2::launch_dring<768, fa2::OPT_DEFAULT>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 1024 && abl == 1000) return fa2::launch_dring<1024, fa2::OPT_DEFAULT>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 640 && abl == 1001) return fa2::launch_dring<640, fa2::OPT_DEFAULT, false>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 768 && abl == 1001) return fa2::launch_dring<768, fa2::OPT_DEFAULT, false>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 1024 && abl == 1001) return fa2::launch_dring<1024, fa2::OPT_DEFAULT, false>(q, k, v, o, B, H, N, (hipStream_t)stream);
   // 530.. = row sums on the matrix pipe (OPT_SUMM)
   if (D == 64 && abl == 530) return fa2::launch_dsplit<64, 1, 4, 13 | fa2::OPT_STAGGER | fa2::OPT_PRE | fa2::OPT_SUMM>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 64 && abl == 531) return fa2::launch_dsplit<64, 1, 2, 13 | fa2::OPT_STAGGER | fa2::OPT_PRE | fa2::OPT_SUMM>(q, k, v, o, B, H, N, (hipStream_t)stream);

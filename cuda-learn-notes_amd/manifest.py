@@ -103,7 +103,7 @@ _FA_VT = [
 ]
 _FA_SPLIT_Q_IMPL = ("planner fa2_plan(shape, stages) [csrc/flash_attn.hip]: stages=1 -> fa2_fwd<load-then-compute>; "
                     "stages=2 -> fa2_fwd_m16x<D=64|128> / fa2_fwd_m16<D=256> (>=192 workgroups of 256 rows) | fa2_fwd_dsplit2<D=64> (>=256 workgroups of 512 rows) | fa2_fwd_v2<D<=256, 8|4|2 waves> | "
-                    "fa2_fwd_dsplit<512; 320 / 384 on its LDS geometry with the real d split evenly> | fa2_fwd_dwide<768 (+PAD 640), 1024>; mfma_32x32x16 (m16: 16x16x32), f32 acc "
+                    "fa2_fwd_dsplit<512; 320 / 384 on its LDS geometry with the real d split evenly> | fa2_fwd_dring<640 | 768 | 1024>; mfma_32x32x16 / 16x16x32, f32 acc "
                     "(see DISPATCH_EXAMPLES)")
 _add("flash_attn", "FA", "fa2_fwd_splitkv<D<=128>: 4 waves share 32 query rows, KV tile split over the waves, cross-wave "
      "row max through LDS (the structurally distinct split-KV rung)", "flash_attn_mma_stages_split_kv")
@@ -325,12 +325,12 @@ DISPATCH_EXAMPLES = [
     (_TQKV, (1, 32, 4096, 512), 2, "fa2_fwd_dsplit<D=512,NSP=2,BC=32> 8 waves, two groups one phase apart"),
     (_TQKV, (1, 16, 4096, 384), 2, "fa2_fwd_dsplit<D=384,NSP=2,BC=32,LDS geometry of D=512> 8 waves, pairs split the real d evenly"),
     (_TQKV, (1, 16, 4096, 320), 2, "fa2_fwd_dsplit<D=320,NSP=2,BC=32,LDS geometry of D=512> 8 waves, pairs split the real d evenly"),
-    (_TQKV, (1, 16, 4096, 640), 2, "fa2_fwd_dwide<D=768,PAD=640> 6 waves split d"),
-    (_TQKV, (1, 16, 4096, 1024), 2, "fa2_fwd_dwide<D=1024> 8 waves split d"),
+    (_TQKV, (1, 16, 4096, 640), 2, "fa2_fwd_dring<D=640,BC=16,2-slot K/V rings> 8 waves, 4 split d (160 columns each), 64 rows"),
+    (_TQKV, (1, 16, 4096, 1024), 2, "fa2_fwd_dring<D=1024,BC=16,2-slot K/V rings,row groups one phase apart> 8 waves, 4 split d (256 columns each), 64 rows"),
     # stages = 1 above D = 256: the load-then-compute kernel with the output head dim sliced over blockIdx.z
     (_TQKV, (1, 32, 4096, 512), 1, "fa2_fwd<D=512,DV=256,BC=64,load-then-compute> 4 waves x 32 rows, output head dim sliced over 2 workgroups"),
     (_TQKV, (1, 16, 4096, 1024), 1, "fa2_fwd<D=1024,DV=256,BC=32,load-then-compute> 4 waves x 32 rows, output head dim sliced over 4 workgroups"),
-    (_TQKV, (1, 16, 4160, 768), 1, "fa2_fwd_dwide<D=768> 6 waves split d" + _IGN),  # N % 128 != 0: the load-then-compute kernel does not tile it
+    (_TQKV, (1, 16, 4160, 768), 1, "fa2_fwd_dring<D=768,BC=16,2-slot K/V rings> 8 waves, 4 split d (192 columns each), 64 rows" + _IGN),  # N % 128 != 0: the load-then-compute kernel does not tile it
 ]
 
 

@@ -201,6 +201,33 @@ def test_baseline_configs_sampled_rows(hg, dev, size):
         assert (err <= ATOL + RTOL * truth.abs()).all(), (name, err.max().item())
 
 
+@pytest.mark.parametrize("size", [4096, 8192])
+def test_baseline_configs_full_matrix(hg, dev, size):
+    """BASELINE config C3 (4096^3, 8192^3): EVERY element of C against a GPU fp32 product (torch.matmul on fp32 copies of the
+    operands: rocBLAS SGEMM, exact-f32 matrix instruction), which is itself pinned to the CPU fp32 oracle on sampled rows
+    (the round-2 test looked at 64 sampled rows only). NN and TN rungs of the headline family."""
+    from cuda_learn_notes_amd.bench_utils import as_col_major, make_block_swizzle_stride
+    M = N = K = size
+    torch.manual_seed(size + 1)
+    a = torch.randn(M, K, dtype=torch.half, device=dev)
+    b = torch.randn(K, N, dtype=torch.half, device=dev)
+    truth = a.float() @ b.float()
+    rows = torch.arange(0, M, M // 32)[:32]
+    cpu_truth = a[rows].cpu().float() @ b.cpu().float()
+    # fp32 accumulation order differs between the two fp32 products: |sum| ~ 64-90, 4096-8192 terms
+    assert (truth[rows].cpu() - cpu_truth).abs().max().item() <= 2e-3
+    stride = make_block_swizzle_stride(N, K)
+    bt = as_col_major(b)
+    for name, bb in (("hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem", b),
+                     ("hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_tn_swizzle_x4", bt)):
+        c = torch.zeros(M, N, dtype=torch.half, device=dev)
+        getattr(hg, name)(a, bb, c, 2, True, stride)
+        err = (c.float() - truth).abs()
+        bad = err > ATOL + RTOL * truth.abs()
+        assert not bad.any().item(), (name, int(bad.sum().item()), err.max().item())
+    del truth
+
+
 @pytest.mark.parametrize("M,N,K", [(4096, 8192, 2048), (2048, 1024, 8192), (3072, 3072, 3072), (16384, 16384, 1024),
                                    (1536, 2560, 4096), (64, 128, 64), (12800, 12800, 512), (2560, 2560, 2560),
                                    (6144, 6144, 512), (192, 256, 64), (3072, 4096, 192), (4096, 4096, 96),

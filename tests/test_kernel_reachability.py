@@ -1,0 +1,114 @@
+"""CPU: every attention / one-wave-per-SIMD HGEMM kernel that is linked into the PRODUCT library is reachable from the
+dispatch code, and everything the dispatch code can name is linked in (round 2 shipped two attention
+instantiations -- fa2_fwd_w4_kernel<64,8>, <128,0> -- that no plan could select).
+
+Kernel list: the host-side kernel handles of libcln_amd.so (`nm`: one weak object per __global__ instantiation, named as the
+kernel). Reachable set: cln_describe() evaluated over a grid of (name, shape, stages) -- the same planner code the launch
+path runs (csrc/flash_attn.hip fa2_plan, csrc/hgemm.hip best_plan)."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_handles(so):
+    nm, filt = shutil.which("nm"), shutil.which("c++filt")
+    if not nm or not filt:
+        pytest.skip("binutils nm / c++filt not available")
+    out = subprocess.run([nm, so], capture_output=True, text=True, check=True).stdout
+    names = [ln.split()[2] for ln in out.splitlines() if len(ln.split()) == 3 and ln.split()[1] in "VvWwDd" and "_kernel" in ln and "__device_stub__" not in ln]  # template kernels: weak objects, plain kernels: data objects
+    dem = subprocess.run([filt], input="\n".join(n.replace("DF16_", "Dh") for n in names), capture_output=True, text=True, check=True).stdout
+    res = []
+    for d in dem.splitlines():
+        m = re.match(r"(?:void )?((?:\w+::)*\w+_kernel)(?:<(.*?)>)?\(", d)
+        if m:
+            res.append((m.group(1), [a.strip() for a in (m.group(2) or "").split(",")]))
+    return res
+
+
+def test_attention_kernels_in_the_product_library_are_exactly_the_plannable_ones(built):
+    from cuda_learn_notes_amd import _loader
+    m = built.manifest
+    linked = set()
+    for fam, a in kernel_handles(_loader.so_path("libcln_amd.so")):
+        if not fam.startswith(("fa2::", "fa::")):
+            continue
+        f = fam.split("::")[1]
+        if f == "fa2_fwd_kernel":
+            assert a[4] == "false", (fam, a)  # PREFETCH = true (the round-1 pipeline) is not dispatched any more
+            linked.add(("fa2_fwd", int(a[0]), a[3] == "true"))
+        elif f == "fa2_fwd_v2_kernel":
+            linked.add(("fa2_fwd_v2", int(a[0]), int(a[1]), a[2] == "true"))
+        elif f == "fa2_fwd_dsplit_kernel":
+            linked.add(("fa2_fwd_dsplit", int(a[5]) or int(a[0])))
+        elif f == "fa2_fwd_m16_pair_kernel":
+            assert a == ["2", "false", "false"], a
+            linked.add(("fa2_fwd_m16", 256))
+        elif f == "fa2_fwd_dsplit2_kernel":
+            assert a == ["4", "false"], a
+            linked.add(("fa2_fwd_dsplit2", 64))
+        elif f in ("fa2_fwd_m16x_kernel", "fa2_fwd_dring_kernel", "fa2_fwd_splitkv_kernel"):
+            linked.add((f[:-len("_kernel")], int(a[0])))
+        else:
+            raise AssertionError("attention kernel family the planner does not know: %s<%s>" % (fam, ", ".join(a)))
+    plannable = set()
+    names = [("flash_attn_mma_stages_split_kv", False), ("flash_attn_mma_stages_split_q_shared_qkv", False),
+             ("flash_attn_mma_stages_split_q_shared_qkv_swizzle_qkv", True), ("flash_attn_mma_stages_split_q_tiling_qkv", False),
+             ("flash_attn_mma_stages_split_q_tiling_qk_swizzle_qkv", True)]
+    for name, vt in names:
+        for D in (32, 64, 96, 128, 256, 320, 384, 512, 640, 768, 1024):
+            for (B, H) in ((1, 1), (1, 8), (4, 8), (1, 48), (2, 96)):
+                for N in (64, 128, 192, 256, 512, 1024, 2048, 4096, 8192):
+                    for stages in (1, 2):
+                        try:
+                            t = m.describe(name, (B, H, N, D), stages)
+                        except ValueError:
+                            continue
+                        fam = t.split("<")[0]
+                        d = int(re.search(r"<D=(\d+)", t).group(1))
+                        if fam == "fa2_fwd":
+                            plannable.add((fam, d, vt))
+                        elif fam == "fa2_fwd_v2":
+                            plannable.add((fam, d, int(re.search(r"NW=(\d+)", t).group(1)), vt))
+                        else:
+                            assert not vt, t
+                            plannable.add((fam, d))
+    assert linked - plannable == set(), sorted(linked - plannable)   # nothing dead in the product library
+    assert plannable - linked == set(), sorted(plannable - linked)   # nothing the planner names is missing
+
+
+def test_one_wave_per_simd_hgemm_instantiations_are_exactly_the_plannable_ones(built):
+    from cuda_learn_notes_amd import _loader
+    m = built.manifest
+    linked = set()
+    fams = set()
+    for fam, a in kernel_handles(_loader.so_path("libcln_amd.so")):
+        if fam.startswith("hgemm::"):
+            fams.add(fam.split("::")[1])
+        if fam == "hgemm::hgemm_w4_kernel":
+            assert a[1:4] == ["2", "26", "0"], a  # LDS epilogue, the production schedule, no ablation
+            linked.add((int(a[0]), int(a[4]), int(a[5]), a[6] == "true"))
+    assert fams == {"hgemm_w4_kernel", "hgemm_pp_kernel", "hgemm_pp32_kernel", "hgemm_ring_kernel", "hgemm_1stage_kernel", "hgemm_mfma_naive_kernel",
+                    "hgemm_valu_tile_kernel", "hgemm_naive_f16_kernel", "hgemm_sliced_k_f16_kernel"}, sorted(fams)
+    plannable = set()
+    rows = [("hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem", 0), ("hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_tn_swizzle_x4", 1),
+            ("hgemm_wmma_m16n16k16_mma4x2_warp4x4_stages_dsmem", 0), ("hgemm_wmma_m16n16k16_mma4x4_warp4x4_stages_dsmem", 0),
+            ("hgemm_mma_stages_block_swizzle_tn_cute", 1)]
+    sizes = [256, 320, 384, 512, 768, 960, 1280, 1920, 2304, 2560, 2816, 3072, 3200, 4096, 4608, 4800, 6144]
+    for name, layout in rows:
+        for M in sizes:
+            for N in sizes:
+                for K in (384, 448, 512, 4096, 4160):
+                    try:
+                        t = m.describe(name, (M, N, K), 2)
+                    except ValueError:
+                        continue
+                    mm = re.match(r"hgemm_w4<(\d+)x(\d+)x64", t)
+                    if mm:
+                        plannable.add((layout, int(mm.group(1)), int(mm.group(2)), bool((K // 64) & 1)))
+    assert linked - plannable == set(), sorted(linked - plannable)
+    assert plannable - linked == set(), sorted(plannable - linked)
