@@ -15,7 +15,6 @@
 #include "flash_attn_large_d.cuh"
 #include "flash_attn_splitkv.cuh"
 #include "flash_attn_v2.cuh"
-#include "flash_attn_dsplit2.cuh"
 #include "flash_attn_m16.cuh"
 #include "flash_attn_m16x_api.h"
 #include <string.h>
@@ -23,7 +22,7 @@
 namespace {
 
 enum FaFamily { FAM_SPLIT_KV = 0, FAM_SPLIT_Q = 1 };
-enum FaKind { K_NONE = 0, K_SPLITKV, K_LOAD_THEN_COMPUTE, K_V2, K_DSPLIT, K_DRING, K_DSPLIT64R, K_M16 };
+enum FaKind { K_NONE = 0, K_SPLITKV, K_LOAD_THEN_COMPUTE, K_V2, K_DSPLIT, K_DRING, K_M16X64R, K_M16 };
 
 struct FaPlan {
   int rc = CLN_OK;     // CLN_ERR_* when the shape is not supported
@@ -56,11 +55,12 @@ FaPlan fa2_plan(int family, bool vt, int B, int H, int N, int D, int stages, int
   p.stages_honoured = stages != 1;
   if (small_d) {
     if (!vt && D == 64 && N % 512 == 0) {
-      // >= 512 query rows per CU, in (nearly) whole rounds of 256 workgroups: the ping-pong kernel with 64 rows per wave
-      // (flash_attn_dsplit2.cuh; every K / V fragment feeds two MFMAs): [1,48,8192,64] 1008 -> 1047-1068 TF,
-      // [2,32,4096,64] 967 -> 1020, [1,16,16384,64] 980 -> 1058 (profiles/r02_fa_64rows_probe.log)
+      // >= 512 query rows per CU, in (nearly) whole rounds of 256 workgroups: 64 query rows per wave -- every K / V fragment
+      // feeds four 16x16x32 MFMAs (flash_attn_m16x.cuh with RPW = 64, 64-key tiles; round 2 ran the 32x32x16 form of
+      // flash_attn_dsplit2.cuh here): [1,48,8192,64] 1063 -> 1138 TF, [2,32,4096,64] 1032 -> 1094, [1,16,16384,64] 1076 -> 1152
+      // (profiles/r03_fa_m16x_64rows_probe.log)
       const long long wgs = bh * (N / 512), rounds = (wgs + 255) / 256;
-      if (wgs >= 256 && wgs * 100 >= rounds * 256 * 88) return p.kind = K_DSPLIT64R, p.d_inst = 64, p.nw = 8, p.bc = 64, p;
+      if (wgs >= 256 && wgs * 100 >= rounds * 256 * 88) return p.kind = K_M16X64R, p.d_inst = 64, p.nw = 8, p.bc = 64, p;
     }
     if (!vt && N % 256 == 0 && bh * (N / 256) >= 192) {
       // enough 256-row workgroups to occupy most of the chip:
@@ -167,12 +167,12 @@ int fa2_run(const FaPlan& p, const void* q, const void* k, const void* v, void* 
       }
 #undef FA_V2
       return CLN_ERR_UNSUPPORTED;
-    case K_DSPLIT64R:
-      if constexpr (!VT) return fa2::launch_dsplit2<4>(q, k, v, o, B, H, N, s);
+    case K_M16X64R:
+      if constexpr (!VT) return fa2::m16x_run(64, 64, q, k, v, o, B, H, N, s);
       return CLN_ERR_UNSUPPORTED;
     case K_M16:
       if constexpr (!VT) {
-        if (D == 64 || D == 128) return fa2::m16x_run(D, q, k, v, o, B, H, N, s);  // 128-key tiles; own compile unit
+        if (D == 64 || D == 128) return fa2::m16x_run(D, 32, q, k, v, o, B, H, N, s);  // 128-key tiles; own compile unit
         if (D == 256) return fa2::launch_m16_pair<2, false, false>(q, k, v, o, B, H, N, s);
       }
       return CLN_ERR_UNSUPPORTED;
@@ -219,9 +219,9 @@ int fa2_describe(int family, bool vt, int B, int H, int N, int D, int stages, in
     case K_V2:
       return snprintf(buf, len, "fa2_fwd_v2<D=%d,NW=%d,BC=64,prefetch%s%s> %d waves x 32 rows%s", D, p.nw,
                       D <= 128 ? ",pre-scaled Q" : "", vts, p.nw, st);
-    case K_DSPLIT64R:
-      return snprintf(buf, len, "fa2_fwd_dsplit2<D=64,BC=64,pre-scaled Q> 8 waves x 64 rows, two groups one phase apart, K/V "
-                                "fragments shared by 2 row groups%s", st);
+    case K_M16X64R:
+      return snprintf(buf, len, "fa2_fwd_m16x64r<D=64,BC=64,16x16x32 MFMA,pre-scaled Q,sum-checked softmax> 8 waves x 64 rows, two groups one "
+                                "phase apart, K/V fragments shared by 4 query blocks%s", st);
     case K_M16:
       if (D <= 128)
         return snprintf(buf, len, "fa2_fwd_m16x<D=%d,BC=%d,16x16x32 MFMA,pre-scaled Q,sum-checked softmax> 8 waves x 32 rows, two groups "

@@ -8,11 +8,13 @@
 
 namespace fa2 {
 
-// The dispatched forms (fa2_plan, flash_attn.hip): NDEF = 4 (half of the exponentials under the PV MFMAs), phase-A priority,
-// split prologue -- the best of profiles/r03_fa_m16x_probe.log at both head dims.
-int m16x_run(int D, const void* q, const void* k, const void* v, void* o, int B, int H, int N, hipStream_t s) {
-  if (D == 64) return launch_m16x<64, 32, 128, 8, 4, M16X_PRIO | M16X_SPLIT_PROLOGUE>(q, k, v, o, B, H, N, s);
-  if (D == 128) return launch_m16x<128, 32, 128, 4, 4, M16X_PRIO | M16X_SPLIT_PROLOGUE>(q, k, v, o, B, H, N, s);
+// The dispatched forms (fa2_plan, flash_attn.hip). 32 rows per wave (256-row workgroups, 128-key tiles): NDEF = 4 (half of the
+// exponentials under the PV MFMAs), phase-A priority, split prologue -- the best of profiles/r03_fa_m16x_probe.log at both head
+// dims. 64 rows per wave (D = 64, 512-row workgroups, 64-key tiles; long sequences): NDEF = 1 of the 4 key blocks.
+int m16x_run(int D, int rows_per_wave, const void* q, const void* k, const void* v, void* o, int B, int H, int N, hipStream_t s) {
+  if (D == 64 && rows_per_wave == 32) return launch_m16x<64, 32, 128, 8, 4, M16X_PRIO | M16X_SPLIT_PROLOGUE>(q, k, v, o, B, H, N, s);
+  if (D == 128 && rows_per_wave == 32) return launch_m16x<128, 32, 128, 4, 4, M16X_PRIO | M16X_SPLIT_PROLOGUE>(q, k, v, o, B, H, N, s);
+  if (D == 64 && rows_per_wave == 64) return launch_m16x<64, 64, 64, 4, 1, M16X_PRIO | M16X_SPLIT_PROLOGUE>(q, k, v, o, B, H, N, s);
   return CLN_ERR_UNSUPPORTED;
 }
 

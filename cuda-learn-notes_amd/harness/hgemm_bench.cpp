@@ -129,6 +129,8 @@ int main(int argc, char** argv) {
          time_sec([&] { hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_tn_swizzle_x4(a.p, b.p, c.p, S, S, S, 2, 1, st, nullptr); }, repeat, 20)},
         {"vendor (rocBLAS) NN", time_sec([&] { hgemm_cublas_tensor_op_nn(a.p, b.p, c.p, S, S, S, nullptr); }, repeat, 20)},
         {"vendor (rocBLAS) TN", time_sec([&] { hgemm_cublas_tensor_op_tn(a.p, b.p, c.p, S, S, S, nullptr); }, repeat, 20)},
+        {"vendor (hipBLASLt) NN", time_sec([&] { cln_hgemm_hipblaslt_nn(a.p, b.p, c.p, S, S, S, nullptr); }, repeat, 20)},
+        {"vendor (hipBLASLt) TN", time_sec([&] { cln_hgemm_hipblaslt_tn(a.p, b.p, c.p, S, S, S, nullptr); }, repeat, 20)},
     };
     for (const Row& r : rows) printf("%6d %34s %10.2f %10.1f\n", S, r.tag, r.sec * 1e6, fl / r.sec * 1e-12);
   }

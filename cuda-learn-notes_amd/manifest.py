@@ -102,7 +102,7 @@ _FA_VT = [
     "flash_attn_mma_stages_split_q_tiling_qk_swizzle_qkv",
 ]
 _FA_SPLIT_Q_IMPL = ("planner fa2_plan(shape, stages) [csrc/flash_attn.hip]: stages=1 -> fa2_fwd<load-then-compute>; "
-                    "stages=2 -> fa2_fwd_m16x<D=64|128> / fa2_fwd_m16<D=256> (>=192 workgroups of 256 rows) | fa2_fwd_dsplit2<D=64> (>=256 workgroups of 512 rows) | fa2_fwd_v2<D<=256, 8|4|2 waves> | "
+                    "stages=2 -> fa2_fwd_m16x<D=64|128> / fa2_fwd_m16<D=256> (>=192 workgroups of 256 rows) | fa2_fwd_m16x64r<D=64> (>=256 workgroups of 512 rows) | fa2_fwd_v2<D<=256, 8|4|2 waves> | "
                     "fa2_fwd_dsplit<512; 320 / 384 on its LDS geometry with the real d split evenly> | fa2_fwd_dring<640 | 768 | 1024>; mfma_32x32x16 / 16x16x32, f32 acc "
                     "(see DISPATCH_EXAMPLES)")
 _add("flash_attn", "FA", "fa2_fwd_splitkv<D<=128>: 4 waves share 32 query rows, KV tile split over the waves, cross-wave "
@@ -313,7 +313,7 @@ DISPATCH_EXAMPLES = [
      "fa2_fwd_splitkv<D=64> 4 waves share 32 rows, 128-key tiles split over the waves, cross-wave max via LDS" + _IGN),
     (_SQKV, (4, 8, 2048, 64), 1, "fa2_fwd<D=64,BC=64,load-then-compute> 4 waves x 32 rows"),
     (_SQKV, (4, 8, 2048, 64), 2, "fa2_fwd_m16x<D=64,BC=128,16x16x32 MFMA,pre-scaled Q,sum-checked softmax> 8 waves x 32 rows, two groups one phase apart"),
-    (_SQKV, (1, 48, 8192, 64), 2, "fa2_fwd_dsplit2<D=64,BC=64,pre-scaled Q> 8 waves x 64 rows, two groups one phase apart, K/V fragments shared by 2 row groups"),
+    (_SQKV, (1, 48, 8192, 64), 2, "fa2_fwd_m16x64r<D=64,BC=64,16x16x32 MFMA,pre-scaled Q,sum-checked softmax> 8 waves x 64 rows, two groups one phase apart, K/V fragments shared by 4 query blocks"),
     (_SQKV, (2, 24, 4096, 64), 2, "fa2_fwd_m16x<D=64,BC=128,16x16x32 MFMA,pre-scaled Q,sum-checked softmax> 8 waves x 32 rows, two groups one phase apart"),
     (_SQKV, (4, 8, 2048, 128), 2, "fa2_fwd_m16x<D=128,BC=128,16x16x32 MFMA,pre-scaled Q,sum-checked softmax> 8 waves x 32 rows, two groups one phase apart"),
     (_SQKV, (2, 32, 4096, 256), 2, "fa2_fwd_m16<D=256,BC=32,16x16x32 MFMA> 8 waves x 32 rows, two groups one phase apart"),

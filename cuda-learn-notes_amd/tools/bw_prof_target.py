@@ -50,12 +50,54 @@ CALLS = [  # (tag, substring of the kernel name, algorithmic bytes, callable)
     ("embedding_f32x4_pack", "embedding", 2 * o.numel() * 4, lambda: so.embedding_f32x4_pack(idx.data_ptr(), w.data_ptr(), o.data_ptr(), 4096, 1024, 4096, st())),
     ("histogram_i32x4", "histogram", hist_in.numel() * 4, lambda: so.histogram_i32x4(hist_in.data_ptr(), hist_out.data_ptr(), hist_in.numel(), 1024, st())),
 ]
+# steady-state rows: the scripts' own large shape [8192, 8192] -- a launch is 4x longer, the ~2 us ramp and
+# (reduce) the ~3 us fan-in of 256 device-scope atomics weigh a quarter as much; fp16 = 134 MB, fp32 = 268 MB (past the 256 MiB
+# Infinity Cache). Allocated after the 4096^2 rows have run.
+S2 = K2 = 8192
+
+
+def big_calls():
+    xb = torch.randn(S2, K2, device=dev)
+    yb = torch.zeros_like(xb)
+    xbh, ybh = xb.half(), yb.half()
+    x2bh = torch.randn(S2, K2, device=dev, dtype=torch.half)
+    nb = xb.numel()
+    keep = (xb, yb, xbh, ybh, x2bh)
+    return keep, [
+        ("elementwise_add_f16x8_pack@8192", "add", 3 * nb * 2, lambda: so.elementwise_add_f16x8_pack(xbh.data_ptr(), x2bh.data_ptr(), ybh.data_ptr(), nb, st())),
+        ("block_all_reduce_sum_f32x4_f32@8192", "reduce_sum", nb * 4, lambda: so.block_all_reduce_sum_f32x4_f32(xb.data_ptr(), z.data_ptr(), nb, st())),
+        ("block_all_reduce_sum_f16x8_pack_f32@8192", "reduce_sum", nb * 2, lambda: so.block_all_reduce_sum_f16x8_pack_f32(xbh.data_ptr(), z.data_ptr(), nb, st())),
+        ("safe_softmax_f32x4_per_token@8192", "softmax", 2 * nb * 4, lambda: so.safe_softmax_f32x4_per_token(xb.data_ptr(), yb.data_ptr(), S2, K2, st())),
+        ("safe_softmax_f16x8_pack_f32_per_token@8192", "softmax", 2 * nb * 2, lambda: so.safe_softmax_f16x8_pack_f32_per_token(xbh.data_ptr(), ybh.data_ptr(), S2, K2, st())),
+        ("layer_norm_f16x8_pack_f32@8192", "layer_norm", 2 * nb * 2, lambda: so.layer_norm_f16x8_pack_f32(xbh.data_ptr(), ybh.data_ptr(), f(1.0), f(0.0), S2, K2, st())),
+        ("rms_norm_f16x8_pack_f32@8192", "rms_norm", 2 * nb * 2, lambda: so.rms_norm_f16x8_pack_f32(xbh.data_ptr(), ybh.data_ptr(), f(1.0), S2, K2, st())),
+        ("relu_f16x8_pack@8192", "unary", 2 * nb * 2, lambda: so.relu_f16x8_pack(xbh.data_ptr(), ybh.data_ptr(), nb, st())),
+        ("rope_f32x4_pack@8192", "rope", 2 * nb * 4, lambda: so.rope_f32x4_pack(xb.data_ptr(), yb.data_ptr(), S2, K2, 0, st())),
+    ]
+
+
 order = []
-for tag, sub, nbytes, fn in CALLS:
-    for _ in range(25):
-        rc = fn()
-        assert rc == 0, (tag, rc)
-    torch.cuda.synchronize()
-    order.append({"tag": tag, "kernel_substring": sub, "bytes": nbytes, "launches": 25})
+
+
+def run(calls):
+    for tag, sub, nbytes, fn in calls:
+        for _ in range(25):
+            rc = fn()
+            assert rc == 0, (tag, rc)
+        torch.cuda.synchronize()
+        order.append({"tag": tag, "kernel_substring": sub, "bytes": nbytes, "launches": 25})
+
+
+run(CALLS)
+# larger gathers / counts for the indexing rows: 64 Ki rows of 1024 floats (268 MB out), 2^26 histogram inputs (268 MB)
+idx2 = torch.randint(0, 65536, (65536,), device=dev, dtype=torch.int32)
+w2 = torch.randn(65536, 1024, device=dev)
+o2 = torch.zeros(65536, 1024, device=dev)
+hist_in2 = torch.randint(0, 1024, (1 << 26,), device=dev, dtype=torch.int32)
+run([("embedding_f32x4_pack@65536x1024", "embedding", 2 * o2.numel() * 4, lambda: so.embedding_f32x4_pack(idx2.data_ptr(), w2.data_ptr(), o2.data_ptr(), 65536, 1024, 65536, st())),
+     ("histogram_i32x4@2^26", "histogram", hist_in2.numel() * 4, lambda: so.histogram_i32x4(hist_in2.data_ptr(), hist_out.data_ptr(), hist_in2.numel(), 1024, st()))])
+del w2, o2, hist_in2, w, o, hist_in
+keep, calls = big_calls()
+run(calls)
 out = os.environ.get("BW_PROF_ORDER", os.path.join(ROOT, "gpurun_out", "bw_prof_order.json"))
 json.dump(order, open(out, "w"), indent=1)

@@ -25,7 +25,7 @@ pmc hg_fetch FETCH_SIZE -- $HG
 pmc hg_write WRITE_SIZE -- $HG
 pmc hg_sq SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE -- $HG
 python $T/pmc_summary.py hgemm $OUT/${TAG}_pmc_hgemm.json $OUT/pmc_hg_fetch $OUT/pmc_hg_write $OUT/pmc_hg_sq > /dev/null
-for D in 64 128; do
+for D in 64 128 256; do  # 256: the production fa2_fwd_m16_pair_kernel (no trace / PMC pass of it existed in round 2)
   FA="fa 4 8 2048 $D 2 12"
   pmc fa${D}_fetch FETCH_SIZE -- $FA
   pmc fa${D}_write WRITE_SIZE -- $FA

@@ -7,7 +7,9 @@
 #   5. rocprofv3 kernel-trace of the bandwidth kernels (bw_prof_*)                         -> <tag>_bw_rocprof.json
 #   6. the re-authored reference scripts on the GPU (run_all_scripts.sh)                   -> <tag>_reference_style_scripts_on_gpu.log
 #   7. C++ harness                                                                         -> <tag>_hgemm_bench_cpp.log
-TAG=${1:-r02}
+#   8. stages = 1 vs 2 of the attention names, the hipBLASLt row, the bit-repeatability stress -> <tag>_fa_stage1_vs_stage2.log,
+#      <tag>_hipblaslt_probe.log, <tag>_determinism_stress.log
+TAG=${1:-r03}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$REPO/gpurun_out; T=$REPO/cuda-learn-notes_amd/tools
 mkdir -p $OUT; cd $REPO; export PYTHONUNBUFFERED=1
 # a box whose GPU faults on the first launch (seen once in round 2: every later command then hangs to its timeout) must
@@ -23,5 +25,8 @@ timeout 600 bash $T/fa_trace.sh $TAG > $OUT/${TAG}_fa_trace.log 2>&1; echo "fa_t
 python $T/bw_prof_summary.py $(ls $OUT/bwprof/*kernel_trace.csv $OUT/bwprof/*/*kernel_trace.csv 2>/dev/null | head -1) $OUT/bw_prof_order.json $OUT/${TAG}_bw_rocprof.json > $OUT/${TAG}_bw_rocprof.txt 2>&1; echo "bw rc=$?"
 timeout 900 bash $T/run_all_scripts.sh > $OUT/${TAG}_reference_style_scripts_on_gpu.log 2>&1; echo "scripts rc=$?"
 timeout 300 $REPO/cuda-learn-notes_amd/harness/hgemm_bench 200 > $OUT/${TAG}_hgemm_bench_cpp.log 2>&1; echo "harness rc=$?"
+timeout 200 python $T/fa_stage_probe.py 2>&1 | grep STAGE > $OUT/${TAG}_fa_stage1_vs_stage2.log; echo "stage probe rc=$?"
+timeout 200 python $T/vendor_lt_probe.py 2>&1 | grep "^LT" > $OUT/${TAG}_hipblaslt_probe.log; echo "hipblaslt rc=$?"
+timeout 400 python $T/determinism_stress.py 200 2>&1 | grep DET > $OUT/${TAG}_determinism_stress.log; echo "determinism rc=$?"
 cut -c1-1500 $OUT/${TAG}_bench_20steps.json; echo; cat $OUT/${TAG}_fa_kernel_trace.csv; cat $OUT/${TAG}_bw_rocprof.txt
 ls -la $OUT/${TAG}_* | head -40

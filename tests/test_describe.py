@@ -93,7 +93,7 @@ def test_flash_attn_planner_invariants_over_a_grid_of_shapes(built):
     row / key granularity divides N (a launcher would otherwise refuse at run time what describe promised)."""
     m = built.manifest
     tq, sq = "flash_attn_mma_stages_split_q_tiling_qkv", "flash_attn_mma_stages_split_q_shared_qkv"
-    rows_per_wg = {"fa2_fwd_m16": 256, "fa2_fwd_m16x": 256, "fa2_fwd_dsplit2": 512, "fa2_fwd_dsplit": 128, "fa2_fwd_dring": 64, "fa2_fwd_v2": 64}
+    rows_per_wg = {"fa2_fwd_m16": 256, "fa2_fwd_m16x": 256, "fa2_fwd_m16x64r": 512, "fa2_fwd_dsplit": 128, "fa2_fwd_dring": 64, "fa2_fwd_v2": 64}
     fam_seen = set()
     for D in (32, 64, 96, 128, 256, 320, 384, 512, 640, 768, 1024):
         for (B, H) in ((1, 1), (1, 8), (4, 8), (1, 48), (2, 96), (1, 256)):
@@ -106,7 +106,7 @@ def test_flash_attn_planner_invariants_over_a_grid_of_shapes(built):
                 fam_seen.add((fam, D))
                 assert N % rows_per_wg[fam] == 0 or fam == "fa2_fwd_v2", (B, H, N, D, t)
                 wgs256 = B * H * (N // 256) if N % 256 == 0 else 0
-                if D in (64, 128, 256) and wgs256 >= 192 and not (D == 64 and t.startswith("fa2_fwd_dsplit2")):
+                if D in (64, 128, 256) and wgs256 >= 192 and not (D == 64 and t.startswith("fa2_fwd_m16x64r")):
                     assert fam == ("fa2_fwd_m16" if D == 256 else "fa2_fwd_m16x") and "16x16x32" in t, (B, H, N, D, t)
                 if D in (320, 384, 512):
                     assert fam == "fa2_fwd_dsplit", t
@@ -114,7 +114,7 @@ def test_flash_attn_planner_invariants_over_a_grid_of_shapes(built):
                     assert fam == "fa2_fwd_dring", t
                 if D <= 256:  # the shared-QKV name (max head dim 256) plans the same kernel
                     assert m.describe(sq, (B, H, N, D), 2) == t
-    for want in (("fa2_fwd_m16x", 64), ("fa2_fwd_m16x", 128), ("fa2_fwd_m16", 256), ("fa2_fwd_dsplit2", 64), ("fa2_fwd_v2", 32),
+    for want in (("fa2_fwd_m16x", 64), ("fa2_fwd_m16x", 128), ("fa2_fwd_m16", 256), ("fa2_fwd_m16x64r", 64), ("fa2_fwd_v2", 32),
                  ("fa2_fwd_dsplit", 512), ("fa2_fwd_dring", 1024), ("fa2_fwd_dring", 640)):
         assert want in fam_seen, (want, sorted(fam_seen))
     with pytest.raises(ValueError):  # "headdim not support!" of the shared-QKV rung (MAX_HEADDIM_CFG: 256)

@@ -528,12 +528,13 @@ def test_key_split_attention_probe(built, dev, oracle, abl):
 
 
 def test_pingpong_kernel_with_64_rows_per_wave(fa, built, dev, oracle):
-    """flash_attn_dsplit2.cuh (D = 64, >= 256 workgroups of 512 rows in whole rounds): the planner must pick it for these
+    """64 query rows per wave (flash_attn_m16x.cuh, RPW = 64; round 2: flash_attn_dsplit2.cuh) at D = 64, >= 256 workgroups of 512
+    rows in whole rounds: the planner must pick it for these
     shapes; random data plus the creeping-max / late-jump / early-spike regimes (rescale of BOTH row groups of a wave,
     only one of which grows), sampled heads against the fp64 oracle, and bit-repeatability."""
     name = "flash_attn_mma_stages_split_q_shared_qkv"
     for (B, H, N) in ((1, 256, 512), (2, 64, 1024)):
-        assert built.manifest.describe(name, (B, H, N, 64), 2).startswith("fa2_fwd_dsplit2"), (B, H, N)
+        assert built.manifest.describe(name, (B, H, N, 64), 2).startswith("fa2_fwd_m16x64r"), (B, H, N)
         q, k, v = seeded(71 + N, B, H, N, 64), seeded(72 + N, B, H, N, 64), seeded(73 + N, B, H, N, 64)
         if N == 1024:
             ramp = torch.linspace(0.2, 1.6, N).view(1, 1, N, 1)

@@ -48,9 +48,8 @@ def test_attention_kernels_in_the_product_library_are_exactly_the_plannable_ones
         elif f == "fa2_fwd_m16_pair_kernel":
             assert a == ["2", "false", "false"], a
             linked.add(("fa2_fwd_m16", 256))
-        elif f == "fa2_fwd_dsplit2_kernel":
-            assert a == ["4", "false"], a
-            linked.add(("fa2_fwd_dsplit2", 64))
+        elif f == "fa2_fwd_m16x_kernel" and a[1] == "64":
+            linked.add(("fa2_fwd_m16x64r", int(a[0])))
         elif f in ("fa2_fwd_m16x_kernel", "fa2_fwd_dring_kernel", "fa2_fwd_splitkv_kernel"):
             linked.add((f[:-len("_kernel")], int(a[0])))
         else:
