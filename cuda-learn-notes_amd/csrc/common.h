@@ -230,6 +230,22 @@ __device__ __forceinline__ int cln_fresh_lane() {
   return l;
 }
 
+// hipcc (ROCm 7.2) puts no early-clobber on an MFMA destination: the LAST MFMA that reads a dying A / B fragment may be given
+// that fragment's registers as its destination (`v_mfma_f32_16x16x32_f16 v[66:69], v[66:69], v[34:37], 0`). On MI355X such
+// an instruction intermittently returns wrong values when another wave's MFMAs interleave with it on the same SIMD: round 3
+// traced the D = 256 attention kernel's ~1 % wrong launches and the D = 512 probe's 100 % to it (tools/mfma_overlap_scan.py,
+// profiles/r03_fa_mfma_overlap_bisect.log; the failure rate follows the number of such instructions in the loop). This
+// empty statement reads the result AND both operands right behind the MFMA, so the operands are alive across it and the
+// register allocator must keep them disjoint from the destination. It emits no instruction and draws no hazard padding.
+template <typename R, typename A, typename B>
+__device__ __forceinline__ void cln_mfma_keep(const R& r, const A& a, const B& b) {
+#if defined(__HIP_DEVICE_COMPILE__)  // (the host pass of hipcc parses device functions too: "v" is no x86 constraint)
+  asm volatile("" ::"v"(r), "v"(a), "v"(b));
+#else
+  (void)r, (void)a, (void)b;
+#endif
+}
+
 __device__ __forceinline__ h8 h8_cat(h4 lo, h4 hi) {
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }

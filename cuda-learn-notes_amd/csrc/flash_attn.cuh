@@ -164,6 +164,7 @@ __global__ __launch_bounds__(256) void fa2_fwd_kernel(const half_t* __restrict__
       for (int ks = 0; ks < D / 16; ++ks) {
         const h8 kf = *reinterpret_cast<const h8*>(kp + ks * 32);
         s[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[t], 0, 0, 0);
+        cln_mfma_keep(s[t], kf, qf[ks]);  // destination disjoint from the operands (common.h)
       }
     }
 
@@ -219,6 +220,7 @@ __global__ __launch_bounds__(256) void fa2_fwd_kernel(const half_t* __restrict__
           vf = h8_cat(lds_read_tr16(vp), lds_read_tr16(vp + 8 * G::VS));
         }
         ot[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[st], ot[b], 0, 0, 0);
+        cln_mfma_keep(ot[b], vf, pf[st]);
       }
     }
   }

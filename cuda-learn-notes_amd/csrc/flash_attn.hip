@@ -103,7 +103,11 @@ FaPlan fa2_plan(int family, bool vt, int B, int H, int N, int D, int stages, int
   }
   p.stages_honoured = stages != 1;
   switch (D) {
-    case 320: case 384: case 512:
+    case 512:  // config C5: the d-split PAIR kernel on 16x16x32 MFMAs, scores scaled in fp32 (flash_attn_m16.cuh, round 3: +2.7 %
+      // over the 32x32x16 form at identical max-abs-error once its MFMA destinations were kept off the operand registers)
+      if (N % 128 != 0) return p.rc = CLN_ERR_UNSUPPORTED, p;
+      return p.kind = K_M16, p.d_inst = 512, p.nw = 8, p.bc = 32, p;
+    case 320: case 384:
       if (N % 128 != 0) return p.rc = CLN_ERR_UNSUPPORTED, p;
       return p.kind = K_DSPLIT, p.d_inst = 512, p.nw = 8, p.bc = 32, p;
     case 640: case 768:
@@ -174,6 +178,7 @@ int fa2_run(const FaPlan& p, const void* q, const void* k, const void* v, void* 
       if constexpr (!VT) {
         if (D == 64 || D == 128) return fa2::m16x_run(D, 32, q, k, v, o, B, H, N, s);  // 128-key tiles; own compile unit
         if (D == 256) return fa2::launch_m16_pair<2, false, false>(q, k, v, o, B, H, N, s);
+        if (D == 512) return fa2::launch_m16_pair<2, true, false>(q, k, v, o, B, H, N, s);
       }
       return CLN_ERR_UNSUPPORTED;
     case K_DSPLIT:
@@ -226,6 +231,8 @@ int fa2_describe(int family, bool vt, int B, int H, int N, int D, int stages, in
       if (D <= 128)
         return snprintf(buf, len, "fa2_fwd_m16x<D=%d,BC=%d,16x16x32 MFMA,pre-scaled Q,sum-checked softmax> 8 waves x 32 rows, two groups "
                                   "one phase apart%s", D, p.bc, st);
+      if (D == 512)
+        return snprintf(buf, len, "fa2_fwd_m16<D=512,BC=32,16x16x32 MFMA,pairs of waves split d> 8 waves, 128 rows, two groups one phase apart%s", st);
       return snprintf(buf, len, "fa2_fwd_m16<D=%d,BC=%d,16x16x32 MFMA> 8 waves x 32 rows, two groups one phase apart%s", D, p.bc, st);
     case K_DSPLIT:
       if (p.d_inst != D)

@@ -196,6 +196,8 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_dring_kernel(const half_t* __r
         const h8 kf = *reinterpret_cast<const h8*>(kb + k_addr(ks));
         s[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[0][ks], s[0], 0, 0, 0);
         s[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[1][ks], s[1], 0, 0, 0);
+        cln_mfma_keep(s[0], kf, qf[0][ks]);  // destinations disjoint from the operands (common.h)
+        cln_mfma_keep(s[1], kf, qf[1][ks]);
         if (ks == 0) {
           if constexpr (!STAGGER) req_v(j + 1);
           else if (rg == 0) req_k(j + 1);
@@ -272,6 +274,7 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_dring_kernel(const half_t* __r
         const char* vp = vb + v_addr(b);
         const h8 vf = h8_cat(lds_read_tr16(vp), lds_read_tr16(vp + 8 * G::ROW));
         ot[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, ot[b], 0, 0, 0);
+        cln_mfma_keep(ot[b], vf, pf);
       }
     }
     wait_young(!STAGGER);

@@ -247,6 +247,7 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
         if (ABL & 16) s[t % BCB][t / BCB] += (float)kf[t % PD][0];
         else if (PRE && t < BCB) s[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[t % PD], qf[0], minit, 0, 0, 0);  // chain starts at -m
         else s[t % BCB] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[t % PD], qf[t / BCB], s[t % BCB], 0, 0, 0);
+        cln_mfma_keep(s[t % BCB], kf[t % PD], qf[t / BCB]);  // destination disjoint from the operands (common.h)
         if (t + PD < NQK) kf[t % PD] = k_frag(t + PD);
         if (!(ABL & 1) && (t % DSTEP) == DSTEP - 1 && t / DSTEP < G::PPW) dma_piece(jn, (j + 1) & 1, t / DSTEP);
         if (PD > 1 || (t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
@@ -376,6 +377,7 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
         for (int idx = i0; idx < i1; ++idx) {
           const int st = idx / (DHR / 32), b = idx % (DHR / 32);
           ot[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[idx % PD], pf[st], ot[b], 0, 0, 0);
+          cln_mfma_keep(ot[b], vf[idx % PD], pf[st]);
           if constexpr (SUMM)
             if (b == DHR / 32 - 1) lacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf[st], lacc, 0, 0, 0);
           if (idx + PD < NPV) vf[idx % PD] = v_frag(idx + PD);

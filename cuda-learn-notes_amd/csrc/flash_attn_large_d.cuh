@@ -23,10 +23,8 @@ inline int launch_fa2_large_d(const void* q, const void* k, const void* v, void*
     // zero-padded round-1 form.
     case 320: return fa2::launch_dsplit<512, 2, 1, fa2::OPT_DEFAULT, 0, 320>(q, k, v, o, B, H, N, s);
     case 384: return fa2::launch_dsplit<512, 2, 1, fa2::OPT_DEFAULT, 0, 384>(q, k, v, o, B, H, N, s);
-    // D = 512 (config C5): pairs of waves split the head dim, two 4-wave groups one phase apart
-    // (flash_attn_dsplit.cuh): 990-1000 TF at [1,32,4096,512] vs 487 for the register-resident O-slice kernel
-    // (flash_attn_bigd.cuh, still used for D = 768) and 411 for the v1 path (profiles/r01_fa_dsplit_probe.log)
-    case 512: return fa2::launch_dsplit<512, 2, 1, fa2::OPT_DEFAULT>(q, k, v, o, B, H, N, s);
+    // (D = 512, config C5, is planned onto the 16x16x32 pair kernel of flash_attn_m16.cuh since round 3; this 32x32x16 form --
+    // 990-1010 TF at [1,32,4096,512] -- stays as the geometry of 320 / 384 and as probe variant 210)
     // D = 640 / 768 / 1024 (flash_attn_dring.cuh): [1,16,4096,D] 604 -> 649 / 684 -> 703 / 691 -> 780 TF, [1,8,8192,1024] 657 -> 804
     // over the d-wide kernel (profiles/r03_fa_dring_probe.log); the two row groups run one phase apart at D = 1024 only
     // (lock-step measured 1-4 % faster at 640 / 768)

@@ -156,6 +156,7 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16_kernel(const half_t* __res
         for (int qb = 0; qb < NQB; ++qb) {
           if (ks == 0) s[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[t % PD], qf[qb][0], minit[qb], 0, 0, 0);  // chain starts at -m
           else s[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[t % PD], qf[qb][ks], s[kb][qb], 0, 0, 0);
+          cln_mfma_keep(s[kb][qb], kf[t % PD], qf[qb][ks]);  // destination disjoint from the operands (common.h)
         }
         if (t + PD < NQK) kf[t % PD] = k_frag(t + PD);
         if ((t % DSTEP) == DSTEP - 1) dma_piece(jn, (j + 1) & 1, t / DSTEP);
@@ -235,7 +236,10 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16_kernel(const half_t* __res
       for (int idx = i0; idx < i1; ++idx) {
         const int u = idx / NDB, b = idx % NDB;
 #pragma unroll
-        for (int qb = 0; qb < NQB; ++qb) ot[b][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[idx % PD], pf[u][qb], ot[b][qb], 0, 0, 0);
+        for (int qb = 0; qb < NQB; ++qb) {
+          ot[b][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[idx % PD], pf[u][qb], ot[b][qb], 0, 0, 0);
+          cln_mfma_keep(ot[b][qb], vf[idx % PD], pf[u][qb]);
+        }
         if (idx + PD < NPV) vf[idx % PD] = v_frag(idx + PD);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -328,7 +332,7 @@ struct GeoM16Pair {
 
 // PRE = false: Q stays as loaded; the (summed) scores are scaled and made relative to the running max in fp32, one v_fma per
 // score (16 per lane and tile) -- the accuracy of the 32x32x16 kernels at these head dims.
-template <int PD = 2, bool PAIR = true, bool PRE = true>
+template <int PD = 2, bool PAIR = true, bool PRE = true, int DBG = 0>
 __global__ __launch_bounds__(512, 2) void fa2_fwd_m16_pair_kernel(const half_t* __restrict__ Q, const half_t* __restrict__ K,
                                                                   const half_t* __restrict__ V, half_t* __restrict__ O,
                                                                   int N, int n_qblk, int n_heads, float scale_log2e) {
@@ -382,6 +386,7 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16_pair_kernel(const half_t* 
   for (int b = 0; b < NDB; ++b)
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb) ot[b][qb] = f4{0.f, 0.f, 0.f, 0.f};
+  float dbg_stale = 0.f;
   float m_run[NQB], l_run[NQB];
   f4 minit[NQB];
 #pragma unroll
@@ -448,17 +453,29 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16_pair_kernel(const half_t* 
 #pragma unroll
         for (int qb = 0; qb < NQB; ++qb) {
           if (ks == 0) {
-            const f4 c0 = lead ? minit[qb] : f4{0.f, 0.f, 0.f, 0.f};
-            s[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[t % PD], qf[qb][0], c0, 0, 0, 0);
+            if constexpr (!PRE && (DBG & 16384) != 0) {
+              // zero-C chain start with an EARLY-CLOBBER destination: it cannot be given the registers of its A / B operand
+              asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(s[kb][qb]) : "v"(kf[t % PD]), "v"(qf[qb][0]));
+            } else {
+              const f4 c0 = lead ? minit[qb] : f4{0.f, 0.f, 0.f, 0.f};
+              s[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[t % PD], qf[qb][0], c0, 0, 0, 0);
+            }
           } else {
             s[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[t % PD], qf[qb][ks], s[kb][qb], 0, 0, 0);
           }
+          if constexpr ((DBG & 32768) == 0) cln_mfma_keep(s[kb][qb], kf[t % PD], qf[qb][ks]);  // destination disjoint from the operands (common.h; DBG 32768: the round-2 code)
         }
+        // keep the K fragment alive past its MFMAs: hipcc may otherwise give the LAST MFMA that reads it the fragment's
+        // registers as its destination (no early-clobber on v_mfma_f32_16x16x32_f16) -- see mfma_overlap_scan.py
+        if constexpr ((DBG & 8192) != 0) asm volatile("" ::"v"(kf[t % PD]));
+        if constexpr ((DBG & 1024) != 0) asm volatile("s_nop 15" ::: "memory");
+        if constexpr ((DBG & 2048) != 0) asm volatile("s_sleep 1" ::: "memory");
         if (t + PD < NQK) kf[t % PD] = k_frag(t + PD);
         if ((t % DSTEP) == DSTEP - 1) dma_piece(jn, (j + 1) & 1, t / DSTEP);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    if constexpr ((DBG & 1) != 0) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
     if constexpr (PAIR)
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb)
@@ -469,21 +486,64 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16_pair_kernel(const half_t* 
     asm volatile("" ::: "memory");
 
     // ================= phase B: S = own + partner's partial, softmax, O^T[half] += V[:, half]^T P^T
+    f4 pp_first[2];
     if constexpr (PAIR)
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
       for (int qb = 0; qb < NQB; ++qb) {
         const f4 pp = *reinterpret_cast<const f4*>(sx_peer + (kb * NQB + qb) * 1024);
+        if constexpr ((DBG & 512) != 0) {
+          if (kb == 0 && qb == 0) pp_first[0] = pp;
+          if (kb == 1 && qb == 0) pp_first[1] = pp;
+        }
         s[kb][qb] += pp;
       }
-    if constexpr (!PRE)
+    if constexpr ((DBG & 2) != 0) {
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr ((DBG & 64) != 0) asm volatile("s_sleep 4" ::: "memory");
+    if constexpr ((DBG & 16) != 0)
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
       for (int qb = 0; qb < NQB; ++qb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s[kb][qb][r] = fmaf(s[kb][qb][r], scale_log2e, -m_run[qb]);  // log2 domain, relative
+        for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(s[kb][qb][r]));  // per-element opacity: no SLP pairing into v_pk_fma_f32
+    if constexpr ((DBG & 8) != 0) {
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+    float sc_v = scale_log2e;
+    if constexpr ((DBG & 4) != 0) asm volatile("" : "+v"(sc_v));  // the scale in a VGPR (no SGPR-pair operand of a packed f32 op)
+    if constexpr (!PRE && (DBG & (128 | 256)) != 0) {
+      // bisect: the packed fma written by hand with the scale in an SGPR PAIR; 128: the high lane reads the LOW dword of the
+      // pair (op_sel_hi 0), 256: the high lane reads the HIGH dword (what hipcc emits)
+      const unsigned sb = __builtin_amdgcn_readfirstlane(__float_as_uint(scale_log2e));
+      const unsigned long long sp = ((unsigned long long)sb << 32) | sb;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int qb = 0; qb < NQB; ++qb)
+#pragma unroll
+          for (int r = 0; r < 4; r += 2) {
+            f2 a = f2{s[kb][qb][r], s[kb][qb][r + 1]}, o2;
+            const f2 c = f2{m_run[qb], m_run[qb]};
+            if constexpr ((DBG & 128) != 0)
+              asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(o2) : "v"(a), "s"(sp), "v"(c));
+            else
+              asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,1,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(o2) : "v"(a), "s"(sp), "v"(c));
+            s[kb][qb][r] = o2[0], s[kb][qb][r + 1] = o2[1];
+          }
+    } else if constexpr (!PRE)
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int qb = 0; qb < NQB; ++qb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[kb][qb][r] = fmaf(s[kb][qb][r], sc_v, -m_run[qb]);  // log2 domain, relative
     h8 vf[PD];
 #pragma unroll
     for (int i = 0; i < PD; ++i) vf[i] = v_frag(i);
@@ -526,6 +586,14 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16_pair_kernel(const half_t* 
         }
       }
     }
+    if constexpr (PAIR && (DBG & 512) != 0) {  // bisect: was the partner's partial complete when it was read?
+      asm volatile("s_sleep 8" ::: "memory");
+      const f4 a = *reinterpret_cast<const volatile f4*>(sx_peer), b = *reinterpret_cast<const volatile f4*>(sx_peer + 2048);
+      bool diff = false;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) diff |= (a[r] != pp_first[0][r]) | (b[r] != pp_first[1][r]);
+      if (__builtin_amdgcn_ballot_w64(diff) != 0) dbg_stale += 1.0f;
+    }
     h8 pf[NQB];  // the one 32-key step: k-slot 8*g4 + e <-> key 16*(e >> 2) + 4*g4 + (e & 3)
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb) {
@@ -544,7 +612,11 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16_pair_kernel(const half_t* 
 #pragma unroll
     for (int db = 0; db < NPV; ++db) {
 #pragma unroll
-      for (int qb = 0; qb < NQB; ++qb) ot[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[db % PD], pf[qb], ot[db][qb], 0, 0, 0);
+      for (int qb = 0; qb < NQB; ++qb) {
+        ot[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[db % PD], pf[qb], ot[db][qb], 0, 0, 0);
+        if constexpr ((DBG & 32768) == 0) cln_mfma_keep(ot[db][qb], vf[db % PD], pf[qb]);
+      }
+      if constexpr ((DBG & 4096) != 0) asm volatile("s_sleep 1" ::: "memory");
       if (db + PD < NPV) vf[db % PD] = v_frag(db + PD);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -569,6 +641,7 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16_pair_kernel(const half_t* 
       const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_tot), __float_as_uint(l_tot), false, false);
       l_tot = __uint_as_float(s32[0]) + __uint_as_float(s32[1]);
     }
+    if constexpr ((DBG & 512) != 0) l_tot = dbg_stale > 0.f ? l_tot * 1e-3f : l_tot;  // a detected stale read blows the row up by 1000
     const float inv = 1.0f / l_tot;
 #pragma unroll
     for (int b = 0; b < NDB; ++b) {
@@ -589,15 +662,15 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16_pair_kernel(const half_t* 
   }
 }
 
-template <int PD = 2, bool PAIR = true, bool PRE = true>
+template <int PD = 2, bool PAIR = true, bool PRE = true, int DBG = 0>
 int launch_m16_pair(const void* q, const void* k, const void* v, void* o, int B, int H, int N, hipStream_t stream) {
   using G = GeoM16Pair<PAIR>;
   if (N % G::BR != 0) return CLN_ERR_UNSUPPORTED;
   static cln_lds_attr lds_attr;  // per device, thread-safe (common.h)
-  if (cln_ensure_lds(lds_attr, reinterpret_cast<const void*>(&fa2_fwd_m16_pair_kernel<PD, PAIR, PRE>), G::LDS_BYTES) != CLN_OK) return CLN_ERR_LAUNCH;
+  if (cln_ensure_lds(lds_attr, reinterpret_cast<const void*>(&fa2_fwd_m16_pair_kernel<PD, PAIR, PRE, DBG>), G::LDS_BYTES) != CLN_OK) return CLN_ERR_LAUNCH;
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)G::D);
   const int n_qblk = N / G::BR;
-  CLN_LAUNCH((fa2_fwd_m16_pair_kernel<PD, PAIR, PRE>), dim3(n_qblk * B * H), dim3(G::NT), G::LDS_BYTES, stream,
+  CLN_LAUNCH((fa2_fwd_m16_pair_kernel<PD, PAIR, PRE, DBG>), dim3(n_qblk * B * H), dim3(G::NT), G::LDS_BYTES, stream,
              (const half_t*)q, (const half_t*)k, (const half_t*)v, (half_t*)o, N, n_qblk, B * H, scale_log2e);
   return cln_check_launch();
 }

@@ -188,6 +188,7 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
         for (int qb = 0; qb < NQB; ++qb) {
           if (ks == 0) s[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[t % PD], qf[qb][0], minit[qb], 0, 0, 0);  // chain starts at -m
           else s[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[t % PD], qf[qb][ks], s[kb][qb], 0, 0, 0);
+          cln_mfma_keep(s[kb][qb], kf[t % PD], qf[qb][ks]);  // destination disjoint from the operands (common.h)
         }
         __builtin_amdgcn_sched_barrier(0);  // the MFMAs of the step first: the VALU slice runs in their shadow
         if (t + PD < NQK) kf[t % PD] = k_frag(t + PD);
@@ -269,7 +270,10 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
     for (int idx = 0; idx < NPV; ++idx) {
       const int u = idx / NDB, b = idx % NDB;
 #pragma unroll
-      for (int qb = 0; qb < NQB; ++qb) ot[b][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[idx % PD], pf[u][qb], ot[b][qb], 0, 0, 0);
+      for (int qb = 0; qb < NQB; ++qb) {
+        ot[b][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[idx % PD], pf[u][qb], ot[b][qb], 0, 0, 0);
+        cln_mfma_keep(ot[b][qb], vf[idx % PD], pf[u][qb]);
+      }
       if (idx + PD < NPV) vf[idx % PD] = v_frag(idx + PD);
       // deferred items at DRATE per step: all of them are done before the first P^T step that holds a deferred block
 #pragma unroll

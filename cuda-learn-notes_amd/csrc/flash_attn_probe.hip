@@ -90,9 +90,39 @@ CLN_API int cln_fa2_variant(int D, int nw, int vt, int opt, int abl, const void*
   // 544 = scores scaled in fp32 (Q not pre-scaled)
   if (D == 256 && abl == 544) return fa2::launch_m16_pair<2, false, false>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 512 && abl == 544) return fa2::launch_m16_pair<2, true, false>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  // 550 + DBG: bisecting the wrong results of 544 (1 = pad before the partial stores, 2 = drain the exchange reads, 4 = scale in a
+  // VGPR, 8 = a second barrier behind the exchange reads)
+  if (D == 512 && abl == 551) return fa2::launch_m16_pair<2, true, false, 1>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 512 && abl == 552) return fa2::launch_m16_pair<2, true, false, 2>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 512 && abl == 554) return fa2::launch_m16_pair<2, true, false, 4>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 512 && abl == 566) return fa2::launch_m16_pair<2, true, false, 16>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 512 && abl == 614) return fa2::launch_m16_pair<2, true, false, 64>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 512 && abl == 678) return fa2::launch_m16_pair<2, true, false, 128>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 512 && abl == 806) return fa2::launch_m16_pair<2, true, false, 256>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 512 && abl == 1062) return fa2::launch_m16_pair<2, true, false, 512>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 512 && abl == 1574) return fa2::launch_m16_pair<2, true, false, 1024>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 512 && abl == 2598) return fa2::launch_m16_pair<2, true, false, 2048>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 512 && abl == 4646) return fa2::launch_m16_pair<2, true, false, 4096>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 512 && abl == 1100) return fa2::launch_m16_pair<4, true, false, 0>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 512 && abl == 1101) return fa2::launch_m16_pair<1, true, false, 0>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 512 && abl == 8742) return fa2::launch_m16_pair<2, true, false, 8192>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 512 && abl == 8743) return fa2::launch_m16_pair<2, true, false, 8192 + 2048>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 512 && abl == 8744) return fa2::launch_m16_pair<2, true, false, 8192 + 4096>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 512 && abl == 8745) return fa2::launch_m16_pair<1, true, false, 8192>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 256 && abl == 8742) return fa2::launch_m16_pair<2, false, false, 8192>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 512 && abl == 16928) return fa2::launch_m16_pair<2, true, false, 16384>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 512 && abl == 16929) return fa2::launch_m16_pair<2, true, false, 16384 + 2048>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 512 && abl == 16930) return fa2::launch_m16_pair<2, true, false, 16384 + 4096>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 512 && abl == 16931) return fa2::launch_m16_pair<1, true, false, 16384>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 512 && abl == 16932) return fa2::launch_m16_pair<2, true, false, 16384 + 1>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 256 && abl == 16928) return fa2::launch_m16_pair<2, false, false, 16384>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  // 5440 = the ROUND-2 code of 544 / of the D = 256 production kernel (no cln_mfma_keep: MFMA destinations on operand registers)
+  if (D == 512 && abl == 5440) return fa2::launch_m16_pair<2, true, false, 32768>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 256 && abl == 5440) return fa2::launch_m16_pair<2, false, false, 32768>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 512 && abl == 558) return fa2::launch_m16_pair<2, true, false, 8>(q, k, v, o, B, H, N, (hipStream_t)stream);
   // 800.. = the sum-checked optimistic softmax form (flash_attn_m16x.cuh, its own compile unit): abl = 800 + code,
   //         code = 16 * (NDEF - 1) + OX (OX: 1 = phase-A priority, 4 = split prologue); 860.. = prefetch depth 4; 880.. = 64 rows per wave
-  if (abl >= 800 && abl < 1000) return fa2::m16x_probe_run(D, abl - 800, q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (abl >= 800 && abl < 1000 && D <= 128) return fa2::m16x_probe_run(D, abl - 800, q, k, v, o, B, H, N, (hipStream_t)stream);
   // 1000 = the ring kernel for head dims 640 / 768 / 1024 (flash_attn_dring.cuh), row groups one phase apart; 1001 = lock-step
   if (D == 640 && abl == 1000) return fa2::launch_dring<640, fa2::OPT_DEFAULT>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 768 && abl == 1000) return fa2::launch_dring<768, fa2::OPT_DEFAULT>(q, k, v, o, B, H, N, (hipStream_t)stream);

@@ -90,6 +90,7 @@ __global__ __launch_bounds__(256) void fa2_fwd_splitkv_kernel(const half_t* __re
       for (int ks = 0; ks < D / 16; ++ks) {
         const h8 kf = *reinterpret_cast<const h8*>(kp + ks * 16);
         s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s, 0, 0, 0);
+        cln_mfma_keep(s, kf, qf[ks]);  // destination disjoint from the operands (common.h)
       }
 #pragma unroll
       for (int u = 0; u < D / 16; ++u) {
@@ -136,6 +137,7 @@ __global__ __launch_bounds__(256) void fa2_fwd_splitkv_kernel(const half_t* __re
           const char* vp = v_lds + (kv_base + (i >> 2)) * G::VS + (b * 32 + ((lane >> 4) & 1) * 16 + (i & 3) * 4) * 2;
           const h8 vf = h8_cat(lds_read_tr16(vp), lds_read_tr16(vp + 8 * G::VS));
           ot[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[st], ot[b], 0, 0, 0);
+          cln_mfma_keep(ot[b], vf, pf[st]);
         }
       }
     }

@@ -60,7 +60,7 @@ struct Geo {
 
 // (D = 128 with 2-wave workgroups does not fit 256 registers without spilling: it takes the one-wave-per-SIMD budget)
 template <int D, int NW, bool VT, int OPT, int ABL>
-__global__ __launch_bounds__(NW * 64, ((D > 128 || (D == 128 && NW == 2)) ? 1 : 2)) void fa2_fwd_v2_kernel(const half_t* __restrict__ Q,
+__global__ __launch_bounds__(NW * 64, ((D > 128 || (D >= 96 && NW == 2)) ? 1 : 2)) void fa2_fwd_v2_kernel(const half_t* __restrict__ Q,
                                                                 const half_t* __restrict__ K,
                                                                 const half_t* __restrict__ V,
                                                                 half_t* __restrict__ O, int N, int n_qblk,
@@ -221,6 +221,8 @@ __global__ __launch_bounds__(NW * 64, ((D > 128 || (D == 128 && NW == 2)) ? 1 : 
         for (int u = 0; u < GRP; ++u) {
           s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka[u], qf[g0 + u], s0, 0, 0, 0);
           s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kc[u], qf[g0 + u], s1, 0, 0, 0);
+          cln_mfma_keep(s0, ka[u], qf[g0 + u]);  // destinations disjoint from the operands (common.h)
+          cln_mfma_keep(s1, kc[u], qf[g0 + u]);
         }
       }
     } else {
@@ -236,6 +238,8 @@ __global__ __launch_bounds__(NW * 64, ((D > 128 || (D == 128 && NW == 2)) ? 1 : 
       }
       s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf0, qf[ks], s0, 0, 0, 0);
       s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf1, qf[ks], s1, 0, 0, 0);
+      cln_mfma_keep(s0, kf0, qf[ks]);
+      cln_mfma_keep(s1, kf1, qf[ks]);
     }
     if constexpr ((OPT & OPT_PRIO) != 0) __builtin_amdgcn_s_setprio(0);
     }
@@ -376,6 +380,7 @@ __global__ __launch_bounds__(NW * 64, ((D > 128 || (D == 128 && NW == 2)) ? 1 : 
           vf = h8_cat(lds_read_tr16(vp), lds_read_tr16(vp + 8 * G::VS));
         }
         ot[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[st], ot[b], 0, 0, 0);
+        cln_mfma_keep(ot[b], vf, pf[st]);
       }
     }
     if constexpr ((OPT & OPT_PRIO) != 0) __builtin_amdgcn_s_setprio(0);

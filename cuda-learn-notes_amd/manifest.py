@@ -102,8 +102,8 @@ _FA_VT = [
     "flash_attn_mma_stages_split_q_tiling_qk_swizzle_qkv",
 ]
 _FA_SPLIT_Q_IMPL = ("planner fa2_plan(shape, stages) [csrc/flash_attn.hip]: stages=1 -> fa2_fwd<load-then-compute>; "
-                    "stages=2 -> fa2_fwd_m16x<D=64|128> / fa2_fwd_m16<D=256> (>=192 workgroups of 256 rows) | fa2_fwd_m16x64r<D=64> (>=256 workgroups of 512 rows) | fa2_fwd_v2<D<=256, 8|4|2 waves> | "
-                    "fa2_fwd_dsplit<512; 320 / 384 on its LDS geometry with the real d split evenly> | fa2_fwd_dring<640 | 768 | 1024>; mfma_32x32x16 / 16x16x32, f32 acc "
+                    "stages=2 -> fa2_fwd_m16x<D=64|128> / fa2_fwd_m16<D=256> (>=192 workgroups of 256 rows) | fa2_fwd_m16<D=512> (pairs of waves split d) | fa2_fwd_m16x64r<D=64> (>=256 workgroups of 512 rows) | fa2_fwd_v2<D<=256, 8|4|2 waves> | "
+                    "fa2_fwd_dsplit<320 / 384 on the D = 512 LDS geometry with the real d split evenly> | fa2_fwd_dring<640 | 768 | 1024>; mfma_32x32x16 / 16x16x32, f32 acc "
                     "(see DISPATCH_EXAMPLES)")
 _add("flash_attn", "FA", "fa2_fwd_splitkv<D<=128>: 4 waves share 32 query rows, KV tile split over the waves, cross-wave "
      "row max through LDS (the structurally distinct split-KV rung)", "flash_attn_mma_stages_split_kv")
@@ -322,7 +322,7 @@ DISPATCH_EXAMPLES = [
     (_SQKV, (1, 2, 192, 64), 1, "fa2_fwd_v2<D=64,NW=2,BC=64,prefetch,pre-scaled Q> 2 waves x 32 rows" + _IGN),
     (_SQKV + "_swizzle_qkv", (4, 8, 2048, 128), 2, "fa2_fwd_v2<D=128,NW=8,BC=64,prefetch,pre-scaled Q,V^T> 8 waves x 32 rows"),
     (_SQKV + "_swizzle_qkv", (4, 8, 2048, 128), 1, "fa2_fwd<D=128,BC=64,load-then-compute,V^T> 4 waves x 32 rows"),
-    (_TQKV, (1, 32, 4096, 512), 2, "fa2_fwd_dsplit<D=512,NSP=2,BC=32> 8 waves, two groups one phase apart"),
+    (_TQKV, (1, 32, 4096, 512), 2, "fa2_fwd_m16<D=512,BC=32,16x16x32 MFMA,pairs of waves split d> 8 waves, 128 rows, two groups one phase apart"),
     (_TQKV, (1, 16, 4096, 384), 2, "fa2_fwd_dsplit<D=384,NSP=2,BC=32,LDS geometry of D=512> 8 waves, pairs split the real d evenly"),
     (_TQKV, (1, 16, 4096, 320), 2, "fa2_fwd_dsplit<D=320,NSP=2,BC=32,LDS geometry of D=512> 8 waves, pairs split the real d evenly"),
     (_TQKV, (1, 16, 4096, 640), 2, "fa2_fwd_dring<D=640,BC=16,2-slot K/V rings> 8 waves, 4 split d (160 columns each), 64 rows"),

@@ -38,7 +38,7 @@ def test_stages_knob_selects_a_different_flash_attn_kernel(built):
     # above D = 256 too (reference kStage of the tiling kernels, flash_attn_mma_tiling_qkv.cu:63, :189-223): config C5
     tq = "flash_attn_mma_stages_split_q_tiling_qkv"
     one5, two5 = m.describe(tq, (1, 32, 4096, 512), 1), m.describe(tq, (1, 32, 4096, 512), 2)
-    assert "load-then-compute" in one5 and two5.startswith("fa2_fwd_dsplit<D=512") and "stages ignored" not in two5
+    assert "load-then-compute" in one5 and two5.startswith("fa2_fwd_m16<D=512") and "stages ignored" not in two5
     for D in (320, 384, 640, 768, 1024):
         assert "load-then-compute" in m.describe(tq, (1, 16, 4096, D), 1), D
     # where the load-then-compute kernel does not tile N, the one pipeline serves both stage counts and says so
@@ -104,18 +104,21 @@ def test_flash_attn_planner_invariants_over_a_grid_of_shapes(built):
                     continue
                 fam = t.split("<")[0]
                 fam_seen.add((fam, D))
-                assert N % rows_per_wg[fam] == 0 or fam == "fa2_fwd_v2", (B, H, N, D, t)
+                rows = 128 if (fam, D) == ("fa2_fwd_m16", 512) else rows_per_wg[fam]  # the D = 512 pair form: 4 pairs x 32 rows
+                assert N % rows == 0 or fam == "fa2_fwd_v2", (B, H, N, D, t)
                 wgs256 = B * H * (N // 256) if N % 256 == 0 else 0
                 if D in (64, 128, 256) and wgs256 >= 192 and not (D == 64 and t.startswith("fa2_fwd_m16x64r")):
                     assert fam == ("fa2_fwd_m16" if D == 256 else "fa2_fwd_m16x") and "16x16x32" in t, (B, H, N, D, t)
-                if D in (320, 384, 512):
+                if D in (320, 384):
                     assert fam == "fa2_fwd_dsplit", t
+                if D == 512:
+                    assert fam == "fa2_fwd_m16" and "pairs of waves split d" in t, t
                 if D in (640, 768, 1024):
                     assert fam == "fa2_fwd_dring", t
                 if D <= 256:  # the shared-QKV name (max head dim 256) plans the same kernel
                     assert m.describe(sq, (B, H, N, D), 2) == t
     for want in (("fa2_fwd_m16x", 64), ("fa2_fwd_m16x", 128), ("fa2_fwd_m16", 256), ("fa2_fwd_m16x64r", 64), ("fa2_fwd_v2", 32),
-                 ("fa2_fwd_dsplit", 512), ("fa2_fwd_dring", 1024), ("fa2_fwd_dring", 640)):
+                 ("fa2_fwd_dsplit", 384), ("fa2_fwd_m16", 512), ("fa2_fwd_dring", 1024), ("fa2_fwd_dring", 640)):
         assert want in fam_seen, (want, sorted(fam_seen))
     with pytest.raises(ValueError):  # "headdim not support!" of the shared-QKV rung (MAX_HEADDIM_CFG: 256)
         m.describe(sq, (1, 32, 4096, 512), 2)

@@ -39,7 +39,7 @@ def test_production_attention_instantiations_are_in_the_report(tmp_path):
     kernels_x, _ = kr.report(os.path.join(ROOT, "cuda-learn-notes_amd", "csrc", "flash_attn_m16x.hip"), keep=str(tmp_path))
     names = [k["demangled"] for k in kernels + kernels_x]
     assert len(kernels_x) == 3, [k["demangled"] for k in kernels_x]  # the product unit holds the three dispatched forms only
-    for want in ("fa2_fwd_dsplit_kernel<512, 2, 1,", "fa2_fwd_m16x_kernel<64, 32, 128, 8, 4, 5>", "fa2_fwd_m16x_kernel<128, 32, 128, 4, 4, 5>", "fa2_fwd_m16_pair_kernel<2, false, false>",
+    for want in ("fa2_fwd_dsplit_kernel<512, 2, 1,", "fa2_fwd_m16x_kernel<64, 32, 128, 8, 4, 5>", "fa2_fwd_m16x_kernel<128, 32, 128, 4, 4, 5>", "fa2_fwd_m16_pair_kernel<2, false, false, 0>", "fa2_fwd_m16_pair_kernel<2, true, false, 0>",
                  "fa2_fwd_v2_kernel<128, 2, true", "fa2_fwd_splitkv_kernel<64>", "fa2_fwd_dring_kernel<1024, 15, true>", "fa2_fwd_dring_kernel<640, 15, false>", "fa2_fwd_m16x_kernel<64, 64, 64, 4, 1, 5>"):
         assert any(want in n for n in names), want
 
@@ -67,7 +67,8 @@ def test_production_attention_kernels_use_the_16x16x32_matrix_shape(tmp_path):
     kernels, s = kr.report(os.path.join(ROOT, "cuda-learn-notes_amd", "csrc", "flash_attn.hip"), keep=str(tmp_path))
     kernels_x, sx = kr.report(os.path.join(ROOT, "cuda-learn-notes_amd", "csrc", "flash_attn_m16x.hip"), keep=str(tmp_path))
     text = open(s).read() + open(sx).read()
-    for want in ("fa2_fwd_m16x_kernel<64, 32, 128, 8, 4, 5>", "fa2_fwd_m16x_kernel<128, 32, 128, 4, 4, 5>", "fa2_fwd_m16_pair_kernel<2, false, false>"):
+    for want in ("fa2_fwd_m16x_kernel<64, 32, 128, 8, 4, 5>", "fa2_fwd_m16x_kernel<128, 32, 128, 4, 4, 5>", "fa2_fwd_m16_pair_kernel<2, false, false, 0>",
+                 "fa2_fwd_m16_pair_kernel<2, true, false, 0>"):
         k = [k for k in kernels + kernels_x if want in k["demangled"]]
         assert len(k) == 1, want
         body = text[text.index("\n" + k[0]["name"] + ":"):]
@@ -82,3 +83,24 @@ def test_production_attention_kernels_use_the_16x16x32_matrix_shape(tmp_path):
             assert body.count("v_mfma_f32_16x16x32_f16") == 64, body.count("v_mfma_f32_16x16x32_f16")
             assert 96 <= body.count("v_exp_f32") <= 100, body.count("v_exp_f32")
             assert "v_pk_add_f32" not in body  # -fno-slp-vectorize on this unit (see flash_attn_m16x.hip)
+
+
+MFMA_SOURCES = ["flash_attn.hip", "flash_attn_m16x.hip", "hgemm.hip", "hgemm_ring_nn.hip", "hgemm_ring_tn.hip", "sgemm.hip"]
+
+
+@pytest.mark.parametrize("src", MFMA_SOURCES)
+def test_no_mfma_destination_on_its_operand_registers(src, tmp_path):
+    """Round 3 root cause of the D = 256 attention kernel's ~1 % wrong launches (and of the D = 512 probe that DESIGN r2 9.1
+    listed as "wrong, cause not found"): hipcc puts no early-clobber on an MFMA destination, so the last MFMA that reads a
+    dying A / B fragment may WRITE ITS RESULT OVER THAT FRAGMENT (`v_mfma_f32_16x16x32_f16 v[66:69], v[66:69], v[34:37], 0`);
+    on MI355X such an instruction intermittently returns wrong values when another wave's MFMAs interleave on the same SIMD
+    (profiles/r03_fa_mfma_overlap_bisect.log: the failure rate follows the number of such instructions; with none, every
+    timing variant is bit-stable). `cln_mfma_keep` (csrc/common.h) keeps the operands alive across the MFMA; this test keeps
+    every code object of the product library free of the pattern."""
+    import kernel_resources as kr
+    import mfma_overlap_scan as scan
+    _, s = kr.report(os.path.join(ROOT, "cuda-learn-notes_amd", "csrc", src), keep=str(tmp_path))
+    text = open(s).read()
+    assert text.count("v_mfma") > 0, src
+    bad = scan.scan(text)
+    assert not bad, [(n[:60], l) for n, l in bad[:6]]
