@@ -241,7 +241,7 @@ int fa2_describe(int family, bool vt, int B, int H, int N, int D, int stages, in
                       D == 512 ? 2 : 1, p.bc, st);
     case K_DRING:
       return snprintf(buf, len, "fa2_fwd_dring<D=%d,BC=16,2-slot K/V rings%s> 8 waves, 4 split d (%d columns each), 64 rows%s", D,
-                      D == 1024 ? ",row groups one phase apart" : "", D / 4, st);
+                      D == 1024 ? ",row groups one phase apart,phase-2 priority" : "", D / 4, st);
     default: return CLN_ERR_UNSUPPORTED;
   }
 }

@@ -180,6 +180,8 @@ __global__ __launch_bounds__(256, 1) void fa2_fwd_bigd_kernel(const half_t* __re
       for (int ks = 0; ks < D / 16; ++ks) {
         if ((OPT & OPT_STAGGER) != 0 && (ks & 1)) s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks % PD], qf[ks], s1, 0, 0, 0);
         else s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks % PD], qf[ks], s, 0, 0, 0);
+        cln_mfma_keep(s, kf[ks % PD], qf[ks]);  // destination disjoint from the operands (common.h)
+        if ((OPT & OPT_STAGGER) != 0) cln_mfma_keep(s1, kf[ks % PD], qf[ks]);
         if (ks + PD < D / 16) kf[ks % PD] = k_frag(ks + PD);
         else if ((OPT & OPT_VPRE) != 0) vpre[ks + PD - D / 16] = v_frag(ks + PD - D / 16);  // V under the QK^T tail
         __builtin_amdgcn_sched_barrier(0);
@@ -193,6 +195,7 @@ __global__ __launch_bounds__(256, 1) void fa2_fwd_bigd_kernel(const half_t* __re
       for (int ks = 0; ks < D / 16; ++ks) {
         const h8 kf = k_frag(ks);
         s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s, 0, 0, 0);
+        cln_mfma_keep(s, kf, qf[ks]);  // destination disjoint from the operands (common.h)
         // fence the scheduler every 4 k-steps: without it all D/16 fragment reads are hoisted ahead of the MFMA
         // chain and the kernel spills (the register file is full by design)
         if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
@@ -256,6 +259,7 @@ __global__ __launch_bounds__(256, 1) void fa2_fwd_bigd_kernel(const half_t* __re
       for (int idx = 0; idx < NPV; ++idx) {
         const int st = idx / (DV / 32), b = idx % (DV / 32);
         ot[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vpre[idx % PD], pf[st], ot[b], 0, 0, 0);
+        cln_mfma_keep(ot[b], vpre[idx % PD], pf[st]);  // destination disjoint from the operands (common.h)
         if (idx + PD < NPV) vpre[idx % PD] = v_frag(idx + PD);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -265,6 +269,7 @@ __global__ __launch_bounds__(256, 1) void fa2_fwd_bigd_kernel(const half_t* __re
         const int st = idx / (DV / 32), b = idx % (DV / 32);
         const h8 vf = v_frag(idx);
         ot[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[st], ot[b], 0, 0, 0);
+        cln_mfma_keep(ot[b], vf, pf[st]);  // destination disjoint from the operands (common.h)
         if ((b & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
     }

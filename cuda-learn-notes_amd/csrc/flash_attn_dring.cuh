@@ -52,7 +52,7 @@ __device__ __forceinline__ void dring_wait_vm() {
 // otherwise). Every interval between two workgroup barriers then carries ONE tile request issued by all eight waves
 // (even intervals K, odd intervals V), every request is two intervals ahead of its first reader, and the wait before
 // every barrier leaves exactly the one younger request in flight.
-template <int D, int OPT, bool STAGGER = true>
+template <int D, int OPT, bool STAGGER = true, int PRIO = 0>
 __global__ __launch_bounds__(512, 2) void fa2_fwd_dring_kernel(const half_t* __restrict__ Q, const half_t* __restrict__ K,
                                                                const half_t* __restrict__ V, half_t* __restrict__ O,
                                                                int N, int n_qblk, int n_heads, float scale_log2e) {
@@ -187,6 +187,7 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_dring_kernel(const half_t* __r
   for (int j = 0; j < T; ++j) {
     const int slot = j & 1;
     // ================= phase 1: partial S^T over this wave's quarter of d
+    if constexpr (PRIO != 0) __builtin_amdgcn_s_setprio(0);
     {
       f4 s[2];
       s[0] = f4{0.f, 0.f, 0.f, 0.f}, s[1] = f4{0.f, 0.f, 0.f, 0.f};
@@ -213,6 +214,7 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_dring_kernel(const half_t* __r
     asm volatile("" ::: "memory");
 
     // ================= phase 2: S = sum of the four partials, softmax, O^T += V^T P^T
+    if constexpr (PRIO != 0) __builtin_amdgcn_s_setprio(1);
     {
       float s8[8];
       {
@@ -319,15 +321,15 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_dring_kernel(const half_t* __r
   }
 }
 
-template <int D, int OPT, bool STAGGER = true>
+template <int D, int OPT, bool STAGGER = true, int PRIO = 0>
 int launch_dring(const void* q, const void* k, const void* v, void* o, int B, int H, int N, hipStream_t stream) {
   using G = GeoRing<D>;
   if (N % G::BR != 0) return CLN_ERR_UNSUPPORTED;
   static cln_lds_attr lds_attr;  // per device, thread-safe (common.h)
-  if (cln_ensure_lds(lds_attr, reinterpret_cast<const void*>(&fa2_fwd_dring_kernel<D, OPT, STAGGER>), G::LDS_BYTES) != CLN_OK) return CLN_ERR_LAUNCH;
+  if (cln_ensure_lds(lds_attr, reinterpret_cast<const void*>(&fa2_fwd_dring_kernel<D, OPT, STAGGER, PRIO>), G::LDS_BYTES) != CLN_OK) return CLN_ERR_LAUNCH;
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)D);
   const int n_qblk = N / G::BR;
-  CLN_LAUNCH((fa2_fwd_dring_kernel<D, OPT, STAGGER>), dim3(n_qblk * B * H), dim3(G::NT), G::LDS_BYTES, stream, (const half_t*)q,
+  CLN_LAUNCH((fa2_fwd_dring_kernel<D, OPT, STAGGER, PRIO>), dim3(n_qblk * B * H), dim3(G::NT), G::LDS_BYTES, stream, (const half_t*)q,
              (const half_t*)k, (const half_t*)v, (half_t*)o, N, n_qblk, B * H, scale_log2e);
   return cln_check_launch();
 }

@@ -175,6 +175,7 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_dsplit2_kernel(const half_t* _
         for (int g = 0; g < 2; ++g) {
           if (t < BCB) s[g][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[t % PD], qf[g][0], minit[g], 0, 0, 0);  // chain starts at -m
           else s[g][t % BCB] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[t % PD], qf[g][t / BCB], s[g][t % BCB], 0, 0, 0);
+          cln_mfma_keep(s[g][t % BCB], kf[t % PD], qf[g][t / BCB]);  // destination disjoint from the operands (common.h)
         }
         if (t + PD < NQK) kf[t % PD] = k_frag(t + PD);
         if ((t % (NQK / PPW)) == NQK / PPW - 1) dma_piece(jt0 + jn, (j + 1) & 1, t / (NQK / PPW));
@@ -256,7 +257,10 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_dsplit2_kernel(const half_t* _
       for (int idx = i0; idx < i1; ++idx) {
         const int st = idx / NDB, b = idx % NDB;
 #pragma unroll
-        for (int g = 0; g < 2; ++g) ot[g][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[idx % PD], pf[g][st], ot[g][b], 0, 0, 0);
+        for (int g = 0; g < 2; ++g) {
+          ot[g][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[idx % PD], pf[g][st], ot[g][b], 0, 0, 0);
+          cln_mfma_keep(ot[g][b], vf[idx % PD], pf[g][st]);
+        }
         if (idx + PD < NPV) vf[idx % PD] = v_frag(idx + PD);
         __builtin_amdgcn_sched_barrier(0);
       }

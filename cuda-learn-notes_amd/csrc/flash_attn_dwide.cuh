@@ -144,6 +144,7 @@ __global__ __launch_bounds__(GeoWide<D>::NT, 1) void fa2_fwd_dwide_kernel(const 
     for (int ks = 0; ks < NK; ++ks) {
       const h8 kf = k_frag(ks);
       s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s, 0, 0, 0);
+      cln_mfma_keep(s, kf, qf[ks]);  // destination disjoint from the operands (common.h)
       if ((ks % (NK / G::PPW)) == NK / G::PPW - 1) dma_v(j, ks / (NK / G::PPW));
       if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
@@ -210,6 +211,7 @@ __global__ __launch_bounds__(GeoWide<D>::NT, 1) void fa2_fwd_dwide_kernel(const 
       const int st = idx / (G::DH / 32), b = idx % (G::DH / 32);
       const h8 vf = v_frag(idx);
       ot[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[st], ot[b], 0, 0, 0);
+      cln_mfma_keep(ot[b], vf, pf[st]);  // destination disjoint from the operands (common.h)
       if ((idx % (NPV / G::PPW)) == NPV / G::PPW - 1) dma_k(jn, idx / (NPV / G::PPW));
       if ((idx & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }

@@ -441,6 +441,7 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16_pair_kernel(const half_t* 
       return h8_cat(lds_read_tr16(vp), lds_read_tr16(vp + 16 * G::ROW));
     };
     // ================= phase A: partial S^T over this wave's half of d
+    if constexpr ((DBG & 65536) != 0) __builtin_amdgcn_s_setprio(0);
     f4 s[NKB][NQB];
     {
       h8 kf[PD];
@@ -486,6 +487,7 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16_pair_kernel(const half_t* 
     asm volatile("" ::: "memory");
 
     // ================= phase B: S = own + partner's partial, softmax, O^T[half] += V[:, half]^T P^T
+    if constexpr ((DBG & 65536) != 0) __builtin_amdgcn_s_setprio(1);  // the VALU-carrying phase wins the issue arbitration
     f4 pp_first[2];
     if constexpr (PAIR)
 #pragma unroll

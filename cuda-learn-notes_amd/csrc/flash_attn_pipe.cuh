@@ -114,6 +114,7 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_pipe_kernel(const half_t* __re
   for (int t = 0; t < NQK; ++t) {
     const h8 kf = k_frag(0, t);
     s_a[t % BCB] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[t / BCB], s_a[t % BCB], 0, 0, 0);
+    cln_mfma_keep(s_a[t % BCB], kf, qf[t / BCB]);  // destination disjoint from the operands (common.h)
     if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
   }
 
@@ -181,6 +182,7 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_pipe_kernel(const half_t* __re
       for (int t = 0; t < NQK; ++t) {
         if (!(ABL & 16))
           s_nxt[t % BCB] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[t % PD], qf[t / BCB], s_nxt[t % BCB], 0, 0, 0);
+          cln_mfma_keep(s_nxt[t % BCB], kf[t % PD], qf[t / BCB]);  // destination disjoint from the operands (common.h)
         if (t + PD < NQK) kf[t % PD] = k_frag(tk, t + PD);
         if (!(ABL & 1) && (t % (NQK / G::PPW)) == NQK / G::PPW - 1) dma_piece(jd, t / (NQK / G::PPW));
         // softmax slice: elements e0 .. e0 + EPM - 1 of the flattened (kb, r) index; pairs feed one packed conversion
@@ -221,6 +223,7 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_pipe_kernel(const half_t* __re
         for (int idx = 0; idx < NPV; ++idx) {
           const int st = idx / (D / 32), b = idx % (D / 32);
           ot[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[idx % PD], pf[st], ot[b], 0, 0, 0);
+          cln_mfma_keep(ot[b], vf[idx % PD], pf[st]);  // destination disjoint from the operands (common.h)
           if (idx + PD < NPV) vf[idx % PD] = v_frag(j, idx + PD);
           __builtin_amdgcn_sched_barrier(0);
         }

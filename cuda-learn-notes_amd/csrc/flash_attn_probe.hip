@@ -119,6 +119,11 @@ CLN_API int cln_fa2_variant(int D, int nw, int vt, int opt, int abl, const void*
   // 5440 = the ROUND-2 code of 544 / of the D = 256 production kernel (no cln_mfma_keep: MFMA destinations on operand registers)
   if (D == 512 && abl == 5440) return fa2::launch_m16_pair<2, true, false, 32768>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 256 && abl == 5440) return fa2::launch_m16_pair<2, false, false, 32768>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 512 && abl == 545) return fa2::launch_m16_pair<2, true, false, 65536>(q, k, v, o, B, H, N, (hipStream_t)stream);   // phase-B priority
+  if (D == 256 && abl == 545) return fa2::launch_m16_pair<2, false, false, 65536>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 1024 && abl == 1002) return fa2::launch_dring<1024, fa2::OPT_DEFAULT, true, 1>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 768 && abl == 1002) return fa2::launch_dring<768, fa2::OPT_DEFAULT, true, 1>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 768 && abl == 1003) return fa2::launch_dring<768, fa2::OPT_DEFAULT, false, 1>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 512 && abl == 558) return fa2::launch_m16_pair<2, true, false, 8>(q, k, v, o, B, H, N, (hipStream_t)stream);
   // 800.. = the sum-checked optimistic softmax form (flash_attn_m16x.cuh, its own compile unit): abl = 800 + code,
   //         code = 16 * (NDEF - 1) + OX (OX: 1 = phase-A priority, 4 = split prologue); 860.. = prefetch depth 4; 880.. = 64 rows per wave

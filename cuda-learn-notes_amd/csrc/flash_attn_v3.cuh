@@ -146,7 +146,9 @@ __global__ __launch_bounds__(NW * 64, (D > 128 ? 1 : 2)) void fa2_fwd_v3_kernel(
       const h8 kf0 = *reinterpret_cast<const h8*>(kb + k_off + ks * 32);
       const h8 kf1 = *reinterpret_cast<const h8*>(kb + k_off + 32 * G::KS + ks * 32);
       a = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf0, qf[ks], a, 0, 0, 0);
+      cln_mfma_keep(a, kf0, qf[ks]);  // destination disjoint from the operands (common.h)
       b = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf1, qf[ks], b, 0, 0, 0);
+      cln_mfma_keep(b, kf1, qf[ks]);  // destination disjoint from the operands (common.h)
     }
   };
   auto rowmax = [&](const f16v& a, const f16v& b) {
@@ -194,7 +196,9 @@ __global__ __launch_bounds__(NW * 64, (D > 128 ? 1 : 2)) void fa2_fwd_v3_kernel(
 #pragma unroll
       for (int ks = 0; ks < D / 16; ++ks) {
         n0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kpre[2 * ks], qf[ks], n0, 0, 0, 0);
+        cln_mfma_keep(n0, kpre[2 * ks], qf[ks]);  // destination disjoint from the operands (common.h)
         n1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kpre[2 * ks + 1], qf[ks], n1, 0, 0, 0);
+        cln_mfma_keep(n1, kpre[2 * ks + 1], qf[ks]);  // destination disjoint from the operands (common.h)
       }
     } else if constexpr (NEXT) {
       qk(n0, n1, kb_next);
@@ -255,6 +259,7 @@ __global__ __launch_bounds__(NW * 64, (D > 128 ? 1 : 2)) void fa2_fwd_v3_kernel(
           vf = h8_cat(lds_read_tr16(vp), lds_read_tr16(vp + 8 * G::VS));
         }
         ot[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[st], ot[b], 0, 0, 0);
+        cln_mfma_keep(ot[b], vf, pf[st]);  // destination disjoint from the operands (common.h)
       }
     }
     if constexpr ((OPT & OPT_PRIO) != 0) __builtin_amdgcn_s_setprio(0);

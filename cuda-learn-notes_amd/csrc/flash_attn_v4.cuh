@@ -127,7 +127,9 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_v4_kernel(const half_t* __rest
       const h8 kf0 = *reinterpret_cast<const h8*>(kb + k_off + ks * 32);
       const h8 kf1 = *reinterpret_cast<const h8*>(kb + k_off + 32 * G::KS + ks * 32);
       s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf0, qf[ks], s0, 0, 0, 0);
+      cln_mfma_keep(s0, kf0, qf[ks]);  // destination disjoint from the operands (common.h)
       s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf1, qf[ks], s1, 0, 0, 0);
+      cln_mfma_keep(s1, kf1, qf[ks]);  // destination disjoint from the operands (common.h)
     }
     if constexpr ((OPT & OPT_PRIO) != 0) __builtin_amdgcn_s_setprio(0);
   };
@@ -189,6 +191,7 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_v4_kernel(const half_t* __rest
           vf = h8_cat(lds_read_tr16(vp), lds_read_tr16(vp + 8 * G::VS));
         }
         ot[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[st], ot[b], 0, 0, 0);
+        cln_mfma_keep(ot[b], vf, pf[st]);  // destination disjoint from the operands (common.h)
       }
     }
     if constexpr ((OPT & OPT_PRIO) != 0) __builtin_amdgcn_s_setprio(0);

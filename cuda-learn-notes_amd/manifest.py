@@ -326,7 +326,7 @@ DISPATCH_EXAMPLES = [
     (_TQKV, (1, 16, 4096, 384), 2, "fa2_fwd_dsplit<D=384,NSP=2,BC=32,LDS geometry of D=512> 8 waves, pairs split the real d evenly"),
     (_TQKV, (1, 16, 4096, 320), 2, "fa2_fwd_dsplit<D=320,NSP=2,BC=32,LDS geometry of D=512> 8 waves, pairs split the real d evenly"),
     (_TQKV, (1, 16, 4096, 640), 2, "fa2_fwd_dring<D=640,BC=16,2-slot K/V rings> 8 waves, 4 split d (160 columns each), 64 rows"),
-    (_TQKV, (1, 16, 4096, 1024), 2, "fa2_fwd_dring<D=1024,BC=16,2-slot K/V rings,row groups one phase apart> 8 waves, 4 split d (256 columns each), 64 rows"),
+    (_TQKV, (1, 16, 4096, 1024), 2, "fa2_fwd_dring<D=1024,BC=16,2-slot K/V rings,row groups one phase apart,phase-2 priority> 8 waves, 4 split d (256 columns each), 64 rows"),
     # stages = 1 above D = 256: the load-then-compute kernel with the output head dim sliced over blockIdx.z
     (_TQKV, (1, 32, 4096, 512), 1, "fa2_fwd<D=512,DV=256,BC=64,load-then-compute> 4 waves x 32 rows, output head dim sliced over 2 workgroups"),
     (_TQKV, (1, 16, 4096, 1024), 1, "fa2_fwd<D=1024,DV=256,BC=32,load-then-compute> 4 waves x 32 rows, output head dim sliced over 4 workgroups"),
