@@ -52,7 +52,8 @@ def fa_roofline(kern, shape, pmc_file, dev, bu, profiles, kernel_desc=""):
     ms = bu.time_region_events(fn, iters)
     flops = bu.mha_flops_conventional(B_, H_, N_, D)
     ach = flops / (ms * 1e-3) * 1e-12
-    ksub = kernel_desc.split("<")[0] + "_kernel" if kernel_desc else ""  # counters must come from THIS kernel family
+    fam = kernel_desc.split("<")[0]  # counters must come from THIS kernel family
+    ksub = {"fa2_fwd_m16": "fa2_fwd_m16_pair_kernel", "fa2_fwd_m16x64r": "fa2_fwd_m16x_kernel"}.get(fam, fam + "_kernel") if fam else ""
     busy, src = bu.pmc_value(profiles, pmc_file, "mfma_busy_frac", ksub)
     traffic, _ = bu.pmc_value(profiles, pmc_file, "hbm_traffic_bytes_per_launch", ksub)
     return {"bound": "mfma", "achieved": round(ach, 2), "peak": bu.PEAK_FP16_MFMA_TFLOPS, "unit": "TFLOP/s",

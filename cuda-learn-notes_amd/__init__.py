@@ -18,7 +18,7 @@ def load(*groups):
 
 def hgemm_lib():
     """Mirror of `import toy_hgemm` / try_load_hgemm_library (kernels/hgemm/tools/utils.py:116-132)."""
-    return load("hgemm", "hgemm_vendor")
+    return load("hgemm", "hgemm_vendor", "hgemm_vendor_lt")
 
 
 def flash_attn_lib():

@@ -7,7 +7,7 @@ rows need one (no CPU fallback).
   python hgemm.py --mma --MNK 4096          # BASELINE config C3
   python hgemm.py --mma-all --wmma-all --cuda-all --mma-tn --cute-tn --torch
 
-Rows whose tag contains "cublas" run the rocBLAS row (libcln_amd_vendor.so). Each row also goes to the
+Rows whose tag contains "cublas" run the rocBLAS row, "(hipblaslt)" / "tn(hipblaslt)" the hipBLASLt row (libcln_amd_vendor.so). Each row also goes to the
 JSON side channel ($CLN_AMD_BENCH_JSON) with its MFMA-roofline fraction.
 """
 import argparse
@@ -132,6 +132,9 @@ def row_table(a):
                 "hgemm_mma_stages_block_swizzle_tn_cute", st, sw, True)
     add(not a.disable_cublas_tn and (tn or ct), "tn(cublas)", "hgemm_cublas_tensor_op_tn", None, False, True)
     add(not a.disable_cublas and default, "(cublas)", "hgemm_cublas_tensor_op_nn")
+    # the second vendor baseline (not in the reference: hipBLASLt is what MI355X GEMM numbers are usually quoted on)
+    add(not a.disable_cublas_tn and (tn or ct), "tn(hipblaslt)", "cln_hgemm_hipblaslt_tn", None, False, True)
+    add(not a.disable_cublas and default, "(hipblaslt)", "cln_hgemm_hipblaslt_nn")
     return [r for r in rows if r[0]]
 
 
@@ -207,13 +210,15 @@ def run_benchmark(perf_func, a, b, tag, out=None, stages=-1, swizzle=False, swiz
         improve = round((TFLOPS - MAX_TFLOPS) / MAX_TFLOPS * 100, 2) if MAX_TFLOPS > 0 else 0
         MAX_TFLOPS = TFLOPS
         print(line + f"(+{improve:.2f}%)")
-    elif not only_show_improved or is_cublas:
+    elif not only_show_improved or is_cublas or "hipblaslt" in tag:
         print(line)
     if show_matrix:
         print(out)
     if args.plot_flops:
         STATIS_INFO.setdefault(tag, []).append(TFLOPS)
-        if not is_cublas:
+        if "hipblaslt" in tag:
+            pass  # a baseline row: not a candidate for the top-k table
+        elif not is_cublas:
             TOATL_TFLOPS[tag] = TOATL_TFLOPS.get(tag, 0) + TFLOPS
         elif tag == "tn(cublas)":
             CUBLAS_TN_TOTAL_TFLOPS += TFLOPS
@@ -248,7 +253,7 @@ def get_topk_tflops():
 
 def get_best_tflops():
     """Per size, the best TFLOPS over all non-vendor rows (reference :211-220)."""
-    rows = [v for t, v in STATIS_INFO.items() if "cublas" not in t and "MNK" not in t and t != "(best)"]
+    rows = [v for t, v in STATIS_INFO.items() if "cublas" not in t and "hipblaslt" not in t and "MNK" not in t and t != "(best)"]
     n = min(len(r) for r in rows) if rows else 0
     return [max(r[i] for r in rows) for i in range(n)]
 

@@ -128,6 +128,7 @@ def test_hgemm_script_runs_on_the_gpu(built, dev):
     vals = {(r[1], r[2]) for r in rows if "cublas" not in r[0]}
     cub = [(r[1], r[2]) for r in rows if r[0] == "(cublas)"]
     assert cub, "vendor row missing"
+    assert any(r[0] == "(hipblaslt)" for r in rows), "hipBLASLt row missing"
     # every kernel row prints the same first/last element of C as the vendor row, to fp16 rounding of |C| ~ 32
     for (a, b) in vals:
         assert abs(float(a) - float(cub[0][0])) <= 0.13 and abs(float(b) - float(cub[0][1])) <= 0.13, (a, b, cub[0])
