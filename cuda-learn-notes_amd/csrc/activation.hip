@@ -47,13 +47,13 @@ template <> __device__ __forceinline__ half_t st<half_t>(float v) { return (half
 // VEC elements per lane; PACKED: one VEC*sizeof(T)-byte access, else VEC accesses of CHUNK elements
 // (f16x8 = four half2 accesses in the reference, f32x4 = one float4).
 template <typename Op, typename T, int VEC, int CHUNK>
-__global__ __launch_bounds__(256) void unary_kernel(const T* __restrict__ x, T* __restrict__ y, long long n) {
+__global__ __launch_bounds__(256) void unary_kernel(const T* __restrict__ x, T* __restrict__ y, long long n, int stream_nt) {
   typedef T chunk_t __attribute__((ext_vector_type(CHUNK)));
   const long long nvec = n / VEC;
   const long long stride = (long long)gridDim.x * 256;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride) {
     if constexpr (VEC == 1) {
-      y[i] = st<T>(Op::f(ld(x[i])));
+      cln_store_stream(y + i, st<T>(Op::f(ld(x[i]))), stream_nt);
     } else {
       chunk_t v[VEC / CHUNK];
 #pragma unroll
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void unary_kernel(const T* __restrict__ x, T* 
       for (int c = 0; c < VEC / CHUNK; ++c) {
 #pragma unroll
         for (int e = 0; e < CHUNK; ++e) v[c][e] = st<T>(Op::f(ld(v[c][e])));
-        *reinterpret_cast<chunk_t*>(y + i * VEC + c * CHUNK) = v[c];
+        cln_store_stream(reinterpret_cast<chunk_t*>(y + i * VEC + c * CHUNK), v[c], stream_nt);
       }
     }
   }
@@ -77,7 +77,7 @@ int launch_unary(const void* x, void* y, long long n, hipStream_t st_) {
   if (n == 0) return CLN_OK;
   if (sizeof(T) * CHUNK >= 16 && (!cln_aligned16(x) || !cln_aligned16(y))) return CLN_ERR_BAD_ARG;
   const int grid = cln_stream_grid(n / VEC + 1, 256);
-  CLN_LAUNCH((unary_kernel<Op, T, VEC, CHUNK>), dim3(grid), dim3(256), 0, st_, (const T*)x, (T*)y, n);
+  CLN_LAUNCH((unary_kernel<Op, T, VEC, CHUNK>), dim3(grid), dim3(256), 0, st_, (const T*)x, (T*)y, n, cln_stream_nt(2LL * n * (long long)sizeof(T)));
   return cln_check_launch();
 }
 

@@ -85,18 +85,55 @@ typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u2 __attribute__((ext_vector_type(2)));
 
 #define CLN_WAVE 64
+#ifndef CLN_STREAM_WGS_PER_CU
+#define CLN_STREAM_WGS_PER_CU 32
+#endif
+
+// Streaming stores. A launch whose tensors fill the 256 MB MALL together (or more) writes its output with non-temporal
+// stores (global_store ... nt): the write stream then leaves the MALL to the read stream. Measured on y = 2x over f32x4
+// (tools/ubench/stream_nt.hip, profiles/r03_stream_nt_ubench.log): 256 MB in + 256 MB out 4.1-4.8 -> 6.2-6.8 TB/s; no
+// difference at 64 + 64 MB (everything is MALL-resident) and at >= 512 + 512 MB (nothing is); non-temporal LOADS on top
+// of it lose the gain again. On the kernels (profiles/r03_bw_streaming_stores_probe.log): 8192^2 f32 softmax 5.45 -> 6.88
+// TB/s, rope 5.27 -> 6.85, three-tensor f16 add 5.22 -> 7.20, embedding 65536 x 1024 6.18 -> 6.94; at exactly 256 MB (the
+// 8192^2 f16 rows) +0.5-5 %.
+static inline int cln_stream_nt(long long footprint_bytes) { return footprint_bytes >= (256LL << 20) ? 1 : 0; }
 
 // Grid sizing for HBM-bound streaming kernels: enough workgroups to cover all
 // 256 CUs several times over, grid-stride for the rest (cdna guide G11).
 static inline int cln_stream_grid(long long work_items, int block) {
   long long g = (work_items + block - 1) / block;
-  const long long cap = 256LL * 16;
+  const long long cap = 256LL * CLN_STREAM_WGS_PER_CU;
   if (g > cap) g = cap;
   if (g < 1) g = 1;
   return (int)g;
 }
 
 #ifdef __HIPCC__
+template <int BYTES> struct cln_raw;
+template <> struct cln_raw<16> { typedef u4 type; };
+template <> struct cln_raw<8> { typedef u2 type; };
+template <> struct cln_raw<4> { typedef unsigned int type; };
+template <> struct cln_raw<2> { typedef unsigned short type; };
+template <> struct cln_raw<1> { typedef unsigned char type; };
+// *dst = v, as a non-temporal store when `nt` (a launch-uniform flag: cln_stream_nt of the launch's footprint). The nt form is
+// inline asm: with __builtin_nontemporal_store under a run-time flag hipcc merges the two stores of the diamond into ONE
+// plain store (the merge drops the nt bit). The trailing s_nop covers the "store of > 64 bits, then a write to its data
+// registers" wait state, which the hazard pass cannot see inside an asm statement.
+template <typename P>
+__device__ __forceinline__ void cln_store_stream(P* dst, const P& v, int nt) {
+  typedef typename cln_raw<sizeof(P)>::type R;
+  if (nt) {
+    const R raw = __builtin_bit_cast(R, v);
+    if constexpr (sizeof(P) == 16) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(dst), "v"(raw) : "memory");
+    else if constexpr (sizeof(P) == 8) asm volatile("global_store_dwordx2 %0, %1, off nt\n\ts_nop 1" ::"v"(dst), "v"(raw) : "memory");
+    else if constexpr (sizeof(P) == 4) asm volatile("global_store_dword %0, %1, off nt" ::"v"(dst), "v"(raw) : "memory");
+    else if constexpr (sizeof(P) == 2) asm volatile("global_store_short %0, %1, off nt" ::"v"(dst), "v"((unsigned int)raw) : "memory");
+    else asm volatile("global_store_byte %0, %1, off nt" ::"v"(dst), "v"((unsigned int)raw) : "memory");
+  } else {
+    *dst = v;
+  }
+}
+
 // ---------------------------------------------------------------- wave64 reductions
 // All-lanes reductions on the VALU only (no LDS round trips): four DPP steps inside a 16-lane row
 // (quad_perm xor 1, xor 2, row_half_mirror, row_mirror), then v_permlane16_swap / v_permlane32_swap (gfx950)

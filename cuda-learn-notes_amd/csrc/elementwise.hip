@@ -2,8 +2,9 @@
 //
 // Replaces the kernels + bindings of reference kernels/elementwise/elementwise.cu:24-108
 // (kernels) and :122-177 (TORCH_BINDING_ELEM_ADD launch-shape macro + PYBIND11_MODULE).
-// Design for gfx950: every rung is a grid-stride loop over a capped grid (256 CUs x 16
-// workgroups of 256 threads = 4 waves), the rung name fixes only the per-lane access width
+// Design for gfx950: every rung is a grid-stride loop over a capped grid (256 CUs x 32
+// workgroups of 256 threads = every wave slot of the chip; outputs of launches that fill the MALL are written with
+// non-temporal stores, common.h cln_store_stream), the rung name fixes only the per-lane access width
 // (4 B, 16 B, 2 B, 4 B, 4x4 B, 16 B), exactly what the reference ladder teaches.
 #include "common.h"
 
@@ -11,10 +12,10 @@ namespace {
 
 template <typename VT>
 __global__ __launch_bounds__(256) void add_vec_kernel(const VT* __restrict__ a, const VT* __restrict__ b,
-                                                      VT* __restrict__ c, long long nvec) {
+                                                      VT* __restrict__ c, long long nvec, int stream_nt) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long stride = (long long)gridDim.x * blockDim.x;
-  for (; i < nvec; i += stride) c[i] = a[i] + b[i];
+  for (; i < nvec; i += stride) cln_store_stream(c + i, (VT)(a[i] + b[i]), stream_nt);
 }
 
 // scalar tail (n not a multiple of the vector width)
@@ -27,17 +28,17 @@ __global__ void add_tail_kernel(const T* a, const T* b, T* c, long long start, l
 // "f16x8" rung: eight halves per thread moved as four separate 4-byte half2 accesses
 // (reference elementwise.cu:62-86); the "_pack" rung below moves them as one 16-byte access.
 __global__ __launch_bounds__(256) void add_f16x8_unpacked_kernel(const h2* __restrict__ a, const h2* __restrict__ b,
-                                                                 h2* __restrict__ c, long long ngroups) {
+                                                                 h2* __restrict__ c, long long ngroups, int stream_nt) {
   long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (; g < ngroups; g += stride) {
     const long long i = g * 4;
     h2 a0 = a[i + 0], a1 = a[i + 1], a2 = a[i + 2], a3 = a[i + 3];
     h2 b0 = b[i + 0], b1 = b[i + 1], b2 = b[i + 2], b3 = b[i + 3];
-    c[i + 0] = a0 + b0;
-    c[i + 1] = a1 + b1;
-    c[i + 2] = a2 + b2;
-    c[i + 3] = a3 + b3;
+    cln_store_stream(c + i + 0, (h2)(a0 + b0), stream_nt);
+    cln_store_stream(c + i + 1, (h2)(a1 + b1), stream_nt);
+    cln_store_stream(c + i + 2, (h2)(a2 + b2), stream_nt);
+    cln_store_stream(c + i + 3, (h2)(a3 + b3), stream_nt);
   }
 }
 
@@ -50,7 +51,7 @@ int launch_add(const void* a, const void* b, void* c, long long n, hipStream_t s
   if (nvec > 0) {
     const int grid = cln_stream_grid(nvec, 256);
     CLN_LAUNCH((add_vec_kernel<VT>), dim3(grid), dim3(256), 0, stream, (const VT*)a, (const VT*)b, (VT*)c,
-                       nvec);
+                       nvec, cln_stream_nt(3LL * n * (long long)sizeof(T)));
   }
   const long long done = nvec * VEC;
   if (done < n) {
@@ -82,7 +83,7 @@ CLN_API int elementwise_add_f16x8(const void* a, const void* b, void* c, long lo
   if (ngroups > 0) {
     const int grid = cln_stream_grid(ngroups, 256);
     CLN_LAUNCH(add_f16x8_unpacked_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const h2*)a,
-                       (const h2*)b, (h2*)c, ngroups);
+                       (const h2*)b, (h2*)c, ngroups, cln_stream_nt(6LL * n));
   }
   if (ngroups * 8 < n) {
     CLN_LAUNCH((add_tail_kernel<half_t>), dim3(1), dim3(64), 0, (hipStream_t)stream, (const half_t*)a,

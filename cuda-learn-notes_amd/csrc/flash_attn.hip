@@ -31,6 +31,7 @@ struct FaPlan {
   int nw = 0;          // waves per workgroup
   int bc = 0;          // keys per KV tile
   bool stages_honoured = true;  // false: stages = 1 and 2 run the same (prefetching) kernel for this shape
+  bool one_stage = false;       // head dims above 256 at stages = 1: the production kernel with every tile fetch waited for at issue
 };
 
 FaPlan fa2_plan(int family, bool vt, int B, int H, int N, int D, int stages, int max_d) {
@@ -94,14 +95,12 @@ FaPlan fa2_plan(int family, bool vt, int B, int H, int N, int D, int stages, int
   }
   if (vt) return p.rc = CLN_ERR_UNSUPPORTED, p;
   // ---- head dims above 256 ("fine-grained tiling" rungs, flash_attn_large_d.cuh). The reference's tiling kernels template
-  // on kStage 1 / 2 (flash_attn_mma_tiling_qkv.cu:63, :189-223): stages = 1 runs the load-then-compute kernel here too
-  // (flash_attn.cuh with PREFETCH = false: whole K rows of a tile in LDS, the OUTPUT head dim sliced over blockIdx.z, S
-  // recomputed per slice -- the slow, structurally simple rung); stages = 2 the d-split / d-wide pipelines.
-  if (stages == 1 && N % 128 == 0 && bh <= 65535 && (D == 320 || D == 384 || D == 512 || D == 640 || D == 768 || D == 1024)) {
-    p.kind = K_LOAD_THEN_COMPUTE, p.d_inst = D, p.nw = 4, p.bc = D <= 512 ? 64 : 32;
-    return p;
-  }
-  p.stages_honoured = stages != 1;
+  // on kStage 1 / 2 (flash_attn_mma_tiling_qkv.cu:63, :189-223: with kStage = 1 a tile is loaded, waited for, then used).
+  // stages = 1 here: the SAME d-split / ring kernels with every tile fetch waited for where it is issued, so no load runs
+  // under compute (`one_stage`); stages = 2: the pipelines. (Round 3's first form ran the 4-wave kernel of flash_attn.cuh
+  // with the output head dim sliced and S recomputed per slice: 94 TF at D = 768 / 1024, profiles/r03_fa_stage1_vs_stage2.log.)
+  p.one_stage = stages == 1;
+  p.stages_honoured = stages != 1 || p.one_stage;
   switch (D) {
     case 512:  // config C5: the d-split PAIR kernel on 16x16x32 MFMAs, scores scaled in fp32 (flash_attn_m16.cuh, round 3: +2.7 %
       // over the 32x32x16 form at identical max-abs-error once its MFMA destinations were kept off the operand registers)
@@ -142,16 +141,6 @@ int fa2_run(const FaPlan& p, const void* q, const void* k, const void* v, void* 
         case 128: return fa::launch_fa2<128, 128, 64, VT, false>(q, k, v, o, B, H, N, s);
         case 256: return fa::launch_fa2<256, 256, 64, VT, false>(q, k, v, o, B, H, N, s);
       }
-      if constexpr (!VT) {  // head dims above 256: output head dim sliced over blockIdx.z (DV), S recomputed per slice
-        switch (D) {
-          case 320: return fa::launch_fa2<320, 160, 64, false, false>(q, k, v, o, B, H, N, s);
-          case 384: return fa::launch_fa2<384, 192, 64, false, false>(q, k, v, o, B, H, N, s);
-          case 512: return fa::launch_fa2<512, 256, 64, false, false>(q, k, v, o, B, H, N, s);
-          case 640: return fa::launch_fa2<640, 320, 32, false, false>(q, k, v, o, B, H, N, s);
-          case 768: return fa::launch_fa2<768, 192, 32, false, false>(q, k, v, o, B, H, N, s);
-          case 1024: return fa::launch_fa2<1024, 256, 32, false, false>(q, k, v, o, B, H, N, s);
-        }
-      }
       return CLN_ERR_UNSUPPORTED;
     case K_V2:
 #define FA_V2(DD, OPTT, HAS8)                                                                          \
@@ -178,18 +167,19 @@ int fa2_run(const FaPlan& p, const void* q, const void* k, const void* v, void* 
       if constexpr (!VT) {
         if (D == 64 || D == 128) return fa2::m16x_run(D, 32, q, k, v, o, B, H, N, s);  // 128-key tiles; own compile unit
         if (D == 256) return fa2::launch_m16_pair<2, false, false>(q, k, v, o, B, H, N, s);
-        if (D == 512) return fa2::launch_m16_pair<2, true, false>(q, k, v, o, B, H, N, s);
+        if (D == 512) return p.one_stage ? fa2::launch_m16_pair<2, true, false, 131072>(q, k, v, o, B, H, N, s)
+                                         : fa2::launch_m16_pair<2, true, false>(q, k, v, o, B, H, N, s);
       }
       return CLN_ERR_UNSUPPORTED;
     case K_DSPLIT:
       if constexpr (!VT) {
         // (the D = 64 / 128 forms of this kernel -- 32x32x16 MFMAs -- are in the probe library: variants 500 of kind 8)
         // (D = 256 moved to the 16x16x32 kernel; its 32x32x16 form is probe variant 220 of kind 8)
-        return fa::launch_fa2_large_d(q, k, v, o, B, H, N, D, s);
+        return fa::launch_fa2_large_d(q, k, v, o, B, H, N, D, s, p.one_stage);
       }
       return CLN_ERR_UNSUPPORTED;
     case K_DRING:
-      if constexpr (!VT) return fa::launch_fa2_large_d(q, k, v, o, B, H, N, D, s);
+      if constexpr (!VT) return fa::launch_fa2_large_d(q, k, v, o, B, H, N, D, s, p.one_stage);
       return CLN_ERR_UNSUPPORTED;
     default: return CLN_ERR_UNSUPPORTED;
   }
@@ -208,18 +198,13 @@ int fa2_dispatch(int family, const void* q, const void* k, const void* v, void* 
 int fa2_describe(int family, bool vt, int B, int H, int N, int D, int stages, int max_d, char* buf, int len) {
   const FaPlan p = fa2_plan(family, vt, B, H, N, D, stages, max_d);
   if (p.rc != CLN_OK) return p.rc;
-  const char* st = p.stages_honoured ? "" : " [stages ignored: one pipeline]";
+  const char* st = p.one_stage ? " [single stage: every tile fetch waited for where it is issued]" : p.stages_honoured ? "" : " [stages ignored: one pipeline]";
   const char* vts = vt ? ",V^T" : "";
   switch (p.kind) {
     case K_SPLITKV:
       return snprintf(buf, len, "fa2_fwd_splitkv<D=%d> 4 waves share 32 rows, 128-key tiles split over the waves, "
                                 "cross-wave max via LDS%s", D, st);
     case K_LOAD_THEN_COMPUTE:
-      if (D > 256) {
-        const int dv = D == 320 ? 160 : D == 384 ? 192 : D == 640 ? 320 : D == 768 ? 192 : 256;
-        return snprintf(buf, len, "fa2_fwd<D=%d,DV=%d,BC=%d,load-then-compute> 4 waves x 32 rows, output head dim sliced over %d "
-                                  "workgroups", D, dv, p.bc, D / dv);
-      }
       return snprintf(buf, len, "fa2_fwd<D=%d,BC=64,load-then-compute%s> 4 waves x 32 rows", D, vts);
     case K_V2:
       return snprintf(buf, len, "fa2_fwd_v2<D=%d,NW=%d,BC=64,prefetch%s%s> %d waves x 32 rows%s", D, p.nw,

@@ -120,8 +120,15 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_dring_kernel(const half_t* __r
   const int T = N / G::BC;
   __builtin_assume(T > 0);
   auto clampt = [&](int t) __attribute__((always_inline)) { return t < T ? t : T - 1; };  // past the end: refill a dead slot (keeps the counts uniform)
-  auto req_k = [&](int t) __attribute__((always_inline)) { dma_tile(Kh, k_voff, clampt(t), lds0 + (t & 1) * G::TILE); };
-  auto req_v = [&](int t) __attribute__((always_inline)) { dma_tile(Vh, v_voff, clampt(t), lds0 + 2 * G::TILE + (t & 1) * G::TILE); };
+  // OPT_1STAGE = the `stages = 1` form: every tile request is waited for where it is issued (no load runs under compute)
+  auto req_k = [&](int t) __attribute__((always_inline)) {
+    dma_tile(Kh, k_voff, clampt(t), lds0 + (t & 1) * G::TILE);
+    if constexpr ((OPT & OPT_1STAGE) != 0) hgemm::wait_vmcnt<0>();
+  };
+  auto req_v = [&](int t) __attribute__((always_inline)) {
+    dma_tile(Vh, v_voff, clampt(t), lds0 + 2 * G::TILE + (t & 1) * G::TILE);
+    if constexpr ((OPT & OPT_1STAGE) != 0) hgemm::wait_vmcnt<0>();
+  };
   auto wait_young = [&](bool two) __attribute__((always_inline)) {  // leave this wave's one / two youngest tile requests in flight
     if constexpr (G::NP % G::NW == 0) {
       if (two) dring_wait_vm<2 * PPW>();

@@ -249,7 +249,11 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
         else s[t % BCB] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[t % PD], qf[t / BCB], s[t % BCB], 0, 0, 0);
         cln_mfma_keep(s[t % BCB], kf[t % PD], qf[t / BCB]);  // destination disjoint from the operands (common.h)
         if (t + PD < NQK) kf[t % PD] = k_frag(t + PD);
-        if (!(ABL & 1) && (t % DSTEP) == DSTEP - 1 && t / DSTEP < G::PPW) dma_piece(jn, (j + 1) & 1, t / DSTEP);
+        if (!(ABL & 1) && (t % DSTEP) == DSTEP - 1 && t / DSTEP < G::PPW) {
+          dma_piece(jn, (j + 1) & 1, t / DSTEP);
+          // ABL 256 = the `stages = 1` form: every tile fetch is waited for where it is issued, no load runs under compute
+          if constexpr ((ABL & 256) != 0) hgemm::wait_vmcnt<0>();
+        }
         if (PD > 1 || (t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
     }

@@ -16,7 +16,18 @@
 
 namespace fa {
 inline int launch_fa2_large_d(const void* q, const void* k, const void* v, void* o, int B, int H, int N, int D,
-                              hipStream_t s) {
+                              hipStream_t s, bool one_stage = false) {
+  if (one_stage) {  // `stages = 1`: the same kernels with every tile fetch waited for where it is issued (no load under compute)
+    constexpr int O1 = fa2::OPT_DEFAULT | fa2::OPT_1STAGE;
+    switch (D) {
+      case 320: return fa2::launch_dsplit<512, 2, 1, fa2::OPT_DEFAULT, 256, 320>(q, k, v, o, B, H, N, s);
+      case 384: return fa2::launch_dsplit<512, 2, 1, fa2::OPT_DEFAULT, 256, 384>(q, k, v, o, B, H, N, s);
+      case 640: return fa2::launch_dring<640, O1, false>(q, k, v, o, B, H, N, s);
+      case 768: return fa2::launch_dring<768, O1, false>(q, k, v, o, B, H, N, s);
+      case 1024: return fa2::launch_dring<1024, O1, true, 1>(q, k, v, o, B, H, N, s);
+      default: return CLN_ERR_UNSUPPORTED;
+    }
+  }
   switch (D) {
     // D = 320 / 384: the D = 512 kernel's LDS geometry with the pair of waves splitting the REAL head dim evenly (no MFMA
     // on padding): 745-817 / 793-876 TF at [1,16,4096,D] (profiles/r02_fa_native_320_384.log) vs 585 / 695 for the

@@ -472,7 +472,11 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16_pair_kernel(const half_t* 
         if constexpr ((DBG & 1024) != 0) asm volatile("s_nop 15" ::: "memory");
         if constexpr ((DBG & 2048) != 0) asm volatile("s_sleep 1" ::: "memory");
         if (t + PD < NQK) kf[t % PD] = k_frag(t + PD);
-        if ((t % DSTEP) == DSTEP - 1) dma_piece(jn, (j + 1) & 1, t / DSTEP);
+        if ((t % DSTEP) == DSTEP - 1) {
+          dma_piece(jn, (j + 1) & 1, t / DSTEP);
+          // DBG 131072 = the `stages = 1` form: every tile fetch is waited for where it is issued, no load runs under compute
+          if constexpr ((DBG & 131072) != 0) hgemm::wait_vmcnt<0>();
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     }

@@ -117,7 +117,7 @@ int launch_hist(const void* a, void* y, long long n, int nbins, hipStream_t st) 
 // T: element type, VEC: elements per lane, PACKED: one 16-byte (VEC*sizeof(T)) access vs VEC scalar accesses
 template <typename T, int VEC, bool PACKED>
 __global__ __launch_bounds__(256) void embedding_kernel(const int* __restrict__ idx, const T* __restrict__ weight,
-                                                        T* __restrict__ out, long long n, int emb, int vocab) {
+                                                        T* __restrict__ out, long long n, int emb, int vocab, int stream_nt) {
   const int ppr = emb / VEC;  // packs per row
   const long long total = n * ppr;
   const long long stride = (long long)gridDim.x * 256;
@@ -132,10 +132,10 @@ __global__ __launch_bounds__(256) void embedding_kernel(const int* __restrict__ 
       typedef T vec_t __attribute__((ext_vector_type(VEC)));
       vec_t v = *reinterpret_cast<const vec_t*>(src);
       if (!ok) v = vec_t(0);
-      *reinterpret_cast<vec_t*>(dst) = v;
+      cln_store_stream(reinterpret_cast<vec_t*>(dst), v, stream_nt);
     } else {
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) dst[e] = ok ? src[e] : (T)0;
+      for (int e = 0; e < VEC; ++e) cln_store_stream(dst + e, ok ? src[e] : (T)0, stream_nt);
     }
   }
 }
@@ -149,7 +149,7 @@ int launch_emb(const void* idx, const void* weight, void* out, long long n, int 
   const long long total = n * (emb / VEC);
   const int grid = cln_stream_grid(total, 256);
   CLN_LAUNCH((embedding_kernel<T, VEC, PACKED>), dim3(grid), dim3(256), 0, st, (const int*)idx, (const T*)weight,
-             (T*)out, n, emb, vocab);
+             (T*)out, n, emb, vocab, cln_stream_nt(2LL * n * emb * (long long)sizeof(T)));  // gathered rows + output
   return cln_check_launch();
 }
 

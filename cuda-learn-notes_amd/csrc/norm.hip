@@ -34,7 +34,7 @@ __device__ __forceinline__ float row_sum(float v, float* scratch) {
 }
 
 template <typename T, int VEC, int MAXV>
-__global__ void layer_norm_kernel(const T* __restrict__ x, T* __restrict__ y, float g, float b, int K) {
+__global__ void layer_norm_kernel(const T* __restrict__ x, T* __restrict__ y, float g, float b, int K, int stream_nt) {
   __shared__ float scratch[2][16];
   const size_t off = (size_t)blockIdx.x * K;
   RowRegs<T, VEC, MAXV> r;
@@ -61,11 +61,11 @@ __global__ void layer_norm_kernel(const T* __restrict__ x, T* __restrict__ y, fl
   for (int i = 0; i < MAXV; ++i)
 #pragma unroll
     for (int e = 0; e < VEC; ++e) r.x[i][e] = fmaf(r.x[i][e], a, b);
-  r.store(y + off, K);
+  r.store(y + off, K, stream_nt);
 }
 
 template <typename T, int VEC, int MAXV>
-__global__ void rms_norm_kernel(const T* __restrict__ x, T* __restrict__ y, float g, int K) {
+__global__ void rms_norm_kernel(const T* __restrict__ x, T* __restrict__ y, float g, int K, int stream_nt) {
   __shared__ float scratch[16];
   const size_t off = (size_t)blockIdx.x * K;
   RowRegs<T, VEC, MAXV> r;
@@ -80,7 +80,7 @@ __global__ void rms_norm_kernel(const T* __restrict__ x, T* __restrict__ y, floa
   for (int i = 0; i < MAXV; ++i)
 #pragma unroll
     for (int e = 0; e < VEC; ++e) r.x[i][e] = r.x[i][e] * a;
-  r.store(y + off, K);
+  r.store(y + off, K, stream_nt);
 }
 
 template <typename T, int VEC>
@@ -90,7 +90,7 @@ int launch_ln(const void* x, void* y, float g, float b, int N, int K, hipStream_
   if (K % VEC) return CLN_ERR_UNSUPPORTED;
   const int nt = row_threads(K, VEC), vpt = vecs_per_thread(K, VEC, nt);
 #define CALL(MV)                                                                                              \
-  CLN_LAUNCH((layer_norm_kernel<T, VEC, MV>), dim3(N), dim3(nt), 0, st, (const T*)x, (T*)y, g, b, K)
+  CLN_LAUNCH((layer_norm_kernel<T, VEC, MV>), dim3(N), dim3(nt), 0, st, (const T*)x, (T*)y, g, b, K, cln_stream_nt(2LL * N * K * (long long)sizeof(T)))
   ROWWISE_DISPATCH_MAXV(vpt, CALL);
 #undef CALL
   return cln_check_launch();
@@ -102,7 +102,7 @@ int launch_rms(const void* x, void* y, float g, int N, int K, hipStream_t st) {
   if (K % VEC) return CLN_ERR_UNSUPPORTED;
   const int nt = row_threads(K, VEC), vpt = vecs_per_thread(K, VEC, nt);
 #define CALL(MV) \
-  CLN_LAUNCH((rms_norm_kernel<T, VEC, MV>), dim3(N), dim3(nt), 0, st, (const T*)x, (T*)y, g, K)
+  CLN_LAUNCH((rms_norm_kernel<T, VEC, MV>), dim3(N), dim3(nt), 0, st, (const T*)x, (T*)y, g, K, cln_stream_nt(2LL * N * K * (long long)sizeof(T)))
   ROWWISE_DISPATCH_MAXV(vpt, CALL);
 #undef CALL
   return cln_check_launch();

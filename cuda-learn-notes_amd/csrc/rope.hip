@@ -34,7 +34,7 @@ __device__ __forceinline__ void rotate(float x1, float x2, float ang, float& o1,
 // than the memory traffic (43 us vs 20 us at 4096 x 4096). A row of threads still reads a row of x contiguously.
 template <int PAIRS>
 __global__ __launch_bounds__(256) void rope_kernel(const float* __restrict__ x, float* __restrict__ out,
-                                                   int seq_len, int half_hidden, int ref_quirk) {
+                                                   int seq_len, int half_hidden, int ref_quirk, int stream_nt) {
   const int units_per_row = half_hidden / PAIRS;
   const int u = blockIdx.x * 256 + threadIdx.x;
   if (u >= units_per_row) return;
@@ -54,9 +54,9 @@ __global__ __launch_bounds__(256) void rope_kernel(const float* __restrict__ x, 
 #pragma unroll
     for (int p = 0; p < PAIRS; ++p) rotate(v[2 * p], v[2 * p + 1], (float)t * freq[p], o[2 * p], o[2 * p + 1]);
     if constexpr (PAIRS == 2) {
-      *reinterpret_cast<f4*>(out + off) = *reinterpret_cast<const f4*>(o);
+      cln_store_stream(reinterpret_cast<f4*>(out + off), *reinterpret_cast<const f4*>(o), stream_nt);
     } else {
-      *reinterpret_cast<f2*>(out + off) = *reinterpret_cast<const f2*>(o);
+      cln_store_stream(reinterpret_cast<f2*>(out + off), *reinterpret_cast<const f2*>(o), stream_nt);
     }
   }
 }
@@ -74,7 +74,7 @@ int launch_rope(const void* x, void* out, int seq_len, int hidden, int ref_quirk
   if (gy < 1) gy = 1;
   if (gy > 65535) gy = 65535;
   CLN_LAUNCH((rope_kernel<PAIRS>), dim3(gx, gy), dim3(256), 0, st, (const float*)x, (float*)out, seq_len,
-                     half_hidden, ref_quirk);
+                     half_hidden, ref_quirk, cln_stream_nt(8LL * seq_len * hidden));
   return cln_check_launch();
 }
 

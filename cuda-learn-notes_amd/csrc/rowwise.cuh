@@ -51,7 +51,7 @@ struct RowRegs {
       }
     }
   }
-  __device__ __forceinline__ void store(T* row, int K) const {
+  __device__ __forceinline__ void store(T* row, int K, int nt = 0) const {
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
       const int col = (i * blockDim.x + threadIdx.x) * VEC;
@@ -59,7 +59,7 @@ struct RowRegs {
         Pack<T, VEC> p;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) p.v[e] = from_f32<T>(x[i][e]);
-        *reinterpret_cast<Pack<T, VEC>*>(row + col) = p;
+        cln_store_stream(reinterpret_cast<Pack<T, VEC>*>(row + col), p, nt);
       }
     }
   }

@@ -61,7 +61,7 @@ int launch_global(const void* x, void* y, void* total, long long n, hipStream_t 
 }
 
 template <typename T, int VEC, int MAXV, int MODE>
-__global__ void softmax_row_kernel(const T* __restrict__ x, T* __restrict__ y, int H) {
+__global__ void softmax_row_kernel(const T* __restrict__ x, T* __restrict__ y, int H, int stream_nt) {
   __shared__ float scratch[16];
   const size_t off = (size_t)blockIdx.x * H;
   RowRegs<T, VEC, MAXV> r;
@@ -117,7 +117,7 @@ __global__ void softmax_row_kernel(const T* __restrict__ x, T* __restrict__ y, i
   for (int i = 0; i < MAXV; ++i)
 #pragma unroll
     for (int e = 0; e < VEC; ++e) r.x[i][e] *= inv;
-  r.store(y + off, H);
+  r.store(y + off, H, stream_nt);
 }
 
 template <typename T, int VEC, int MODE>
@@ -127,7 +127,7 @@ int launch_rows(const void* x, void* y, int S, int H, hipStream_t st) {
   if (H % VEC) return CLN_ERR_UNSUPPORTED;
   const int nt = row_threads(H, VEC), vpt = vecs_per_thread(H, VEC, nt);
 #define CALL(MV) \
-  CLN_LAUNCH((softmax_row_kernel<T, VEC, MV, MODE>), dim3(S), dim3(nt), 0, st, (const T*)x, (T*)y, H)
+  CLN_LAUNCH((softmax_row_kernel<T, VEC, MV, MODE>), dim3(S), dim3(nt), 0, st, (const T*)x, (T*)y, H, cln_stream_nt(2LL * S * H * (long long)sizeof(T)))
   ROWWISE_DISPATCH_MAXV(vpt, CALL);
 #undef CALL
   return cln_check_launch();

@@ -101,7 +101,7 @@ _FA_VT = [
     "flash_attn_mma_stages_split_q_shared_kv_swizzle_qkv", "flash_attn_mma_stages_split_q_shared_qkv_swizzle_qkv",
     "flash_attn_mma_stages_split_q_tiling_qk_swizzle_qkv",
 ]
-_FA_SPLIT_Q_IMPL = ("planner fa2_plan(shape, stages) [csrc/flash_attn.hip]: stages=1 -> fa2_fwd<load-then-compute>; "
+_FA_SPLIT_Q_IMPL = ("planner fa2_plan(shape, stages) [csrc/flash_attn.hip]: stages=1 -> fa2_fwd<load-then-compute> (D <= 256), the stage-2 kernel of the head dim with every tile fetch waited for where it is issued (D > 256); "
                     "stages=2 -> fa2_fwd_m16x<D=64|128> / fa2_fwd_m16<D=256> (>=192 workgroups of 256 rows) | fa2_fwd_m16<D=512> (pairs of waves split d) | fa2_fwd_m16x64r<D=64> (>=256 workgroups of 512 rows) | fa2_fwd_v2<D<=256, 8|4|2 waves> | "
                     "fa2_fwd_dsplit<320 / 384 on the D = 512 LDS geometry with the real d split evenly> | fa2_fwd_dring<640 | 768 | 1024>; mfma_32x32x16 / 16x16x32, f32 acc "
                     "(see DISPATCH_EXAMPLES)")
@@ -271,6 +271,7 @@ _W4X2 = "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem"
 _SQKV = "flash_attn_mma_stages_split_q_shared_qkv"
 _TQKV = "flash_attn_mma_stages_split_q_tiling_qkv"
 _IGN = " [stages ignored: one pipeline]"
+_ONE = " [single stage: every tile fetch waited for where it is issued]"
 DISPATCH_EXAMPLES = [
     # HGEMM: BASELINE configs C2 (1024^3) and C3 (4096^3 / 8192^3) and the mid sizes
     (_W4X2, (4096, 4096, 4096), 2, "hgemm_w4<256x256x64,4 waves,128x128 wave tiles,cross-tile LDS-DMA,LDS epilogue,NN>"),
@@ -327,10 +328,10 @@ DISPATCH_EXAMPLES = [
     (_TQKV, (1, 16, 4096, 320), 2, "fa2_fwd_dsplit<D=320,NSP=2,BC=32,LDS geometry of D=512> 8 waves, pairs split the real d evenly"),
     (_TQKV, (1, 16, 4096, 640), 2, "fa2_fwd_dring<D=640,BC=16,2-slot K/V rings> 8 waves, 4 split d (160 columns each), 64 rows"),
     (_TQKV, (1, 16, 4096, 1024), 2, "fa2_fwd_dring<D=1024,BC=16,2-slot K/V rings,row groups one phase apart,phase-2 priority> 8 waves, 4 split d (256 columns each), 64 rows"),
-    # stages = 1 above D = 256: the load-then-compute kernel with the output head dim sliced over blockIdx.z
-    (_TQKV, (1, 32, 4096, 512), 1, "fa2_fwd<D=512,DV=256,BC=64,load-then-compute> 4 waves x 32 rows, output head dim sliced over 2 workgroups"),
-    (_TQKV, (1, 16, 4096, 1024), 1, "fa2_fwd<D=1024,DV=256,BC=32,load-then-compute> 4 waves x 32 rows, output head dim sliced over 4 workgroups"),
-    (_TQKV, (1, 16, 4160, 768), 1, "fa2_fwd_dring<D=768,BC=16,2-slot K/V rings> 8 waves, 4 split d (192 columns each), 64 rows" + _IGN),  # N % 128 != 0: the load-then-compute kernel does not tile it
+    # stages = 1 above D = 256: the same kernel, single stage
+    (_TQKV, (1, 32, 4096, 512), 1, "fa2_fwd_m16<D=512,BC=32,16x16x32 MFMA,pairs of waves split d> 8 waves, 128 rows, two groups one phase apart" + _ONE),
+    (_TQKV, (1, 16, 4096, 1024), 1, "fa2_fwd_dring<D=1024,BC=16,2-slot K/V rings,row groups one phase apart,phase-2 priority> 8 waves, 4 split d (256 columns each), 64 rows" + _ONE),
+    (_TQKV, (1, 16, 4160, 768), 1, "fa2_fwd_dring<D=768,BC=16,2-slot K/V rings> 8 waves, 4 split d (192 columns each), 64 rows" + _ONE),
 ]
 
 

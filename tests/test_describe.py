@@ -38,11 +38,13 @@ def test_stages_knob_selects_a_different_flash_attn_kernel(built):
     # above D = 256 too (reference kStage of the tiling kernels, flash_attn_mma_tiling_qkv.cu:63, :189-223): config C5
     tq = "flash_attn_mma_stages_split_q_tiling_qkv"
     one5, two5 = m.describe(tq, (1, 32, 4096, 512), 1), m.describe(tq, (1, 32, 4096, 512), 2)
-    assert "load-then-compute" in one5 and two5.startswith("fa2_fwd_m16<D=512") and "stages ignored" not in two5
+    # above D = 256 stages = 1 is the SAME kernel family with every tile fetch waited for where it is issued
+    assert one5.startswith("fa2_fwd_m16<D=512") and "single stage" in one5
+    assert two5.startswith("fa2_fwd_m16<D=512") and "single stage" not in two5 and "stages ignored" not in two5
     for D in (320, 384, 640, 768, 1024):
-        assert "load-then-compute" in m.describe(tq, (1, 16, 4096, D), 1), D
-    # where the load-then-compute kernel does not tile N, the one pipeline serves both stage counts and says so
-    assert "stages ignored" in m.describe(tq, (1, 16, 4160, 768), 1)
+        for N in (4096, 4160 if D >= 640 else 4224):  # sequence lengths the stage-2 kernel tiles are tiled by stage 1 too
+            one, two = m.describe(tq, (1, 16, N, D), 1), m.describe(tq, (1, 16, N, D), 2)
+            assert one == two + " [single stage: every tile fetch waited for where it is issued]", (D, N, one, two)
     # the split-KV rung is its own kernel, not an alias of the split-Q dispatcher
     assert m.describe("flash_attn_mma_stages_split_kv", (4, 8, 2048, 64), 2).startswith("fa2_fwd_splitkv")
     with pytest.raises(ValueError):

@@ -246,3 +246,56 @@ def test_rope_reference_kernel_quirk_mode(lib, dev, oracle):
         out2 = torch.zeros(512, 256, device=dev)
         getattr(lib, name)(x.to(dev), out2, ref_quirk=False)
         assert (out2.cpu() - oracle.rope_torch(x)).abs().max() < 2e-3, name
+
+
+# ------------------------------------------------------------------ streaming (non-temporal) store path
+def test_launches_past_the_mall_use_streaming_stores_and_give_the_same_bits(built, lib, dev):
+    """A launch whose tensors exceed the 256 MB MALL together writes its output with non-temporal stores
+    (csrc/common.h cln_stream_nt / cln_store_stream). Same arithmetic, so an [8192, 8192] fp32 launch (512 MB: the
+    streaming path) must equal, bit for bit, the same rows computed as two [4096, 8192] launches (256 MB each: the plain
+    path, which the tests above hold to the oracle). Every kernel family that has the path, every access width."""
+    act = built.load("activation")
+    S, H = 8192, 8192
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = torch.randn(S, H, device=dev, generator=g) * 2.0
+    halves = ((0, S // 2), (S // 2, S))
+
+    def check(call, dtype, names):
+        xin = x.to(dtype)
+        for name in names:
+            big = torch.full((S, H), 7.0, device=dev, dtype=dtype)
+            call(name, xin, big)
+            for (a, b) in halves:
+                part = torch.full((b - a, H), 7.0, device=dev, dtype=dtype)
+                call(name, xin[a:b], part)
+                assert torch.equal(big[a:b], part), name
+            del big
+
+    check(lambda n, i, o: getattr(lib, n)(i, o), torch.float32, ("safe_softmax_f32x4_per_token", "softmax_f32_per_token"))
+    check(lambda n, i, o: getattr(lib, n)(i, o, 1.5, -0.25), torch.float32, ("layer_norm_f32x4", "layer_norm_f32"))
+    check(lambda n, i, o: getattr(lib, n)(i, o, 1.5), torch.float32, ("rms_norm_f32x4", "rms_norm_f32"))
+    check(lambda n, i, o: getattr(act, n)(i, o), torch.float32, ("gelu_f32x4", "relu_f32"))
+    # fp16 tensors of this shape are 128 MB each: 256 MB per two-tensor launch = the threshold, streaming path as well
+    check(lambda n, i, o: getattr(lib, n)(i, o), torch.float16, ("safe_softmax_f16x8_pack_f32_per_token", "safe_softmax_f16x2_f32_per_token"))
+    check(lambda n, i, o: getattr(lib, n)(i, o, 1.5, -0.25), torch.float16, ("layer_norm_f16x8_pack_f32", "layer_norm_f16_f32"))
+    check(lambda n, i, o: getattr(lib, n)(i, o, 1.5), torch.float16, ("rms_norm_f16x8_pack_f32", "rms_norm_f16x8_f32"))
+    check(lambda n, i, o: getattr(act, n)(i, o), torch.float16, ("relu_f16x8_pack", "swish_f16x2", "elu_f16"))
+    xh = x.half()
+    yh = torch.randn(S, H, device=dev, generator=g).half()
+    for name in ("elementwise_add_f16x8_pack", "elementwise_add_f16x8", "elementwise_add_f16x2", "elementwise_add_f16"):
+        big = torch.zeros(S, H, device=dev, dtype=torch.half)
+        getattr(lib, name)(xh, yh, big)
+        assert torch.equal(big, xh + yh), name  # one rounding of the exact sum on both sides
+    big = torch.zeros(S, H, device=dev)
+    y32 = yh.float()
+    lib.elementwise_add_f32x4(x, y32, big)
+    assert torch.equal(big, x + y32)
+    # rope: position-dependent, so the reference is the same kernel on the plain path in four row blocks ... of the SAME
+    # positions, which the API cannot express; use the property instead: every pair keeps its norm, and row 0 is unchanged
+    out = torch.zeros(S, H, device=dev)
+    lib.rope_f32x4_pack(x, out)
+    assert torch.equal(out[0], x[0])
+    assert torch.allclose(out.view(S, -1, 2).norm(dim=-1), x.view(S, -1, 2).norm(dim=-1), atol=1e-4, rtol=1e-4)
+    small = torch.zeros(2048, H, device=dev)
+    lib.rope_f32x4_pack(x[:2048].contiguous(), small)  # 128 MB: plain path, same positions 0..2047
+    assert torch.equal(out[:2048], small)

@@ -84,6 +84,24 @@ def test_large_head_dims_tiling(fa, built, dev, oracle, D):
         assert (o.double() - ref).abs().max().item() <= TOL, name
 
 
+@pytest.mark.parametrize("D", [320, 384, 512, 640, 768, 1024])
+def test_stages_one_above_d256_is_the_single_stage_form_of_the_same_kernel(fa, built, dev, oracle, D):
+    """stages = 1 above D = 256 (reference kStage of the tiling kernels, flash_attn_mma_tiling_qkv.cu:63, :189-223): the
+    stage-2 kernel with every tile fetch waited for where it is issued -- same arithmetic in the same order, so the two
+    results are bit-identical; several KV tiles, a rescale-forcing spike, a ragged tile count where the kernel allows one."""
+    name = "flash_attn_mma_stages_split_q_tiling_qkv"
+    for (B, H, N) in ((1, 2, 256), (2, 3, 640 if D >= 640 else 768)):
+        q, k, v = seeded(17, B, H, N, D), seeded(18, B, H, N, D), seeded(19, B, H, N, D)
+        k[0, 0, N - 56] = q[0, 0, 7] * 1.5
+        one, two = built.manifest.describe(name, (B, H, N, D), 1), built.manifest.describe(name, (B, H, N, D), 2)
+        assert "single stage" in one and one.startswith(two), (one, two)
+        ref = oracle.attention_fp64(q, k, v)
+        o1 = run(fa, built, name, q, k, v, 1, dev)
+        o2 = run(fa, built, name, q, k, v, 2, dev)
+        assert (o1.double() - ref).abs().max().item() <= TOL
+        assert torch.equal(o1, o2)
+
+
 @pytest.mark.parametrize("B,H,N", [(1, 1, 128), (2, 3, 384), (1, 8, 1024), (1, 5, 2048)])
 def test_d512_dsplit_kernel_shapes(fa, built, dev, oracle, B, H, N):
     """D = 512 runs on the d-split ping-pong kernel (flash_attn_dsplit.cuh): one query block / 4 KV tiles, head

@@ -46,7 +46,8 @@ def test_attention_kernels_in_the_product_library_are_exactly_the_plannable_ones
         elif f == "fa2_fwd_dsplit_kernel":
             linked.add(("fa2_fwd_dsplit", int(a[5]) or int(a[0])))
         elif f == "fa2_fwd_m16_pair_kernel":
-            assert a in (["2", "false", "false", "0"], ["2", "true", "false", "0"]), a  # fragment depth 2, scores scaled in fp32, no debug bits
+            # fragment depth 2, scores scaled in fp32, no debug bits (131072 = the single-stage form `stages = 1` selects at D = 512)
+            assert a in (["2", "false", "false", "0"], ["2", "true", "false", "0"], ["2", "true", "false", "131072"]), a
             linked.add(("fa2_fwd_m16", 512 if a[1] == "true" else 256))
         elif f == "fa2_fwd_m16x_kernel" and a[1] == "64":
             linked.add(("fa2_fwd_m16x64r", int(a[0])))
