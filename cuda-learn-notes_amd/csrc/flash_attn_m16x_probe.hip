@@ -5,6 +5,7 @@
 // steps into v_pk_add_f32, which drags the exponentials of a whole phase behind its last MFMA and is slower than two
 // plain adds beside MFMAs (MI355X_MICROARCH.md, per-instruction constants). Linked into the probe library only.
 #include "flash_attn_m16x.cuh"
+#include "flash_attn_m16s.cuh"
 #include "flash_attn_m16x_api.h"
 
 namespace fa2 {
@@ -22,6 +23,15 @@ int m16x_probe_run(int D, int code, const void* q, const void* k, const void* v,
   MX(128, 5, 32, 128, 4, 1, 5) MX(128, 21, 32, 128, 4, 2, 5) MX(128, 49, 32, 128, 4, 4, 1) MX(128, 53, 32, 128, 4, 4, 5) MX(128, 54, 32, 128, 4, 4, 6)
   MX(128, 85, 32, 128, 4, 6, 5)
 #undef MX
+  // 150 + id: the one-wave-per-SIMD form (flash_attn_m16s.cuh: 4 waves x 64 rows), <D, BC, PD, NDEF>
+#define MS(DD, CODE, BCC, PDD, NDEFF, FINEE) \
+  if (D == DD && code == CODE) return launch_m16s<DD, BCC, PDD, NDEFF, FINEE>(q, k, v, o, B, H, N, s);
+  // 150 / 151: the VALU slice of a step behind ALL its MFMAs (NDEF = 1 / 2); 153 / 155: one MFMA, then its share of the slice
+  // (fragment prefetch depth 4 / 8). (NDEF = 1 with the fine interleave returned wrong results on the GPU: hipcc is free to
+  // copy an S^T register right behind the asm MFMA that writes it, and its hazard pass cannot see that MFMA -- the form is
+  // correct only where the allocator happens not to; profiles/r03_fa_m16s_one_wave_per_simd_probe.log.)
+  MS(64, 150, 64, 4, 1, false) MS(64, 151, 64, 4, 2, false) MS(64, 153, 64, 4, 2, true) MS(64, 155, 64, 8, 2, true)
+#undef MS
   return CLN_ERR_UNSUPPORTED;
 }
 

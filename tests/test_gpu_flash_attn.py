@@ -525,6 +525,33 @@ def test_attention_on_16x16x32_mfma_probe_forms(built, dev, oracle, D, abl, N):
         assert (o.cpu().double() - ref).abs().max().item() <= TOL_AMPLIFIED_KEYS, (B, H, N, D, abl)
 
 
+@pytest.mark.parametrize("abl", [950, 951, 953, 955])
+def test_one_wave_per_simd_attention_on_16x16x32_probe(built, dev, oracle, abl):
+    """flash_attn_m16s.cuh (probe library): the sum-checked kernel as a one-wave-per-SIMD stream, 4 waves x
+    64 rows, asm MFMAs with S^T in VGPRs / O^T in AGPRs. Several tile counts, rescale regimes (the cold path), and 200
+    repeated launches bit-identical (the form depends on hand-kept MFMA -> VALU distances)."""
+    from cuda_learn_notes_amd import host
+    D = 64
+    for (B, H, N) in ((1, 2, 256), (2, 3, 512), (1, 8, 1024)):
+        q, k, v = seeded(71 + N, B, H, N, D), seeded(72 + N, B, H, N, D), seeded(73 + N, B, H, N, D)
+        if N == 1024:
+            ramp = torch.linspace(0.2, 1.6, N).view(1, 1, N, 1)
+            k = (k.float() * ramp).half()
+            k[0, 0, 900] = q[0, 0, 5] * 3.0
+            k[0, 1, 10] = q[0, 1, 300] * 5.0
+            k[0, H - 1, 1000] = q[0, H - 1, 1023] * 4.0
+        qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
+        o = torch.zeros(B, H, N, D, dtype=torch.half, device=dev)
+        host.fa2_variant((8, 0, 0, abl), qd, kd, vd, o)
+        assert torch.isfinite(o).all()
+        ref = oracle.attention_fp64(q, k, v)
+        assert (o.cpu().double() - ref).abs().max().item() <= TOL_AMPLIFIED_KEYS, (B, H, N)
+        first = o.clone()
+        for _ in range(200 if N == 1024 else 20):
+            host.fa2_variant((8, 0, 0, abl), qd, kd, vd, o)
+            assert torch.equal(o, first)
+
+
 @pytest.mark.parametrize("abl", [710, 711])
 def test_key_split_attention_probe(built, dev, oracle, abl):
     """flash_attn_dsplit2.cuh KVS = true (probe library): the two wave groups walk one half of the KV tiles each and merge
