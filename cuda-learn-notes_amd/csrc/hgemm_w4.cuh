@@ -207,9 +207,9 @@ __global__ __launch_bounds__(256, 1) void hgemm_w4_kernel(const half_t* __restri
     const char* src = late ? (p < FM ? a_old : b_old) : (p < FM ? a_src : b_src);
     if (set_m0)
       asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\ts_add_u32 m0, m0, 0x1000"
-                   :: "v"(voff), "s"(src), "s"(img + (unsigned)(p * 4 + wave) * 1024u) : "memory", "scc");
+                   :: "v"(voff), "s"(src), "s"(img + (unsigned)(p * 4 + wave) * 1024u) : "memory", "scc", "m0");
     else
-      asm volatile("global_load_lds_dwordx4 %0, %1\n\ts_add_u32 m0, m0, 0x1000" :: "v"(voff), "s"(src) : "memory", "scc");
+      asm volatile("global_load_lds_dwordx4 %0, %1\n\ts_add_u32 m0, m0, 0x1000" :: "v"(voff), "s"(src) : "memory", "scc", "m0");
   };
   auto advance = [&]() {
     a_old = a_src;
