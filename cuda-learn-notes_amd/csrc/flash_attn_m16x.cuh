@@ -26,7 +26,7 @@
 
 namespace fa2 {
 
-enum : int { M16X_PRIO = 1, M16X_PRIO_B = 2, M16X_SPLIT_PROLOGUE = 4 };
+enum : int { M16X_PRIO = 1, M16X_PRIO_B = 2, M16X_SPLIT_PROLOGUE = 4, M16X_PRIO_STATIC = 8 };  // 8: s_setprio 1 once for the second-dispatched group, no flips
 
 template <int D_, int RPW_, int BC_, int PD = 4, int NDEF = 1, int OX = 0>
 __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __restrict__ Q, const half_t* __restrict__ K,
@@ -137,6 +137,9 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
   const int v_row = 4 * g4 + (i16 >> 2);
   const int vbase = v_row * G::ROW + (((((i16 & 3) >> 1)) ^ G::swz_v(v_row)) << 4) + ((i16 & 1) << 3);
 
+  if constexpr ((OX & M16X_PRIO_STATIC) != 0) {
+    if (grp == 1) __builtin_amdgcn_s_setprio(1);
+  }
   if (grp == 1) {  // group 1 runs one phase behind group 0
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
