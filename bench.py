@@ -220,9 +220,18 @@ def main():
             import torch.nn.functional as F
             fa = pkg.flash_attn_lib()
             sq, tq = fa.flash_attn_mma_stages_split_q_shared_qkv, fa.flash_attn_mma_stages_split_q_tiling_qkv
-            # north_star's attention target is "FA2 fwd D=64 >= FlashAttention-2-ROCm"; neither `flash_attn` nor `aiter` is in
-            # the image, so the comparator rows below are a PROXY (torch SDPA, whose backends all run AOTriton kernels here)
-            extras["fa2_rocm_comparator"] = "absent: torch SDPA/AOTriton proxy (flash_attn / aiter not importable in this image)"
+            # north_star's attention target is "FA2 fwd D=64 >= FlashAttention-2-ROCm". The Python packages (`flash_attn`, `aiter`)
+            # are not in the image; the kernels they dispatch to are: AMD's ck_tile FMHA forward, instantiated from the image's
+            # /opt/rocm/include/ck_tile into the vendor library (csrc/fa2_vendor_ck.hip) -> `ck_tile_fmha` in each roofline object
+            # (D = 64 / 128). torch SDPA (AOTriton kernels under every backend here) stays beside it.
+            try:
+                ck = pkg.load("fa2_vendor_ck").cln_fa2_ck_tile_fwd
+                extras["fa2_rocm_comparator"] = ("ck_tile FMHA forward (the kernel family FlashAttention-2-ROCm / aiter dispatch to), compiled "
+                                                 "from the image's ck_tile headers: `ck_tile_fmha` rows; flash_attn / aiter themselves are not "
+                                                 "importable in this image; torch SDPA (AOTriton) rows beside it")
+            except Exception as e:
+                ck = None
+                extras["fa2_rocm_comparator"] = "absent: torch SDPA/AOTriton proxy (ck_tile row failed to load: %s)" % str(e)[:120]
             for key, kern, shape, pmc in (("roofline_fa2_c4_d64", sq, (4, 8, 2048, 64), "pmc_fa_d64"),
                                           ("roofline_fa2_d128", sq, (4, 8, 2048, 128), "pmc_fa_d128"),
                                           ("roofline_fa2_c5_d512", tq, (1, 32, 4096, 512), "pmc_fa_d512")):
@@ -232,6 +241,16 @@ def main():
                 # the FlashAttention-2-ROCm row available on the box is torch SDPA (the `flash_attn` package is not in
                 # the image): each backend forced in turn, so the row says WHICH implementation it is
                 r["torch_sdpa"] = bu.sdpa_rows(q, k, v, side_ms)
+                if ck is not None and shape[3] in (64, 128):
+                    try:
+                        flops = bu.mha_flops_conventional(*shape)
+                        row = {"async_pipeline_tflops": round(flops / (side_ms(lambda: ck(q, k, v, o, 0), 50) * 1e-3) * 1e-12, 2)}
+                        if shape[3] == 128:
+                            row["v3_gfx950_tflops"] = round(flops / (side_ms(lambda: ck(q, k, v, o, 3), 50) * 1e-3) * 1e-12, 2)
+                        row["ours_over_best"] = round(r["achieved"] / max(row.values()), 3)
+                        r["ck_tile_fmha"] = row
+                    except Exception as e:
+                        r["ck_tile_fmha"] = {"error": str(e)[:160]}
                 out[key] = r
                 del q, k, v, o
             for tag, (B_, H_, N_, D) in (("fa2_fwd_d64_large", (1, 48, 8192, 64)), ("fa2_fwd_d128_large", (2, 32, 4096, 128)),

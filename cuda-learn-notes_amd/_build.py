@@ -1,7 +1,7 @@
 """Build the gfx950 shared objects in-tree with hipcc (no torch headers, no pybind, no hipify).
 
   csrc/*.hip  --hipcc -c-->  build/*.o  --hipcc -shared-->  lib/libcln_amd.so         (the product: reference names only)
-  csrc/hgemm_vendor.hip  ------------------------------->  lib/libcln_amd_vendor.so  (-lrocblas comparison row)
+  csrc/hgemm_vendor*.hip, fa2_vendor_ck.hip  ----------->  lib/libcln_amd_vendor.so  (comparison rows: rocBLAS, hipBLASLt, ck_tile FMHA)
   csrc/*_probe.hip  ------------------------------------>  lib/libcln_amd_probe.so   (TEST-ONLY: tuning hooks, ablation and
                                                            probe instantiations; nothing in the product path loads it)
 
@@ -26,14 +26,15 @@ KERNEL_SOURCES = [
     "elementwise.hip", "activation.hip", "blas1.hip", "indexing.hip", "reduce.hip", "softmax.hip", "norm.hip", "rope.hip",
     "sgemm.hip", "hgemm.hip", "hgemm_ring_nn.hip", "hgemm_ring_tn.hip", "flash_attn.hip", "flash_attn_m16x.hip", "describe.hip",
 ]
-VENDOR_SOURCES = ["hgemm_vendor.hip", "hgemm_vendor_lt.hip"]
+VENDOR_SOURCES = ["hgemm_vendor.hip", "hgemm_vendor_lt.hip", "fa2_vendor_ck.hip"]  # the last: ck_tile FMHA instances (~1 min of hipcc)
 # test-only library; it re-links the two ring compile units for the explicit (tile, BK, stages) hook
 PROBE_SOURCES = ["hgemm_probe.hip", "flash_attn_probe.hip", "flash_attn_m16x_probe.hip"]
 PROBE_SHARED = ["hgemm_ring_nn.hip", "hgemm_ring_tn.hip"]
 CFLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-ffp-contract=fast",
           "-I" + CSRC]
 # per-file additions (the reason is stated at the top of each file)
-EXTRA_FLAGS = {"flash_attn_m16x.hip": ["-fno-slp-vectorize"], "flash_attn_m16x_probe.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"flash_attn_m16x.hip": ["-fno-slp-vectorize"], "flash_attn_m16x_probe.hip": ["-fno-slp-vectorize"],
+               "fa2_vendor_ck.hip": ["-I/opt/rocm/include", "-Wno-everything"]}
 
 
 def hipcc():

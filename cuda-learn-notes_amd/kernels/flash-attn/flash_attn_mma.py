@@ -8,8 +8,9 @@ without a GPU; the kernel rows need one (no CPU fallback).
   python flash_attn_mma.py --B 4 --H 8 --N 2048 --D 64 --check       # BASELINE config C4
   python flash_attn_mma.py --B 1 --H 32 --N 4096 --D 512 --sdpa      # config C5
 
-The `(flash)` row of the reference (flash_attn pip package) is replaced by torch SDPA on ROCm, which is
-the check target here for every D (the reference uses SDPA only for D > 256).
+The `(flash)` row of the reference (flash_attn pip package, not in the ROCm image) is replaced by two rows: `(ck_tile fmha)`
+-- AMD's ck_tile FMHA forward kernels, what that package's ROCm backend dispatches to, compiled from the image's headers
+(D = 64 / 128) -- and torch SDPA, which is the check target here for every D (the reference uses SDPA only for D > 256).
 """
 import argparse
 from functools import partial
@@ -127,7 +128,7 @@ def run_benchmark(perf_func, q, k, v, tag, out=None, s=None, stages=-1, warmup=N
     show_matrix = args.show_matrix if show_matrix is None else show_matrix
     only_show_improved = (not args.show_all) if only_show_improved is None else only_show_improved
     if args.tag_hints:
-        hints = args.tag_hints.strip().split(",") + ["flash", "sdpa", "unfused"]
+        hints = args.tag_hints.strip().split(",") + ["flash", "sdpa", "unfused", "ck_tile"]
         if not any(h in tag for h in hints):
             return None, None
     if not args.build_others and any(t in tag for t in ("s2g", "rr")):
@@ -179,7 +180,7 @@ def run_benchmark(perf_func, q, k, v, tag, out=None, s=None, stages=-1, warmup=N
         improve = round((TFLOPS - MAX_TFLOPS) / MAX_TFLOPS * 100, 2) if MAX_TFLOPS > 0 else 0
         MAX_TFLOPS = TFLOPS
         print(line + f"(+{improve:.2f}%)")
-    elif (not only_show_improved) or ("flash" in tag) or ("sdpa" in tag):
+    elif (not only_show_improved) or ("flash" in tag) or ("sdpa" in tag) or ("ck_tile" in tag):
         print(line)
     if show_matrix:
         print(out)
@@ -248,12 +249,19 @@ def check_all_close(out_flash_or_sdpa, out_mma, tag: str = "out_mma", check_all:
     return ok
 
 
+CK_FMHA = None  # set by main(): AMD's ck_tile FMHA forward through libcln_amd_vendor.so
+
+
 def main():
-    global MAX_TFLOPS
+    global MAX_TFLOPS, CK_FMHA
     if not HAS_GPU:
         sys.exit("flash_attn_mma.py: no GPU visible; the kernel rows have no CPU path "
                  "(the CPU oracle lives in oracle/ and is exercised by tests/)")
     lib = package().flash_attn_lib()
+    try:  # the vendor comparison row; a missing vendor library never stops the kernel rows
+        CK_FMHA = package().load("fa2_vendor_ck").cln_fa2_ck_tile_fwd
+    except Exception:
+        CK_FMHA = None
     seed = args.seed if args.seed else random.choice(range(10000))
     torch.manual_seed(seed)
     random.seed(seed)
@@ -278,8 +286,16 @@ def main():
                             outs[tag], _ = run_benchmark(getattr(lib, fname), q, k, tv if vt else v, tag, o, stages=stages)
                         except RuntimeError as e:
                             print(f"{tag:>50}: skipped ({e})")
-                    # the `(flash)` row of the reference needs the flash_attn pip package (not in the ROCm image): the
-                    # comparison row is torch SDPA for every D (the reference itself switches to SDPA for D > 256)
+                    # the `(flash)` row of the reference is flash_attn_func (:591). The flash_attn pip package is not in the
+                    # ROCm image, but the kernels its ROCm backend dispatches to are: AMD's ck_tile FMHA forward, compiled from
+                    # the image's headers into the vendor library (csrc/fa2_vendor_ck.hip; D = 64 / 128)
+                    if D in (64, 128) and CK_FMHA is not None:
+                        try:
+                            outs["(ck_tile fmha)"], _ = run_benchmark(lambda a, b, c, out: CK_FMHA(a, b, c, out, 0), q, k, v,
+                                                                      "(ck_tile fmha)", o)
+                        except RuntimeError as e:
+                            print(f"{'(ck_tile fmha)':>50}: skipped ({e})")
+                    # ... and torch SDPA for every D (the reference itself switches to SDPA for D > 256)
                     run_sdpa = args.run_torch_sdpa
                     args.run_torch_sdpa = run_sdpa or args.check or D > 256
                     out_sdpa, _ = run_benchmark(partial(sdpa, use_flash=(D <= 256)), q, k, v, "(sdpa)")

@@ -59,6 +59,11 @@ _add("hgemm_vendor", "G3", "rocblas_gemm_ex f16/f32-acc TN", "hgemm_cublas_tenso
 # second vendor comparison row (NOT a reference name, hence the cln_ prefix): hipBLASLt, csrc/hgemm_vendor_lt.hip
 _add("hgemm_vendor_lt", "G3", "hipblasLtMatmul f16/f32-acc NN, heuristic's top algorithm", "cln_hgemm_hipblaslt_nn")
 _add("hgemm_vendor_lt", "G3", "hipblasLtMatmul f16/f32-acc TN, heuristic's top algorithm", "cln_hgemm_hipblaslt_tn")
+# attention comparison row (NOT a reference name): AMD's ck_tile FMHA forward kernels -- what FlashAttention-2-ROCm / aiter
+# dispatch to -- instantiated from /opt/rocm/include/ck_tile; the `stages` slot of the signature carries the variant
+# (0 = async pipeline, D = 64 / 128; 3 = the gfx950 "v3" kernel, D = 128). csrc/fa2_vendor_ck.hip
+_add("fa2_vendor_ck", "FA", "ck_tile::FmhaFwdKernel<BlockFmhaPipelineQRKSVSAsync> (D = 64 / 128) | ck_tile::FmhaFwdV3Kernel (D = 128, variant 3)",
+     "cln_fa2_ck_tile_fwd")
 _add("hgemm", "G3", "mfma_naive<NN> 1 wave/16x16 tile, mfma_16x16x16",
      "hgemm_wmma_m16n16k16_naive", "hgemm_mma_m16n8k16_naive")
 _add("hgemm", "G3", "mfma_1stage<64x128x32,2 waves,NN>", "hgemm_wmma_m16n16k16_mma4x2")
@@ -234,7 +239,7 @@ assert len(BY_NAME) == len(ENTRIES), "duplicate exported name"
 SO_OF_LIB = {
     "hgemm": "libcln_amd.so", "flash_attn": "libcln_amd.so", "elementwise": "libcln_amd.so",
     "reduce": "libcln_amd.so", "softmax": "libcln_amd.so", "layer_norm": "libcln_amd.so",
-    "rms_norm": "libcln_amd.so", "rope": "libcln_amd.so", "hgemm_vendor": "libcln_amd_vendor.so", "hgemm_vendor_lt": "libcln_amd_vendor.so",
+    "rms_norm": "libcln_amd.so", "rope": "libcln_amd.so", "hgemm_vendor": "libcln_amd_vendor.so", "hgemm_vendor_lt": "libcln_amd_vendor.so", "fa2_vendor_ck": "libcln_amd_vendor.so",
     "histogram": "libcln_amd.so", "embedding": "libcln_amd.so", "activation": "libcln_amd.so",
     "sgemm": "libcln_amd.so", "sgemm_vendor": "libcln_amd_vendor.so",
     "dot_product": "libcln_amd.so", "sgemv": "libcln_amd.so", "hgemv": "libcln_amd.so", "mat_transpose": "libcln_amd.so",

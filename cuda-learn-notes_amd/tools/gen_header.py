@@ -44,6 +44,9 @@ GROUPS = [
                      " * bindings :222-261 (init/destroy handle are process-global as in the reference)."),
     ("hgemm_vendor_lt", "Second vendor row (libcln_amd_vendor.so, hipBLASLt; csrc/hgemm_vendor_lt.hip). NOT reference names (hence cln_):\n"
                         " * BASELINE.md's C3 target reads \"rocBLAS/hipBLASLt\"; the reference's own vendor row is cuBLAS (hgemm_cublas.cu:15-84)."),
+    ("fa2_vendor_ck", "Attention vendor row (libcln_amd_vendor.so; csrc/fa2_vendor_ck.hip). NOT a reference name: AMD's ck_tile FMHA forward\n"
+                      " * kernels (the family FlashAttention-2-ROCm and aiter dispatch to; the reference times flash_attn_func,\n"
+                      " * flash_attn_mma.py:10, :591). The `stages` slot carries the variant: 0 = async pipeline (D = 64 / 128), 3 = gfx950 v3 (D = 128)."),
     ("flash_attn", "FlashAttention-2 forward, fp16 [B,H,N,D]; *_swizzle_qkv of share_kv/share_qkv/tiling_qk take V as [B,H,D,N].\n"
                    " * Replaces reference kernels/flash-attn/pybind/flash_attn.cc:182-215\n"
                    " * (`void f(torch::Tensor Q, K, V, O, int stages)`)."),

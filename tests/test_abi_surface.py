@@ -9,7 +9,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # hand-kept copy of the reference surface counts as an independent check
-EXPECTED_COUNTS = {"hgemm": 34, "hgemm_vendor": 4, "hgemm_vendor_lt": 2, "flash_attn": 28, "elementwise": 6, "reduce": 20,
+EXPECTED_COUNTS = {"hgemm": 34, "hgemm_vendor": 4, "hgemm_vendor_lt": 2, "fa2_vendor_ck": 1, "flash_attn": 28, "elementwise": 6, "reduce": 20,
                    "softmax": 11, "layer_norm": 8, "rms_norm": 9, "rope": 3,
                    "histogram": 2, "embedding": 6, "activation": 42,
                    "sgemm": 15, "sgemm_vendor": 2, "dot_product": 5, "sgemv": 3, "hgemv": 3, "mat_transpose": 13}  # last two: SURVEY 8(f) rank 1 (bit-exact indexing kernels)
@@ -29,8 +29,8 @@ def test_manifest_counts(pkg):
     from collections import Counter
     c = Counter(e.lib for e in pkg.manifest.ENTRIES)
     assert dict(c) == EXPECTED_COUNTS
-    assert len(pkg.manifest.ENTRIES) == 216  # 214 reference names + the two hipBLASLt comparison rows (cln_ prefix)
-    assert sum(1 for e in pkg.manifest.ENTRIES if e.name.startswith("cln_")) == 2
+    assert len(pkg.manifest.ENTRIES) == 217  # 214 reference names + the hipBLASLt (2) and ck_tile attention (1) comparison rows (cln_ prefix)
+    assert sum(1 for e in pkg.manifest.ENTRIES if e.name.startswith("cln_")) == 3
     for n in SPOT_NAMES:
         assert n in pkg.manifest.BY_NAME
 

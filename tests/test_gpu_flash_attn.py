@@ -618,3 +618,26 @@ def test_repeated_launches_are_bit_identical_and_right(fa, built, dev, B, H, N, 
         fn(q, k, v, o, 2)
         mismatching += 0 if torch.equal(o, first) else 1
     assert mismatching == 0, mismatching
+
+
+@pytest.mark.parametrize("D", [64, 128])
+def test_ck_tile_fmha_comparator_row_is_a_correct_attention(built, dev, oracle, D):
+    """The vendor comparison row (csrc/fa2_vendor_ck.hip: AMD's ck_tile FMHA forward, the kernel family FlashAttention-2-ROCm
+    dispatches to) computes the same attention as the oracle -- a comparator that is wrong would make every ratio
+    quoted beside it meaningless. Async pipeline at D = 64 / 128, the gfx950 v3 kernel at D = 128; other head dims and
+    variants are refused, not mis-run."""
+    ck = built.load("fa2_vendor_ck").cln_fa2_ck_tile_fwd
+    for (B, H, N) in ((1, 2, 256), (2, 3, 1024)):
+        q, k, v = seeded(31 + N, B, H, N, D), seeded(32 + N, B, H, N, D), seeded(33 + N, B, H, N, D)
+        ref = oracle.attention_fp64(q, k, v)
+        for variant in ((0, 3) if D == 128 else (0,)):
+            o = torch.zeros(B, H, N, D, dtype=torch.half, device=dev)
+            ck(q.to(dev), k.to(dev), v.to(dev), o, variant)
+            assert (o.cpu().double() - ref).abs().max().item() <= TOL, (N, variant)
+    bad = torch.zeros(1, 1, 256, 96, dtype=torch.half, device=dev)
+    with pytest.raises(RuntimeError):
+        ck(bad, bad, bad, torch.zeros_like(bad), 0)
+    q64 = torch.zeros(1, 1, 256, 64, dtype=torch.half, device=dev)
+    with pytest.raises(RuntimeError):
+        ck(q64, q64, q64, torch.zeros_like(q64), 3)  # the v3 kernel exists for D = 128 only
+
