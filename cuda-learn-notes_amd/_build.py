@@ -27,6 +27,9 @@ KERNEL_SOURCES = [
     "sgemm.hip", "hgemm.hip", "hgemm_ring_nn.hip", "hgemm_ring_tn.hip", "flash_attn.hip", "flash_attn_m16x.hip", "describe.hip",
 ]
 VENDOR_SOURCES = ["hgemm_vendor.hip", "hgemm_vendor_lt.hip", "fa2_vendor_ck.hip"]  # the last: ck_tile FMHA instances (~1 min of hipcc)
+# a comparison row whose sources are the ROCm image's ck_tile headers: if they are missing or do not compile, the vendor
+# library is linked without it (the callers treat the row as absent) instead of failing the whole build
+OPTIONAL_SOURCES = {"fa2_vendor_ck.hip"}
 # test-only library; it re-links the two ring compile units for the explicit (tile, BK, stages) hook
 PROBE_SOURCES = ["hgemm_probe.hip", "flash_attn_probe.hip", "flash_attn_m16x_probe.hip"]
 PROBE_SHARED = ["hgemm_ring_nn.hip", "hgemm_ring_tn.hip"]
@@ -69,6 +72,9 @@ def _compile_one(src, hdr_digest, verbose):
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
+        if src in OPTIONAL_SOURCES:
+            print("warning: optional comparison row %s did not compile, building without it:\n%s" % (src, r.stderr[-600:]), file=sys.stderr)
+            return None, False
         raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-4000:]))
     with open(stamp, "w") as f:
         f.write(digest)
@@ -101,7 +107,7 @@ def build(verbose=False, force=False):
     if force or not os.path.exists(main_so) or any(objs[s][1] for s in KERNEL_SOURCES):
         _link([objs[s][0] for s in KERNEL_SOURCES], main_so, [], verbose)
     if force or not os.path.exists(vend_so) or any(objs[s][1] for s in VENDOR_SOURCES):
-        _link([objs[s][0] for s in VENDOR_SOURCES], vend_so, ["-L/opt/rocm/lib", "-lrocblas", "-lhipblaslt"], verbose)
+        _link([objs[s][0] for s in VENDOR_SOURCES if objs[s][0] is not None], vend_so, ["-L/opt/rocm/lib", "-lrocblas", "-lhipblaslt"], verbose)
     if force or not os.path.exists(probe_so) or any(objs[s][1] for s in PROBE_SOURCES + PROBE_SHARED):
         _link([objs[s][0] for s in PROBE_SOURCES + PROBE_SHARED], probe_so, [], verbose)
     return main_so, vend_so, probe_so
