@@ -7,8 +7,8 @@
 #   5. rocprofv3 kernel-trace of the bandwidth kernels (bw_prof_*)                         -> <tag>_bw_rocprof.json
 #   6. the re-authored reference scripts on the GPU (run_all_scripts.sh)                   -> <tag>_reference_style_scripts_on_gpu.log
 #   7. C++ harness                                                                         -> <tag>_hgemm_bench_cpp.log
-#   8. stages = 1 vs 2 of the attention names, the hipBLASLt row, the bit-repeatability stress -> <tag>_fa_stage1_vs_stage2.log,
-#      <tag>_hipblaslt_probe.log, <tag>_determinism_stress.log
+#   8. stages = 1 vs 2 of the attention names, the hipBLASLt row, the bit-repeatability stress, the ck_tile FMHA comparator
+#      -> <tag>_fa_stage1_vs_stage2.log, <tag>_hipblaslt_probe.log, <tag>_determinism_stress.log, <tag>_fa_ck_tile_comparator.log
 TAG=${1:-r03}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$REPO/gpurun_out; T=$REPO/cuda-learn-notes_amd/tools
 mkdir -p $OUT; cd $REPO; export PYTHONUNBUFFERED=1
@@ -28,5 +28,6 @@ timeout 300 $REPO/cuda-learn-notes_amd/harness/hgemm_bench 200 > $OUT/${TAG}_hge
 timeout 200 python $T/fa_stage_probe.py 2>&1 | grep STAGE > $OUT/${TAG}_fa_stage1_vs_stage2.log; echo "stage probe rc=$?"
 timeout 200 python $T/vendor_lt_probe.py 2>&1 | grep "^LT" > $OUT/${TAG}_hipblaslt_probe.log; echo "hipblaslt rc=$?"
 timeout 400 python $T/determinism_stress.py 200 2>&1 | grep DET > $OUT/${TAG}_determinism_stress.log; echo "determinism rc=$?"
+timeout 300 python $T/fa_ck_probe.py 2>&1 | grep "^CK" > $OUT/${TAG}_fa_ck_tile_comparator.log; echo "ck_tile comparator rc=$?"
 cut -c1-1500 $OUT/${TAG}_bench_20steps.json; echo; cat $OUT/${TAG}_fa_kernel_trace.csv; cat $OUT/${TAG}_bw_rocprof.txt
 ls -la $OUT/${TAG}_* | head -40
