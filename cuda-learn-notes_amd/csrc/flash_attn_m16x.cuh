@@ -26,7 +26,7 @@
 
 namespace fa2 {
 
-enum : int { M16X_PRIO = 1, M16X_PRIO_B = 2, M16X_SPLIT_PROLOGUE = 4, M16X_PRIO_STATIC = 8 };  // 8: s_setprio 1 once for the second-dispatched group, no flips
+enum : int { M16X_PRIO = 1, M16X_PRIO_B = 2, M16X_SPLIT_PROLOGUE = 4, M16X_PRIO_STATIC = 8, M16X_NT_STORE = 16 };  // 8: s_setprio 1 once for the second-dispatched group, no flips
 
 template <int D_, int RPW_, int BC_, int PD = 4, int NDEF = 1, int OX = 0>
 __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __restrict__ Q, const half_t* __restrict__ K,
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
   for (int it = 0; it < (G::RPW * LPR) / 64; ++it) {
     const int idx = it * 64 + lane_e;
     const int row = idx / LPR, c = idx % LPR;
-    *reinterpret_cast<u4*>(og + (size_t)row * D + c * 8) = *reinterpret_cast<const u4*>(ob + row * G::OS + c * 16);
+    cln_store_stream(reinterpret_cast<u4*>(og + (size_t)row * D + c * 8), *reinterpret_cast<const u4*>(ob + row * G::OS + c * 16), (OX & M16X_NT_STORE) != 0 ? 1 : 0);
   }
 }
 

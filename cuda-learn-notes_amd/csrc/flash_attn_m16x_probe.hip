@@ -19,10 +19,12 @@ int m16x_probe_run(int D, int code, const void* q, const void* k, const void* v,
   MX(64, 48, 32, 128, 8, 4, 0) MX(64, 49, 32, 128, 8, 4, 1) MX(64, 53, 32, 128, 8, 4, 5) MX(64, 54, 32, 128, 8, 4, 6) MX(64, 52, 32, 128, 8, 4, 4)
   MX(64, 69, 32, 128, 8, 5, 5) MX(64, 85, 32, 128, 8, 6, 5)
   MX(64, 101, 32, 128, 4, 4, 5)
+  MX(64, 62, 32, 128, 8, 4, 21) MX(64, 134, 64, 64, 4, 1, 21)  // 21 = the shipped options + non-temporal O stores
   MX(64, 60, 32, 128, 8, 4, 12) MX(64, 61, 32, 128, 8, 4, 13) MX(64, 133, 64, 64, 4, 1, 12)  // static priority for the second group (12), on top of the phase-A flips (13)
   MX(64, 120, 64, 64, 4, 1, 0) MX(64, 125, 64, 64, 4, 1, 5) MX(64, 141, 64, 64, 4, 2, 5)
   MX(128, 5, 32, 128, 4, 1, 5) MX(128, 21, 32, 128, 4, 2, 5) MX(128, 49, 32, 128, 4, 4, 1) MX(128, 53, 32, 128, 4, 4, 5) MX(128, 54, 32, 128, 4, 4, 6)
   MX(128, 85, 32, 128, 4, 6, 5)
+  MX(128, 62, 32, 128, 4, 4, 21)
   MX(128, 60, 32, 128, 4, 4, 12) MX(128, 61, 32, 128, 4, 4, 13)
 #undef MX
   // 150 + id: the one-wave-per-SIMD form (flash_attn_m16s.cuh: 4 waves x 64 rows), <D, BC, PD, NDEF>

@@ -93,19 +93,23 @@ int plan_tile(int plan) {
 // ping-pong over a 2 x 64-deep ring with split DMA, which is also what an out-of-range `stages` gets), 4 -> k-half
 // ping-pong over a 4 x 32-deep ring, 3/5 -> plain multi-stage ring. The other hgemm_w4 tile forms (192 / 160 / 128-wide)
 // have ONE pipeline: `stages` is ignored there and cln_describe says so.
+// EPI 3: C through the wave-private LDS staging, then NON-TEMPORAL 16-byte stores -- the output does not displace the A / B panels the other
+// workgroups (and, back to back, the next launch) still read from L2 / MALL: +1.3-1.5 % at 4096^3, +3.4-3.6 % at 8192^3 over plain stores,
+// same bits (profiles/r03_hgemm_c_store_probe.log; write-through `sc0 sc1` stores: +1.4 % / -0.2 %)
+constexpr int W4_EPILOGUE = 3;
 constexpr int W4_PRODUCTION = 26;  // schedule 10 (one DMA piece per 8 MFMAs, running on into the next tile), boustrophedon MFMA order
 template <int LAYOUT>
 int best_dispatch(const void* a, const void* b, void* c, int M, int N, int K, int stages, int swizzle, int stride,
                   hipStream_t st) {
   int plan = best_plan(M, N, K);
-  if (plan == PLAN_W192) return launch_w4<LAYOUT, 2, W4_PRODUCTION, 0, 192, 192>(a, b, c, M, N, K, swizzle, stride, st);
-  if (plan == PLAN_W192x256) return launch_w4<LAYOUT, 2, W4_PRODUCTION, 0, 192, 256>(a, b, c, M, N, K, swizzle, stride, st);
-  if (plan == PLAN_W256x192) return launch_w4<LAYOUT, 2, W4_PRODUCTION, 0, 256, 192>(a, b, c, M, N, K, swizzle, stride, st);
-  if (plan == PLAN_W160) return launch_w4<LAYOUT, 2, W4_PRODUCTION, 0, 160, 160>(a, b, c, M, N, K, swizzle, stride, st);
-  if (plan == PLAN_W128x256) return launch_w4<LAYOUT, 2, W4_PRODUCTION, 0, 128, 256>(a, b, c, M, N, K, swizzle, stride, st);
-  if (plan == PLAN_W256x128) return launch_w4<LAYOUT, 2, W4_PRODUCTION, 0, 256, 128>(a, b, c, M, N, K, swizzle, stride, st);
+  if (plan == PLAN_W192) return launch_w4<LAYOUT, W4_EPILOGUE, W4_PRODUCTION, 0, 192, 192>(a, b, c, M, N, K, swizzle, stride, st);
+  if (plan == PLAN_W192x256) return launch_w4<LAYOUT, W4_EPILOGUE, W4_PRODUCTION, 0, 192, 256>(a, b, c, M, N, K, swizzle, stride, st);
+  if (plan == PLAN_W256x192) return launch_w4<LAYOUT, W4_EPILOGUE, W4_PRODUCTION, 0, 256, 192>(a, b, c, M, N, K, swizzle, stride, st);
+  if (plan == PLAN_W160) return launch_w4<LAYOUT, W4_EPILOGUE, W4_PRODUCTION, 0, 160, 160>(a, b, c, M, N, K, swizzle, stride, st);
+  if (plan == PLAN_W128x256) return launch_w4<LAYOUT, W4_EPILOGUE, W4_PRODUCTION, 0, 128, 256>(a, b, c, M, N, K, swizzle, stride, st);
+  if (plan == PLAN_W256x128) return launch_w4<LAYOUT, W4_EPILOGUE, W4_PRODUCTION, 0, 256, 128>(a, b, c, M, N, K, swizzle, stride, st);
   if (plan == PLAN_W256) {
-    if (stages == 2) return launch_w4<LAYOUT, 2, W4_PRODUCTION>(a, b, c, M, N, K, swizzle, stride, st);
+    if (stages == 2) return launch_w4<LAYOUT, W4_EPILOGUE, W4_PRODUCTION>(a, b, c, M, N, K, swizzle, stride, st);
     plan = PLAN_PP256;
   }
   if (plan == PLAN_PP192) return launch_pp<LAYOUT, 2, 4, 0, 0, 192>(a, b, c, M, N, K, swizzle, stride, st);
@@ -214,7 +218,7 @@ template <int LAYOUT, int BM, int BN>
 static int fixed_tile_dispatch(int ring_tile, const void* a, const void* b, void* c, int M, int N, int K, int stages,
                                int swizzle, int swizzle_stride, hipStream_t stream) {
   if (fixed_tile_runs_w4<LAYOUT, BM, BN>(M, N, K, stages))
-    return launch_w4<LAYOUT, 2, W4_PRODUCTION, 0, BM, BN>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+    return launch_w4<LAYOUT, W4_EPILOGUE, W4_PRODUCTION, 0, BM, BN>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
   if constexpr (LAYOUT == TN) return ring_dispatch_tn(ring_tile, a, b, c, M, N, K, stages, swizzle, swizzle_stride, stream);
   else return ring_dispatch_nn(ring_tile, a, b, c, M, N, K, stages, swizzle, swizzle_stride, stream);
 }

@@ -95,6 +95,10 @@ CLN_API int cln_hgemm_variant(int kind, int layout, int tile, int bk, int stages
       W4_CASE(20) W4_CASE(25) W4_CASE(26) W4_CASE(27) W4_CASE(28)
       case 104: return layout == TN ? launch_w4<TN, 1, 4>(a, b, c, M, N, K, swizzle, swizzle_stride, stream)
                                     : launch_w4<NN, 1, 4>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+      case 203: return layout == TN ? launch_w4<TN, 3, 26>(a, b, c, M, N, K, swizzle, swizzle_stride, stream)   // non-temporal C stores
+                                    : launch_w4<NN, 3, 26>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+      case 204: return layout == TN ? launch_w4<TN, 4, 26>(a, b, c, M, N, K, swizzle, swizzle_stride, stream)   // write-through C stores
+                                    : launch_w4<NN, 4, 26>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
       case 111: return launch_w4<NN, 1, 4, 1>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);  // no-store + ablations
       case 112: return launch_w4<NN, 1, 4, 2>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
       case 113: return launch_w4<NN, 1, 4, 3>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);

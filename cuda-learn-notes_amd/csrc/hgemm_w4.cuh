@@ -34,7 +34,7 @@ namespace hgemm {
 
 // Epilogue through LDS for a wave tile of FN x 16 columns (128 or 96): [64 rows][FN*32 + 16 B] wave-private region,
 // passes of up to 64 rows; a lane streams 16 bytes, one store instruction = 4 (5) rows x 256 (192) contiguous bytes.
-template <int FM, int FN>
+template <int FM, int FN, int NT = 0>  // NT (probe): 1 = non-temporal C stores, 2 = write-through (sc0 sc1)
 __device__ __forceinline__ void store_wide_tile_via_lds(half_t* Cmat, int N, int row0, int col0, int lane, char* wave_lds,
                                                         const f4 (&acc)[FM][FN]) {
   static_assert(FN == 8 || FN == 6 || FN == 5 || FN == 4, "128-, 96-, 80- or 64-column wave tile");
@@ -61,7 +61,10 @@ __device__ __forceinline__ void store_wide_tile_via_lds(half_t* Cmat, int N, int
       const int r = it * RPI + lane / LPR;
       if (it * RPI < rows && lane < RPI * LPR && r < rows) {
         const u4 v = *reinterpret_cast<const u4*>(wave_lds + r * RS + (lane % LPR) * 16);
-        *reinterpret_cast<u4*>(Cmat + (size_t)(row0 + h0 * 16 + r) * N + col0 + (lane % LPR) * 8) = v;
+        u4* dst = reinterpret_cast<u4*>(Cmat + (size_t)(row0 + h0 * 16 + r) * N + col0 + (lane % LPR) * 8);
+        if constexpr (NT == 1) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+        else if constexpr (NT == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+        else *dst = v;
       }
     }
   }
@@ -335,9 +338,9 @@ __global__ __launch_bounds__(256, 1) void hgemm_w4_kernel(const half_t* __restri
   for (int i = 0; i < FM; ++i)
 #pragma unroll
     for (int j = 0; j < FN; ++j) asm volatile("" : "+a"(acc[i][j]));
-  if constexpr (EPI == 2) {
+  if constexpr (EPI >= 2) {  // EPI 3 / 4 (probe library): the same epilogue with non-temporal / write-through C stores
     // B1 of the last tile: every wave is past its last fragment read; no DMA is in flight
-    store_wide_tile_via_lds<FM, FN>(Cmat, N, m0 + wm * C::WTM, n0 + wn * C::WTN, lane, smem + wave * (64 * (FN * 32 + 16)), acc);
+    store_wide_tile_via_lds<FM, FN, EPI - 2>(Cmat, N, m0 + wm * C::WTM, n0 + wn * C::WTN, lane, smem + wave * (64 * (FN * 32 + 16)), acc);
   } else {  // measurement-only variant: keep the accumulators live, store (almost) nothing
     float s = 0.f;
 #pragma unroll
@@ -356,7 +359,7 @@ int launch_w4(const void* a, const void* b, void* c, int M, int N, int K, int sw
               hipStream_t stream) {
   using C = W4Cfg<BM, BN, LAYOUT>;
   // the odd-tile-count form exists for the production schedule only (the probe variants keep K % 128 == 0)
-  constexpr bool HAS_ODD = ABL == 0 && EPI == 2 && (VAR == 26 || BM != 256 || BN != 256);
+  constexpr bool HAS_ODD = ABL == 0 && EPI >= 2 && (VAR == 26 || BM != 256 || BN != 256);
   const bool odd = (K / 64) & 1;
   if (M % BM || N % BN || !w4_k_ok(K) || (odd && !HAS_ODD)) return CLN_ERR_UNSUPPORTED;
   const int tiles_m = M / BM, tiles_n = N / BN;

@@ -90,7 +90,7 @@ def test_one_wave_per_simd_hgemm_instantiations_are_exactly_the_plannable_ones(b
         if fam.startswith("hgemm::"):
             fams.add(fam.split("::")[1])
         if fam == "hgemm::hgemm_w4_kernel":
-            assert a[1:4] == ["2", "26", "0"], a  # LDS epilogue, the production schedule, no ablation
+            assert a[1:4] == ["3", "26", "0"], a  # LDS epilogue with non-temporal C stores, the production schedule, no ablation
             linked.add((int(a[0]), int(a[4]), int(a[5]), a[6] == "true"))
     assert fams == {"hgemm_w4_kernel", "hgemm_pp_kernel", "hgemm_pp32_kernel", "hgemm_ring_kernel", "hgemm_1stage_kernel", "hgemm_mfma_naive_kernel",
                     "hgemm_valu_tile_kernel", "hgemm_naive_f16_kernel", "hgemm_sliced_k_f16_kernel"}, sorted(fams)
