@@ -16,7 +16,10 @@ def test_every_run_time_dispatched_name_describes_itself(built):
     """All FA names and all G6 HGEMM names answer; statically bound names say so (LookupError)."""
     m = built.manifest
     for e in m.ENTRIES:
-        if e.sig == "FA":
+        if e.sig == "FA" and e.lib != "flash_attn":  # the ck_tile comparison row: a vendor kernel, not one of ours
+            with pytest.raises(LookupError):
+                m.describe(e.name, (4, 8, 2048, 64), 0)
+        elif e.sig == "FA":
             D = 64
             txt = m.describe(e.name, (4, 8, 2048, D), 2)
             assert txt.startswith("fa2_fwd"), (e.name, txt)
