@@ -178,9 +178,15 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_dring_kernel(const half_t* __r
     else return voffs[b];
   };
   // partial-S exchange image of a wave: [32 rows][16 keys] fp32, 64-byte rows, 16-byte chunk ^= (row >> 2) & 3
-  char* sx_w = smem + G::RING + wave * 2048 + i16 * 64 + ((g4 ^ ((i16 >> 2) & 3)) << 4);  // + qb * 1024
-  const char* sx_r = smem + G::RING + rg * 4 * 2048 + l31 * 64;                            // + p * 2048 + chunk
-  const int sw_r = (l31 >> 2) & 3;
+  // chunk swizzle of a row (rows repeat every 16): sw = bit 2 | (bit 3 ^ bit 1) << 1. It has to be conflict-free under TWO rules:
+  // the ds_read_b128 of the 32x32 layout is served in 16-lane groups over 256 B -- (row & 3, sw) must be distinct over 16 rows --
+  // and the ds_write_b128 of the 16x16 layout in 8-lane groups over 128 B -- (row & 1, sw) distinct over 8 consecutive rows. The first
+  // form, sw = (row >> 2) & 3, met only the read rule: every write was a 2-way conflict (SQ_LDS_BANK_CONFLICT 135 k cycles per CU and
+  // launch at [1,16,4096,1024], 8 per write; 4 k with this one -- profiles/r03_fa_dring_lds_counters.log)
+  auto sx_sw = [](int row) { return ((row >> 2) & 1) | ((((row >> 3) ^ (row >> 1)) & 1) << 1); };
+  char* sx_w = smem + G::RING + wave * 2048 + i16 * 64 + ((g4 ^ sx_sw(i16)) << 4);  // + qb * 1024
+  const char* sx_r = smem + G::RING + rg * 4 * 2048 + l31 * 64;                      // + p * 2048 + chunk
+  const int sw_r = sx_sw(l31 & 15);
   const int sx_c0 = (hi ^ sw_r) << 4, sx_c1 = ((2 + hi) ^ sw_r) << 4;
 
   if constexpr (STAGGER) {
@@ -201,7 +207,7 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_dring_kernel(const half_t* __r
       const char* kb = smem + slot * G::TILE;
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
-        const h8 kf = *reinterpret_cast<const h8*>(kb + k_addr(ks));
+        const h8 kf = (OPT & OPT_ABL_K) != 0 ? qf[1][ks] : *reinterpret_cast<const h8*>(kb + k_addr(ks));
         s[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[0][ks], s[0], 0, 0, 0);
         s[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[1][ks], s[1], 0, 0, 0);
         cln_mfma_keep(s[0], kf, qf[0][ks]);  // destinations disjoint from the operands (common.h)
@@ -212,8 +218,12 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_dring_kernel(const half_t* __r
           else req_v(j + 1);
         }
       }
-      *reinterpret_cast<f4*>(sx_w) = s[0];
-      *reinterpret_cast<f4*>(sx_w + 1024) = s[1];
+      if constexpr ((OPT & OPT_ABL_XW) == 0) {
+        *reinterpret_cast<f4*>(sx_w) = s[0];
+        *reinterpret_cast<f4*>(sx_w + 1024) = s[1];
+      } else {
+        asm volatile("" ::"v"(s[0]), "v"(s[1]));
+      }
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the partial is in LDS
     wait_young(!STAGGER);
@@ -227,7 +237,7 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_dring_kernel(const half_t* __r
       {
         f4 a0 = *reinterpret_cast<const f4*>(sx_r + sx_c0), a1 = *reinterpret_cast<const f4*>(sx_r + sx_c1);
 #pragma unroll
-        for (int p = 1; p < 4; ++p) {
+        for (int p = 1; p < ((OPT & OPT_ABL_XR) != 0 ? 1 : 4); ++p) {
           const f4 t0 = *reinterpret_cast<const f4*>(sx_r + p * 2048 + sx_c0), t1v = *reinterpret_cast<const f4*>(sx_r + p * 2048 + sx_c1);
           a0 += t0, a1 += t1v;
         }
@@ -281,7 +291,7 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_dring_kernel(const half_t* __r
 #pragma unroll
       for (int b = 0; b < NDB; ++b) {
         const char* vp = vb + v_addr(b);
-        const h8 vf = h8_cat(lds_read_tr16(vp), lds_read_tr16(vp + 8 * G::ROW));
+        const h8 vf = (OPT & OPT_ABL_V) != 0 ? qf[0][b % NKS] : h8_cat(lds_read_tr16(vp), lds_read_tr16(vp + 8 * G::ROW));
         ot[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, ot[b], 0, 0, 0);
         cln_mfma_keep(ot[b], vf, pf);
       }

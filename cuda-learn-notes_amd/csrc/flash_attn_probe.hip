@@ -121,6 +121,13 @@ CLN_API int cln_fa2_variant(int D, int nw, int vt, int opt, int abl, const void*
   if (D == 256 && abl == 5440) return fa2::launch_m16_pair<2, false, false, 32768>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 512 && abl == 545) return fa2::launch_m16_pair<2, true, false, 65536>(q, k, v, o, B, H, N, (hipStream_t)stream);   // phase-B priority
   if (D == 256 && abl == 545) return fa2::launch_m16_pair<2, false, false, 65536>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  // 1010..1014: ablations of the D = 1024 ring kernel for the LDS counters (garbage results): no K fragment reads, no V reads, one of the
+  // four partial-S reads, no partial-S writes, all four
+  if (D == 1024 && abl == 1010) return fa2::launch_dring<1024, fa2::OPT_DEFAULT | fa2::OPT_ABL_K, true, 1>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 1024 && abl == 1011) return fa2::launch_dring<1024, fa2::OPT_DEFAULT | fa2::OPT_ABL_V, true, 1>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 1024 && abl == 1012) return fa2::launch_dring<1024, fa2::OPT_DEFAULT | fa2::OPT_ABL_XR, true, 1>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 1024 && abl == 1013) return fa2::launch_dring<1024, fa2::OPT_DEFAULT | fa2::OPT_ABL_XW, true, 1>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 1024 && abl == 1014) return fa2::launch_dring<1024, fa2::OPT_DEFAULT | fa2::OPT_ABL_K | fa2::OPT_ABL_V | fa2::OPT_ABL_XR | fa2::OPT_ABL_XW, true, 1>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 1024 && abl == 1002) return fa2::launch_dring<1024, fa2::OPT_DEFAULT, true, 1>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 768 && abl == 1002) return fa2::launch_dring<768, fa2::OPT_DEFAULT, true, 1>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 768 && abl == 1003) return fa2::launch_dring<768, fa2::OPT_DEFAULT, false, 1>(q, k, v, o, B, H, N, (hipStream_t)stream);
