@@ -297,7 +297,8 @@ def test_one_wave_per_simd_kernel(hg, built, dev, layout):
             c = torch.zeros(M, N, dtype=torch.half, device=dev)
             fn(ad, bb, c, 2, bool(rep & 1), 512)
             assert torch.equal(c, base), (M, N, K, rep)
-        for var in ((26,) if (K // 64) & 1 else (0, 1, 3, 4, 9, 10, 13, 20, 25, 26, 27, 28)):  # odd tile counts: production schedule only
+        # odd tile counts: production schedule only; 203 / 204 = production schedule with non-temporal (what ships) / write-through C stores
+        for var in ((26, 203, 204) if (K // 64) & 1 else (0, 1, 3, 4, 9, 10, 13, 20, 25, 26, 27, 28, 203, 204)):
             c = torch.zeros(M, N, dtype=torch.half, device=dev)
             host.hgemm_variant(14, layout, 1, 64, var, ad, bb, c, swizzle=1, swizzle_stride=512)
             assert torch.equal(c, base), (M, N, K, var)
