@@ -52,7 +52,7 @@ __device__ __forceinline__ void dring_wait_vm() {
 // otherwise). Every interval between two workgroup barriers then carries ONE tile request issued by all eight waves
 // (even intervals K, odd intervals V), every request is two intervals ahead of its first reader, and the wait before
 // every barrier leaves exactly the one younger request in flight.
-template <int D, int OPT, bool STAGGER = true, int PRIO = 0>
+template <int D, int OPT, bool STAGGER = true, int PRIO = 0, int KPF = 1, int VPF = 1>
 __global__ __launch_bounds__(512, 2) void fa2_fwd_dring_kernel(const half_t* __restrict__ Q, const half_t* __restrict__ K,
                                                                const half_t* __restrict__ V, half_t* __restrict__ O,
                                                                int N, int n_qblk, int n_heads, float scale_log2e) {
@@ -122,10 +122,12 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_dring_kernel(const half_t* __r
   auto clampt = [&](int t) __attribute__((always_inline)) { return t < T ? t : T - 1; };  // past the end: refill a dead slot (keeps the counts uniform)
   // OPT_1STAGE = the `stages = 1` form: every tile request is waited for where it is issued (no load runs under compute)
   auto req_k = [&](int t) __attribute__((always_inline)) {
+    if constexpr ((OPT & OPT_ABL_DMA) != 0) return;  // probe ablation: no K / V traffic at all after the prologue
     dma_tile(Kh, k_voff, clampt(t), lds0 + (t & 1) * G::TILE);
     if constexpr ((OPT & OPT_1STAGE) != 0) hgemm::wait_vmcnt<0>();
   };
   auto req_v = [&](int t) __attribute__((always_inline)) {
+    if constexpr ((OPT & OPT_ABL_DMA) != 0) return;
     dma_tile(Vh, v_voff, clampt(t), lds0 + 2 * G::TILE + (t & 1) * G::TILE);
     if constexpr ((OPT & OPT_1STAGE) != 0) hgemm::wait_vmcnt<0>();
   };
@@ -205,18 +207,31 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_dring_kernel(const half_t* __r
       f4 s[2];
       s[0] = f4{0.f, 0.f, 0.f, 0.f}, s[1] = f4{0.f, 0.f, 0.f, 0.f};
       const char* kb = smem + slot * G::TILE;
+      // KPF K fragments in flight: with one (the first form of this kernel) every k-step paid a whole LDS round trip between its
+      // read and its MFMAs -- "R w MM R w MM ..." in the ISA -- and the time of the fragment reads was ADDED to the matrix time
+      // (ablations in profiles/r03_fa_dring_lds_counters.log)
+      constexpr int KD = KPF < NKS ? KPF : NKS;
+      auto rd_k = [&](int ks) __attribute__((always_inline)) -> h8 {
+        if constexpr ((OPT & OPT_ABL_K) != 0) return qf[1][ks];
+        else return *reinterpret_cast<const h8*>(kb + k_addr(ks));
+      };
+      h8 kf[KD];
+#pragma unroll
+      for (int i = 0; i < KD; ++i) kf[i] = rd_k(i);
+      if constexpr (KD > 1) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
-        const h8 kf = (OPT & OPT_ABL_K) != 0 ? qf[1][ks] : *reinterpret_cast<const h8*>(kb + k_addr(ks));
-        s[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[0][ks], s[0], 0, 0, 0);
-        s[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[1][ks], s[1], 0, 0, 0);
-        cln_mfma_keep(s[0], kf, qf[0][ks]);  // destinations disjoint from the operands (common.h)
-        cln_mfma_keep(s[1], kf, qf[1][ks]);
+        s[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[ks % KD], qf[0][ks], s[0], 0, 0, 0);
+        s[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[ks % KD], qf[1][ks], s[1], 0, 0, 0);
+        cln_mfma_keep(s[0], kf[ks % KD], qf[0][ks]);  // destinations disjoint from the operands (common.h)
+        cln_mfma_keep(s[1], kf[ks % KD], qf[1][ks]);
+        if (ks + KD < NKS) kf[ks % KD] = rd_k(ks + KD);
         if (ks == 0) {
           if constexpr (!STAGGER) req_v(j + 1);
           else if (rg == 0) req_k(j + 1);
           else req_v(j + 1);
         }
+        if constexpr (KD > 1) __builtin_amdgcn_sched_barrier(0);
       }
       if constexpr ((OPT & OPT_ABL_XW) == 0) {
         *reinterpret_cast<f4*>(sx_w) = s[0];
@@ -233,6 +248,20 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_dring_kernel(const half_t* __r
     // ================= phase 2: S = sum of the four partials, softmax, O^T += V^T P^T
     if constexpr (PRIO != 0) __builtin_amdgcn_s_setprio(1);
     {
+      const char* vb = smem + slot * G::TILE;
+      constexpr int VD = VPF < NDB ? VPF : NDB;
+      auto rd_v = [&](int b) __attribute__((always_inline)) -> h8 {
+        if constexpr ((OPT & OPT_ABL_V) != 0) return qf[0][b % NKS];
+        else {
+          const char* vp = vb + v_addr(b);
+          return h8_cat(lds_read_tr16(vp), lds_read_tr16(vp + 8 * G::ROW));
+        }
+      };
+      h8 vf[VD];
+      if constexpr (VD > 1) {  // the first V fragments fly under the softmax
+#pragma unroll
+        for (int i = 0; i < VD; ++i) vf[i] = rd_v(i);
+      }
       float s8[8];
       {
         f4 a0 = *reinterpret_cast<const f4*>(sx_r + sx_c0), a1 = *reinterpret_cast<const f4*>(sx_r + sx_c1);
@@ -287,13 +316,14 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_dring_kernel(const half_t* __r
         }
         l_run += psum;
       }
-      const char* vb = smem + slot * G::TILE;
+      if constexpr (VD == 1) vf[0] = rd_v(0);
+      else __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int b = 0; b < NDB; ++b) {
-        const char* vp = vb + v_addr(b);
-        const h8 vf = (OPT & OPT_ABL_V) != 0 ? qf[0][b % NKS] : h8_cat(lds_read_tr16(vp), lds_read_tr16(vp + 8 * G::ROW));
-        ot[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, ot[b], 0, 0, 0);
-        cln_mfma_keep(ot[b], vf, pf);
+        ot[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[b % VD], pf, ot[b], 0, 0, 0);
+        cln_mfma_keep(ot[b], vf[b % VD], pf);
+        if (b + VD < NDB) vf[b % VD] = rd_v(b + VD);
+        if constexpr (VD > 1) __builtin_amdgcn_sched_barrier(0);
       }
     }
     wait_young(!STAGGER);
@@ -338,15 +368,15 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_dring_kernel(const half_t* __r
   }
 }
 
-template <int D, int OPT, bool STAGGER = true, int PRIO = 0>
+template <int D, int OPT, bool STAGGER = true, int PRIO = 0, int KPF = 1, int VPF = 1>
 int launch_dring(const void* q, const void* k, const void* v, void* o, int B, int H, int N, hipStream_t stream) {
   using G = GeoRing<D>;
   if (N % G::BR != 0) return CLN_ERR_UNSUPPORTED;
   static cln_lds_attr lds_attr;  // per device, thread-safe (common.h)
-  if (cln_ensure_lds(lds_attr, reinterpret_cast<const void*>(&fa2_fwd_dring_kernel<D, OPT, STAGGER, PRIO>), G::LDS_BYTES) != CLN_OK) return CLN_ERR_LAUNCH;
+  if (cln_ensure_lds(lds_attr, reinterpret_cast<const void*>(&fa2_fwd_dring_kernel<D, OPT, STAGGER, PRIO, KPF, VPF>), G::LDS_BYTES) != CLN_OK) return CLN_ERR_LAUNCH;
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)D);
   const int n_qblk = N / G::BR;
-  CLN_LAUNCH((fa2_fwd_dring_kernel<D, OPT, STAGGER, PRIO>), dim3(n_qblk * B * H), dim3(G::NT), G::LDS_BYTES, stream, (const half_t*)q,
+  CLN_LAUNCH((fa2_fwd_dring_kernel<D, OPT, STAGGER, PRIO, KPF, VPF>), dim3(n_qblk * B * H), dim3(G::NT), G::LDS_BYTES, stream, (const half_t*)q,
              (const half_t*)k, (const half_t*)v, (half_t*)o, N, n_qblk, B * H, scale_log2e);
   return cln_check_launch();
 }

@@ -22,8 +22,8 @@ inline int launch_fa2_large_d(const void* q, const void* k, const void* v, void*
     switch (D) {
       case 320: return fa2::launch_dsplit<512, 2, 1, fa2::OPT_DEFAULT, 256, 320>(q, k, v, o, B, H, N, s);
       case 384: return fa2::launch_dsplit<512, 2, 1, fa2::OPT_DEFAULT, 256, 384>(q, k, v, o, B, H, N, s);
-      case 640: return fa2::launch_dring<640, O1, false>(q, k, v, o, B, H, N, s);
-      case 768: return fa2::launch_dring<768, O1, false>(q, k, v, o, B, H, N, s);
+      case 640: return fa2::launch_dring<640, O1, false, 0, 2, 2>(q, k, v, o, B, H, N, s);
+      case 768: return fa2::launch_dring<768, O1, false, 0, 2, 2>(q, k, v, o, B, H, N, s);
       case 1024: return fa2::launch_dring<1024, O1, true, 1>(q, k, v, o, B, H, N, s);
       default: return CLN_ERR_UNSUPPORTED;
     }
@@ -39,8 +39,10 @@ inline int launch_fa2_large_d(const void* q, const void* k, const void* v, void*
     // D = 640 / 768 / 1024 (flash_attn_dring.cuh): [1,16,4096,D] 604 -> 649 / 684 -> 703 / 691 -> 780 TF, [1,8,8192,1024] 657 -> 804
     // over the d-wide kernel (profiles/r03_fa_dring_probe.log); the two row groups run one phase apart at D = 1024 only
     // (lock-step measured 1-4 % faster at 640 / 768)
-    case 640: return fa2::launch_dring<640, fa2::OPT_DEFAULT, false>(q, k, v, o, B, H, N, s);
-    case 768: return fa2::launch_dring<768, fa2::OPT_DEFAULT, false>(q, k, v, o, B, H, N, s);
+    // two K and two V fragments in flight at 640 / 768 (+5 % / +1.5 % over one; deeper: no gain; D = 1024 has no registers for it:
+    // profiles/r03_fa_dring_prefetch_probe.log)
+    case 640: return fa2::launch_dring<640, fa2::OPT_DEFAULT, false, 0, 2, 2>(q, k, v, o, B, H, N, s);
+    case 768: return fa2::launch_dring<768, fa2::OPT_DEFAULT, false, 0, 2, 2>(q, k, v, o, B, H, N, s);
     case 1024: return fa2::launch_dring<1024, fa2::OPT_DEFAULT, true, 1>(q, k, v, o, B, H, N, s);  // + phase-2 priority: +4.4 %
     default: return CLN_ERR_UNSUPPORTED;
   }

@@ -128,6 +128,15 @@ CLN_API int cln_fa2_variant(int D, int nw, int vt, int opt, int abl, const void*
   if (D == 1024 && abl == 1012) return fa2::launch_dring<1024, fa2::OPT_DEFAULT | fa2::OPT_ABL_XR, true, 1>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 1024 && abl == 1013) return fa2::launch_dring<1024, fa2::OPT_DEFAULT | fa2::OPT_ABL_XW, true, 1>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 1024 && abl == 1014) return fa2::launch_dring<1024, fa2::OPT_DEFAULT | fa2::OPT_ABL_K | fa2::OPT_ABL_V | fa2::OPT_ABL_XR | fa2::OPT_ABL_XW, true, 1>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  // 1020 + 10 * KPF + VPF (two digits each < 10): fragment prefetch depths of the ring kernel, production stagger / priority per head dim
+#define DR_PF(DD, ST, PR, KP, VP) \
+  if (D == DD && abl == 1100 + 10 * KP + VP) return fa2::launch_dring<DD, fa2::OPT_DEFAULT, ST, PR, KP, VP>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  DR_PF(640, false, 0, 1, 1) DR_PF(640, false, 0, 3, 3) DR_PF(640, false, 0, 5, 5) DR_PF(640, false, 0, 5, 3)
+  DR_PF(768, false, 0, 1, 1) DR_PF(768, false, 0, 3, 3) DR_PF(768, false, 0, 4, 4) DR_PF(768, false, 0, 6, 4)
+  DR_PF(1024, true, 1, 2, 1)  // (deeper forms spill at D = 1024: 4-19 registers, -42 ... -49 %)
+#undef DR_PF
+  if (D == 1024 && abl == 1015) return fa2::launch_dring<1024, fa2::OPT_DEFAULT | fa2::OPT_ABL_DMA, true, 1>(q, k, v, o, B, H, N, (hipStream_t)stream);  // no K / V DMA after the prologue
+  if (D == 1024 && abl == 1016) return fa2::launch_dring<1024, fa2::OPT_DEFAULT | fa2::OPT_ABL_DMA | fa2::OPT_ABL_K | fa2::OPT_ABL_V | fa2::OPT_ABL_XR | fa2::OPT_ABL_XW, true, 1>(q, k, v, o, B, H, N, (hipStream_t)stream);  // MFMAs, softmax and barriers only
   if (D == 1024 && abl == 1002) return fa2::launch_dring<1024, fa2::OPT_DEFAULT, true, 1>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 768 && abl == 1002) return fa2::launch_dring<768, fa2::OPT_DEFAULT, true, 1>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 768 && abl == 1003) return fa2::launch_dring<768, fa2::OPT_DEFAULT, false, 1>(q, k, v, o, B, H, N, (hipStream_t)stream);

@@ -82,7 +82,7 @@ def run(ABLS, B, H, N, D):
     torch.manual_seed(0)
     for t in (q, k, v):
         t.copy_(torch.randn(B, H, N, D, dtype=torch.half, device=dev))
-    cands = [(t, f) for t, f in cands if ok.get(t, False)]
+    cands = [(t, f) for t, f in cands if ok.get(t, False) or os.environ.get("FA_TIME_BAD")]  # FA_TIME_BAD=1: time the ablation variants (wrong by design) too
     for tag, fn in cands:
         prewarm(fn)
     res = {t: [] for t, _ in cands}
