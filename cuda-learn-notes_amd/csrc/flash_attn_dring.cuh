@@ -131,6 +131,17 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_dring_kernel(const half_t* __r
     dma_tile(Vh, v_voff, clampt(t), lds0 + 2 * G::TILE + (t & 1) * G::TILE);
     if constexpr ((OPT & OPT_1STAGE) != 0) hgemm::wait_vmcnt<0>();
   };
+  // OPT_SPREAD: the PPW pieces of a tile request go out one at a time between the MFMAs of the phase instead of back to back at its
+  // head (an LDS-DMA instruction holds the wave's issue for 60-180 clocks; four in a row stall its MFMAs that long)
+  auto piece_of = [&](bool is_v, int t, int i) __attribute__((always_inline)) {
+    if constexpr ((OPT & OPT_ABL_DMA) != 0) return;
+    const char* src = (is_v ? Vh : Kh) + (size_t)clampt(t) * G::TILE;
+    const unsigned dst = lds0 + (is_v ? 2 * G::TILE : 0) + (t & 1) * G::TILE + (unsigned)(i * G::NW + wave) * 1024u;
+    const unsigned vo = is_v ? v_voff[i < PPW ? i : 0] : k_voff[i < PPW ? i : 0];
+    if (i * G::NW + G::NW <= G::NP) hgemm::glds16_asm(src, vo, dst);
+    else if (!short_wave) hgemm::glds16_asm(src, vo, dst);
+    if constexpr ((OPT & OPT_1STAGE) != 0) hgemm::wait_vmcnt<0>();
+  };
   auto wait_young = [&](bool two) __attribute__((always_inline)) {  // leave this wave's one / two youngest tile requests in flight
     if constexpr (G::NP % G::NW == 0) {
       if (two) dring_wait_vm<2 * PPW>();
@@ -226,7 +237,14 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_dring_kernel(const half_t* __r
         cln_mfma_keep(s[0], kf[ks % KD], qf[0][ks]);  // destinations disjoint from the operands (common.h)
         cln_mfma_keep(s[1], kf[ks % KD], qf[1][ks]);
         if (ks + KD < NKS) kf[ks % KD] = rd_k(ks + KD);
-        if (ks == 0) {
+        if constexpr ((OPT & OPT_SPREAD) != 0) {
+          constexpr int STRIDE = NKS / PPW > 0 ? NKS / PPW : 1;
+          if (ks % STRIDE == 0 && ks / STRIDE < PPW) {
+            if constexpr (!STAGGER) piece_of(true, j + 1, ks / STRIDE);
+            else if (rg == 0) piece_of(false, j + 1, ks / STRIDE);
+            else piece_of(true, j + 1, ks / STRIDE);
+          }
+        } else if (ks == 0) {
           if constexpr (!STAGGER) req_v(j + 1);
           else if (rg == 0) req_k(j + 1);
           else req_v(j + 1);
@@ -274,9 +292,11 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_dring_kernel(const half_t* __r
         for (int e = 0; e < 4; ++e) s8[e] = a0[e], s8[4 + e] = a1[e];
       }
       // lock-step: the K slot of tile j is free since the last barrier; staggered: see the interval table above
-      if constexpr (!STAGGER) req_k(j + 2);
-      else if (rg == 0) req_v(j + 1);
-      else req_k(j + 2);
+      if constexpr ((OPT & OPT_SPREAD) == 0) {
+        if constexpr (!STAGGER) req_k(j + 2);
+        else if (rg == 0) req_v(j + 1);
+        else req_k(j + 2);
+      }
       float mx = s8[0];
 #pragma unroll
       for (int e = 1; e < 8; ++e) mx = fmaxf(mx, s8[e]);
@@ -323,6 +343,14 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_dring_kernel(const half_t* __r
         ot[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[b % VD], pf, ot[b], 0, 0, 0);
         cln_mfma_keep(ot[b], vf[b % VD], pf);
         if (b + VD < NDB) vf[b % VD] = rd_v(b + VD);
+        if constexpr ((OPT & OPT_SPREAD) != 0) {
+          constexpr int STRIDE = NDB / PPW > 0 ? NDB / PPW : 1;
+          if (b % STRIDE == 0 && b / STRIDE < PPW) {
+            if constexpr (!STAGGER) piece_of(false, j + 2, b / STRIDE);
+            else if (rg == 0) piece_of(true, j + 1, b / STRIDE);
+            else piece_of(false, j + 2, b / STRIDE);
+          }
+        }
         if constexpr (VD > 1) __builtin_amdgcn_sched_barrier(0);
       }
     }

@@ -129,6 +129,11 @@ CLN_API int cln_fa2_variant(int D, int nw, int vt, int opt, int abl, const void*
   if (D == 1024 && abl == 1013) return fa2::launch_dring<1024, fa2::OPT_DEFAULT | fa2::OPT_ABL_XW, true, 1>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 1024 && abl == 1014) return fa2::launch_dring<1024, fa2::OPT_DEFAULT | fa2::OPT_ABL_K | fa2::OPT_ABL_V | fa2::OPT_ABL_XR | fa2::OPT_ABL_XW, true, 1>(q, k, v, o, B, H, N, (hipStream_t)stream);
   // 1020 + 10 * KPF + VPF (two digits each < 10): fragment prefetch depths of the ring kernel, production stagger / priority per head dim
+  // 1200 + ...: the same with the DMA pieces of a tile request spread over the phase (OPT_SPREAD)
+#define DR_SP(DD, ST, PR, KP, VP) \
+  if (D == DD && abl == 1200 + 10 * KP + VP) return fa2::launch_dring<DD, fa2::OPT_DEFAULT | fa2::OPT_SPREAD, ST, PR, KP, VP>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  DR_SP(640, false, 0, 2, 2) DR_SP(640, false, 0, 1, 1) DR_SP(768, false, 0, 2, 2) DR_SP(768, false, 0, 1, 1) DR_SP(1024, true, 1, 1, 1) DR_SP(1024, true, 1, 2, 1)
+#undef DR_SP
 #define DR_PF(DD, ST, PR, KP, VP) \
   if (D == DD && abl == 1100 + 10 * KP + VP) return fa2::launch_dring<DD, fa2::OPT_DEFAULT, ST, PR, KP, VP>(q, k, v, o, B, H, N, (hipStream_t)stream);
   DR_PF(640, false, 0, 1, 1) DR_PF(640, false, 0, 3, 3) DR_PF(640, false, 0, 5, 5) DR_PF(640, false, 0, 5, 3)

@@ -24,7 +24,7 @@
 
 namespace fa2 {
 
-enum : int { OPT_DEFER = 1, OPT_PRIO = 2, OPT_LDS_EPI = 4, OPT_XCD = 8, OPT_STAGGER = 16, OPT_ONES = 32, OPT_SOLO = 64, OPT_PK = 512, OPT_VPRE = 1024, OPT_KPRE = 2048, OPT_SOFTEXP = 4096, OPT_SOFTEXP_HALF = 8192, OPT_PRE = 16384, OPT_PD8 = 32768, OPT_PD16 = 65536, OPT_SUMM = 131072, OPT_1STAGE = 262144, OPT_ABL_K = 1 << 19, OPT_ABL_V = 1 << 20, OPT_ABL_XR = 1 << 21, OPT_ABL_XW = 1 << 22, OPT_ABL_DMA = 1 << 23, OPT_ABL_BAR = 1 << 24, OPT_DEFAULT = 15 };  // OPT_ABL_*: probe ablations of the ring kernel (results are garbage by design)
+enum : int { OPT_DEFER = 1, OPT_PRIO = 2, OPT_LDS_EPI = 4, OPT_XCD = 8, OPT_STAGGER = 16, OPT_ONES = 32, OPT_SOLO = 64, OPT_PK = 512, OPT_VPRE = 1024, OPT_KPRE = 2048, OPT_SOFTEXP = 4096, OPT_SOFTEXP_HALF = 8192, OPT_PRE = 16384, OPT_PD8 = 32768, OPT_PD16 = 65536, OPT_SUMM = 131072, OPT_1STAGE = 262144, OPT_ABL_K = 1 << 19, OPT_ABL_V = 1 << 20, OPT_ABL_XR = 1 << 21, OPT_ABL_XW = 1 << 22, OPT_ABL_DMA = 1 << 23, OPT_ABL_BAR = 1 << 24, OPT_SPREAD = 1 << 25, OPT_DEFAULT = 15 };  // OPT_ABL_*: probe ablations of the ring kernel (results are garbage by design)
 enum : int { ABL_NO_SOFTMAX = 1, ABL_NO_STAGE = 2, ABL_NO_FRAG_READS = 4, ABL_NO_BARRIER = 8 };
 
 // exp2 on the plain VALU (experiment): ubench/overlap.hip shows v_exp_f32 does not overlap with the SIMD partner's
