@@ -103,6 +103,7 @@ CLN_API int cln_hgemm_variant(int kind, int layout, int tile, int bk, int stages
       case 112: return launch_w4<NN, 1, 4, 2>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
       case 113: return launch_w4<NN, 1, 4, 3>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
       case 114: return launch_w4<NN, 1, 4, 4>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+      case 118: return launch_w4<NN, 1, 4, 8>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);   // every DMA piece re-reads one KiB (issue cost without traffic)
       case 117: return launch_w4<NN, 1, 4, 7>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
       default: return CLN_ERR_BAD_ARG;
     }

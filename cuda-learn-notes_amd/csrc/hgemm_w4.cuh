@@ -206,8 +206,10 @@ __global__ __launch_bounds__(256, 1) void hgemm_w4_kernel(const half_t* __restri
   const char* a_old = a_src;  // sources of the tile whose late pieces are still to be issued (one tile behind a_src)
   const char* b_old = b_src;
   auto piece_m0 = [&](int p, unsigned img, bool late, bool set_m0) {
-    const unsigned voff = voff_of(p);
-    const char* src = late ? (p < FM ? a_old : b_old) : (p < FM ? a_src : b_src);
+    // ABL & 8 (probe; garbage results): every piece re-reads the SAME first KiB of A -- the instruction count and the LDS writes of the
+    // real kernel, no L2 / fabric traffic: separates the issue cost of the LDS-DMA instructions from the cost of the bytes they move
+    const unsigned voff = (ABL & 8) ? (unsigned)(lane * 16) : voff_of(p);
+    const char* src = (ABL & 8) ? reinterpret_cast<const char*>(A) : late ? (p < FM ? a_old : b_old) : (p < FM ? a_src : b_src);
     if (set_m0)
       asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\ts_add_u32 m0, m0, 0x1000"
                    :: "v"(voff), "s"(src), "s"(img + (unsigned)(p * 4 + wave) * 1024u) : "memory", "scc", "m0");
