@@ -41,10 +41,11 @@ FaPlan fa2_plan(int family, bool vt, int B, int H, int N, int D, int stages, int
   if (D > max_d) return p.rc = CLN_ERR_UNSUPPORTED, p;  // "headdim not support!"
   const long long bh = (long long)B * H;
   if (family == FAM_SPLIT_KV) {
-    // the split-KV rung: its own kernel (flash_attn_splitkv.cuh); it has no cross-tile prefetch to switch off
+    // the split-KV rung: its own kernel (flash_attn_splitkv.cuh); stages = 1 loads a tile and uses it, stages >= 2 keeps the next
+    // tile's K fragments in flight in a second set of registers (reference kStage of flash_attn_mma_split_kv.cu)
     if ((D != 32 && D != 64 && D != 96 && D != 128) || N % 32 != 0) return p.rc = CLN_ERR_UNSUPPORTED, p;
     if (bh > 65535) return p.rc = CLN_ERR_UNSUPPORTED, p;  // this kernel carries B*H in gridDim.y
-    p.kind = K_SPLITKV, p.d_inst = D, p.nw = 4, p.bc = 128, p.stages_honoured = false;
+    p.kind = K_SPLITKV, p.d_inst = D, p.nw = 4, p.bc = 128, p.one_stage = stages == 1;
     return p;
   }
   const bool small_d = D == 32 || D == 64 || D == 96 || D == 128 || D == 256;
@@ -126,10 +127,10 @@ int fa2_run(const FaPlan& p, const void* q, const void* k, const void* v, void* 
     case K_SPLITKV:
       if constexpr (!VT) {
         switch (D) {
-          case 32: return fa2::launch_splitkv<32>(q, k, v, o, B, H, N, s);
-          case 64: return fa2::launch_splitkv<64>(q, k, v, o, B, H, N, s);
-          case 96: return fa2::launch_splitkv<96>(q, k, v, o, B, H, N, s);
-          case 128: return fa2::launch_splitkv<128>(q, k, v, o, B, H, N, s);
+          case 32: return p.one_stage ? fa2::launch_splitkv<32, false>(q, k, v, o, B, H, N, s) : fa2::launch_splitkv<32, true>(q, k, v, o, B, H, N, s);
+          case 64: return p.one_stage ? fa2::launch_splitkv<64, false>(q, k, v, o, B, H, N, s) : fa2::launch_splitkv<64, true>(q, k, v, o, B, H, N, s);
+          case 96: return p.one_stage ? fa2::launch_splitkv<96, false>(q, k, v, o, B, H, N, s) : fa2::launch_splitkv<96, true>(q, k, v, o, B, H, N, s);
+          case 128: return p.one_stage ? fa2::launch_splitkv<128, false>(q, k, v, o, B, H, N, s) : fa2::launch_splitkv<128, true>(q, k, v, o, B, H, N, s);
         }
       }
       return CLN_ERR_UNSUPPORTED;
@@ -202,8 +203,8 @@ int fa2_describe(int family, bool vt, int B, int H, int N, int D, int stages, in
   const char* vts = vt ? ",V^T" : "";
   switch (p.kind) {
     case K_SPLITKV:
-      return snprintf(buf, len, "fa2_fwd_splitkv<D=%d> 4 waves share 32 rows, 128-key tiles split over the waves, "
-                                "cross-wave max via LDS%s", D, st);
+      return snprintf(buf, len, "fa2_fwd_splitkv<D=%d,%s> 4 waves share 32 rows, 128-key tiles split over the waves, "
+                                "cross-wave max via LDS", D, p.one_stage ? "load-then-compute" : "next K fragments prefetched into registers");
     case K_LOAD_THEN_COMPUTE:
       return snprintf(buf, len, "fa2_fwd<D=%d,BC=64,load-then-compute%s> 4 waves x 32 rows", D, vts);
     case K_V2:

@@ -38,7 +38,9 @@ struct GeoSplitKV {
   static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
-template <int D>
+// PREFETCH (the `stages = 2` form; reference kStage, flash_attn_mma_split_kv.cu template parameter): the K fragments of tile j + 1 are
+// loaded into a second set of registers while tile j is computed; `stages = 1` loads a tile, waits, then uses it.
+template <int D, bool PREFETCH = false>
 __global__ __launch_bounds__(256) void fa2_fwd_splitkv_kernel(const half_t* __restrict__ Q, const half_t* __restrict__ K,
                                                              const half_t* __restrict__ V, half_t* __restrict__ O,
                                                              int N, float scale_log2e) {
@@ -69,6 +71,28 @@ __global__ __launch_bounds__(256) void fa2_fwd_splitkv_kernel(const half_t* __re
   float m_run = -INFINITY, l_run = 0.f;
 
   const int T = (N + G::BC - 1) / G::BC;
+  // this wave's V rows of a tile -> registers (idx = lane + 64 u: row idx / (D/8), 16-byte chunk idx % (D/8)), its K fragments
+  // straight from global: lane (key = l31) reads d = 16*ks + 8*hi .. +7
+  auto load_v = [&](int key0, u4 (&vreg)[D / 16]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < D / 16; ++u) {
+      const int idx = lane + u * 64, row = idx / (D / 8), ch = idx % (D / 8);
+      vreg[u] = *reinterpret_cast<const u4*>(Vh + (size_t)(key0 + row) * D + ch * 8);
+    }
+  };
+  auto load_k = [&](int key0, h8 (&kf)[D / 16]) __attribute__((always_inline)) {
+    const half_t* kp = Kh + (size_t)(key0 + l31) * D + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < D / 16; ++ks) kf[ks] = *reinterpret_cast<const h8*>(kp + ks * 16);
+  };
+  // PREFETCH keeps the NEXT tile's K fragments in flight in a second register set (they are what the first MFMA of a tile waits
+  // for); the V rows are loaded at the top of their own tile and fly under its QK^T MFMAs in both forms. (Prefetching V as well costs a
+  // third of the occupancy at D = 64 -- 144 -> 180 registers -- and measured 6 % slower than no prefetch.)
+  h8 kf_cur[D / 16], kf_nxt[PREFETCH ? D / 16 : 1];
+  u4 v_cur[D / 16];
+  if constexpr (PREFETCH) {
+    if (wave * 32 < N) load_k(wave * 32, kf_cur);
+  }
   for (int j = 0; j < T; ++j) {
     const int key0 = j * G::BC + wave * 32;
     const bool active = key0 < N;  // wave-uniform; N % 32 == 0
@@ -77,25 +101,23 @@ __global__ __launch_bounds__(256) void fa2_fwd_splitkv_kernel(const half_t* __re
     for (int r = 0; r < 16; ++r) s[r] = 0.f;
     float mx = -INFINITY;
     if (active) {
-      // ---- this wave's V rows -> wave-private LDS image (issued first: the loads fly under the QK^T MFMAs)
-      u4 vreg[D / 16];
-#pragma unroll
-      for (int u = 0; u < D / 16; ++u) {
-        const int idx = lane + u * 64, row = idx / (D / 8), ch = idx % (D / 8);
-        vreg[u] = *reinterpret_cast<const u4*>(Vh + (size_t)(key0 + row) * D + ch * 8);
+      load_v(key0, v_cur);  // issued first: the loads fly under the QK^T MFMAs
+      if constexpr (PREFETCH) {
+        if (key0 + G::BC < N) load_k(key0 + G::BC, kf_nxt);
+      } else {
+        load_k(key0, kf_cur);
       }
-      // ---- S^T block = K_w Q^T, K fragments straight from global: lane (key = l31) reads d = 16*ks + 8*hi .. +7
-      const half_t* kp = Kh + (size_t)(key0 + l31) * D + hi * 8;
+      // ---- S^T block = K_w Q^T
 #pragma unroll
       for (int ks = 0; ks < D / 16; ++ks) {
-        const h8 kf = *reinterpret_cast<const h8*>(kp + ks * 16);
-        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s, 0, 0, 0);
-        cln_mfma_keep(s, kf, qf[ks]);  // destination disjoint from the operands (common.h)
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf_cur[ks], qf[ks], s, 0, 0, 0);
+        cln_mfma_keep(s, kf_cur[ks], qf[ks]);  // destination disjoint from the operands (common.h)
       }
+      // ---- this wave's V rows -> wave-private LDS image
 #pragma unroll
       for (int u = 0; u < D / 16; ++u) {
         const int idx = lane + u * 64, row = idx / (D / 8), ch = idx % (D / 8);
-        *reinterpret_cast<u4*>(v_lds + row * G::VS + ch * 16) = vreg[u];
+        *reinterpret_cast<u4*>(v_lds + row * G::VS + ch * 16) = v_cur[u];
       }
       mx = s[0];
 #pragma unroll
@@ -141,6 +163,10 @@ __global__ __launch_bounds__(256) void fa2_fwd_splitkv_kernel(const half_t* __re
         }
       }
     }
+    if constexpr (PREFETCH) {
+#pragma unroll
+      for (int u = 0; u < D / 16; ++u) kf_cur[u] = kf_nxt[u];
+    }
   }
 
   // ---- epilogue: O = (sum over waves of O^T_w) / (sum over waves and lane halves of l_w)
@@ -179,16 +205,16 @@ __global__ __launch_bounds__(256) void fa2_fwd_splitkv_kernel(const half_t* __re
   }
 }
 
-template <int D>
+template <int D, bool PREFETCH = false>
 int launch_splitkv(const void* q, const void* k, const void* v, void* o, int B, int H, int N, hipStream_t stream) {
   using G = GeoSplitKV<D>;
   if (N % 32 != 0) return CLN_ERR_UNSUPPORTED;
   static cln_lds_attr lds_attr;  // per device, thread-safe (common.h)
   if (G::LDS_BYTES > 48 * 1024 &&
-      cln_ensure_lds(lds_attr, reinterpret_cast<const void*>(&fa2_fwd_splitkv_kernel<D>), G::LDS_BYTES) != CLN_OK)
+      cln_ensure_lds(lds_attr, reinterpret_cast<const void*>(&fa2_fwd_splitkv_kernel<D, PREFETCH>), G::LDS_BYTES) != CLN_OK)
     return CLN_ERR_LAUNCH;
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)D);
-  CLN_LAUNCH((fa2_fwd_splitkv_kernel<D>), dim3(N / G::BR, B * H), dim3(G::NT), G::LDS_BYTES, stream,
+  CLN_LAUNCH((fa2_fwd_splitkv_kernel<D, PREFETCH>), dim3(N / G::BR, B * H), dim3(G::NT), G::LDS_BYTES, stream,
              (const half_t*)q, (const half_t*)k, (const half_t*)v, (half_t*)o, N, scale_log2e);
   return cln_check_launch();
 }

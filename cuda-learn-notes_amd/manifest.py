@@ -316,7 +316,9 @@ DISPATCH_EXAMPLES = [
     ("hgemm_wmma_m16n16k16_mma4x2_warp4x4_stages_dsmem", (4096, 4096, 256), 2, "mfma_ring<256x128x64,8 waves,stages=2,NN>"),
     # flash-attn: config C4, its small-grid and D = 128 siblings, the stages knob, config C5 and the padded head dims
     ("flash_attn_mma_stages_split_kv", (4, 8, 2048, 64), 2,
-     "fa2_fwd_splitkv<D=64> 4 waves share 32 rows, 128-key tiles split over the waves, cross-wave max via LDS" + _IGN),
+     "fa2_fwd_splitkv<D=64,next K fragments prefetched into registers> 4 waves share 32 rows, 128-key tiles split over the waves, cross-wave max via LDS"),
+    ("flash_attn_mma_stages_split_kv", (4, 8, 2048, 64), 1,
+     "fa2_fwd_splitkv<D=64,load-then-compute> 4 waves share 32 rows, 128-key tiles split over the waves, cross-wave max via LDS"),
     (_SQKV, (4, 8, 2048, 64), 1, "fa2_fwd<D=64,BC=64,load-then-compute> 4 waves x 32 rows"),
     (_SQKV, (4, 8, 2048, 64), 2, "fa2_fwd_m16x<D=64,BC=128,16x16x32 MFMA,pre-scaled Q,sum-checked softmax> 8 waves x 32 rows, two groups one phase apart"),
     (_SQKV, (1, 48, 8192, 64), 2, "fa2_fwd_m16x64r<D=64,BC=64,16x16x32 MFMA,pre-scaled Q,sum-checked softmax> 8 waves x 64 rows, two groups one phase apart, K/V fragments shared by 4 query blocks"),

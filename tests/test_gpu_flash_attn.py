@@ -355,9 +355,17 @@ def test_split_kv_rung(fa, built, dev, oracle, D, B, H, N):
     tail after 16 full tiles; every row vs the fp64 oracle, both `stages` values."""
     q, k, v = seeded(81, B, H, N, D), seeded(82, B, H, N, D), seeded(83, B, H, N, D)
     ref = oracle.attention_fp64(q, k, v)
+    outs = {}
     for stages in (1, 2):
         o = run(fa, built, "flash_attn_mma_stages_split_kv", q, k, v, stages, dev)
         assert (o.double() - ref).abs().max().item() <= TOL, stages
+        outs[stages] = o
+    # stages = 1 loads a tile and uses it, stages = 2 keeps the next tile in flight in registers: different kernels
+    # (cln_describe says so), the same arithmetic in the same order
+    d1 = built.manifest.describe("flash_attn_mma_stages_split_kv", (B, H, N, D), 1)
+    d2 = built.manifest.describe("flash_attn_mma_stages_split_kv", (B, H, N, D), 2)
+    assert "load-then-compute" in d1 and "prefetched" in d2 and "stages ignored" not in d1 + d2
+    assert torch.equal(outs[1], outs[2])
 
 
 def test_split_kv_rung_rescale_and_uniform(fa, built, dev, oracle):
