@@ -35,7 +35,11 @@ def smi():
 
 
 w4 = lambda v, x=None, y=None, lay=0: (lambda: host.hgemm_variant(14, lay, 1, 64, v, x if x is not None else a, y if y is not None else (bt if lay else b), c, 1, 2048))
-cands = [("w4 v4 NN", w4(4)), ("w4 v4 snake", w4(20)), ("w4 v4 B-major", w4(36)), ("w4 v4 B-major snake", w4(52)),
+if os.environ.get("CLK_CSTORE"):  # the C-store forms of the production schedule: plain (26), non-temporal (203 = what ships), write-through (204)
+    cands = [("w4 26 plain C stores NN", w4(26)), ("w4 26 nt C stores NN", w4(203)), ("w4 26 sc0sc1 C stores NN", w4(204)),
+             ("w4 26 plain C stores TN", w4(26, lay=1)), ("w4 26 nt C stores TN", w4(203, lay=1)), ("rocblas TN", lambda: hg.hgemm_cublas_tensor_op_tn(a, bt, c))]
+else:
+  cands = [("w4 v4 NN", w4(4)), ("w4 v4 snake", w4(20)), ("w4 v4 B-major", w4(36)), ("w4 v4 B-major snake", w4(52)),
          ("w4 v4 TN", w4(4, lay=1)), ("w4 v4 TN snake", w4(20, lay=1)), ("w4 v4 TN B-major", w4(36, lay=1)), ("w4 v4 TN B-major snake", w4(52, lay=1)),
          ("w4 mfma-only", w4(117)), ("w4 mfma-only snake", w4(120)), ("w4 mfma-only B-major", w4(136)), ("w4 mfma-only B-m snake", w4(152)),
          ("rocblas TN", lambda: hg.hgemm_cublas_tensor_op_tn(a, bt, c)),
