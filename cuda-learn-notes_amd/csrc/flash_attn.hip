@@ -56,7 +56,7 @@ FaPlan fa2_plan(int family, bool vt, int B, int H, int N, int D, int stages, int
   }
   p.stages_honoured = stages != 1;
   if (small_d) {
-    if (!vt && D == 64 && N % 512 == 0) {
+    if (D == 64 && N % 512 == 0) {  // (both V layouts)
       // >= 512 query rows per CU, in (nearly) whole rounds of 256 workgroups: 64 query rows per wave -- every K / V fragment
       // feeds four 16x16x32 MFMAs (flash_attn_m16x.cuh with RPW = 64, 64-key tiles; round 2 ran the 32x32x16 form of
       // flash_attn_dsplit2.cuh here): [1,48,8192,64] 1063 -> 1138 TF, [2,32,4096,64] 1032 -> 1094, [1,16,16384,64] 1076 -> 1152
@@ -64,7 +64,7 @@ FaPlan fa2_plan(int family, bool vt, int B, int H, int N, int D, int stages, int
       const long long wgs = bh * (N / 512), rounds = (wgs + 255) / 256;
       if (wgs >= 256 && wgs * 100 >= rounds * 256 * 88) return p.kind = K_M16X64R, p.d_inst = 64, p.nw = 8, p.bc = 64, p;
     }
-    if (!vt && N % 256 == 0 && bh * (N / 256) >= 192) {
+    if ((!vt || D == 64 || D == 128) && N % 256 == 0 && bh * (N / 256) >= 192) {  // D = 256: non-transposed V only
       // enough 256-row workgroups to occupy most of the chip:
       //  D = 64 / 128: ping-pong kernel on 16x16x32 MFMAs (the energy-cheaper matrix shape, +3.5-5 % at D = 64 and
       //                +5.5-6.5 % at D = 128 over the 32x32x16 form of flash_attn_dsplit.cuh, profiles/r02_fa_m16_probe.log)
@@ -147,7 +147,7 @@ int fa2_run(const FaPlan& p, const void* q, const void* k, const void* v, void* 
 #define FA_V2(DD, OPTT, HAS8)                                                                          \
   case DD:                                                                                             \
     if (p.nw == 8) {                                                                                   \
-      if constexpr (HAS8 || VT) return fa2::launch_v2<DD, 8, VT, OPTT>(q, k, v, o, B, H, N, s);       \
+      if constexpr (HAS8) return fa2::launch_v2<DD, 8, VT, OPTT>(q, k, v, o, B, H, N, s);             \
       else return CLN_ERR_UNSUPPORTED; /* the plan never names it: these shapes run fa2_fwd_m16x */   \
     }                                                                                                  \
     if (p.nw == 4) return fa2::launch_v2<DD, 4, VT, OPTT>(q, k, v, o, B, H, N, s);                     \
@@ -162,11 +162,10 @@ int fa2_run(const FaPlan& p, const void* q, const void* k, const void* v, void* 
 #undef FA_V2
       return CLN_ERR_UNSUPPORTED;
     case K_M16X64R:
-      if constexpr (!VT) return fa2::m16x_run(64, 64, q, k, v, o, B, H, N, s);
-      return CLN_ERR_UNSUPPORTED;
+      return fa2::m16x_run(64, 64, VT, q, k, v, o, B, H, N, s);
     case K_M16:
+      if (D == 64 || D == 128) return fa2::m16x_run(D, 32, VT, q, k, v, o, B, H, N, s);  // 128-key tiles; own compile unit
       if constexpr (!VT) {
-        if (D == 64 || D == 128) return fa2::m16x_run(D, 32, q, k, v, o, B, H, N, s);  // 128-key tiles; own compile unit
         if (D == 256) return fa2::launch_m16_pair<2, false, false>(q, k, v, o, B, H, N, s);
         if (D == 512) return p.one_stage ? fa2::launch_m16_pair<2, true, false, 131072>(q, k, v, o, B, H, N, s)
                                          : fa2::launch_m16_pair<2, true, false>(q, k, v, o, B, H, N, s);
@@ -211,12 +210,12 @@ int fa2_describe(int family, bool vt, int B, int H, int N, int D, int stages, in
       return snprintf(buf, len, "fa2_fwd_v2<D=%d,NW=%d,BC=64,prefetch%s%s> %d waves x 32 rows%s", D, p.nw,
                       D <= 128 ? ",pre-scaled Q" : "", vts, p.nw, st);
     case K_M16X64R:
-      return snprintf(buf, len, "fa2_fwd_m16x64r<D=64,BC=64,16x16x32 MFMA,pre-scaled Q,sum-checked softmax> 8 waves x 64 rows, two groups one "
-                                "phase apart, K/V fragments shared by 4 query blocks%s", st);
+      return snprintf(buf, len, "fa2_fwd_m16x64r<D=64,BC=64,16x16x32 MFMA,pre-scaled Q,sum-checked softmax%s> 8 waves x 64 rows, two groups one "
+                                "phase apart, K/V fragments shared by 4 query blocks%s", vts, st);
     case K_M16:
       if (D <= 128)
-        return snprintf(buf, len, "fa2_fwd_m16x<D=%d,BC=%d,16x16x32 MFMA,pre-scaled Q,sum-checked softmax> 8 waves x 32 rows, two groups "
-                                  "one phase apart%s", D, p.bc, st);
+        return snprintf(buf, len, "fa2_fwd_m16x<D=%d,BC=%d,16x16x32 MFMA,pre-scaled Q,sum-checked softmax%s> 8 waves x 32 rows, two groups "
+                                  "one phase apart%s", D, p.bc, vts, st);
       if (D == 512)
         return snprintf(buf, len, "fa2_fwd_m16<D=512,BC=32,16x16x32 MFMA,pairs of waves split d> 8 waves, 128 rows, two groups one phase apart%s", st);
       return snprintf(buf, len, "fa2_fwd_m16<D=%d,BC=%d,16x16x32 MFMA> 8 waves x 32 rows, two groups one phase apart%s", D, p.bc, st);

@@ -28,7 +28,7 @@ namespace fa2 {
 
 enum : int { M16X_PRIO = 1, M16X_PRIO_B = 2, M16X_SPLIT_PROLOGUE = 4, M16X_PRIO_STATIC = 8, M16X_NT_STORE = 16 };  // 8: s_setprio 1 once for the second-dispatched group, no flips
 
-template <int D_, int RPW_, int BC_, int PD = 4, int NDEF = 1, int OX = 0>
+template <int D_, int RPW_, int BC_, int PD = 4, int NDEF = 1, int OX = 0, bool VT = false>
 __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __restrict__ Q, const half_t* __restrict__ K,
                                                               const half_t* __restrict__ V, half_t* __restrict__ O,
                                                               int N, int n_qblk, int n_heads, float scale_log2e) {
@@ -62,13 +62,20 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
   const int q_row0 = qb_i * G::BR + wave * G::RPW;
   const unsigned lds0 = hgemm::lds_addr_of(smem);
 
+  // VT (the three *_swizzle_qkv names that take V as [B,H,D,N], reference flash_attn_mma_share_qkv.cu swizzle_qkv form): the V image of a
+  // tile is D rows (one per d) of BC keys = RV bytes; a row is contiguous in memory, rows are N * 2 bytes apart. Chunk swizzle by row as
+  // the K image of the same row length: row & 15 (256-byte rows), (row >> 1) & 7 (128-byte rows).
+  constexpr int RV = G::BC * 2, CPRV = RV / 16, RPPV = 1024 / RV;
+  auto swz_vt = [](int row) { return RV == 128 ? (row >> 1) & 7 : row & 15; };
   const char* src_h = reinterpret_cast<const char*>((grp == 0 ? K : V) + head);
-  const int lr = lane / G::CPR, lc = lane % G::CPR;
-  const int sw_src = grp == 0 ? G::swz_k(widx * G::RPP + lr) : G::swz_v(widx * G::RPP + lr);
-  const unsigned src_lane = (unsigned)(lr * G::ROW) + (unsigned)((lc ^ sw_src) << 4);
+  const bool vt_loader = VT && grp == 1;
+  const int lr = vt_loader ? lane / CPRV : lane / G::CPR, lc = vt_loader ? lane % CPRV : lane % G::CPR;
+  const int sw_src = grp == 0 ? G::swz_k(widx * G::RPP + lr) : VT ? swz_vt(widx * RPPV + lr) : G::swz_v(widx * G::RPP + lr);
+  const unsigned src_lane = vt_loader ? (unsigned)lr * (unsigned)N * 2u + (unsigned)((lc ^ sw_src) << 4)
+                                      : (unsigned)(lr * G::ROW) + (unsigned)((lc ^ sw_src) << 4);
   auto dma_piece = [&](int jt, int slot, int i) __attribute__((always_inline)) {
     const int piece = i * 4 + widx;
-    const char* s = src_h + (size_t)jt * G::TILE + piece * 1024;
+    const char* s = vt_loader ? src_h + (size_t)jt * RV + (size_t)(piece * RPPV) * (size_t)N * 2u : src_h + (size_t)jt * G::TILE + piece * 1024;
     hgemm::glds16_asm(s, src_lane, lds0 + slot * G::STAGE + grp * G::TILE + piece * 1024);
   };
 
@@ -135,7 +142,8 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
 
   const int kbase = i16 * G::ROW + ((g4 ^ G::swz_k(i16)) << 4);
   const int v_row = 4 * g4 + (i16 >> 2);
-  const int vbase = v_row * G::ROW + (((((i16 & 3) >> 1)) ^ G::swz_v(v_row)) << 4) + ((i16 & 1) << 3);
+  const int vbase = VT ? i16 * RV + (((swz_vt(i16)) ^ (g4 >> 1)) << 4) + ((g4 & 1) << 3)  // V^T image: row = d, keys 4 g4 .. of a 32-key step
+                       : v_row * G::ROW + (((((i16 & 3) >> 1)) ^ G::swz_v(v_row)) << 4) + ((i16 & 1) << 3);
 
   if constexpr ((OX & M16X_PRIO_STATIC) != 0) {
     if (grp == 1) __builtin_amdgcn_s_setprio(1);
@@ -154,8 +162,15 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
     };
     auto v_frag = [&](int idx) __attribute__((always_inline)) {
       const int u = idx / NDB, db = idx % NDB;
-      const char* vp = smem + (vb_j ^ (db << 5)) + (32 * u) * G::ROW;
-      return h8_cat(lds_read_tr16(vp), lds_read_tr16(vp + 16 * G::ROW));
+      if constexpr (VT) {
+        // A operand row = d = 16 db + i16; k-slots 8 g4 .. + 7 = keys 32u + 4 g4 .. + 3 and 32u + 16 + 4 g4 .. + 3 (the order the P
+        // registers have): two plain 8-byte reads 32 bytes apart in the row (chunks 4u + g4/2 and + 2, swizzled by the row)
+        const char* vp = smem + (vb_j ^ ((4 * u) << 4)) + (16 * db) * RV;
+        return h8_cat(*reinterpret_cast<const h4*>(vp), *reinterpret_cast<const h4*>(smem + ((vb_j ^ ((4 * u + 2) << 4)) + (16 * db) * RV)));
+      } else {
+        const char* vp = smem + (vb_j ^ (db << 5)) + (32 * u) * G::ROW;
+        return h8_cat(lds_read_tr16(vp), lds_read_tr16(vp + 16 * G::ROW));
+      }
     };
     f4 s[NKB][NQB];
     h8 pf[NU][NQB];
@@ -326,15 +341,15 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
   }
 }
 
-template <int D_, int RPW_, int BC_, int PD = 4, int NDEF = 1, int OX = 0>
+template <int D_, int RPW_, int BC_, int PD = 4, int NDEF = 1, int OX = 0, bool VT = false>
 int launch_m16x(const void* q, const void* k, const void* v, void* o, int B, int H, int N, hipStream_t stream) {
   using G = GeoM16<D_, RPW_, BC_>;
   if (N % G::BR != 0) return CLN_ERR_UNSUPPORTED;
   static cln_lds_attr lds_attr;  // per device, thread-safe (common.h)
-  if (cln_ensure_lds(lds_attr, reinterpret_cast<const void*>(&fa2_fwd_m16x_kernel<D_, RPW_, BC_, PD, NDEF, OX>), G::LDS_BYTES) != CLN_OK) return CLN_ERR_LAUNCH;
+  if (cln_ensure_lds(lds_attr, reinterpret_cast<const void*>(&fa2_fwd_m16x_kernel<D_, RPW_, BC_, PD, NDEF, OX, VT>), G::LDS_BYTES) != CLN_OK) return CLN_ERR_LAUNCH;
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)G::D);
   const int n_qblk = N / G::BR;
-  CLN_LAUNCH((fa2_fwd_m16x_kernel<D_, RPW_, BC_, PD, NDEF, OX>), dim3(n_qblk * B * H), dim3(G::NT), G::LDS_BYTES, stream,
+  CLN_LAUNCH((fa2_fwd_m16x_kernel<D_, RPW_, BC_, PD, NDEF, OX, VT>), dim3(n_qblk * B * H), dim3(G::NT), G::LDS_BYTES, stream,
              (const half_t*)q, (const half_t*)k, (const half_t*)v, (half_t*)o, N, n_qblk, B * H, scale_log2e);
   return cln_check_launch();
 }

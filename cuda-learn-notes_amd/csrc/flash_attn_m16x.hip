@@ -11,10 +11,17 @@ namespace fa2 {
 // The dispatched forms (fa2_plan, flash_attn.hip). 32 rows per wave (256-row workgroups, 128-key tiles): NDEF = 4 (half of the
 // exponentials under the PV MFMAs), phase-A priority, split prologue -- the best of profiles/r03_fa_m16x_probe.log at both head
 // dims. 64 rows per wave (D = 64, 512-row workgroups, 64-key tiles; long sequences): NDEF = 1 of the 4 key blocks.
-int m16x_run(int D, int rows_per_wave, const void* q, const void* k, const void* v, void* o, int B, int H, int N, hipStream_t s) {
-  if (D == 64 && rows_per_wave == 32) return launch_m16x<64, 32, 128, 8, 4, M16X_PRIO | M16X_SPLIT_PROLOGUE>(q, k, v, o, B, H, N, s);
-  if (D == 128 && rows_per_wave == 32) return launch_m16x<128, 32, 128, 4, 4, M16X_PRIO | M16X_SPLIT_PROLOGUE>(q, k, v, o, B, H, N, s);
-  if (D == 64 && rows_per_wave == 64) return launch_m16x<64, 64, 64, 4, 1, M16X_PRIO | M16X_SPLIT_PROLOGUE>(q, k, v, o, B, H, N, s);
+int m16x_run(int D, int rows_per_wave, bool vt, const void* q, const void* k, const void* v, void* o, int B, int H, int N, hipStream_t s) {
+  constexpr int OX = M16X_PRIO | M16X_SPLIT_PROLOGUE;
+  if (!vt) {
+    if (D == 64 && rows_per_wave == 32) return launch_m16x<64, 32, 128, 8, 4, OX>(q, k, v, o, B, H, N, s);
+    if (D == 128 && rows_per_wave == 32) return launch_m16x<128, 32, 128, 4, 4, OX>(q, k, v, o, B, H, N, s);
+    if (D == 64 && rows_per_wave == 64) return launch_m16x<64, 64, 64, 4, 1, OX>(q, k, v, o, B, H, N, s);
+  } else {  // V given as [B,H,D,N] (the three *_swizzle_qkv names): the same kernels with the V^T tile image and plain 8-byte fragment reads
+    if (D == 64 && rows_per_wave == 32) return launch_m16x<64, 32, 128, 8, 4, OX, true>(q, k, v, o, B, H, N, s);
+    if (D == 128 && rows_per_wave == 32) return launch_m16x<128, 32, 128, 4, 4, OX, true>(q, k, v, o, B, H, N, s);
+    if (D == 64 && rows_per_wave == 64) return launch_m16x<64, 64, 64, 4, 1, OX, true>(q, k, v, o, B, H, N, s);
+  }
   return CLN_ERR_UNSUPPORTED;
 }
 

@@ -113,7 +113,7 @@ _FA_SPLIT_Q_IMPL = ("planner fa2_plan(shape, stages) [csrc/flash_attn.hip]: stag
 _add("flash_attn", "FA", "fa2_fwd_splitkv<D<=128>: 4 waves share 32 query rows, KV tile split over the waves, cross-wave "
      "row max through LDS (the structurally distinct split-KV rung)", "flash_attn_mma_stages_split_kv")
 _add("flash_attn", "FA", _FA_SPLIT_Q_IMPL, *[n for n in _FA_PLAIN if n != "flash_attn_mma_stages_split_kv"])
-_add("flash_attn", "FA", "planner as above with V transposed [B,H,D,N]: fa2_fwd<load-then-compute,V^T> | fa2_fwd_v2<V^T>",
+_add("flash_attn", "FA", "planner as above with V transposed [B,H,D,N]: fa2_fwd<load-then-compute,V^T> | fa2_fwd_m16x<D=64|128,V^T> / fa2_fwd_m16x64r<V^T> | fa2_fwd_v2<V^T>",
      *_FA_VT)
 
 # max head dim per function (reference flash_attn_mma.py:436-506; C side enforces the same)
@@ -328,7 +328,8 @@ DISPATCH_EXAMPLES = [
     (_SQKV, (2, 8, 2048, 64), 2, "fa2_fwd_v2<D=64,NW=4,BC=64,prefetch,pre-scaled Q> 4 waves x 32 rows"),
     (_SQKV, (1, 2, 256, 64), 2, "fa2_fwd_v2<D=64,NW=2,BC=64,prefetch,pre-scaled Q> 2 waves x 32 rows"),
     (_SQKV, (1, 2, 192, 64), 1, "fa2_fwd_v2<D=64,NW=2,BC=64,prefetch,pre-scaled Q> 2 waves x 32 rows" + _IGN),
-    (_SQKV + "_swizzle_qkv", (4, 8, 2048, 128), 2, "fa2_fwd_v2<D=128,NW=8,BC=64,prefetch,pre-scaled Q,V^T> 8 waves x 32 rows"),
+    (_SQKV + "_swizzle_qkv", (4, 8, 2048, 128), 2, "fa2_fwd_m16x<D=128,BC=128,16x16x32 MFMA,pre-scaled Q,sum-checked softmax,V^T> 8 waves x 32 rows, two groups one phase apart"),
+    (_SQKV + "_swizzle_qkv", (2, 8, 2048, 128), 2, "fa2_fwd_v2<D=128,NW=4,BC=64,prefetch,pre-scaled Q,V^T> 4 waves x 32 rows"),  # small grid: the v2 kernel
     (_SQKV + "_swizzle_qkv", (4, 8, 2048, 128), 1, "fa2_fwd<D=128,BC=64,load-then-compute,V^T> 4 waves x 32 rows"),
     (_TQKV, (1, 32, 4096, 512), 2, "fa2_fwd_m16<D=512,BC=32,16x16x32 MFMA,pairs of waves split d> 8 waves, 128 rows, two groups one phase apart"),
     (_TQKV, (1, 16, 4096, 384), 2, "fa2_fwd_dsplit<D=384,NSP=2,BC=32,LDS geometry of D=512> 8 waves, pairs split the real d evenly"),

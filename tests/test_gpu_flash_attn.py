@@ -649,3 +649,25 @@ def test_ck_tile_fmha_comparator_row_is_a_correct_attention(built, dev, oracle, 
     with pytest.raises(RuntimeError):
         ck(q64, q64, q64, torch.zeros_like(q64), 3)  # the v3 kernel exists for D = 128 only
 
+
+
+@pytest.mark.parametrize("B,H,N,D", [(2, 96, 256, 64), (1, 48, 1024, 64), (2, 96, 256, 128), (1, 48, 1024, 128), (4, 64, 512, 64), (1, 64, 2048, 64)])
+def test_transposed_v_names_on_the_sum_checked_kernel(fa, built, dev, oracle, B, H, N, D):
+    """The three *_swizzle_qkv names that take V as [B,H,D,N] run the V^T form of fa2_fwd_m16x / fa2_fwd_m16x64r when the grid fills
+    the chip (round 3; the 8-wave v2 kernel before): V^T tile image with the row swizzle of the K image, plain 8-byte fragment
+    reads in the P registers' key order. Same arithmetic in the same order as the [B,H,N,D] form -> bit-identical to it; rows
+    vs the fp64 oracle on a few heads; a late dominant key (the cold path) and an early spike."""
+    vt_name, name = "flash_attn_mma_stages_split_q_shared_qkv_swizzle_qkv", "flash_attn_mma_stages_split_q_shared_qkv"
+    d_vt, d_pl = built.manifest.describe(vt_name, (B, H, N, D), 2), built.manifest.describe(name, (B, H, N, D), 2)
+    assert d_vt.startswith(("fa2_fwd_m16x<", "fa2_fwd_m16x64r<")) and "V^T" in d_vt and d_vt.replace(",V^T", "") == d_pl, (d_vt, d_pl)
+    q, k, v = seeded(301 + N, B, H, N, D), seeded(302 + N, B, H, N, D), seeded(303 + N, B, H, N, D)
+    k[0, 0, N - 3] = q[0, 0, 5] * 3.0
+    k[0, H - 1, 2] = q[0, H - 1, 20] * 4.0
+    o_vt = run(fa, built, vt_name, q, k, v, 2, dev)
+    o_pl = run(fa, built, name, q, k, v, 2, dev)
+    assert torch.equal(o_vt, o_pl)
+    for (b, h) in ((0, 0), (0, H - 1), (B - 1, H // 2)):
+        ref = oracle.attention_fp64(q[b:b + 1, h:h + 1], k[b:b + 1, h:h + 1], v[b:b + 1, h:h + 1])
+        assert (o_vt[b:b + 1, h:h + 1].double() - ref).abs().max().item() <= TOL_AMPLIFIED_KEYS, (b, h)
+    for other in ("flash_attn_mma_stages_split_q_shared_kv_swizzle_qkv", "flash_attn_mma_stages_split_q_tiling_qk_swizzle_qkv"):
+        assert torch.equal(run(fa, built, other, q, k, v, 2, dev), o_vt), other

@@ -49,9 +49,9 @@ def test_attention_kernels_in_the_product_library_are_exactly_the_plannable_ones
             # fragment depth 2, scores scaled in fp32, no debug bits (131072 = the single-stage form `stages = 1` selects at D = 512)
             assert a in (["2", "false", "false", "0"], ["2", "true", "false", "0"], ["2", "true", "false", "131072"]), a
             linked.add(("fa2_fwd_m16", 512 if a[1] == "true" else 256))
-        elif f == "fa2_fwd_m16x_kernel" and a[1] == "64":
-            linked.add(("fa2_fwd_m16x64r", int(a[0])))
-        elif f in ("fa2_fwd_m16x_kernel", "fa2_fwd_dring_kernel", "fa2_fwd_splitkv_kernel"):
+        elif f == "fa2_fwd_m16x_kernel":  # 7th argument: V given transposed ([B,H,D,N], the *_swizzle_qkv names)
+            linked.add(("fa2_fwd_m16x64r" if a[1] == "64" else "fa2_fwd_m16x", int(a[0]), a[6] == "true"))
+        elif f in ("fa2_fwd_dring_kernel", "fa2_fwd_splitkv_kernel"):
             linked.add((f[:-len("_kernel")], int(a[0])))
         else:
             raise AssertionError("attention kernel family the planner does not know: %s<%s>" % (fam, ", ".join(a)))
@@ -74,6 +74,9 @@ def test_attention_kernels_in_the_product_library_are_exactly_the_plannable_ones
                             plannable.add((fam, d, vt))
                         elif fam == "fa2_fwd_v2":
                             plannable.add((fam, d, int(re.search(r"NW=(\d+)", t).group(1)), vt))
+                        elif fam in ("fa2_fwd_m16x", "fa2_fwd_m16x64r"):
+                            assert ("V^T" in t) == vt, t
+                            plannable.add((fam, d, vt))
                         else:
                             assert not vt, t
                             plannable.add((fam, d))
