@@ -20,7 +20,7 @@ pmc() {  # name, counters..., then "--", then target args
   local name=$1; shift; local ctrs=(); while [ "$1" != "--" ]; do ctrs+=("$1"); shift; done; shift
   rocprofv3 --kernel-trace --output-format csv --pmc "${ctrs[@]}" -d $OUT/pmc_$name -o pmc -- python $T/prof_target.py "$@" > $OUT/pmc_$name.log 2>&1
 }
-HG="hgemm 14 0 1 64 26 4096 12"  # kind 14, schedule 26 = the production one-wave-per-SIMD kernel (csrc/hgemm.hip W4_PRODUCTION)
+HG="hgemm 14 0 1 64 203 4096 12"  # kind 14, variant 203 = production schedule 26 with the production epilogue 3 (non-temporal C stores; csrc/hgemm.hip W4_PRODUCTION, W4_EPILOGUE)
 pmc hg_fetch FETCH_SIZE -- $HG
 pmc hg_write WRITE_SIZE -- $HG
 pmc hg_sq SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE -- $HG
