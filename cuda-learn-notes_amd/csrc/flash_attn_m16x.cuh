@@ -26,7 +26,12 @@
 
 namespace fa2 {
 
-enum : int { M16X_PRIO = 1, M16X_PRIO_B = 2, M16X_SPLIT_PROLOGUE = 4, M16X_PRIO_STATIC = 8, M16X_NT_STORE = 16 };  // 8: s_setprio 1 once for the second-dispatched group, no flips
+enum : int { M16X_PRIO = 1, M16X_PRIO_B = 2, M16X_SPLIT_PROLOGUE = 4, M16X_PRIO_STATIC = 8, M16X_NT_STORE = 16,
+              // probe ablations (results are garbage by design): no K fragment reads, no V fragment reads, no exponentials, no LDS-DMA after the prologue
+              M16X_ABL_K = 32, M16X_ABL_V = 64, M16X_ABL_EXP = 128, M16X_ABL_DMA = 256,
+              // QK^T steps of TWO key blocks interleaved (kb, kb+1 at k-step 0, then both at k-step 1): a dependent MFMA on one accumulator
+              // then sits 2 * NQB MFMAs behind the one it depends on instead of NQB (D = 64: NKS = 2)
+              M16X_PAIRED_QK = 512 };  // 8: s_setprio 1 once for the second-dispatched group, no flips
 
 template <int D_, int RPW_, int BC_, int PD = 4, int NDEF = 1, int OX = 0, bool VT = false>
 __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __restrict__ Q, const half_t* __restrict__ K,
@@ -156,13 +161,24 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
   for (int j = 0; j < T; ++j) {
     const int jn = j + 1 < T ? j + 1 : T - 1;
     const int kb_j = kbase + (j & 1) * G::STAGE, vb_j = vbase + (j & 1) * G::STAGE + G::TILE;
+    constexpr bool PAIRED = (OX & M16X_PAIRED_QK) != 0 && NKS == 2 && NKB % 2 == 0 && NOPT % 2 == 0;
+    auto kb_of = [](int t) { return PAIRED ? 2 * (t / 4) + (t & 1) : t / NKS; };
+    auto ks_of = [](int t) { return PAIRED ? (t >> 1) & 1 : t % NKS; };
     auto k_frag = [&](int t) __attribute__((always_inline)) {
-      const int kb = t / NKS, ks = t % NKS;
-      return *reinterpret_cast<const h8*>(smem + (kb_j ^ (ks << 6)) + kb * 16 * G::ROW);
+      const int kb = kb_of(t), ks = ks_of(t);
+      if constexpr ((OX & M16X_ABL_K) != 0) {
+        h8 x = qf[kb % NQB][ks];
+        asm volatile("" : "+v"(x));  // opaque: identical MFMAs of different key blocks must not be merged
+        return x;
+      } else return *reinterpret_cast<const h8*>(smem + (kb_j ^ (ks << 6)) + kb * 16 * G::ROW);
     };
     auto v_frag = [&](int idx) __attribute__((always_inline)) {
       const int u = idx / NDB, db = idx % NDB;
-      if constexpr (VT) {
+      if constexpr ((OX & M16X_ABL_V) != 0) {
+        h8 x = qf[db % NQB][u % NKS];
+        asm volatile("" : "+v"(x));
+        return x;
+      } else if constexpr (VT) {
         // A operand row = d = 16 db + i16; k-slots 8 g4 .. + 7 = keys 32u + 4 g4 .. + 3 and 32u + 16 + 4 g4 .. + 3 (the order the P
         // registers have): two plain 8-byte reads 32 bytes apart in the row (chunks 4u + g4/2 and + 2, swizzled by the row)
         const char* vp = smem + (vb_j ^ ((4 * u) << 4)) + (16 * db) * RV;
@@ -180,8 +196,8 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
     // item it of key block kb: query block it >> 1, registers (it & 1) * 2, + 1 -> k-slots of P^T step kb >> 1
     auto exp_item = [&](int kb, int it, float (&acc)[NQB]) __attribute__((always_inline)) {
       const int qb = it >> 1, r = (it & 1) * 2;
-      const float a0 = __builtin_amdgcn_exp2f(s[kb][qb][r]);
-      const float a1 = __builtin_amdgcn_exp2f(s[kb][qb][r + 1]);
+      const float a0 = (OX & M16X_ABL_EXP) != 0 ? s[kb][qb][r] : __builtin_amdgcn_exp2f(s[kb][qb][r]);
+      const float a1 = (OX & M16X_ABL_EXP) != 0 ? s[kb][qb][r + 1] : __builtin_amdgcn_exp2f(s[kb][qb][r + 1]);
       acc[qb] += a0 + a1;
       const h2 a = __builtin_convertvector(f2{a0, a1}, h2);
       // an input-only empty asm is a chained node of the instruction selector: the item stays in the step it was
@@ -201,7 +217,7 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
       constexpr int DSTEP = NQK / G::PPW;
 #pragma unroll
       for (int t = 0; t < NQK; ++t) {
-        const int kb = t / NKS, ks = t % NKS;
+        const int kb = kb_of(t), ks = ks_of(t);
 #pragma unroll
         for (int qb = 0; qb < NQB; ++qb) {
           if (ks == 0) s[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[t % PD], qf[qb][0], minit[qb], 0, 0, 0);  // chain starts at -m
@@ -210,8 +226,15 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
         }
         __builtin_amdgcn_sched_barrier(0);  // the MFMAs of the step first: the VALU slice runs in their shadow
         if (t + PD < NQK) kf[t % PD] = k_frag(t + PD);
-        if ((t % DSTEP) == DSTEP - 1) dma_piece(jn, (j + 1) & 1, t / DSTEP);
-        if (kb >= 1 && kb - 1 < NOPT) {
+        if ((OX & M16X_ABL_DMA) == 0 && (t % DSTEP) == DSTEP - 1) dma_piece(jn, (j + 1) & 1, t / DSTEP);
+        if constexpr (PAIRED) {
+          // group g = t / 4 works on blocks 2g, 2g + 1; the two blocks of group g - 1 are exponentiated over its four steps
+          const int g = t / 4, r = t % 4, eb = 2 * (g - 1) + (r >> 1);
+          if (g >= 1 && eb < NOPT) {
+#pragma unroll
+            for (int it = (r & 1) * PER_STEP; it < ((r & 1) + 1) * PER_STEP && it < NPAIR; ++it) exp_item(eb, it, psum);
+          }
+        } else if (kb >= 1 && kb - 1 < NOPT) {
 #pragma unroll
           for (int it = ks * PER_STEP; it < (ks + 1) * PER_STEP && it < NPAIR; ++it) exp_item(kb - 1, it, psum);
         }
