@@ -31,7 +31,8 @@ enum : int { M16X_PRIO = 1, M16X_PRIO_B = 2, M16X_SPLIT_PROLOGUE = 4, M16X_PRIO_
               M16X_ABL_K = 32, M16X_ABL_V = 64, M16X_ABL_EXP = 128, M16X_ABL_DMA = 256,
               // QK^T steps of TWO key blocks interleaved (kb, kb+1 at k-step 0, then both at k-step 1): a dependent MFMA on one accumulator
               // then sits 2 * NQB MFMAs behind the one it depends on instead of NQB (D = 64: NKS = 2)
-              M16X_PAIRED_QK = 512 };  // 8: s_setprio 1 once for the second-dispatched group, no flips
+              M16X_PAIRED_QK = 512,
+              M16X_ABL_BAR = 1024 };  // probe ablation: no workgroup barriers inside the KV loop (only meaningful together with the LDS ablations)  // 8: s_setprio 1 once for the second-dispatched group, no flips
 
 template <int D_, int RPW_, int BC_, int PD = 4, int NDEF = 1, int OX = 0, bool VT = false>
 __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __restrict__ Q, const half_t* __restrict__ K,
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
       for (int qb = 0; qb < NQB; ++qb) l_run[qb] += psum[qb];
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
-    __builtin_amdgcn_s_barrier();
+    if constexpr ((OX & M16X_ABL_BAR) == 0) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
     // ================= phase B: O^T += V^T P^T; the deferred key blocks are exponentiated under its first MFMAs
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb) l_run[qb] += psum_d[qb];
     hgemm::wait_vmcnt<0>();  // own DMA pieces of tile j+1 landed
-    __builtin_amdgcn_s_barrier();
+    if constexpr ((OX & M16X_ABL_BAR) == 0) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   }
   if (grp == 0) {
