@@ -32,7 +32,9 @@ enum : int { M16X_PRIO = 1, M16X_PRIO_B = 2, M16X_SPLIT_PROLOGUE = 4, M16X_PRIO_
               // QK^T steps of TWO key blocks interleaved (kb, kb+1 at k-step 0, then both at k-step 1): a dependent MFMA on one accumulator
               // then sits 2 * NQB MFMAs behind the one it depends on instead of NQB (D = 64: NKS = 2)
               M16X_PAIRED_QK = 512,
-              M16X_ABL_BAR = 1024 };  // probe ablation: no workgroup barriers inside the KV loop (only meaningful together with the LDS ablations)  // 8: s_setprio 1 once for the second-dispatched group, no flips
+              M16X_ABL_BAR = 1024,
+              // query blocks visited in snake order (0,1 | 1,0 | ...): every MFMA shares one operand register set with its predecessor
+              M16X_SNAKE = 2048 };  // probe ablation: no workgroup barriers inside the KV loop (only meaningful together with the LDS ablations)  // 8: s_setprio 1 once for the second-dispatched group, no flips
 
 template <int D_, int RPW_, int BC_, int PD = 4, int NDEF = 1, int OX = 0, bool VT = false>
 __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __restrict__ Q, const half_t* __restrict__ K,
@@ -220,7 +222,8 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
       for (int t = 0; t < NQK; ++t) {
         const int kb = kb_of(t), ks = ks_of(t);
 #pragma unroll
-        for (int qb = 0; qb < NQB; ++qb) {
+        for (int qi = 0; qi < NQB; ++qi) {
+          const int qb = (OX & M16X_SNAKE) != 0 && (t & 1) ? NQB - 1 - qi : qi;
           if (ks == 0) s[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[t % PD], qf[qb][0], minit[qb], 0, 0, 0);  // chain starts at -m
           else s[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[t % PD], qf[qb][ks], s[kb][qb], 0, 0, 0);
           cln_mfma_keep(s[kb][qb], kf[t % PD], qf[qb][ks]);  // destination disjoint from the operands (common.h)
@@ -312,7 +315,8 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
     for (int idx = 0; idx < NPV; ++idx) {
       const int u = idx / NDB, b = idx % NDB;
 #pragma unroll
-      for (int qb = 0; qb < NQB; ++qb) {
+      for (int qi = 0; qi < NQB; ++qi) {
+        const int qb = (OX & M16X_SNAKE) != 0 && (idx & 1) ? NQB - 1 - qi : qi;
         ot[b][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[idx % PD], pf[u][qb], ot[b][qb], 0, 0, 0);
         cln_mfma_keep(ot[b][qb], vf[idx % PD], pf[u][qb]);
       }
