@@ -34,7 +34,9 @@ enum : int { M16X_PRIO = 1, M16X_PRIO_B = 2, M16X_SPLIT_PROLOGUE = 4, M16X_PRIO_
               M16X_PAIRED_QK = 512,
               M16X_ABL_BAR = 1024,
               // query blocks visited in snake order (0,1 | 1,0 | ...): every MFMA shares one operand register set with its predecessor
-              M16X_SNAKE = 2048 };  // probe ablation: no workgroup barriers inside the KV loop (only meaningful together with the LDS ablations)  // 8: s_setprio 1 once for the second-dispatched group, no flips
+              M16X_SNAKE = 2048,
+              // one softmax item behind EACH MFMA (M V M V) instead of the step's MFMAs first and its items after them (M M V V)
+              M16X_FINE = 4096 };  // probe ablation: no workgroup barriers inside the KV loop (only meaningful together with the LDS ablations)  // 8: s_setprio 1 once for the second-dispatched group, no flips
 
 template <int D_, int RPW_, int BC_, int PD = 4, int NDEF = 1, int OX = 0, bool VT = false>
 __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __restrict__ Q, const half_t* __restrict__ K,
@@ -221,12 +223,22 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
 #pragma unroll
       for (int t = 0; t < NQK; ++t) {
         const int kb = kb_of(t), ks = ks_of(t);
+        constexpr bool FINE_A = (OX & M16X_FINE) != 0 && !PAIRED;
 #pragma unroll
         for (int qi = 0; qi < NQB; ++qi) {
           const int qb = (OX & M16X_SNAKE) != 0 && (t & 1) ? NQB - 1 - qi : qi;
           if (ks == 0) s[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[t % PD], qf[qb][0], minit[qb], 0, 0, 0);  // chain starts at -m
           else s[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[t % PD], qf[qb][ks], s[kb][qb], 0, 0, 0);
           cln_mfma_keep(s[kb][qb], kf[t % PD], qf[qb][ks]);  // destination disjoint from the operands (common.h)
+          if constexpr (FINE_A) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (kb >= 1 && kb - 1 < NOPT) {  // item i of the step goes behind MFMA i * NQB / PER_STEP
+#pragma unroll
+              for (int i = 0; i < PER_STEP; ++i)
+                if (i * NQB / PER_STEP == qi && ks * PER_STEP + i < NPAIR) exp_item(kb - 1, ks * PER_STEP + i, psum);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
         }
         __builtin_amdgcn_sched_barrier(0);  // the MFMAs of the step first: the VALU slice runs in their shadow
         if (t + PD < NQK) kf[t % PD] = k_frag(t + PD);
@@ -238,7 +250,7 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
 #pragma unroll
             for (int it = (r & 1) * PER_STEP; it < ((r & 1) + 1) * PER_STEP && it < NPAIR; ++it) exp_item(eb, it, psum);
           }
-        } else if (kb >= 1 && kb - 1 < NOPT) {
+        } else if (!FINE_A && kb >= 1 && kb - 1 < NOPT) {
 #pragma unroll
           for (int it = ks * PER_STEP; it < (ks + 1) * PER_STEP && it < NPAIR; ++it) exp_item(kb - 1, it, psum);
         }
@@ -314,16 +326,26 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
 #pragma unroll
     for (int idx = 0; idx < NPV; ++idx) {
       const int u = idx / NDB, b = idx % NDB;
+      constexpr bool FINE_B = (OX & M16X_FINE) != 0;
 #pragma unroll
       for (int qi = 0; qi < NQB; ++qi) {
         const int qb = (OX & M16X_SNAKE) != 0 && (idx & 1) ? NQB - 1 - qi : qi;
         ot[b][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[idx % PD], pf[u][qb], ot[b][qb], 0, 0, 0);
         cln_mfma_keep(ot[b][qb], vf[idx % PD], pf[u][qb]);
+        if constexpr (FINE_B) {
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < DRATE; ++i) {
+            const int it = idx * DRATE + i;
+            if (i * NQB / DRATE == qi && it < NDEF * NPAIR) exp_item(NOPT + it / NPAIR, it % NPAIR, psum_d);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
       if (idx + PD < NPV) vf[idx % PD] = v_frag(idx + PD);
       // deferred items at DRATE per step: all of them are done before the first P^T step that holds a deferred block
 #pragma unroll
-      for (int it = idx * DRATE; it < (idx + 1) * DRATE && it < NDEF * NPAIR; ++it) exp_item(NOPT + it / NPAIR, it % NPAIR, psum_d);
+      for (int it = idx * DRATE; !FINE_B && it < (idx + 1) * DRATE && it < NDEF * NPAIR; ++it) exp_item(NOPT + it / NPAIR, it % NPAIR, psum_d);
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
