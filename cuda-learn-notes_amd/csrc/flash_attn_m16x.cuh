@@ -26,17 +26,23 @@
 
 namespace fa2 {
 
-enum : int { M16X_PRIO = 1, M16X_PRIO_B = 2, M16X_SPLIT_PROLOGUE = 4, M16X_PRIO_STATIC = 8, M16X_NT_STORE = 16,
-              // probe ablations (results are garbage by design): no K fragment reads, no V fragment reads, no exponentials, no LDS-DMA after the prologue
-              M16X_ABL_K = 32, M16X_ABL_V = 64, M16X_ABL_EXP = 128, M16X_ABL_DMA = 256,
-              // QK^T steps of TWO key blocks interleaved (kb, kb+1 at k-step 0, then both at k-step 1): a dependent MFMA on one accumulator
-              // then sits 2 * NQB MFMAs behind the one it depends on instead of NQB (D = 64: NKS = 2)
-              M16X_PAIRED_QK = 512,
-              M16X_ABL_BAR = 1024,
-              // query blocks visited in snake order (0,1 | 1,0 | ...): every MFMA shares one operand register set with its predecessor
-              M16X_SNAKE = 2048,
-              // one softmax item behind EACH MFMA (M V M V) instead of the step's MFMAs first and its items after them (M M V V)
-              M16X_FINE = 4096 };  // probe ablation: no workgroup barriers inside the KV loop (only meaningful together with the LDS ablations)  // 8: s_setprio 1 once for the second-dispatched group, no flips
+// OX bits. Production uses M16X_PRIO | M16X_SPLIT_PROLOGUE (= 5); everything from M16X_PRIO_STATIC up is instantiated only in the
+// probe library (flash_attn_m16x_probe.hip) and its measured effect is in profiles/r03_fa_c4_ablation_probe.log.
+enum : int {
+  M16X_PRIO = 1,            // s_setprio 1 in phase A (VALU-dense), 0 in phase B
+  M16X_PRIO_B = 2,          // the opposite flip
+  M16X_SPLIT_PROLOGUE = 4,  // tile 0's DMA pieces before the Q loads; group 1 does not hold up the first barrier
+  M16X_PRIO_STATIC = 8,     // s_setprio 1 once for the group that runs a phase behind, no flips
+  M16X_NT_STORE = 16,       // non-temporal O stores
+  // ablations (results are garbage by design): no K fragment reads, no V fragment reads, no exponentials, no LDS-DMA after the
+  // prologue, no workgroup barriers inside the KV loop (the last only together with the LDS ablations)
+  M16X_ABL_K = 32, M16X_ABL_V = 64, M16X_ABL_EXP = 128, M16X_ABL_DMA = 256, M16X_ABL_BAR = 1024,
+  // QK^T steps of TWO key blocks interleaved (kb, kb+1 at k-step 0, then both at k-step 1): a dependent MFMA on one accumulator
+  // then sits 2 * NQB MFMAs behind the one it depends on instead of NQB (D = 64: NKS = 2)
+  M16X_PAIRED_QK = 512,
+  M16X_SNAKE = 2048,  // query blocks in snake order (0,1 | 1,0 | ...): every MFMA shares one operand register set with its predecessor
+  M16X_FINE = 4096    // one softmax item behind EACH MFMA (M V M V) instead of the step's MFMAs first and its items after them
+};
 
 template <int D_, int RPW_, int BC_, int PD = 4, int NDEF = 1, int OX = 0, bool VT = false>
 __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __restrict__ Q, const half_t* __restrict__ K,
