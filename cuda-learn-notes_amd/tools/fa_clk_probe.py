@@ -20,7 +20,8 @@ def smi():
 
 
 ABLATE = os.environ.get("FA_CLK_ABLATE")  # energy ablations of the shipped C4 kernel (probe variants 520..527)
-for (B, H, N, D) in (((4, 8, 2048, 64),) if ABLATE else ((4, 8, 2048, 64), (4, 8, 2048, 128), (2, 32, 4096, 128))):
+R3 = os.environ.get("FA_CLK_R3")  # round 3: the sum-checked kernel and its opaque-operand ablations (probe variants 853, 870..884)
+for (B, H, N, D) in (((4, 8, 2048, 64), (2, 24, 4096, 64)) if R3 else ((4, 8, 2048, 64),) if ABLATE else ((4, 8, 2048, 64), (4, 8, 2048, 128), (2, 32, 4096, 128))):
     q, k, v = (torch.randn(B, H, N, D, dtype=torch.half, device=dev) for _ in range(3))
     z = torch.zeros_like(q)
     o = torch.zeros_like(q)
@@ -30,6 +31,10 @@ for (B, H, N, D) in (((4, 8, 2048, 64),) if ABLATE else ((4, 8, 2048, 64), (4, 8
              ("w4 %d" % (608 if D == 64 else 600), lambda: host.fa2_variant((4, 0, 0, 608 if D == 64 else 600), q, k, v, o)),
              ("w4 skeleton 615", lambda: host.fa2_variant((4, 0, 0, 615), q, k, v, o)),
              ("w4 skeleton zeros", lambda: host.fa2_variant((4, 0, 0, 615), z, z, z, o))]
+    if R3:
+        names = {853: "shipped kernel (probe 853)", 870: "no K fragment reads", 871: "no V fragment reads", 872: "no K, V reads", 873: "no exponentials", 874: "no LDS-DMA",
+                 875: "no K, V reads, no DMA", 876: "skeleton (no reads, exp, DMA)", 880: "skeleton, no barriers", 882: "snake order", 884: "M V M V order"}
+        cands = [("shipped", cands[0][1]), ("shipped zeros", cands[1][1])] + [(names[a], lambda a=a: host.fa2_variant((8, 0, 0, a), q, k, v, o)) for a in names]
     if ABLATE:
         names = {500: "shipped (variant 500)", 520: "no DMA", 521: "no exp", 522: "no fragment reads", 523: "no PV MFMA", 524: "no QK MFMA",
                  525: "no MFMA", 526: "no exp, no fragment reads", 527: "no exp, no reads, no DMA"}
