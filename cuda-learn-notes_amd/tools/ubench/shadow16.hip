@@ -5,6 +5,8 @@
 //   MODE 2: works on registers the MFMAs never touch
 //   MODE 3: reads the accumulators the MFMAs wrote FOUR MFMAs earlier (the kernel's dependency) -- accumulators in VGPRs
 //   MODE 4: as 2, but MFMA M V(5) M V(5) instead of M M V(10)
+//   MODE 5 / 6: the same flops on ONE v_mfma_f32_32x32x16_f16 per unit: alone / with the slice behind it (unrelated registers)
+//   MODE 7: 32x32x16, the slice reading the accumulator written two MFMAs earlier
 // at one and two waves per SIMD. Event-timed, ns per loop iteration per SIMD.
 //   hipcc --offload-arch=gfx950 -O3 shadow16.hip -o shadow16 && ./shadow16
 #include <hip/hip_runtime.h>
@@ -12,8 +14,10 @@
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
 
 #define MFMA(C) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(C) : "v"(a), "v"(b));
+#define MFMA32(C) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(C) : "v"(a), "v"(b));
 #define SLICE5(X0, X1, X2, X3, S)                                  \
   asm volatile("v_exp_f32 %0, %1" : "=v"(e0) : "v"(X0));           \
   asm volatile("v_exp_f32 %0, %1" : "=v"(e1) : "v"(X1));           \
@@ -33,7 +37,7 @@ __global__ __launch_bounds__(512) void k(float* out, int n) {
   asm volatile("" : "+v"(x[0]), "+v"(x[1]));
   float s0 = 0.f, s1 = 0.f, e0, e1, t;
   unsigned p;
-  for (int it = 0; it < n; ++it) {
+  for (int it = 0; it < (MODE >= 5 ? 0 : n); ++it) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {  // 4 x (2 MFMAs + slice) per iteration: accumulators 2r, 2r+1; the slice reads (2r + 4) % 8, i.e. written 4-5 MFMAs ago
       constexpr int dummy = 0;
@@ -50,6 +54,22 @@ __global__ __launch_bounds__(512) void k(float* out, int n) {
   }
   float r = s0 + s1;
   for (int i = 0; i < 8; ++i) r += c[i][0] + c[i][3];
+  if constexpr (MODE >= 5) {
+    f16v d[4];
+    for (int i = 0; i < 4; ++i)
+      for (int e = 0; e < 16; ++e) d[i][e] = 0.f;
+    for (int it = 0; it < n; ++it) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f16v& dr = d[(q + 2) % 4];
+        MFMA32(d[q]);
+        if constexpr (MODE == 6) { SLICE5(x[0][0], x[0][1], x[0][2], x[0][3], s0) SLICE5(x[1][0], x[1][1], x[1][2], x[1][3], s1) }
+        if constexpr (MODE == 7) { SLICE5(dr[0], dr[1], dr[2], dr[3], s0) SLICE5(dr[4], dr[5], dr[6], dr[7], s1) }
+      }
+    }
+    r += s0 + s1;
+    for (int i = 0; i < 4; ++i) r += d[i][0] + d[i][15];
+  }
   out[blockIdx.x * blockDim.x + threadIdx.x] = r;
 }
 
@@ -80,6 +100,9 @@ int main() {
     run<2>("M M + slice on unrelated registers", out);
     run<3>("M M + slice reading accumulators written 4 MFMAs ago", out);
     run<4>("M V5 M V5, unrelated registers", out);
+    run<5>("1 MFMA 32x32x16 alone (same flops)", out);
+    run<6>("1 MFMA 32x32x16 + slice on unrelated registers", out);
+    run<7>("1 MFMA 32x32x16 + slice reading the accumulator of 2 MFMAs ago", out);
   }
   return 0;
 }
