@@ -41,7 +41,12 @@ enum : int {
   // then sits 2 * NQB MFMAs behind the one it depends on instead of NQB (D = 64: NKS = 2)
   M16X_PAIRED_QK = 512,
   M16X_SNAKE = 2048,  // query blocks in snake order (0,1 | 1,0 | ...): every MFMA shares one operand register set with its predecessor
-  M16X_FINE = 4096    // one softmax item behind EACH MFMA (M V M V) instead of the step's MFMAs first and its items after them
+  M16X_FINE = 4096,   // one softmax item behind EACH MFMA (M V M V) instead of the step's MFMAs first and its items after them
+  // phase A exponentiates its NOPT blocks behind the LAST NOPT blocks' MFMAs instead of the first ones: a wave's softmax-carrying stretch is
+  // then [second half of A, first half of B] and its bare-MFMA stretch [second half of B, first half of A]; the partner group runs one phase
+  // behind, so one wave of a SIMD is always in its bare stretch while the other carries softmax work. With M16X_PRIO the priority follows
+  // the stretches (1 while carrying softmax work) instead of the phases.
+  M16X_LATE = 8192
 };
 
 template <int D_, int RPW_, int BC_, int PD = 4, int NDEF = 1, int OX = 0, bool VT = false>
@@ -219,7 +224,9 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
     };
 
     // ================= phase A: S^T = K Q^T, block kb - 1 exponentiated behind the MFMAs of block kb
-    if constexpr ((OX & M16X_PRIO) != 0) __builtin_amdgcn_s_setprio(1);
+    constexpr bool LATE = (OX & M16X_LATE) != 0;
+    constexpr int LAG = LATE ? NKB - NOPT : 1;  // block kb - LAG is exponentiated behind the MFMAs of block kb
+    if constexpr ((OX & M16X_PRIO) != 0 && !LATE) __builtin_amdgcn_s_setprio(1);
     if constexpr ((OX & M16X_PRIO_B) != 0) __builtin_amdgcn_s_setprio(0);
     {
       h8 kf[PD];
@@ -230,6 +237,9 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
       for (int t = 0; t < NQK; ++t) {
         const int kb = kb_of(t), ks = ks_of(t);
         constexpr bool FINE_A = (OX & M16X_FINE) != 0 && !PAIRED;
+        if constexpr (LATE && (OX & M16X_PRIO) != 0) {
+          if (t == LAG * NKS) __builtin_amdgcn_s_setprio(1);
+        }
 #pragma unroll
         for (int qi = 0; qi < NQB; ++qi) {
           const int qb = (OX & M16X_SNAKE) != 0 && (t & 1) ? NQB - 1 - qi : qi;
@@ -238,10 +248,10 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
           cln_mfma_keep(s[kb][qb], kf[t % PD], qf[qb][ks]);  // destination disjoint from the operands (common.h)
           if constexpr (FINE_A) {
             __builtin_amdgcn_sched_barrier(0);
-            if (kb >= 1 && kb - 1 < NOPT) {  // item i of the step goes behind MFMA i * NQB / PER_STEP
+            if (kb >= LAG && kb - LAG < NOPT) {  // item i of the step goes behind MFMA i * NQB / PER_STEP
 #pragma unroll
               for (int i = 0; i < PER_STEP; ++i)
-                if (i * NQB / PER_STEP == qi && ks * PER_STEP + i < NPAIR) exp_item(kb - 1, ks * PER_STEP + i, psum);
+                if (i * NQB / PER_STEP == qi && ks * PER_STEP + i < NPAIR) exp_item(kb - LAG, ks * PER_STEP + i, psum);
               __builtin_amdgcn_sched_barrier(0);
             }
           }
@@ -256,9 +266,9 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
 #pragma unroll
             for (int it = (r & 1) * PER_STEP; it < ((r & 1) + 1) * PER_STEP && it < NPAIR; ++it) exp_item(eb, it, psum);
           }
-        } else if (!FINE_A && kb >= 1 && kb - 1 < NOPT) {
+        } else if (!FINE_A && kb >= LAG && kb - LAG < NOPT) {
 #pragma unroll
-          for (int it = ks * PER_STEP; it < (ks + 1) * PER_STEP && it < NPAIR; ++it) exp_item(kb - 1, it, psum);
+          for (int it = ks * PER_STEP; it < (ks + 1) * PER_STEP && it < NPAIR; ++it) exp_item(kb - LAG, it, psum);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -320,7 +330,7 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
     asm volatile("" ::: "memory");
 
     // ================= phase B: O^T += V^T P^T; the deferred key blocks are exponentiated under its first MFMAs
-    if constexpr ((OX & M16X_PRIO) != 0) __builtin_amdgcn_s_setprio(0);
+    if constexpr ((OX & M16X_PRIO) != 0 && !LATE) __builtin_amdgcn_s_setprio(0);
     if constexpr ((OX & M16X_PRIO_B) != 0) __builtin_amdgcn_s_setprio(1);
     float psum_d[NQB];
 #pragma unroll
@@ -333,6 +343,9 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
     for (int idx = 0; idx < NPV; ++idx) {
       const int u = idx / NDB, b = idx % NDB;
       constexpr bool FINE_B = (OX & M16X_FINE) != 0;
+      if constexpr (LATE && (OX & M16X_PRIO) != 0) {
+        if (idx == (NDEF * NPAIR + DRATE - 1) / DRATE) __builtin_amdgcn_s_setprio(0);  // the deferred items are done: bare MFMAs from here
+      }
 #pragma unroll
       for (int qi = 0; qi < NQB; ++qi) {
         const int qb = (OX & M16X_SNAKE) != 0 && (idx & 1) ? NQB - 1 - qi : qi;
