@@ -6,6 +6,7 @@
 // plain adds beside MFMAs (MI355X_MICROARCH.md, per-instruction constants). Linked into the probe library only.
 #include "flash_attn_m16x.cuh"
 #include "flash_attn_m16s.cuh"
+#include "flash_attn_m32x.cuh"
 #include "flash_attn_m16x_api.h"
 
 namespace fa2 {
@@ -44,6 +45,10 @@ int m16x_probe_run(int D, int code, const void* q, const void* k, const void* v,
   // correct only where the allocator happens not to; profiles/r03_fa_m16s_one_wave_per_simd_probe.log.)
   MS(64, 150, 64, 4, 1, false) MS(64, 151, 64, 4, 2, false) MS(64, 153, 64, 4, 2, true) MS(64, 155, 64, 8, 2, true)
 #undef MS
+  // 160 + id: the sum-checked two-group kernel on v_mfma_f32_32x32x16_f16 (flash_attn_m32x.cuh, D = 64, 128-key tiles): <BC, PD, OX>
+  if (D == 64 && code == 160) return launch_m32x<128, 4, 1>(q, k, v, o, B, H, N, s);
+  if (D == 64 && code == 161) return launch_m32x<128, 4, 0>(q, k, v, o, B, H, N, s);
+  if (D == 64 && code == 162) return launch_m32x<128, 8, 1>(q, k, v, o, B, H, N, s);
   return CLN_ERR_UNSUPPORTED;
 }
 
