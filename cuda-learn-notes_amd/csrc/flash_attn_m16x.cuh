@@ -46,7 +46,12 @@ enum : int {
   // then [second half of A, first half of B] and its bare-MFMA stretch [second half of B, first half of A]; the partner group runs one phase
   // behind, so one wave of a SIMD is always in its bare stretch while the other carries softmax work. With M16X_PRIO the priority follows
   // the stretches (1 while carrying softmax work) instead of the phases.
-  M16X_LATE = 8192
+  M16X_LATE = 8192,
+  // the deferred key blocks are not checked by their raw scores at the end of phase A (NDEF * NQB * 4 scores through v_max3 per lane and
+  // tile); instead their OWN partial row sums are compared once, in phase B, right after their last exponential and before the first PV
+  // MFMA that consumes them -- a failing wave rescales O / l there (the PV products of the optimistic blocks are already in O, relative
+  // to the old reference, and are scaled with it) and exponentiates the deferred blocks again
+  M16X_LATE_CHECK = 16384
 };
 
 template <int D_, int RPW_, int BC_, int PD = 4, int NDEF = 1, int OX = 0, bool VT = false>
@@ -279,12 +284,14 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
 #pragma unroll
       for (int qb = 0; qb < NQB; ++qb) {
         bad |= !(psum[qb] <= 32768.0f);
-        float mx = s[NOPT][qb][0];
+        if constexpr ((OX & M16X_LATE_CHECK) == 0) {
+          float mx = s[NOPT][qb][0];
 #pragma unroll
-        for (int kb = NOPT; kb < NKB; ++kb)
+          for (int kb = NOPT; kb < NKB; ++kb)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kb][qb][r]);
-        bad |= mx > 14.0f;
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kb][qb][r]);
+          bad |= mx > 14.0f;
+        }
       }
       const bool first = j == 0;  // tile 0 has no reference yet: it adopts its true maximum
       if (first || __builtin_amdgcn_ballot_w64(bad) != 0) {
@@ -343,6 +350,46 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
     for (int idx = 0; idx < NPV; ++idx) {
       const int u = idx / NDB, b = idx % NDB;
       constexpr bool FINE_B = (OX & M16X_FINE) != 0;
+      if constexpr ((OX & M16X_LATE_CHECK) != 0) {
+        if (idx == (NDEF * NPAIR + DRATE - 1) / DRATE) {  // every deferred exponential is done, none of them has been consumed yet
+          bool bad_d = false;
+#pragma unroll
+          for (int qb = 0; qb < NQB; ++qb) bad_d |= !(psum_d[qb] <= 32768.0f);
+          if (__builtin_amdgcn_ballot_w64(bad_d) != 0) {
+#pragma unroll
+            for (int qb = 0; qb < NQB; ++qb) {
+              float mx = s[NOPT][qb][0];
+#pragma unroll
+              for (int kb = NOPT; kb < NKB; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kb][qb][r]);
+              const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+              mx = fmaxf(__uint_as_float(s16[0]), __uint_as_float(s16[1]));
+              const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+              const float delta = fmaxf(fmaxf(__uint_as_float(s32[0]), __uint_as_float(s32[1])), 0.f);
+              const float alpha = __builtin_amdgcn_exp2f(-delta);
+              m_run[qb] += delta;
+              l_run[qb] *= alpha;  // holds this tile's optimistic blocks already
+#pragma unroll
+              for (int kb = NOPT; kb < NKB; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[kb][qb][r] -= delta;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) minit[qb][r] = -m_run[qb];
+              asm volatile("" : "+v"(minit[qb]));
+#pragma unroll
+              for (int bb = 0; bb < NDB; ++bb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ot[bb][qb][r] *= alpha;
+              psum_d[qb] = 0.f;
+            }
+#pragma unroll
+            for (int kb = NOPT; kb < NKB; ++kb)
+#pragma unroll
+              for (int it = 0; it < NPAIR; ++it) exp_item(kb, it, psum_d);
+          }
+        }
+      }
       if constexpr (LATE && (OX & M16X_PRIO) != 0) {
         if (idx == (NDEF * NPAIR + DRATE - 1) / DRATE) __builtin_amdgcn_s_setprio(0);  // the deferred items are done: bare MFMAs from here
       }

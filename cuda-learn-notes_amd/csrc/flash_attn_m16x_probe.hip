@@ -28,6 +28,7 @@ int m16x_probe_run(int D, int code, const void* q, const void* k, const void* v,
   MX(64, 82, 32, 128, 8, 4, 2053) MX(64, 83, 32, 128, 8, 4, 2565) MX(128, 82, 32, 128, 4, 4, 2053)  // snake order over the query blocks (5 + 2048; 83: + paired QK)
   MX(64, 84, 32, 128, 8, 4, 4101) MX(64, 86, 32, 128, 8, 4, 6149) MX(128, 84, 32, 128, 4, 4, 4101)  // one softmax item behind each MFMA (5 + 4096; 86: + snake)
   MX(64, 87, 32, 128, 8, 4, 8197) MX(64, 88, 32, 128, 8, 4, 8196) MX(128, 87, 32, 128, 4, 4, 8197)  // late phase-A exponentials (5 + 8192; 88: without the priority flips)
+  MX(64, 89, 32, 128, 8, 4, 16389)  // deferred blocks checked by their own row sums in phase B (5 + 16384); the D = 128 and the 64-row forms spill with it
   MX(64, 77, 32, 128, 8, 4, 517) MX(64, 78, 32, 128, 8, 2, 517) MX(64, 79, 32, 128, 8, 6, 517)  // 517 = the shipped options + QK^T steps of two key blocks interleaved
   MX(64, 60, 32, 128, 8, 4, 12) MX(64, 61, 32, 128, 8, 4, 13) MX(64, 133, 64, 64, 4, 1, 12)  // static priority for the second group (12), on top of the phase-A flips (13)
   MX(64, 120, 64, 64, 4, 1, 0) MX(64, 125, 64, 64, 4, 1, 5) MX(64, 141, 64, 64, 4, 2, 5)
