@@ -560,11 +560,13 @@ def test_one_wave_per_simd_attention_on_16x16x32_probe(built, dev, oracle, abl):
             assert torch.equal(o, first)
 
 
-@pytest.mark.parametrize("abl", [960, 961, 962])
+@pytest.mark.parametrize("abl", [960, 961, 962, 889])
 def test_sum_checked_attention_on_32x32x16_probe(built, dev, oracle, abl):
     """flash_attn_m32x.cuh (probe library): the two-group sum-checked D = 64 kernel rebuilt on v_mfma_f32_32x32x16_f16 (S^T in 32 x 32
     blocks, key blocks interleaved in pairs, P^T k-steps in accumulator register order, V^T fragments as two transposing reads 8 key
-    rows apart). Several tile counts incl. one tile, the rescale regime (cold path), 50 repeated launches bit-identical."""
+    rows apart). Several tile counts incl. one tile, the rescale regime (cold path), 50 repeated launches bit-identical.
+    889: the 16x16x32 kernel with the deferred blocks' overflow check moved into phase B (M16X_LATE_CHECK) -- key 1000 of the last head
+    lies in a deferred block of its tile and dominates its row, so the mid-phase rescale path runs."""
     from cuda_learn_notes_amd import host
     D = 64
     for (B, H, N) in ((1, 2, 256), (2, 3, 512), (1, 8, 1024)):
