@@ -40,8 +40,6 @@ __global__ __launch_bounds__(512) void k(float* out, int n) {
   for (int it = 0; it < (MODE >= 5 ? 0 : n); ++it) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {  // 4 x (2 MFMAs + slice) per iteration: accumulators 2r, 2r+1; the slice reads (2r + 4) % 8, i.e. written 4-5 MFMAs ago
-      constexpr int dummy = 0;
-      (void)dummy;
       f4& cr0 = c[(2 * r + 4) % 8];
       f4& cr1 = c[(2 * r + 5) % 8];
       if constexpr (MODE != 1) MFMA(c[2 * r]);
