@@ -188,3 +188,30 @@ def test_the_model_notices_a_wrong_fragment_formula():
     want = np.array([[v[8 * (e >> 2) + 4 * hi[l] + (e & 3), lane[l] & 31] for e in range(8)] for l in range(64)])
     assert np.array_equal(good, want)
     assert not np.array_equal(bad, want)
+
+
+def test_m16x_transposed_v_fragment_is_the_row_major_fragment():
+    """The three *_swizzle_qkv names take V as [B, H, d, N]: the V^T tile image is d rows of BC keys (256-byte rows, chunk swizzle
+    row & 15) and a fragment is two PLAIN 8-byte reads two chunks apart -- it must equal the transposing-read fragment of the
+    row-major image, k-step by k-step (flash_attn_m16x.cuh, VT = true)."""
+    _, _, v = inputs(4)
+    vimg = image(v, swz_v)
+    RV = BC * 2
+    vt = v.T  # [d][key]
+    vtimg = np.zeros(D * BC)
+    for row in range(D):
+        for c in range(BC // 8):
+            vtimg[row * BC + 8 * c:row * BC + 8 * c + 8] = vt[row, 8 * (c ^ (row & 15)):8 * (c ^ (row & 15)) + 8]
+    lane = np.arange(64)
+    i16, g4 = lane & 15, lane >> 4
+    v_row = 4 * g4 + (i16 >> 2)
+    vbase = v_row * ROW + ((((i16 & 3) >> 1) ^ swz_v(v_row)) << 4) + ((i16 & 1) << 3)
+    vtbase = i16 * RV + (((i16 & 15) ^ (g4 >> 1)) << 4) + ((g4 & 1) << 3)
+    for u in range(BC // 32):
+        for db in range(D // 16):
+            addr = (vbase ^ (db << 5)) + 32 * u * ROW
+            row_major = np.concatenate([ds_read_b64_tr_b16(vimg, addr), ds_read_b64_tr_b16(vimg, addr + 16 * ROW)], axis=1)
+            a0 = (vtbase ^ ((4 * u) << 4)) + 16 * db * RV
+            a1 = (vtbase ^ ((4 * u + 2) << 4)) + 16 * db * RV
+            transposed = np.array([np.concatenate([lds_halves(vtimg, a0[l], 4), lds_halves(vtimg, a1[l], 4)]) for l in range(64)])
+            assert np.array_equal(row_major, transposed), (u, db)
