@@ -71,3 +71,26 @@ def test_python_surface_has_every_reference_name(built):
 def test_vendor_handle_entry_points_do_not_need_a_gpu_to_exist(built):
     hg = built.hgemm_lib()
     assert callable(hg.init_cublas_handle) and callable(hg.destroy_cublas_handle)
+
+
+def test_ck_tile_comparator_rejects_bad_arguments_before_any_launch(built):
+    """cln_fa2_ck_tile_fwd (vendor library, fa2_vendor_ck.hip) validates before it touches the device: null pointers and non-positive
+    dims are CLN_ERR_BAD_ARG, a head dim or variant it has no instance for is CLN_ERR_UNSUPPORTED / BAD_ARG. Runs without a GPU.
+    (The symbol is absent when the image's ck_tile headers did not compile: the row is optional, _build.py OPTIONAL_SOURCES.)"""
+    from cuda_learn_notes_amd import _loader
+    vend = ctypes.CDLL(_loader.so_path("libcln_amd_vendor.so"))
+    if not hasattr(vend, "cln_fa2_ck_tile_fwd"):
+        pytest.skip("vendor library was linked without the ck_tile comparator")
+    f = vend.cln_fa2_ck_tile_fwd
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 5 + [ctypes.c_void_p]
+    buf = ctypes.create_string_buffer(64)
+    p = ctypes.addressof(buf)
+    BAD_ARG, UNSUPPORTED = -1, -2
+    assert f(None, p, p, p, 1, 1, 128, 64, 0, None) == BAD_ARG
+    assert f(p, p, p, None, 1, 1, 128, 64, 0, None) == BAD_ARG
+    assert f(p, p, p, p, 0, 1, 128, 64, 0, None) == BAD_ARG
+    assert f(p, p, p, p, 1, 1, 0, 64, 0, None) == BAD_ARG
+    assert f(p, p, p, p, 1, 1, 128, 64, 7, None) == BAD_ARG       # no such variant
+    assert f(p, p, p, p, 1, 1, 128, 96, 0, None) == UNSUPPORTED   # no instance for this head dim
+    assert f(p, p, p, p, 1, 1, 128, 64, 3, None) == UNSUPPORTED   # the gfx950 v3 kernel exists for D = 128 only
