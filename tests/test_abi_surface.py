@@ -94,3 +94,20 @@ def test_ck_tile_comparator_rejects_bad_arguments_before_any_launch(built):
     assert f(p, p, p, p, 1, 1, 128, 64, 7, None) == BAD_ARG       # no such variant
     assert f(p, p, p, p, 1, 1, 128, 96, 0, None) == UNSUPPORTED   # no instance for this head dim
     assert f(p, p, p, p, 1, 1, 128, 64, 3, None) == UNSUPPORTED   # the gfx950 v3 kernel exists for D = 128 only
+
+
+def test_every_product_entry_point_refuses_null_pointers_without_touching_a_device(built):
+    """SURVEY 8(b) 'preconditions (unchecked in reference)': the C entry points check before they launch. Every name of libcln_amd.so
+    called with null tensors and plausible dims returns CLN_ERR_BAD_ARG (or CLN_ERR_UNSUPPORTED where the shape test comes first) --
+    on a box without a GPU, so nothing was launched to find that out."""
+    from cuda_learn_notes_amd import _loader
+    lib = _loader.load_so("libcln_amd.so")
+    seen = 0
+    for e in built.manifest.ENTRIES:
+        if built.manifest.SO_OF_LIB[e.lib] != "libcln_amd.so" or e.sig == "H0":
+            continue
+        args = [None if t is ctypes.c_void_p else (1.0 if t is ctypes.c_float else 128) for t in _loader.ARGTYPES[e.sig]]
+        rc = getattr(lib, e.name)(*args)
+        assert rc in (-1, -2), (e.name, rc)
+        seen += 1
+    assert seen >= 200
