@@ -34,6 +34,7 @@ def parse():
     p.add_argument("--stages", type=int, default=2)
     p.add_argument("--prewarm", type=float, default=0.6, help="seconds of untimed back-to-back launches before warmup")
     p.add_argument("--no-extras", action="store_true", help="skip FA2 / rocBLAS / CPU baseline side measurements")
+    p.add_argument("--no-configs", action="store_true", help="skip the per-config rows (C1, C2, 8192^3, stage sweeps, bandwidth kernels)")
     p.add_argument("--launch", choices=["graph", "eager"], default="eager",
                    help="how the K timed steps reach the GPU: K eager launches from Python (default: host enqueue 9.5 us per step against a "
                         "94 us kernel) or one hipGraph holding the K launches (measured slower: +26 us per kernel node, 1141 vs 1442 TF)")
@@ -55,10 +56,11 @@ def fa_roofline(kern, shape, pmc_file, dev, bu, profiles, kernel_desc=""):
     fam = kernel_desc.split("<")[0]  # counters must come from THIS kernel family
     ksub = {"fa2_fwd_m16": "fa2_fwd_m16_pair_kernel", "fa2_fwd_m16x64r": "fa2_fwd_m16x_kernel"}.get(fam, fam + "_kernel") if fam else ""
     busy, src = bu.pmc_value(profiles, pmc_file, "mfma_busy_frac", ksub)
-    traffic, _ = bu.pmc_value(profiles, pmc_file, "hbm_traffic_bytes_per_launch", ksub)
+    traffic, _ = bu.pmc_value(profiles, pmc_file, "l2_fabric_traffic_bytes_per_launch", ksub)
     return {"bound": "mfma", "achieved": round(ach, 2), "peak": bu.PEAK_FP16_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / bu.PEAK_FP16_MFMA_TFLOPS, 4), "traffic": round(traffic) if traffic else None,
-            "mfma_busy": round(busy, 4) if busy else None, "pmc_source": src, "shape": [B_, H_, N_, D],
+            "mfma_busy": round(busy, 4) if busy else None, "pmc_source": src, "traffic_measured_in_this_run": False,
+            "traffic_is": bu.TRAFFIC_IS, "shape": [B_, H_, N_, D],
             "avg_launch_ms": round(ms, 5), "algorithmic_flops_per_launch": flops,
             "algorithmic_bytes_per_launch": 4.0 * B_ * H_ * N_ * D * 2,
             "tflops_ref_model": round(bu.get_mha_tflops(B_, H_, N_, D, ms * 1e-3), 2)}, (q, k, v, o)
@@ -155,11 +157,13 @@ def main():
     achieved = flops / (ev_ms * 1e-3) * 1e-12
     kernel_desc = pkg.manifest.describe(bu.HEADLINE_HGEMM_NAME, (M, N, K), 2)
     ksub = kernel_desc.split("<")[0] + "_kernel"  # device kernel family the PMC summary must have been taken on
-    traffic, traffic_src = bu.pmc_value(profiles, "pmc_hgemm", "hbm_traffic_bytes_per_launch", ksub) if M == 4096 else (None, None)
+    traffic, traffic_src = bu.pmc_value(profiles, "pmc_hgemm", "l2_fabric_traffic_bytes_per_launch", ksub) if M == 4096 else (None, None)
     busy, _ = bu.pmc_value(profiles, "pmc_hgemm", "mfma_busy_frac", ksub) if M == 4096 else (None, None)
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": bu.PEAK_FP16_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(achieved / bu.PEAK_FP16_MFMA_TFLOPS, 4),
                 "traffic": round(traffic) if traffic else None, "traffic_source": traffic_src,
+                "traffic_measured_in_this_run": False,  # PMC counters cannot be collected from inside the timed process: `traffic` and
+                "traffic_is": bu.TRAFFIC_IS,            # `mfma_busy` are REPLAYED from the committed rocprofv3 pass named in traffic_source
                 "mfma_busy": round(busy, 4) if busy else None,
                 "mfma_busy_note": "SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE of the rocprofv3 counter pass, where the launch takes "
                                   "more cycles than un-profiled (can read below frac); MFMA cycles per launch are fixed by the work",
@@ -268,6 +272,25 @@ def main():
             extras["fa2_error"] = str(e)[:300]
         out["extras"] = extras
         out["cpu_baseline"] = cpu_baseline(a, b, M, N, K)
+        # ---- every other BASELINE.json config and the bandwidth kernels, each with its roofline fraction and the
+        # reference's torch path on the host cores: cuda-learn-notes_amd/bench_configs.py. Released first: the operands above.
+        del a, b, c
+        torch.cuda.empty_cache()
+        if not args.no_configs:
+            from cuda_learn_notes_amd import bench_configs as bc
+            orc = entry.load_oracle()  # cpu_baseline legs only
+            cfg = {}
+            for key, fn in (("c1_elementwise_add_f32", lambda: bc.config_c1(dev, orc)),
+                            ("hgemm", lambda: bc.hgemm_config_rows(pkg, dev, orc)),
+                            ("fa2_stages", lambda: bc.fa_stage_rows(pkg, dev)),
+                            ("bandwidth", lambda: bc.bandwidth_rows(dev, orc))):
+                t0 = time.perf_counter()
+                try:
+                    cfg[key] = fn()
+                except Exception as e:  # noqa: BLE001 -- a side row never takes the headline line down with it
+                    cfg[key] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+                cfg.setdefault("wall_s", {})[key] = round(time.perf_counter() - t0, 1)
+            out["configs"] = cfg
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -1,0 +1,354 @@
+"""Side rows of bench.py: every BASELINE.json config and the bandwidth kernels, each with its own roofline and the
+reference's torch path on the host cores beside it.
+
+  config C1  elementwise_add_f32 [2048,2048]: the kernel rows AND the torch-CPU row the config literally names
+             (reference kernels/elementwise/elementwise.py:59-82)
+  config C2  HGEMM 1024^3 on the 1-stage rungs (hgemm_mma_m16n8k16_naive / _mma2x4_warp4x4; kernels/hgemm/hgemm.py:349-352)
+  config C3  HGEMM 4096^3 and 8192^3 on the headline name, stages in {2,3,4}, NN and TN, next to rocBLAS / hipBLASLt
+             (kernels/hgemm/hgemm.py:353-378)
+  config C4/C5  the attention names at stages 1 and 2 (kernels/flash-attn/flash_attn_mma.py:528-557 runs both)
+  bandwidth  add / reduce / softmax / layer-norm / rms-norm / rope at the reference scripts' [4096,4096] and at [8192,8192],
+             timed over ROTATING buffer sets whose combined footprint is several times the 256 MiB Infinity Cache, so the
+             rate is an HBM rate (a single set re-used back to back is served from the cache: that rate is reported
+             separately as `gbps_same_buffers`, the reference scripts' own protocol)
+
+Timing: one pair of HIP events on the launch stream around a region of back-to-back launches, after a time-based pre-warm
+(bench_utils.time_region_events) -- the same source for our kernels and the vendor rows; no best-of-N. The region is
+launch-inclusive: the ~1.5 us dependent-kernel boundary is inside it, so a 6 us kernel reads lower here than its rocprofv3
+kernel-trace duration (profiles/rNN_bw_rocprof.*); every row carries `launches` so the two can be told apart.
+The torch-CPU rows use the reference's own host functions (oracle/: the checker's restatement of the scripts' torch
+paths, imported here for the cpu_baseline leg only), bounded to about a second each.
+"""
+import ctypes
+import os
+import time
+
+import torch
+
+from . import _loader, manifest
+from . import bench_utils as bu
+
+MALL_BYTES = 256 << 20
+ROTATE_FOOTPRINT = 4 * MALL_BYTES  # combined footprint of the rotating sets: nothing of set i survives until its next use
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _region_ms(calls, min_launches, prewarm_s=0.15, target_ms=40.0):
+    """Mean ms per launch of a ROTATING list of zero-argument callables: pre-warm, then one event-timed region of whole
+    rotations (>= min_launches launches and about target_ms of device time)."""
+    n = len(calls)
+
+    def rotation():
+        for c in calls:
+            c()
+
+    bu.prewarm(rotation, prewarm_s)
+    probe = bu.time_region_events(rotation, 2) / n  # ms per launch, rough
+    reps = max((min_launches + n - 1) // n, int(target_ms / max(probe * n, 1e-4)) + 1)
+    reps = min(reps, max(1, 20000 // n))
+    return bu.time_region_events(rotation, reps) / n, reps * n
+
+
+def _cpu_time(fn, budget_s=0.8, max_iters=50):
+    """Seconds per call of a host function: one untimed call, then as many as fit the budget (at least one)."""
+    fn()
+    t0 = time.perf_counter()
+    fn()
+    one = time.perf_counter() - t0
+    iters = max(1, min(max_iters, int(budget_s / max(one, 1e-6))))
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    return (time.perf_counter() - t0) / iters, iters + 2
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# bandwidth kernels
+def _bw_specs(orc):
+    """(kernel name, dtype, signature kind, algorithmic bytes per element, torch-CPU callable of the same op)"""
+    f = ctypes.c_float
+    return [
+        ("elementwise_add_f32x4", torch.float32, "P3", 12, lambda x, x2: orc.elementwise_add(x, x2)),
+        ("elementwise_add_f16x8_pack", torch.float16, "P3", 6, lambda x, x2: orc.elementwise_add(x, x2)),
+        ("block_all_reduce_sum_f32x4_f32", torch.float32, "R1", 4, lambda x, x2: torch.sum(x)),
+        ("block_all_reduce_sum_f16x8_pack_f32", torch.float16, "R1", 2, lambda x, x2: torch.sum(x)),
+        ("safe_softmax_f32x4_per_token", torch.float32, "XY", 8, lambda x, x2: orc.softmax_per_token(x)),
+        ("safe_softmax_f16x8_pack_f32_per_token", torch.float16, "XY", 4, lambda x, x2: orc.softmax_per_token(x)),
+        ("layer_norm_f32x4", torch.float32, "LN", 8, lambda x, x2: orc.layer_norm_torch(x, 1.0, 0.0)),
+        ("layer_norm_f16x8_pack_f32", torch.float16, "LN", 4, lambda x, x2: orc.layer_norm_torch(x, 1.0, 0.0)),
+        ("rms_norm_f32x4", torch.float32, "RN", 8, lambda x, x2: orc.rms_norm_torch(x, 1.0)),
+        ("rms_norm_f16x8_pack_f32", torch.float16, "RN", 4, lambda x, x2: orc.rms_norm_torch(x, 1.0)),
+        ("rope_f32x4_pack", torch.float32, "RP", 8, lambda x, x2: orc.rope_torch(x)),
+    ]
+
+
+def _bw_call(fn, kind, x, x2, y, z, S, K):
+    """Zero-argument launch of one bandwidth kernel through its C-ABI symbol (raw pointers and sizes; the Python wrapper of
+    host.py adds per-call checks and, for the reductions, a torch.zeros launch -- not part of the kernel's rate)."""
+    n = S * K
+    f = ctypes.c_float
+    xp, x2p, yp, zp = x.data_ptr(), (x2.data_ptr() if x2 is not None else 0), (y.data_ptr() if y is not None else 0), z.data_ptr()
+    st = _stream()
+    if kind == "P3":
+        return lambda: fn(xp, x2p, yp, n, st)
+    if kind == "R1":
+        return lambda: fn(xp, zp, n, st)
+    if kind == "XY":
+        return lambda: fn(xp, yp, S, K, st)
+    if kind == "LN":
+        g, b = f(1.0), f(0.0)
+        return lambda: fn(xp, yp, g, b, S, K, st)
+    if kind == "RN":
+        g = f(1.0)
+        return lambda: fn(xp, yp, g, S, K, st)
+    if kind == "RP":
+        return lambda: fn(xp, yp, S, K, 0, st)
+    raise ValueError(kind)
+
+
+def bandwidth_rows(dev, orc, shapes=((4096, 4096), (8192, 8192)), cpu_shape=(4096, 4096)):
+    """One row per (kernel, shape): achieved GB/s over rotating buffer sets (HBM), the same-buffer rate (reference
+    protocol; Infinity-Cache-assisted when the set is < 256 MiB), fraction of the 8 TB/s spec peak and of the guide's 6.29 TB/s
+    measured copy rate, algorithmic bytes, and the torch op on the host cores at `cpu_shape`."""
+    rows = []
+    z = torch.zeros(4, dtype=torch.float32, device=dev)
+    g = torch.Generator(device="cpu").manual_seed(11)
+    for name, dtype, kind, bpe, cpu_op in _bw_specs(orc):
+        fn = _loader.symbol(name)
+        for (S, K) in shapes:
+            n = S * K
+            esz = 2 if dtype == torch.float16 else 4
+            n_in = 2 if kind == "P3" else 1
+            n_out = 0 if kind == "R1" else 1
+            set_bytes = (n_in + n_out) * n * esz
+            nsets = max(3, (ROTATE_FOOTPRINT + set_bytes - 1) // set_bytes)
+            try:
+                pool = torch.randn(nsets * (n_in + n_out), S, K, device=dev, dtype=dtype)
+            except Exception as e:  # noqa: BLE001 -- out of memory on a small box: report, do not abort the bench
+                rows.append({"kernel": name, "shape": [S, K], "error": str(e)[:120]})
+                continue
+            calls = []
+            for i in range(nsets):
+                base = i * (n_in + n_out)
+                x = pool[base]
+                x2 = pool[base + 1] if n_in == 2 else None
+                y = pool[base + n_in] if n_out else None
+                calls.append(_bw_call(fn, kind, x, x2, y, z, S, K))
+            rc = calls[0]()
+            torch.cuda.synchronize()
+            if rc != 0:
+                rows.append({"kernel": name, "shape": [S, K], "error": "status %d" % rc})
+                del pool, calls
+                continue
+            ms, launches = _region_ms(calls, 3 * nsets)
+            ms_same, _ = _region_ms(calls[:1], 50)
+            nbytes = bpe * n
+            gbps = nbytes / ms * 1e-6
+            row = {"kernel": name, "shape": [S, K], "dtype": "f16" if esz == 2 else "f32",
+                   "algorithmic_bytes": nbytes, "us_per_launch": round(ms * 1e3, 3), "launches": launches,
+                   "gbps": round(gbps, 1), "frac_of_8TBs": round(gbps / bu.PEAK_HBM_GBPS, 4),
+                   "frac_of_measured_copy_6290": round(gbps / 6290.0, 4),
+                   "rotating_sets": int(nsets), "rotating_footprint_MB": round(nsets * set_bytes / 1e6, 1),
+                   "gbps_same_buffers": round(nbytes / ms_same * 1e-6, 1),
+                   "same_buffers_fit_infinity_cache": bool(set_bytes < MALL_BYTES)}
+            if (S, K) == tuple(cpu_shape):
+                xc = torch.randn(S, K, generator=g).to(dtype)
+                x2c = torch.randn(S, K, generator=g).to(dtype)
+                try:
+                    sec, it = _cpu_time(lambda: cpu_op(xc, x2c))
+                    row["cpu_baseline"] = {"value": round(nbytes / sec * 1e-9, 2), "unit": "GB/s", "cores": torch.get_num_threads(),
+                                           "kind": "port", "sample": "torch op of the reference script on CPU, [%d,%d] %s, %d calls "
+                                                                    "(%.3f s each)" % (S, K, str(dtype).replace("torch.", ""), it, sec)}
+                except Exception as e:  # noqa: BLE001
+                    row["cpu_baseline"] = {"error": str(e)[:120]}
+                del xc, x2c
+            rows.append(row)
+            del pool, calls
+            torch.cuda.empty_cache()
+    return rows
+
+
+def config_c1(dev, orc):
+    """BASELINE config C1: elementwise_add_f32, a, b fp32 [2048,2048] (4 Mi elements, 50.33 MB algorithmic): the two f32
+    kernel rows on the GPU (rotating sets) and `torch.add(a, b, out=c)` on the host -- the row the config itself names."""
+    S = K = 2048
+    n = S * K
+    nbytes = 12 * n
+    out = {"shape": [S, K], "algorithmic_bytes": nbytes}
+    z = torch.zeros(4, dtype=torch.float32, device=dev)
+    nsets = (ROTATE_FOOTPRINT + nbytes - 1) // nbytes
+    pool = torch.randn(nsets * 3, S, K, device=dev)
+    for name in ("elementwise_add_f32", "elementwise_add_f32x4"):
+        fn = _loader.symbol(name)
+        calls = [_bw_call(fn, "P3", pool[3 * i], pool[3 * i + 1], pool[3 * i + 2], z, S, K) for i in range(nsets)]
+        ms, launches = _region_ms(calls, 3 * nsets)
+        ms_same, _ = _region_ms(calls[:1], 100)
+        out[name] = {"us_per_launch": round(ms * 1e3, 3), "gbps": round(nbytes / ms * 1e-6, 1),
+                     "frac_of_8TBs": round(nbytes / ms * 1e-6 / bu.PEAK_HBM_GBPS, 4), "launches": launches,
+                     "rotating_sets": int(nsets), "gbps_same_buffers": round(nbytes / ms_same * 1e-6, 1)}
+    # correctness of the row that was just timed, against the host result (bit-exact: fp32 add)
+    a, b, c = pool[0], pool[1], pool[2]
+    _loader.symbol("elementwise_add_f32")(a.data_ptr(), b.data_ptr(), c.data_ptr(), n, _stream())
+    torch.cuda.synchronize()
+    ac, bc = a.cpu(), b.cpu()
+    out["bit_exact_vs_torch_cpu"] = bool(torch.equal(c.cpu(), orc.elementwise_add(ac, bc)))
+    cc = torch.zeros_like(ac)
+    sec, it = _cpu_time(lambda: torch.add(ac, bc, out=cc), budget_s=1.0, max_iters=1000)
+    out["cpu_baseline"] = {"value": round(nbytes / sec * 1e-9, 2), "unit": "GB/s", "ms_per_call": round(sec * 1e3, 4),
+                           "cores": torch.get_num_threads(), "kind": "port",
+                           "sample": "torch.add(a, b, out=c) fp32 [2048,2048] on CPU (elementwise.py:71), %d calls; host cpu_count=%d"
+                                     % (it, os.cpu_count() or 0)}
+    del pool
+    torch.cuda.empty_cache()
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# HGEMM configs
+def _hgemm_ms(fn, flops_ms_hint):
+    bu.prewarm(fn, 0.2)
+    iters = max(20, min(400, int(60.0 / max(flops_ms_hint, 1e-3))))
+    return bu.time_region_events(fn, iters), iters
+
+
+def _tf(flops, ms):
+    return round(flops / (ms * 1e-3) * 1e-12, 2)
+
+
+def hgemm_config_rows(pkg, dev, orc, sizes=(4096, 8192), stage_list=(2, 3, 4)):
+    """Config C3 at every size and stage count the reference's script prints (hgemm.py:353-378: `--mma-all` rows at
+    stages 2/3/4 with block swizzle), NN and TN on the headline names, next to rocBLAS and hipBLASLt; config C2 at 1024^3
+    on the 1-stage rungs. Every row: TFLOPS, fraction of the 2.5 PF dense fp16 peak, the kernel cln_describe names."""
+    hg = pkg.hgemm_lib()
+    nn = hg.hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem
+    tn = hg.hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_tn_swizzle_x4
+    out = {}
+    try:
+        lt = pkg.load("hgemm_vendor_lt")
+    except Exception:  # noqa: BLE001
+        lt = None
+    for M in sizes:
+        N = K = M
+        a = torch.randn(M, K, dtype=torch.half, device=dev)
+        b = torch.randn(K, N, dtype=torch.half, device=dev)
+        c = torch.zeros(M, N, dtype=torch.half, device=dev)
+        bt = bu.as_col_major(b)
+        stride = bu.make_block_swizzle_stride(N, K)
+        flops = bu.hgemm_flops(M, N, K)
+        hint = flops / 1.4e15 * 1e3
+        rows = {"flops": flops, "algorithmic_bytes": bu.hgemm_bytes(M, N, K), "swizzle_stride": stride}
+        for st in stage_list:
+            ms, it = _hgemm_ms(lambda: nn(a, b, c, st, True, stride), hint)
+            rows["nn_stages%d" % st] = {"tflops": _tf(flops, ms), "frac_of_peak": round(_tf(flops, ms) / bu.PEAK_FP16_MFMA_TFLOPS, 4),
+                                        "ms": round(ms, 5), "launches": it,
+                                        "kernel": manifest.describe(bu.HEADLINE_HGEMM_NAME, (M, N, K), st)}
+            ms, it = _hgemm_ms(lambda: tn(a, bt, c, st, True, stride), hint)
+            rows["tn_stages%d" % st] = {"tflops": _tf(flops, ms), "frac_of_peak": round(_tf(flops, ms) / bu.PEAK_FP16_MFMA_TFLOPS, 4),
+                                        "ms": round(ms, 5), "launches": it,
+                                        "kernel": manifest.describe(tn.__name__, (M, N, K), st)}
+        try:
+            hg.init_cublas_handle()
+            ms, _ = _hgemm_ms(lambda: hg.hgemm_cublas_tensor_op_nn(a, b, c), hint)
+            rows["rocblas_nn_tflops"] = _tf(flops, ms)
+            ms, _ = _hgemm_ms(lambda: hg.hgemm_cublas_tensor_op_tn(a, bt, c), hint)
+            rows["rocblas_tn_tflops"] = _tf(flops, ms)
+            hg.destroy_cublas_handle()
+        except Exception as e:  # noqa: BLE001 -- the vendor row is a comparison, never the product
+            rows["rocblas_error"] = str(e)[:160]
+        if lt is not None:
+            try:
+                ms, _ = _hgemm_ms(lambda: lt.cln_hgemm_hipblaslt_nn(a, b, c), hint)
+                rows["hipblaslt_nn_tflops"] = _tf(flops, ms)
+                ms, _ = _hgemm_ms(lambda: lt.cln_hgemm_hipblaslt_tn(a, bt, c), hint)
+                rows["hipblaslt_tn_tflops"] = _tf(flops, ms)
+            except Exception as e:  # noqa: BLE001
+                rows["hipblaslt_error"] = str(e)[:160]
+        vend_nn = [rows[k] for k in ("rocblas_nn_tflops", "hipblaslt_nn_tflops") if k in rows]
+        vend_all = vend_nn + [rows[k] for k in ("rocblas_tn_tflops", "hipblaslt_tn_tflops") if k in rows]
+        for st in stage_list:
+            r = rows["nn_stages%d" % st]
+            if vend_nn:
+                r["pct_of_rocblas_nn"] = round(100.0 * r["tflops"] / rows.get("rocblas_nn_tflops", vend_nn[0]), 1)
+            if vend_all:
+                r["pct_of_best_vendor_row"] = round(100.0 * r["tflops"] / max(vend_all), 1)
+        out["hgemm_%d" % M] = rows
+        del a, b, c, bt
+        torch.cuda.empty_cache()
+
+    # ---- config C2: 1024^3 on the 1-stage rungs; ~3-8 us kernels, launch-inclusive region of 400 launches
+    M = N = K = 1024
+    a = torch.randn(M, K, dtype=torch.half, device=dev)
+    b = torch.randn(K, N, dtype=torch.half, device=dev)
+    c = torch.zeros(M, N, dtype=torch.half, device=dev)
+    flops = bu.hgemm_flops(M, N, K)
+    c2 = {"flops": flops, "algorithmic_bytes": bu.hgemm_bytes(M, N, K),
+          "note": "0.86 us at the 2.5 PF peak: launch/latency-dominated (SURVEY 8(d)); the region is launch-inclusive"}
+    for key, name in (("naive", "hgemm_mma_m16n8k16_naive"), ("mma2x4_warp4x4", "hgemm_mma_m16n8k16_mma2x4_warp4x4")):
+        raw = _loader.symbol(name)
+        ap, bp, cp, st = a.data_ptr(), b.data_ptr(), c.data_ptr(), _stream()
+        call = lambda: raw(ap, bp, cp, M, N, K, st)  # noqa: E731 -- C-ABI directly: the Python wrapper's checks cost as much as the kernel
+        bu.prewarm(call, 0.15)
+        ms = bu.time_region_events(call, 400)
+        c2[key] = {"name": name, "us_per_launch": round(ms * 1e3, 3), "tflops": _tf(flops, ms),
+                   "frac_of_peak": round(_tf(flops, ms) / bu.PEAK_FP16_MFMA_TFLOPS, 4), "impl": manifest.BY_NAME[name].impl}
+    raw = _loader.symbol(bu.HEADLINE_HGEMM_NAME)
+    ap, bp, cp, st = a.data_ptr(), b.data_ptr(), c.data_ptr(), _stream()
+    call = lambda: raw(ap, bp, cp, M, N, K, 2, 0, 1, st)  # noqa: E731
+    bu.prewarm(call, 0.15)
+    ms = bu.time_region_events(call, 400)
+    c2["headline_name_stages2"] = {"us_per_launch": round(ms * 1e3, 3), "tflops": _tf(flops, ms),
+                                   "kernel": manifest.describe(bu.HEADLINE_HGEMM_NAME, (M, N, K), 2)}
+    try:
+        hg.init_cublas_handle()
+        raw = _loader.symbol("hgemm_cublas_tensor_op_nn")
+        call = lambda: raw(ap, bp, cp, M, N, K, st)  # noqa: E731
+        bu.prewarm(call, 0.15)
+        ms = bu.time_region_events(call, 400)
+        c2["rocblas_nn"] = {"us_per_launch": round(ms * 1e3, 3), "tflops": _tf(flops, ms)}
+        hg.destroy_cublas_handle()
+    except Exception as e:  # noqa: BLE001
+        c2["rocblas_error"] = str(e)[:160]
+    # the reference's torch path on the host cores, the WHOLE 1024^3 product (hgemm.py:420-421)
+    ac, bc = a.cpu(), b.cpu()
+    t0 = time.perf_counter()
+    ref = orc.hgemm_fp16_path(ac, bc)
+    dt = time.perf_counter() - t0
+    c2["cpu_baseline"] = {"value": round(flops / dt * 1e-12, 5), "unit": "TFLOPS", "cores": torch.get_num_threads(), "kind": "port",
+                          "sample": "torch.matmul fp16 on CPU, the whole 1024^3 product, 1 call (%.2f s)" % dt}
+    _loader.symbol("hgemm_mma_m16n8k16_mma2x4_warp4x4")(ap, bp, cp, M, N, K, st)
+    torch.cuda.synchronize()
+    c2["max_abs_err_vs_cpu_fp16_matmul"] = round((c.cpu().float() - ref.float()).abs().max().item(), 4)
+    out["hgemm_c2_1024"] = c2
+    del a, b, c
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# attention: the `stages` knob at configs C4 / C5 (+ D = 128)
+def fa_stage_rows(pkg, dev):
+    fa = pkg.flash_attn_lib()
+    sq, tq = fa.flash_attn_mma_stages_split_q_shared_qkv, fa.flash_attn_mma_stages_split_q_tiling_qkv
+    out = {}
+    for key, kern, shape in (("fa2_c4_d64", sq, (4, 8, 2048, 64)), ("fa2_d128", sq, (4, 8, 2048, 128)),
+                             ("fa2_c5_d512", tq, (1, 32, 4096, 512))):
+        B, H, N, D = shape
+        q, k, v = (torch.randn(B, H, N, D, dtype=torch.half, device=dev) for _ in range(3))
+        o1, o2 = torch.zeros_like(q), torch.zeros_like(q)
+        flops = bu.mha_flops_conventional(B, H, N, D)
+        row = {"shape": list(shape), "algorithmic_flops": flops}
+        for st, o in ((1, o1), (2, o2)):
+            fn = lambda: kern(q, k, v, o, st)  # noqa: E731
+            bu.prewarm(fn, 0.2)
+            ms = bu.time_region_events(fn, 200 if N <= 2048 else 40)
+            row["stages%d" % st] = {"tflops_4bhn2d": _tf(flops, ms), "frac_of_peak": round(_tf(flops, ms) / bu.PEAK_FP16_MFMA_TFLOPS, 4),
+                                    "ms": round(ms, 5), "tflops_ref_model": round(bu.get_mha_tflops(B, H, N, D, ms * 1e-3), 2),
+                                    "kernel": manifest.describe(kern.__name__, shape, st)}
+        torch.cuda.synchronize()
+        row["stage1_over_stage2"] = round(row["stages1"]["tflops_4bhn2d"] / row["stages2"]["tflops_4bhn2d"], 3)
+        row["stage1_bit_identical_to_stage2"] = bool(torch.equal(o1, o2))
+        out[key] = row
+        del q, k, v, o1, o2
+    return out

@@ -12,6 +12,10 @@ import torch
 
 PEAK_FP16_MFMA_TFLOPS = 2500.0  # dense fp16/bf16 MFMA, MI355X
 PEAK_HBM_GBPS = 8000.0          # HBM3E spec (6290 measured float4 copy)
+# what `roofline.traffic` counts: rocprofv3 FETCH_SIZE / WRITE_SIZE derive from the L2's fabric-side request counters
+# (TCC_EA0_RDREQ / WRREQ): bytes between the XCD L2s and the memory fabric. Infinity-Cache hits are INSIDE the number, so
+# it is an upper bound of the HBM bytes, not the HBM bytes (MI355X_MICROARCH.md, HBM / Infinity Cache sections).
+TRAFFIC_IS = "L2<->fabric bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); Infinity-Cache hits included: upper bound of HBM bytes"
 HEADLINE_HGEMM_NAME = "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem"  # what it runs: manifest.describe(name, dims, stages)
 
 
@@ -226,30 +230,8 @@ def pmc_value(profiles_dir: str, stem: str, key: str, kernel_sub: str = ""):
         return None, None
     try:
         d = json.load(open(files[-1]))
-        vals = [e[key] for k, e in d.items() if isinstance(e, dict) and key in e and kernel_sub in k]
+        old = key.replace("l2_fabric_", "hbm_")  # summaries written before round 4 call the same numbers hbm_*
+        vals = [e.get(key, e.get(old)) for k, e in d.items() if isinstance(e, dict) and (key in e or old in e) and kernel_sub in k]
         return (vals[-1], os.path.basename(files[-1])) if vals else (None, None)
-    except Exception:
-        return None, None
-
-
-def pmc_traffic(profiles_dir: str, kernel_sub: str, size: int):
-    """HBM bytes per launch of the headline kernel from the committed rocprofv3 PMC summary
-    (profiles/rNN_pmc_<kernel>.json, written by tools/pmc_summary.py on the GPU box; PMC counters cannot be
-    collected from inside the timed process). Only valid for the size the pass was taken at (4096)."""
-    import glob
-    import json
-    import os
-    if size != 4096:
-        return None, None
-    files = sorted(glob.glob(os.path.join(profiles_dir, "r*_pmc_%s.json" % kernel_sub)))
-    if not files:
-        return None, None
-    try:
-        d = json.load(open(files[-1]))
-        best = None
-        for k, e in d.items():
-            if "hbm_traffic_bytes_per_launch" in e:
-                best = e["hbm_traffic_bytes_per_launch"]
-        return (round(best) if best else None), os.path.basename(files[-1])
     except Exception:
         return None, None

@@ -6,7 +6,8 @@
 // q,k,v,o: fp16 [B,H,N,D] contiguous; the *_swizzle_qkv variants of share_kv / share_qkv /
 // tiling_qk take v TRANSPOSED, [B,H,D,N] (reference flash_attn_mma.py:377-378, :542-565).
 // stages (reference kStage template parameter, flash_attn_mma_share_qkv.cu:843-884):
-//   1 = load-then-compute per KV tile (no prefetch: the tile is fetched, two barriers, then used),
+//   1 = a tile is requested, waited for, then used: the stage-2 kernel of the shape with each tile's requests issued in one burst and
+//       waited for right there (no request of a wave in flight while it computes); bit-identical to stages = 2,
 //   2 = the next K/V tile is prefetched under the MFMA phases of the current one.
 // Every name goes through ONE planner (fa2_plan) that picks the gfx950 kernel for (family, shape, stages); the same
 // plan is what cln_describe() prints, so the name -> kernel map in manifest.py is checked against the code
@@ -22,7 +23,7 @@
 namespace {
 
 enum FaFamily { FAM_SPLIT_KV = 0, FAM_SPLIT_Q = 1 };
-enum FaKind { K_NONE = 0, K_SPLITKV, K_LOAD_THEN_COMPUTE, K_V2, K_DSPLIT, K_DRING, K_M16X64R, K_M16 };
+enum FaKind { K_NONE = 0, K_SPLITKV, K_V2, K_DSPLIT, K_DRING, K_M16X64R, K_M16 };
 
 struct FaPlan {
   int rc = CLN_OK;     // CLN_ERR_* when the shape is not supported
@@ -30,8 +31,7 @@ struct FaPlan {
   int d_inst = 0;      // head dim of the instantiation (> D: padded form)
   int nw = 0;          // waves per workgroup
   int bc = 0;          // keys per KV tile
-  bool stages_honoured = true;  // false: stages = 1 and 2 run the same (prefetching) kernel for this shape
-  bool one_stage = false;       // head dims above 256 at stages = 1: the production kernel with every tile fetch waited for at issue
+  bool one_stage = false;       // stages = 1: the stage-2 kernel of the shape with every tile fetch waited for where it is issued
 };
 
 FaPlan fa2_plan(int family, bool vt, int B, int H, int N, int D, int stages, int max_d) {
@@ -49,12 +49,12 @@ FaPlan fa2_plan(int family, bool vt, int B, int H, int N, int D, int stages, int
     return p;
   }
   const bool small_d = D == 32 || D == 64 || D == 96 || D == 128 || D == 256;
-  // ---- stages = 1: load-then-compute (flash_attn.cuh with PREFETCH = false): 4 waves x 32 rows, 64-key tiles
-  if (stages == 1 && small_d && N % 128 == 0 && bh <= 65535) {  // (B*H in gridDim.y)
-    p.kind = K_LOAD_THEN_COMPUTE, p.d_inst = D, p.nw = 4, p.bc = 64;
-    return p;
-  }
-  p.stages_honoured = stages != 1;
+  // ---- stages = 1 (reference kStage = 1, flash_attn_mma_share_qkv.cu:711-762: a tile is requested, waited for, then used): at EVERY head
+  // dim the stage-2 kernel of the shape in its single-stage form -- each tile requested in one burst and waited for where it is requested,
+  // no request of a wave in flight while it computes; same LDS image, same arithmetic, bit-identical output (`one_stage`). Rounds 1-3 ran
+  // a separate 4-wave load-then-compute kernel (flash_attn.cuh) for D <= 256: 0.24-0.44x of stages = 2 (profiles/r03_fa_stage1_vs_stage2.log);
+  // that kernel now lives in the probe library only.
+  p.one_stage = stages == 1;
   if (small_d) {
     if (D == 64 && N % 512 == 0) {  // (both V layouts)
       // >= 512 query rows per CU, in (nearly) whole rounds of 256 workgroups: 64 query rows per wave -- every K / V fragment
@@ -100,8 +100,6 @@ FaPlan fa2_plan(int family, bool vt, int B, int H, int N, int D, int stages, int
   // stages = 1 here: the SAME d-split / ring kernels with every tile fetch waited for where it is issued, so no load runs
   // under compute (`one_stage`); stages = 2: the pipelines. (Round 3's first form ran the 4-wave kernel of flash_attn.cuh
   // with the output head dim sliced and S recomputed per slice: 94 TF at D = 768 / 1024, profiles/r03_fa_stage1_vs_stage2.log.)
-  p.one_stage = stages == 1;
-  p.stages_honoured = stages != 1 || p.one_stage;
   switch (D) {
     case 512:  // config C5: the d-split PAIR kernel on 16x16x32 MFMAs, scores scaled in fp32 (flash_attn_m16.cuh, round 3: +2.7 %
       // over the 32x32x16 form at identical max-abs-error once its MFMA destinations were kept off the operand registers)
@@ -134,40 +132,38 @@ int fa2_run(const FaPlan& p, const void* q, const void* k, const void* v, void* 
         }
       }
       return CLN_ERR_UNSUPPORTED;
-    case K_LOAD_THEN_COMPUTE:
-      switch (D) {
-        case 32: return fa::launch_fa2<32, 32, 64, VT, false>(q, k, v, o, B, H, N, s);
-        case 64: return fa::launch_fa2<64, 64, 64, VT, false>(q, k, v, o, B, H, N, s);
-        case 96: return fa::launch_fa2<96, 96, 64, VT, false>(q, k, v, o, B, H, N, s);
-        case 128: return fa::launch_fa2<128, 128, 64, VT, false>(q, k, v, o, B, H, N, s);
-        case 256: return fa::launch_fa2<256, 256, 64, VT, false>(q, k, v, o, B, H, N, s);
-      }
-      return CLN_ERR_UNSUPPORTED;
     case K_V2:
-#define FA_V2(DD, OPTT, HAS8)                                                                          \
-  case DD:                                                                                             \
+#define FA_V2_NW(DD, OPTT, HAS8)                                                                       \
     if (p.nw == 8) {                                                                                   \
       if constexpr (HAS8) return fa2::launch_v2<DD, 8, VT, OPTT>(q, k, v, o, B, H, N, s);             \
       else return CLN_ERR_UNSUPPORTED; /* the plan never names it: these shapes run fa2_fwd_m16x */   \
     }                                                                                                  \
     if (p.nw == 4) return fa2::launch_v2<DD, 4, VT, OPTT>(q, k, v, o, B, H, N, s);                     \
     return fa2::launch_v2<DD, 2, VT, OPTT>(q, k, v, o, B, H, N, s);
+#define FA_V2(DD, OPTT, HAS8)                                                      \
+  case DD:                                                                         \
+    if (p.one_stage) { FA_V2_NW(DD, (OPTT) | fa2::OPT_1STAGE, HAS8) }              \
+    FA_V2_NW(DD, OPTT, HAS8)
       switch (D) {
         FA_V2(32, 13 | fa2::OPT_PRE, true)
         FA_V2(64, 13 | fa2::OPT_PRE, false)
         FA_V2(96, 15 | fa2::OPT_PRE, true)
         FA_V2(128, 15 | fa2::OPT_PRE, false)
-        case 256: return fa2::launch_v2<256, 4, VT, 15>(q, k, v, o, B, H, N, s);
+        case 256: return p.one_stage ? fa2::launch_v2<256, 4, VT, 15 | fa2::OPT_1STAGE>(q, k, v, o, B, H, N, s)
+                                     : fa2::launch_v2<256, 4, VT, 15>(q, k, v, o, B, H, N, s);
       }
 #undef FA_V2
+#undef FA_V2_NW
       return CLN_ERR_UNSUPPORTED;
     case K_M16X64R:
-      return fa2::m16x_run(64, 64, VT, q, k, v, o, B, H, N, s);
+      return fa2::m16x_run(64, 64, VT, p.one_stage, q, k, v, o, B, H, N, s);
     case K_M16:
-      if (D == 64 || D == 128) return fa2::m16x_run(D, 32, VT, q, k, v, o, B, H, N, s);  // 128-key tiles; own compile unit
+      if (D == 64 || D == 128) return fa2::m16x_run(D, 32, VT, p.one_stage, q, k, v, o, B, H, N, s);  // 128-key tiles; own compile unit
       if constexpr (!VT) {
-        if (D == 256) return fa2::launch_m16_pair<2, false, false>(q, k, v, o, B, H, N, s);
-        if (D == 512) return p.one_stage ? fa2::launch_m16_pair<2, true, false, 131072>(q, k, v, o, B, H, N, s)
+        constexpr int ONE = 262144;  // flash_attn_m16.cuh: the tile requested in one burst at the top of phase A and waited for there
+        if (D == 256) return p.one_stage ? fa2::launch_m16_pair<2, false, false, ONE>(q, k, v, o, B, H, N, s)
+                                         : fa2::launch_m16_pair<2, false, false>(q, k, v, o, B, H, N, s);
+        if (D == 512) return p.one_stage ? fa2::launch_m16_pair<2, true, false, ONE>(q, k, v, o, B, H, N, s)
                                          : fa2::launch_m16_pair<2, true, false>(q, k, v, o, B, H, N, s);
       }
       return CLN_ERR_UNSUPPORTED;
@@ -198,16 +194,14 @@ int fa2_dispatch(int family, const void* q, const void* k, const void* v, void* 
 int fa2_describe(int family, bool vt, int B, int H, int N, int D, int stages, int max_d, char* buf, int len) {
   const FaPlan p = fa2_plan(family, vt, B, H, N, D, stages, max_d);
   if (p.rc != CLN_OK) return p.rc;
-  const char* st = p.one_stage ? " [single stage: every tile fetch waited for where it is issued]" : p.stages_honoured ? "" : " [stages ignored: one pipeline]";
+  const char* st = p.one_stage ? " [single stage: every tile fetch waited for where it is issued]" : "";
   const char* vts = vt ? ",V^T" : "";
   switch (p.kind) {
     case K_SPLITKV:
       return snprintf(buf, len, "fa2_fwd_splitkv<D=%d,%s> 4 waves share 32 rows, 128-key tiles split over the waves, "
                                 "cross-wave max via LDS", D, p.one_stage ? "load-then-compute" : "next K fragments prefetched into registers");
-    case K_LOAD_THEN_COMPUTE:
-      return snprintf(buf, len, "fa2_fwd<D=%d,BC=64,load-then-compute%s> 4 waves x 32 rows", D, vts);
     case K_V2:
-      return snprintf(buf, len, "fa2_fwd_v2<D=%d,NW=%d,BC=64,prefetch%s%s> %d waves x 32 rows%s", D, p.nw,
+      return snprintf(buf, len, "fa2_fwd_v2<D=%d,NW=%d,BC=64,%s%s%s> %d waves x 32 rows%s", D, p.nw, p.one_stage ? "load-then-compute" : "prefetch",
                       D <= 128 ? ",pre-scaled Q" : "", vts, p.nw, st);
     case K_M16X64R:
       return snprintf(buf, len, "fa2_fwd_m16x64r<D=64,BC=64,16x16x32 MFMA,pre-scaled Q,sum-checked softmax%s> 8 waves x 64 rows, two groups one "

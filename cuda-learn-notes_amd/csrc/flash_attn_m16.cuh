@@ -441,6 +441,15 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16_pair_kernel(const half_t* 
       return h8_cat(lds_read_tr16(vp), lds_read_tr16(vp + 16 * G::ROW));
     };
     // ================= phase A: partial S^T over this wave's half of d
+    // DBG 262144 = the `stages = 1` form in ONE burst (round 4): the wave requests all its pieces of tile j + 1 here and waits for them
+    // here; no request of the wave is in flight while it computes (DBG 131072, round 3: the wait after EVERY piece, 0.27x)
+    if constexpr ((DBG & 262144) != 0 && (DBG & 524288) == 0) {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < G::PPW; ++i) dma_piece(jn, (j + 1) & 1, i);
+      hgemm::wait_vmcnt<0>();
+      __builtin_amdgcn_sched_barrier(0);
+    }
     if constexpr ((DBG & 65536) != 0) __builtin_amdgcn_s_setprio(0);
     f4 s[NKB][NQB];
     {
@@ -472,7 +481,7 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16_pair_kernel(const half_t* 
         if constexpr ((DBG & 1024) != 0) asm volatile("s_nop 15" ::: "memory");
         if constexpr ((DBG & 2048) != 0) asm volatile("s_sleep 1" ::: "memory");
         if (t + PD < NQK) kf[t % PD] = k_frag(t + PD);
-        if ((t % DSTEP) == DSTEP - 1) {
+        if ((DBG & 262144) == 0 && (t % DSTEP) == DSTEP - 1) {
           dma_piece(jn, (j + 1) & 1, t / DSTEP);
           // DBG 131072 = the `stages = 1` form: every tile fetch is waited for where it is issued, no load runs under compute
           if constexpr ((DBG & 131072) != 0) hgemm::wait_vmcnt<0>();
@@ -491,6 +500,13 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16_pair_kernel(const half_t* 
     asm volatile("" ::: "memory");
 
     // ================= phase B: S = own + partner's partial, softmax, O^T[half] += V[:, half]^T P^T
+    if constexpr ((DBG & 262144) != 0 && (DBG & 524288) != 0) {  // probe: the stages = 1 burst at the top of phase B instead
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < G::PPW; ++i) dma_piece(jn, (j + 1) & 1, i);
+      hgemm::wait_vmcnt<0>();
+      __builtin_amdgcn_sched_barrier(0);
+    }
     if constexpr ((DBG & 65536) != 0) __builtin_amdgcn_s_setprio(1);  // the VALU-carrying phase wins the issue arbitration
     f4 pp_first[2];
     if constexpr (PAIR)

@@ -51,7 +51,14 @@ enum : int {
   // tile); instead their OWN partial row sums are compared once, in phase B, right after their last exponential and before the first PV
   // MFMA that consumes them -- a failing wave rescales O / l there (the PV products of the optimistic blocks are already in O, relative
   // to the old reference, and are scaled with it) and exponentiates the deferred blocks again
-  M16X_LATE_CHECK = 16384
+  M16X_LATE_CHECK = 16384,
+  // the `stages = 1` form (reference kStage = 1, flash_attn_mma_share_qkv.cu:711-762: a tile is requested, waited for, then used): the
+  // SAME kernel, same LDS image and arithmetic (bit-identical output), but a wave issues all its pieces of tile j + 1 in ONE burst and
+  // waits for them right there (s_waitcnt vmcnt(0)): no request of the wave is in flight while it computes. M16X_ONE_POS (probe) picks the
+  // burst's place in the iteration: 0 = top of phase A, 1 = end of phase A, 2 = top of phase B, 3 = end of phase B.
+  M16X_ONE_STAGE = 32768,
+  M16X_ONE_POS_SHIFT = 16,  // two bits
+  M16X_ONE_POS = 2           // the shipped position: top of phase B (the MFMA-only phase), 0.95-1.0x of stages = 2 (profiles/r04_fa_one_stage_probe.log)
 };
 
 template <int D_, int RPW_, int BC_, int PD = 4, int NDEF = 1, int OX = 0, bool VT = false>
@@ -214,6 +221,15 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
     float psum[NQB];
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb) psum[qb] = 0.f;
+    constexpr bool ONE = (OX & M16X_ONE_STAGE) != 0;
+    constexpr int ONE_POS = (OX >> M16X_ONE_POS_SHIFT) & 3;
+    auto fetch_whole_tile = [&]() __attribute__((always_inline)) {  // stages = 1: request, wait, (later) use
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < G::PPW; ++i) dma_piece(jn, (j + 1) & 1, i);
+      hgemm::wait_vmcnt<0>();
+      __builtin_amdgcn_sched_barrier(0);
+    };
     // item it of key block kb: query block it >> 1, registers (it & 1) * 2, + 1 -> k-slots of P^T step kb >> 1
     auto exp_item = [&](int kb, int it, float (&acc)[NQB]) __attribute__((always_inline)) {
       const int qb = it >> 1, r = (it & 1) * 2;
@@ -231,6 +247,7 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
     // ================= phase A: S^T = K Q^T, block kb - 1 exponentiated behind the MFMAs of block kb
     constexpr bool LATE = (OX & M16X_LATE) != 0;
     constexpr int LAG = LATE ? NKB - NOPT : 1;  // block kb - LAG is exponentiated behind the MFMAs of block kb
+    if constexpr (ONE && ONE_POS == 0) fetch_whole_tile();
     if constexpr ((OX & M16X_PRIO) != 0 && !LATE) __builtin_amdgcn_s_setprio(1);
     if constexpr ((OX & M16X_PRIO_B) != 0) __builtin_amdgcn_s_setprio(0);
     {
@@ -263,7 +280,7 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
         }
         __builtin_amdgcn_sched_barrier(0);  // the MFMAs of the step first: the VALU slice runs in their shadow
         if (t + PD < NQK) kf[t % PD] = k_frag(t + PD);
-        if ((OX & M16X_ABL_DMA) == 0 && (t % DSTEP) == DSTEP - 1) dma_piece(jn, (j + 1) & 1, t / DSTEP);
+        if (!ONE && (OX & M16X_ABL_DMA) == 0 && (t % DSTEP) == DSTEP - 1) dma_piece(jn, (j + 1) & 1, t / DSTEP);
         if constexpr (PAIRED) {
           // group g = t / 4 works on blocks 2g, 2g + 1; the two blocks of group g - 1 are exponentiated over its four steps
           const int g = t / 4, r = t % 4, eb = 2 * (g - 1) + (r >> 1);
@@ -278,6 +295,7 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    if constexpr (ONE && ONE_POS == 1) fetch_whole_tile();
     {
       // ---- the check: partial sums of the optimistic blocks, raw scores of the deferred ones
       bool bad = false;
@@ -339,6 +357,7 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
     // ================= phase B: O^T += V^T P^T; the deferred key blocks are exponentiated under its first MFMAs
     if constexpr ((OX & M16X_PRIO) != 0 && !LATE) __builtin_amdgcn_s_setprio(0);
     if constexpr ((OX & M16X_PRIO_B) != 0) __builtin_amdgcn_s_setprio(1);
+    if constexpr (ONE && ONE_POS == 2) fetch_whole_tile();
     float psum_d[NQB];
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb) psum_d[qb] = 0.f;
@@ -416,6 +435,7 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
     }
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb) l_run[qb] += psum_d[qb];
+    if constexpr (ONE && ONE_POS == 3) fetch_whole_tile();
     hgemm::wait_vmcnt<0>();  // own DMA pieces of tile j+1 landed
     if constexpr ((OX & M16X_ABL_BAR) == 0) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");

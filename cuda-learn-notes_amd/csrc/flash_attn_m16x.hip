@@ -11,8 +11,23 @@ namespace fa2 {
 // The dispatched forms (fa2_plan, flash_attn.hip). 32 rows per wave (256-row workgroups, 128-key tiles): NDEF = 4 (half of the
 // exponentials under the PV MFMAs), phase-A priority, split prologue -- the best of profiles/r03_fa_m16x_probe.log at both head
 // dims. 64 rows per wave (D = 64, 512-row workgroups, 64-key tiles; long sequences): NDEF = 1 of the 4 key blocks.
-int m16x_run(int D, int rows_per_wave, bool vt, const void* q, const void* k, const void* v, void* o, int B, int H, int N, hipStream_t s) {
+// `one_stage` (the names' stages = 1): the same kernels with each tile requested in one burst and waited for where it is requested
+// (M16X_ONE_STAGE), bit-identical output.
+int m16x_run(int D, int rows_per_wave, bool vt, bool one_stage, const void* q, const void* k, const void* v, void* o, int B, int H, int N, hipStream_t s) {
   constexpr int OX = M16X_PRIO | M16X_SPLIT_PROLOGUE;
+  constexpr int O1 = OX | M16X_ONE_STAGE | (M16X_ONE_POS << M16X_ONE_POS_SHIFT);
+  if (one_stage) {
+    if (!vt) {
+      if (D == 64 && rows_per_wave == 32) return launch_m16x<64, 32, 128, 8, 4, O1>(q, k, v, o, B, H, N, s);
+      if (D == 128 && rows_per_wave == 32) return launch_m16x<128, 32, 128, 4, 4, O1>(q, k, v, o, B, H, N, s);
+      if (D == 64 && rows_per_wave == 64) return launch_m16x<64, 64, 64, 4, 1, O1>(q, k, v, o, B, H, N, s);
+    } else {
+      if (D == 64 && rows_per_wave == 32) return launch_m16x<64, 32, 128, 8, 4, O1, true>(q, k, v, o, B, H, N, s);
+      if (D == 128 && rows_per_wave == 32) return launch_m16x<128, 32, 128, 4, 4, O1, true>(q, k, v, o, B, H, N, s);
+      if (D == 64 && rows_per_wave == 64) return launch_m16x<64, 64, 64, 4, 1, O1, true>(q, k, v, o, B, H, N, s);
+    }
+    return CLN_ERR_UNSUPPORTED;
+  }
   if (!vt) {
     if (D == 64 && rows_per_wave == 32) return launch_m16x<64, 32, 128, 8, 4, OX>(q, k, v, o, B, H, N, s);
     if (D == 128 && rows_per_wave == 32) return launch_m16x<128, 32, 128, 4, 4, OX>(q, k, v, o, B, H, N, s);

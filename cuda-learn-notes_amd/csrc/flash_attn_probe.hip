@@ -1,5 +1,6 @@
 // Tuning / ablation hook for the v2 FlashAttention kernel (not part of the reference surface).
 //   int cln_fa2_variant(D, nw, vt, opt, abl, q, k, v, o, B, H, N, stream)
+#include "flash_attn.cuh"
 #include "flash_attn_v3.cuh"
 #include "flash_attn_bigd.cuh"
 #include "flash_attn_dsplit.cuh"
@@ -146,6 +147,19 @@ CLN_API int cln_fa2_variant(int D, int nw, int vt, int opt, int abl, const void*
   if (D == 768 && abl == 1002) return fa2::launch_dring<768, fa2::OPT_DEFAULT, true, 1>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 768 && abl == 1003) return fa2::launch_dring<768, fa2::OPT_DEFAULT, false, 1>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 512 && abl == 558) return fa2::launch_m16_pair<2, true, false, 8>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  // 90 = the 4-wave load-then-compute kernel of rounds 1-3 (flash_attn.cuh, PREFETCH = false): what `stages = 1` ran for D <= 256 until
+  // round 4 made it the single-stage form of the stage-2 kernels (0.24-0.44x of stages = 2, profiles/r03_fa_stage1_vs_stage2.log)
+  if (abl == 90 && !vt && N % 128 == 0) {
+    if (D == 64) return fa::launch_fa2<64, 64, 64, false, false>(q, k, v, o, B, H, N, (hipStream_t)stream);
+    if (D == 128) return fa::launch_fa2<128, 128, 64, false, false>(q, k, v, o, B, H, N, (hipStream_t)stream);
+    if (D == 256) return fa::launch_fa2<256, 256, 64, false, false>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  }
+  // 262144-form of the pair kernel (stages = 1, one burst per tile): 545 at D = 256 / 512; 546 = round 3's wait after every piece (D = 512)
+  if (D == 256 && abl == 545) return fa2::launch_m16_pair<2, false, false, 262144>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 512 && abl == 545) return fa2::launch_m16_pair<2, true, false, 262144>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 256 && abl == 547) return fa2::launch_m16_pair<2, false, false, 262144 | 524288>(q, k, v, o, B, H, N, (hipStream_t)stream);  // burst at the top of phase B
+  if (D == 512 && abl == 547) return fa2::launch_m16_pair<2, true, false, 262144 | 524288>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  if (D == 512 && abl == 546) return fa2::launch_m16_pair<2, true, false, 131072>(q, k, v, o, B, H, N, (hipStream_t)stream);
   // 800.. = the sum-checked optimistic softmax form (flash_attn_m16x.cuh, its own compile unit): abl = 800 + code,
   //         code = 16 * (NDEF - 1) + OX (OX: 1 = phase-A priority, 4 = split prologue); 860.. = prefetch depth 4; 880.. = 64 rows per wave
   if (abl >= 800 && abl < 1000 && D <= 128) return fa2::m16x_probe_run(D, abl - 800, q, k, v, o, B, H, N, (hipStream_t)stream);

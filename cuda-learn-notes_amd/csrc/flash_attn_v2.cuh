@@ -182,7 +182,10 @@ __global__ __launch_bounds__(NW * 64, ((D > 128 || (D >= 96 && NW == 2)) ? 1 : 2
 #pragma unroll
     for (int ks = 0; ks < D / 16; ++ks) qf[ks] = qf[ks] * sc;
   }
-  if (T > 1) load_tile(1);
+  // OPT_1STAGE (the names' stages = 1 on the small-grid shapes): tile j + 1 is requested at the END of tile j and waited for there
+  // (load, wait, write to LDS, barrier, use): no global load of the wave is in flight while it computes; same arithmetic, same bits
+  constexpr bool ONE_STAGE = (OPT & OPT_1STAGE) != 0;
+  if (!ONE_STAGE && T > 1) load_tile(1);
   __syncthreads();
 
   h8 kf_const[2], vf_const;  // ABL_NO_FRAG_READS only
@@ -388,8 +391,16 @@ __global__ __launch_bounds__(NW * 64, ((D > 128 || (D >= 96 && NW == 2)) ? 1 : 2
     // ---- stage: tile j+1 registers -> the other buffer (its readers finished before the last barrier),
     //      then issue tile j+2's global loads (a full iteration to land)
     if constexpr ((ABL & ABL_NO_STAGE) == 0) {
-      if (j + 1 < T) write_tile((j + 1) & 1);
-      if (j + 2 < T) load_tile(j + 2);
+      if constexpr (ONE_STAGE) {
+        if (j + 1 < T) {
+          load_tile(j + 1);
+          __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+          write_tile((j + 1) & 1);
+        }
+      } else {
+        if (j + 1 < T) write_tile((j + 1) & 1);
+        if (j + 2 < T) load_tile(j + 2);
+      }
     }
     if constexpr ((ABL & ABL_NO_BARRIER) == 0) __syncthreads();
   }

@@ -11,6 +11,7 @@
 #include "hgemm_dispatch.h"
 #include "hgemm_mfma.cuh"
 #include "hgemm_w4.cuh"
+#include "hgemm_w4s.cuh"
 #include "hgemm_valu.cuh"
 #include <string.h>
 
@@ -110,6 +111,10 @@ int best_dispatch(const void* a, const void* b, void* c, int M, int N, int K, in
   if (plan == PLAN_W256x128) return launch_w4<LAYOUT, W4_EPILOGUE, W4_PRODUCTION, 0, 256, 128>(a, b, c, M, N, K, swizzle, stride, st);
   if (plan == PLAN_W256) {
     if (stages == 2) return launch_w4<LAYOUT, W4_EPILOGUE, W4_PRODUCTION>(a, b, c, M, N, K, swizzle, stride, st);
+    // stages 3 / 4 / 5: the same one-wave-per-SIMD structure over a ring of `stages` 32-deep K slots (hgemm_w4s.cuh), bit-identical
+    if (stages == 3 && w4s_k_ok(K, 3)) return launch_w4s<LAYOUT, 3, W4_EPILOGUE>(a, b, c, M, N, K, swizzle, stride, st);
+    if (stages == 4 && w4s_k_ok(K, 4)) return launch_w4s<LAYOUT, 4, W4_EPILOGUE>(a, b, c, M, N, K, swizzle, stride, st);
+    if (stages == 5 && w4s_k_ok(K, 5)) return launch_w4s<LAYOUT, 5, W4_EPILOGUE>(a, b, c, M, N, K, swizzle, stride, st);
     plan = PLAN_PP256;
   }
   if (plan == PLAN_PP192) return launch_pp<LAYOUT, 2, 4, 0, 0, 192>(a, b, c, M, N, K, swizzle, stride, st);
@@ -146,6 +151,9 @@ int describe_best(int layout, int M, int N, int K, int stages, char* buf, int le
   if (plan == PLAN_W256x128) return describe_w4(256, 128, layout, buf, len, stages != 2);
   if (plan == PLAN_W256) {
     if (stages == 2) return describe_w4(256, 256, layout, buf, len);
+    if (stages >= 3 && stages <= 5 && w4s_k_ok(K, stages))
+      return snprintf(buf, len, "hgemm_w4s<256x256,ring of %d x 32-deep K slots,4 waves,128x128 wave tiles,LDS-DMA %d slots ahead,LDS epilogue,%s>", stages,
+                      stages - 1, l);
     plan = PLAN_PP256;
   }
   if (plan == PLAN_PP192) return snprintf(buf, len, "hgemm_pp<192x256x64,8 waves,4 slots,LDS epilogue,%s>", l);
@@ -219,6 +227,13 @@ static int fixed_tile_dispatch(int ring_tile, const void* a, const void* b, void
                                int swizzle, int swizzle_stride, hipStream_t stream) {
   if (fixed_tile_runs_w4<LAYOUT, BM, BN>(M, N, K, stages))
     return launch_w4<LAYOUT, W4_EPILOGUE, W4_PRODUCTION, 0, BM, BN>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+  if constexpr (BM == 256 && BN == 256) {  // stages 3 / 4 / 5 on the 256x256 tile: the ring-of-slots form of the same kernel
+    if (M % 256 == 0 && N % 256 == 0 && stages >= 3 && stages <= 5 && w4s_k_ok(K, stages)) {
+      if (stages == 3) return launch_w4s<LAYOUT, 3, W4_EPILOGUE>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+      if (stages == 4) return launch_w4s<LAYOUT, 4, W4_EPILOGUE>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+      return launch_w4s<LAYOUT, 5, W4_EPILOGUE>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+    }
+  }
   if constexpr (LAYOUT == TN) return ring_dispatch_tn(ring_tile, a, b, c, M, N, K, stages, swizzle, swizzle_stride, stream);
   else return ring_dispatch_nn(ring_tile, a, b, c, M, N, K, stages, swizzle, swizzle_stride, stream);
 }
@@ -298,6 +313,9 @@ int cln_hgemm_describe(const char* name, int M, int N, int K, int stages, char* 
       tile_dims(tile, BM, BN, waves);
       if (stages == 2 && M % BM == 0 && N % BN == 0 && w4_k_ok(K))
         return describe_w4(BM, BN, r.layout, buf, len);
+      if (tile == T256 && stages >= 3 && stages <= 5 && M % 256 == 0 && N % 256 == 0 && w4s_k_ok(K, stages))
+        return snprintf(buf, len, "hgemm_w4s<256x256,ring of %d x 32-deep K slots,4 waves,128x128 wave tiles,LDS-DMA %d slots ahead,LDS epilogue,%s>", stages,
+                        stages - 1, r.layout == TN ? "TN" : "NN");
     }
     return describe_ring(tile, r.layout, M, N, K, stages, buf, len);
   }

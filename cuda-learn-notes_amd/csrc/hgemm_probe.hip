@@ -4,6 +4,7 @@
 #include "hgemm_dispatch.h"
 #include "hgemm_mfma.cuh"
 #include "hgemm_w4.cuh"
+#include "hgemm_w4s.cuh"
 
 using namespace hgemm;
 
@@ -121,6 +122,16 @@ CLN_API int cln_hgemm_variant(int kind, int layout, int tile, int bk, int stages
     if (tile == 5) { W4_SHAPE(160, 160) }
 #undef W4_SHAPE
     return CLN_ERR_BAD_ARG;
+  }
+  if (kind == 16) {  // one wave per SIMD over a `stages`-deep ring of 32-deep K slots (hgemm_w4s.cuh); S = 2 exists here only
+#define W4S_CASE(SS)                                                                                     \
+  case SS: return layout == TN ? launch_w4s<TN, SS>(a, b, c, M, N, K, swizzle, swizzle_stride, stream)   \
+                               : launch_w4s<NN, SS>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
+    switch (stages) {
+      W4S_CASE(2) W4S_CASE(3) W4S_CASE(4) W4S_CASE(5)
+      default: return CLN_ERR_BAD_ARG;
+    }
+#undef W4S_CASE
   }
   if (kind == 6) return launch_pp<NN, 1, 4>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);  // 4-slot no-store probe
   if (kind == 7) {  // ablations of the 4-slot no-store probe; `stages` = ABL bits (results are garbage by design)

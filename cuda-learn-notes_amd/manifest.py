@@ -75,13 +75,13 @@ _add("hgemm", "G6", "mfma_ring<128x128,BK by stages,NN>",
      "hgemm_wmma_m16n16k16_mma4x2_warp2x4_stages", "hgemm_wmma_m16n16k16_mma4x2_warp2x4_stages_dsmem",
      "hgemm_mma_m16n8k16_mma2x4_warp4x4_stages", "hgemm_mma_m16n8k16_mma2x4_warp4x4_stages_dsmem")
 _add("hgemm", "G6", "hgemm_w4<256x128> at stages=2 (K % 64 == 0, K >= 384 / 448 for an even / odd K / 64) | mfma_ring<256x128,8 waves,NN>", "hgemm_wmma_m16n16k16_mma4x2_warp4x4_stages_dsmem")
-_add("hgemm", "G6", "hgemm_w4<256x256> at stages=2 (K % 64 == 0, K >= 384 / 448 for an even / odd K / 64) | mfma_ring<256x256,8 waves,NN>", "hgemm_wmma_m16n16k16_mma4x4_warp4x4_stages_dsmem")
-_add("hgemm", "G6", "best<NN>: tile shape by estimated CU utilisation x kernel efficiency (csrc/hgemm.hip best_plan): hgemm_w4<256x256x64, one wave per SIMD> (stages 2; hgemm_pp<256x256x64> when K is not a multiple of 128 or < 384) | hgemm_pp32<4x32 ring> (stages 4) | hgemm_pp<192x256x64> | mfma_ring<128x256> | <64x128> | <64x64> (small problems) | <128x128> (see DISPATCH_EXAMPLES)",
+_add("hgemm", "G6", "hgemm_w4<256x256> at stages=2 (K % 64 == 0, K >= 384 / 448 for an even / odd K / 64) | hgemm_w4s<256x256, ring of `stages` 32-deep slots> at stages 3 / 4 / 5 | mfma_ring<256x256,8 waves,NN>", "hgemm_wmma_m16n16k16_mma4x4_warp4x4_stages_dsmem")
+_add("hgemm", "G6", "best<NN>: tile shape by estimated CU utilisation x kernel efficiency (csrc/hgemm.hip best_plan): hgemm_w4<256x256x64, one wave per SIMD> (stages 2) / hgemm_w4s<256x256, ring of `stages` 32-deep K slots, one wave per SIMD> (stages 3 / 4 / 5; bit-identical) -- hgemm_pp<256x256x64> / hgemm_pp32<4x32 ring> (stages 4) when K is < 384 or has an odd number < 7 of 64-wide tiles | hgemm_pp<192x256x64> | mfma_ring<128x256> | <64x128> | <64x64> (small problems) | <128x128> (see DISPATCH_EXAMPLES)",
      "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem", "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_x4",
      "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_rr",
      "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_swizzle")
 _add("hgemm", "G6", "mfma_ring<128x128,TN>", "hgemm_mma_m16n8k16_mma2x4_warp4x4_stages_dsmem_tn")
-_add("hgemm", "G6", "best<TN>: hgemm_w4 / hgemm_pp / hgemm_pp32 / mfma_ring as for NN (see DISPATCH_EXAMPLES)", "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_tn_swizzle_x4")
+_add("hgemm", "G6", "best<TN>: hgemm_w4 / hgemm_w4s / hgemm_pp / hgemm_pp32 / mfma_ring as for NN (see DISPATCH_EXAMPLES)", "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_tn_swizzle_x4")
 _add("hgemm", "G6", "hgemm_w4<128x256> at stages=2 (K % 64 == 0, K >= 384 / 448 for an even / odd K / 64) | mfma_ring<128x256,8 waves,TN>", "hgemm_mma_stages_block_swizzle_tn_cute")
 
 # ---------------------------------------------------------------- flash-attn (28 + 3)
@@ -106,14 +106,14 @@ _FA_VT = [
     "flash_attn_mma_stages_split_q_shared_kv_swizzle_qkv", "flash_attn_mma_stages_split_q_shared_qkv_swizzle_qkv",
     "flash_attn_mma_stages_split_q_tiling_qk_swizzle_qkv",
 ]
-_FA_SPLIT_Q_IMPL = ("planner fa2_plan(shape, stages) [csrc/flash_attn.hip]: stages=1 -> fa2_fwd<load-then-compute> (D <= 256), the stage-2 kernel of the head dim with every tile fetch waited for where it is issued (D > 256); "
+_FA_SPLIT_Q_IMPL = ("planner fa2_plan(shape, stages) [csrc/flash_attn.hip]: stages=1 -> the stage-2 kernel of the shape in its single-stage form (each tile requested in one burst and waited for where it is requested; bit-identical to stages=2); "
                     "stages=2 -> fa2_fwd_m16x<D=64|128> / fa2_fwd_m16<D=256> (>=192 workgroups of 256 rows) | fa2_fwd_m16<D=512> (pairs of waves split d) | fa2_fwd_m16x64r<D=64> (>=256 workgroups of 512 rows) | fa2_fwd_v2<D<=256, 8|4|2 waves> | "
                     "fa2_fwd_dsplit<320 / 384 on the D = 512 LDS geometry with the real d split evenly> | fa2_fwd_dring<640 | 768 | 1024>; mfma_32x32x16 / 16x16x32, f32 acc "
                     "(see DISPATCH_EXAMPLES)")
 _add("flash_attn", "FA", "fa2_fwd_splitkv<D<=128>: 4 waves share 32 query rows, KV tile split over the waves, cross-wave "
      "row max through LDS (the structurally distinct split-KV rung)", "flash_attn_mma_stages_split_kv")
 _add("flash_attn", "FA", _FA_SPLIT_Q_IMPL, *[n for n in _FA_PLAIN if n != "flash_attn_mma_stages_split_kv"])
-_add("flash_attn", "FA", "planner as above with V transposed [B,H,D,N]: fa2_fwd<load-then-compute,V^T> | fa2_fwd_m16x<D=64|128,V^T> / fa2_fwd_m16x64r<V^T> | fa2_fwd_v2<V^T>",
+_add("flash_attn", "FA", "planner as above with V transposed [B,H,D,N]: fa2_fwd_m16x<D=64|128,V^T> / fa2_fwd_m16x64r<V^T> | fa2_fwd_v2<V^T> (stages=1: their single-stage forms)",
      *_FA_VT)
 
 # max head dim per function (reference flash_attn_mma.py:436-506; C side enforces the same)
@@ -283,8 +283,11 @@ DISPATCH_EXAMPLES = [
     (_W4X2, (4096, 4096, 4096), 0, "hgemm_pp<256x256x64,8 waves,4 slots,split DMA,LDS epilogue,NN>"),
     (_W4X2, (4096, 4096, 320), 2, "hgemm_pp<256x256x64,8 waves,4 slots,split DMA,LDS epilogue,NN>"),
     (_W4X2, (8192, 8192, 8192), 2, "hgemm_w4<256x256x64,4 waves,128x128 wave tiles,cross-tile LDS-DMA,LDS epilogue,NN>"),
-    (_W4X2, (4096, 4096, 4096), 4, "hgemm_pp32<256x256,BK=32 sub-tiles,4-deep ring,NN>"),
-    (_W4X2, (4096, 4096, 4096), 3, "mfma_ring<256x256x32,8 waves,stages=3,NN>"),
+    (_W4X2, (4096, 4096, 4096), 4, "hgemm_w4s<256x256,ring of 4 x 32-deep K slots,4 waves,128x128 wave tiles,LDS-DMA 3 slots ahead,LDS epilogue,NN>"),
+    (_W4X2, (4096, 4096, 4096), 3, "hgemm_w4s<256x256,ring of 3 x 32-deep K slots,4 waves,128x128 wave tiles,LDS-DMA 2 slots ahead,LDS epilogue,NN>"),
+    (_W4X2, (8192, 8192, 8192), 5, "hgemm_w4s<256x256,ring of 5 x 32-deep K slots,4 waves,128x128 wave tiles,LDS-DMA 4 slots ahead,LDS epilogue,NN>"),
+    (_W4X2 + "_tn_swizzle_x4", (4096, 4096, 4096), 3, "hgemm_w4s<256x256,ring of 3 x 32-deep K slots,4 waves,128x128 wave tiles,LDS-DMA 2 slots ahead,LDS epilogue,TN>"),
+    (_W4X2, (4096, 4096, 320), 4, "hgemm_pp32<256x256,BK=32 sub-tiles,4-deep ring,NN>"),  # K too short for the one-wave-per-SIMD kernels
     (_W4X2, (3072, 3072, 3072), 2, "hgemm_w4<192x192x64,4 waves,96x96 wave tiles,cross-tile LDS-DMA,LDS epilogue,NN>"),
     (_W4X2, (2304, 2304, 2304), 2, "hgemm_w4<192x192x64,4 waves,96x96 wave tiles,cross-tile LDS-DMA,LDS epilogue,NN>"),
     (_W4X2, (3072, 3072, 3136), 2, "hgemm_w4<192x192x64,4 waves,96x96 wave tiles,cross-tile LDS-DMA,LDS epilogue,NN>"),
@@ -304,9 +307,10 @@ DISPATCH_EXAMPLES = [
     (_W4X2, (2048, 2048, 2048), 2, "mfma_ring<64x128x64,4 waves,stages=2,NN>"),
     (_W4X2, (1024, 1024, 1024), 2, "mfma_ring<64x64x64,4 waves,stages=2,NN>"),
     (_W4X2 + "_tn_swizzle_x4", (4096, 4096, 4096), 2, "hgemm_w4<256x256x64,4 waves,128x128 wave tiles,cross-tile LDS-DMA,LDS epilogue,TN>"),
-    ("hgemm_mma_m16n8k16_mma2x4_warp4x4_stages_dsmem", (4096, 4096, 4096), 3, "mfma_ring<128x128x64,4 waves,stages=3,NN>"),
-    ("hgemm_mma_m16n8k16_mma2x4_warp4x4_stages_dsmem", (4096, 4096, 4096), 5, "mfma_ring<128x128x64,4 waves,stages=5,NN>"),
-    ("hgemm_wmma_m16n16k16_mma4x4_warp4x4_stages_dsmem", (4096, 4096, 4096), 3, "mfma_ring<256x256x32,8 waves,stages=3,NN>"),
+    ("hgemm_mma_m16n8k16_mma2x4_warp4x4_stages_dsmem", (4096, 4096, 4096), 3, "mfma_ring<128x128x32,4 waves,stages=3,NN>"),
+    ("hgemm_mma_m16n8k16_mma2x4_warp4x4_stages_dsmem", (4096, 4096, 4096), 5, "mfma_ring<128x128x32,4 waves,stages=5,NN>"),
+    ("hgemm_wmma_m16n16k16_mma4x4_warp4x4_stages_dsmem", (4096, 4096, 4096), 3, "hgemm_w4s<256x256,ring of 3 x 32-deep K slots,4 waves,128x128 wave tiles,LDS-DMA 2 slots ahead,LDS epilogue,NN>"),
+    ("hgemm_wmma_m16n16k16_mma4x4_warp4x4_stages_dsmem", (4096, 4096, 128), 3, "mfma_ring<256x256x32,8 waves,stages=3,NN>"),  # fewer than 2 x 3 slots
     ("hgemm_mma_stages_block_swizzle_tn_cute", (4096, 4096, 4096), 2, "hgemm_w4<128x256x64,4 waves,64x128 wave tiles,cross-tile LDS-DMA,LDS epilogue,TN>"),
     ("hgemm_mma_stages_block_swizzle_tn_cute", (4096, 4096, 4096), 3, "mfma_ring<128x256x64,8 waves,stages=3,TN>"),
     ("hgemm_mma_stages_block_swizzle_tn_cute", (4096, 4096, 4160), 2, "hgemm_w4<128x256x64,4 waves,64x128 wave tiles,cross-tile LDS-DMA,LDS epilogue,TN>"),
@@ -319,7 +323,9 @@ DISPATCH_EXAMPLES = [
      "fa2_fwd_splitkv<D=64,next K fragments prefetched into registers> 4 waves share 32 rows, 128-key tiles split over the waves, cross-wave max via LDS"),
     ("flash_attn_mma_stages_split_kv", (4, 8, 2048, 64), 1,
      "fa2_fwd_splitkv<D=64,load-then-compute> 4 waves share 32 rows, 128-key tiles split over the waves, cross-wave max via LDS"),
-    (_SQKV, (4, 8, 2048, 64), 1, "fa2_fwd<D=64,BC=64,load-then-compute> 4 waves x 32 rows"),
+    (_SQKV, (4, 8, 2048, 64), 1, "fa2_fwd_m16x<D=64,BC=128,16x16x32 MFMA,pre-scaled Q,sum-checked softmax> 8 waves x 32 rows, two groups one phase apart" + _ONE),
+    (_SQKV, (1, 48, 8192, 64), 1, "fa2_fwd_m16x64r<D=64,BC=64,16x16x32 MFMA,pre-scaled Q,sum-checked softmax> 8 waves x 64 rows, two groups one phase apart, K/V fragments shared by 4 query blocks" + _ONE),
+    (_SQKV, (2, 32, 4096, 256), 1, "fa2_fwd_m16<D=256,BC=32,16x16x32 MFMA> 8 waves x 32 rows, two groups one phase apart" + _ONE),
     (_SQKV, (4, 8, 2048, 64), 2, "fa2_fwd_m16x<D=64,BC=128,16x16x32 MFMA,pre-scaled Q,sum-checked softmax> 8 waves x 32 rows, two groups one phase apart"),
     (_SQKV, (1, 48, 8192, 64), 2, "fa2_fwd_m16x64r<D=64,BC=64,16x16x32 MFMA,pre-scaled Q,sum-checked softmax> 8 waves x 64 rows, two groups one phase apart, K/V fragments shared by 4 query blocks"),
     (_SQKV, (2, 24, 4096, 64), 2, "fa2_fwd_m16x<D=64,BC=128,16x16x32 MFMA,pre-scaled Q,sum-checked softmax> 8 waves x 32 rows, two groups one phase apart"),
@@ -327,10 +333,10 @@ DISPATCH_EXAMPLES = [
     (_SQKV, (2, 32, 4096, 256), 2, "fa2_fwd_m16<D=256,BC=32,16x16x32 MFMA> 8 waves x 32 rows, two groups one phase apart"),
     (_SQKV, (2, 8, 2048, 64), 2, "fa2_fwd_v2<D=64,NW=4,BC=64,prefetch,pre-scaled Q> 4 waves x 32 rows"),
     (_SQKV, (1, 2, 256, 64), 2, "fa2_fwd_v2<D=64,NW=2,BC=64,prefetch,pre-scaled Q> 2 waves x 32 rows"),
-    (_SQKV, (1, 2, 192, 64), 1, "fa2_fwd_v2<D=64,NW=2,BC=64,prefetch,pre-scaled Q> 2 waves x 32 rows" + _IGN),
+    (_SQKV, (1, 2, 192, 64), 1, "fa2_fwd_v2<D=64,NW=2,BC=64,load-then-compute,pre-scaled Q> 2 waves x 32 rows" + _ONE),
     (_SQKV + "_swizzle_qkv", (4, 8, 2048, 128), 2, "fa2_fwd_m16x<D=128,BC=128,16x16x32 MFMA,pre-scaled Q,sum-checked softmax,V^T> 8 waves x 32 rows, two groups one phase apart"),
     (_SQKV + "_swizzle_qkv", (2, 8, 2048, 128), 2, "fa2_fwd_v2<D=128,NW=4,BC=64,prefetch,pre-scaled Q,V^T> 4 waves x 32 rows"),  # small grid: the v2 kernel
-    (_SQKV + "_swizzle_qkv", (4, 8, 2048, 128), 1, "fa2_fwd<D=128,BC=64,load-then-compute,V^T> 4 waves x 32 rows"),
+    (_SQKV + "_swizzle_qkv", (4, 8, 2048, 128), 1, "fa2_fwd_m16x<D=128,BC=128,16x16x32 MFMA,pre-scaled Q,sum-checked softmax,V^T> 8 waves x 32 rows, two groups one phase apart" + _ONE),
     (_TQKV, (1, 32, 4096, 512), 2, "fa2_fwd_m16<D=512,BC=32,16x16x32 MFMA,pairs of waves split d> 8 waves, 128 rows, two groups one phase apart"),
     (_TQKV, (1, 16, 4096, 384), 2, "fa2_fwd_dsplit<D=384,NSP=2,BC=32,LDS geometry of D=512> 8 waves, pairs split the real d evenly"),
     (_TQKV, (1, 16, 4096, 320), 2, "fa2_fwd_dsplit<D=320,NSP=2,BC=32,LDS geometry of D=512> 8 waves, pairs split the real d evenly"),

@@ -1,7 +1,8 @@
 """Summarise rocprofv3 PMC passes (one directory per pass) into a small JSON for profiles/.
     python pmc_summary.py <kernel-substring> <out.json> <pass_dir>...
 Per kernel whose name contains the substring: mean of every counter over its dispatches (first dispatch
-dropped as warm-up when there are >2). HBM traffic per launch follows MI355X_MICROARCH.md §HBM:
+dropped as warm-up when there are >2). L2<->fabric traffic per launch (an UPPER BOUND of the HBM bytes: Infinity-Cache
+hits are inside FETCH_SIZE, MI355X_MICROARCH.md §HBM / §Infinity Cache; rounds 1-3 wrote these keys as hbm_*):
   bytes = 2 * FETCH_SIZE * 1024  (gfx950: FETCH_SIZE reads exactly half of a wide coalesced stream;
                                   rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB)
         + WRITE_SIZE * 1024      (uncalibrated on gfx950; reported separately as well)
@@ -57,11 +58,11 @@ def main():
             m[c] = sum(v) / len(v)
         e = {"counters": m, "meta": meta[k]}
         if "FETCH_SIZE" in m:
-            e["hbm_read_bytes_per_launch"] = 2.0 * m["FETCH_SIZE"] * 1024
+            e["l2_fabric_read_bytes_per_launch"] = 2.0 * m["FETCH_SIZE"] * 1024
         if "WRITE_SIZE" in m:
-            e["hbm_write_bytes_per_launch"] = m["WRITE_SIZE"] * 1024
+            e["l2_fabric_write_bytes_per_launch"] = m["WRITE_SIZE"] * 1024
         if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
-            e["hbm_traffic_bytes_per_launch"] = e["hbm_read_bytes_per_launch"] + e["hbm_write_bytes_per_launch"]
+            e["l2_fabric_traffic_bytes_per_launch"] = e["l2_fabric_read_bytes_per_launch"] + e["l2_fabric_write_bytes_per_launch"]
         if "SQ_VALU_MFMA_BUSY_CYCLES" in m and "GRBM_GUI_ACTIVE" in m:
             # MFMA_BUSY is summed over all SIMDs (1024), GUI_ACTIVE over the 8 XCDs
             e["mfma_busy_frac"] = (m["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0) / (m["GRBM_GUI_ACTIVE"] / 8.0)

@@ -32,12 +32,16 @@ def test_every_run_time_dispatched_name_describes_itself(built):
 
 
 def test_stages_knob_selects_a_different_flash_attn_kernel(built):
-    """stages=1 -> load-then-compute, stages=2 -> prefetching pipeline (reference kStage, share_qkv.cu:843-884);
-    where one pipeline serves both, the description says so."""
+    """stages=1 -> the single-stage form of the stage-2 kernel of the shape (a tile is requested, waited for, then used), stages=2 ->
+    prefetching pipeline (reference kStage, share_qkv.cu:843-884); at every head dim, both V layouts."""
     m = built.manifest
     n = "flash_attn_mma_stages_split_q_shared_qkv"
-    one, two = m.describe(n, (4, 8, 2048, 64), 1), m.describe(n, (4, 8, 2048, 64), 2)
-    assert "load-then-compute" in one and "load-then-compute" not in two
+    for shape in ((4, 8, 2048, 64), (1, 48, 8192, 64), (4, 8, 2048, 128), (2, 32, 4096, 256), (1, 2, 256, 96), (4, 8, 1024, 64)):
+        one, two = m.describe(n, shape, 1), m.describe(n, shape, 2)
+        assert one.replace("load-then-compute", "prefetch") == two + " [single stage: every tile fetch waited for where it is issued]", (shape, one, two)
+        assert "stages ignored" not in one + two
+    one = m.describe(n + "_swizzle_qkv", (4, 8, 2048, 64), 1)
+    assert one.startswith("fa2_fwd_m16x<D=64") and "V^T" in one and "single stage" in one
     # above D = 256 too (reference kStage of the tiling kernels, flash_attn_mma_tiling_qkv.cu:63, :189-223): config C5
     tq = "flash_attn_mma_stages_split_q_tiling_qkv"
     one5, two5 = m.describe(tq, (1, 32, 4096, 512), 1), m.describe(tq, (1, 32, 4096, 512), 2)

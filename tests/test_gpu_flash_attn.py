@@ -384,18 +384,30 @@ def test_split_kv_rung_rescale_and_uniform(fa, built, dev, oracle):
     assert (o.double() - v.double().mean(dim=2, keepdim=True).expand(B, H, N, D)).abs().max().item() <= 1e-3
 
 
-@pytest.mark.parametrize("D", [32, 64, 96, 128, 256])
-def test_stages_one_is_the_load_then_compute_kernel(fa, built, dev, oracle, D):
-    """stages=1 dispatches fa2_fwd<load-then-compute> (manifest.describe says which kernel runs); both V layouts,
-    several tiles, a rescale-forcing spike."""
-    B, H, N = 2, 3, 384
+# (B, H, N, D): the large-grid kernels (fa2_fwd_m16x at 64 / 128, fa2_fwd_m16x64r, fa2_fwd_m16<256>) and the small-grid v2 kernel
+ONE_STAGE_SHAPES = [(4, 8, 2048, 64), (1, 128, 1024, 64), (1, 96, 512, 128), (4, 8, 2048, 128), (1, 96, 512, 256), (2, 3, 384, 32), (2, 3, 384, 64),
+                    (2, 3, 384, 96), (2, 3, 384, 128), (2, 3, 384, 256)]
+
+
+@pytest.mark.parametrize("B,H,N,D", ONE_STAGE_SHAPES)
+def test_stages_one_is_the_single_stage_form_of_the_same_kernel(fa, built, dev, oracle, B, H, N, D):
+    """stages = 1 at D <= 256 (reference kStage = 1 of flash_attn_mma_share_qkv.cu:711-762: a tile is requested, waited for,
+    then used): the stage-2 kernel of the shape with each tile's requests issued in one burst and waited for where they are
+    issued -- same arithmetic in the same order, so the result is bit-identical to stages = 2; both V layouts, several KV
+    tiles, a rescale-forcing spike; two heads against the fp64 oracle."""
     q, k, v = seeded(91, B, H, N, D), seeded(92, B, H, N, D), seeded(93, B, H, N, D)
-    k[0, 0, 300] = q[0, 0, 7] * 4.0
-    ref = oracle.attention_fp64(q, k, v)
-    for name in ("flash_attn_mma_stages_split_q_shared_qkv", "flash_attn_mma_stages_split_q_shared_kv_swizzle_qkv"):
-        assert "load-then-compute" in built.manifest.describe(name, (B, H, N, D), 1)
-        o = run(fa, built, name, q, k, v, 1, dev)
-        assert (o.double() - ref).abs().max().item() <= TOL, name
+    k[0, 0, N - 84] = q[0, 0, 7] * 4.0
+    ref = oracle.attention_fp64(q[:, :2], k[:, :2], v[:, :2])
+    names = ["flash_attn_mma_stages_split_q_shared_qkv"]
+    if D in (64, 128) or (B, H, N) == (2, 3, 384):  # V^T forms: the m16x kernels and the small-grid kernel (D = 256 m16: [B,H,N,D] only)
+        names.append("flash_attn_mma_stages_split_q_shared_kv_swizzle_qkv")
+    for name in names:
+        one, two = built.manifest.describe(name, (B, H, N, D), 1), built.manifest.describe(name, (B, H, N, D), 2)
+        assert one.replace("load-then-compute", "prefetch") == two + " [single stage: every tile fetch waited for where it is issued]", (one, two)
+        o1 = run(fa, built, name, q, k, v, 1, dev)
+        o2 = run(fa, built, name, q, k, v, 2, dev)
+        assert (o1[:, :2].double() - ref).abs().max().item() <= TOL_AMPLIFIED_KEYS, name
+        assert torch.equal(o1, o2), name
 
 
 # register-blocked kernel (flash_attn_rb.cuh) through the probe hook: (D, option-set ids of flash_attn_probe.hip)

@@ -318,6 +318,56 @@ def test_one_wave_per_simd_kernel(hg, built, dev, layout):
 
 
 @pytest.mark.parametrize("layout", [0, 1])
+def test_stages_3_4_5_are_the_ring_of_slots_form_of_the_one_wave_per_simd_kernel(hg, built, dev, layout):
+    """hgemm_w4s (csrc/hgemm_w4s.cuh): `stages` = 3 / 4 / 5 on the 256x256 tile is the ring depth of ONE kernel template (reference
+    hgemm_mma_stage.cu:2418-2428 `case 2/3/4/5`), bit-identical to stages = 2 (same MFMA shape, every accumulator sees the 32-deep
+    k-steps in ascending order). Smallest legal K (2 S slots), K / 32 that leaves every remainder of the unrolled round (S = 3: rounds of
+    6 bodies, S = 5: of 10), rectangular grids, block swizzle on and off; the S = 2 form through the probe hook; K too short -> another
+    kernel answers, same bits."""
+    from cuda_learn_notes_amd import host
+    from cuda_learn_notes_amd.bench_utils import as_col_major
+    name = ("hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_tn_swizzle_x4" if layout
+            else "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem")
+    fn = getattr(hg, name)
+    via_name = 0
+    for (M, N, K) in ((256, 256, 384), (512, 256, 448), (256, 768, 512), (768, 512, 640), (256, 256, 704), (1024, 1024, 2048), (4096, 4096, 832),
+                      (3584, 4096, 448), (4096, 4096, 384)):
+        a, b = seeded(370 + K, M, K), seeded(371 + K, K, N)
+        bb = (as_col_major(b) if layout else b).to(dev)
+        ad = a.to(dev)
+        base = torch.zeros(M, N, dtype=torch.half, device=dev)
+        fn(ad, bb, base, 2, True, 512)
+        check(base, a, b)
+        for st in (3, 4, 5):
+            d = built.manifest.describe(name, (M, N, K), st)  # (the tile policy decides by M, N: small grids run a small-tile ring)
+            if built.manifest.describe(name, (M, N, K), 2).startswith("hgemm_w4<256x256"):
+                assert d.startswith("hgemm_w4s<256x256,ring of %d" % st) == (K // 32 >= 2 * st), (M, N, K, st, d)
+                via_name += d.startswith("hgemm_w4s")
+            for rep in range(2):
+                c = torch.zeros(M, N, dtype=torch.half, device=dev)
+                fn(ad, bb, c, st, bool(rep), 512)
+                assert torch.equal(c, base), (M, N, K, st, rep)
+        for S in (2, 3, 4, 5):  # the explicit hook (S = 2 exists only there)
+            if K // 32 < 2 * S:
+                continue
+            c = torch.zeros(M, N, dtype=torch.half, device=dev)
+            host.hgemm_variant(16, layout, 0, 32, S, ad, bb, c, swizzle=1, swizzle_stride=512)
+            assert torch.equal(c, base), (M, N, K, S)
+    assert via_name >= 6
+    # the 256x256 name of the reference's WMMA stage kernel takes the same kernel at stages 3 / 4 / 5
+    wn = "hgemm_wmma_m16n16k16_mma4x4_warp4x4_stages_dsmem"
+    if not layout:
+        a, b = seeded(390, 512, 640), seeded(391, 640, 512)
+        base = torch.zeros(512, 512, dtype=torch.half, device=dev)
+        getattr(hg, wn)(a.to(dev), b.to(dev), base, 2, True, 512)
+        for st in (3, 4, 5):
+            assert built.manifest.describe(wn, (512, 512, 640), st).startswith("hgemm_w4s<256x256,ring of %d" % st)
+            c = torch.zeros(512, 512, dtype=torch.half, device=dev)
+            getattr(hg, wn)(a.to(dev), b.to(dev), c, st, True, 512)
+            assert torch.equal(c, base), st
+
+
+@pytest.mark.parametrize("layout", [0, 1])
 @pytest.mark.parametrize("tile,BM,BN", [(0, 192, 256), (1, 256, 192), (2, 192, 192), (3, 128, 256), (4, 256, 128), (5, 160, 160)])
 def test_one_wave_per_simd_kernel_on_192_tiles(hg, built, dev, layout, tile, BM, BN):
     """The 96-row / 96-column wave tiles of hgemm_w4 (what the tile policy picks at 2304 / 3072 / 4608 / 6144): grids of
@@ -362,7 +412,8 @@ def test_fixed_tile_rungs_on_the_one_wave_per_simd_kernel(hg, built, dev, name, 
     for (mt, nt_, K) in ((1, 1, 384), (3, 2, 640), (2, 5, 1152), (2, 1, 448), (1, 3, 832)):
         M, N = mt * BM, nt_ * BN
         assert built.manifest.describe(name, (M, N, K), 2).startswith("hgemm_w4<%dx%dx64" % (BM, BN)), (M, N, K)
-        assert built.manifest.describe(name, (M, N, K), 3).startswith("mfma_ring<%dx%d" % (BM, BN)), (M, N, K)
+        # stages 3: the ring-of-slots form of the one-wave-per-SIMD kernel on the 256x256 tile, the 8-wave ring of the tile on the others
+        assert built.manifest.describe(name, (M, N, K), 3).startswith("hgemm_w4s<256x256,ring of 3" if (BM, BN) == (256, 256) else "mfma_ring<%dx%d" % (BM, BN)), (M, N, K)
         a, b = seeded(370 + K, M, K), seeded(371 + K, K, N)
         bb = (as_col_major(b) if layout else b).to(dev)
         ad = a.to(dev)

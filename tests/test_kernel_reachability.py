@@ -38,19 +38,17 @@ def test_attention_kernels_in_the_product_library_are_exactly_the_plannable_ones
         if not fam.startswith(("fa2::", "fa::")):
             continue
         f = fam.split("::")[1]
-        if f == "fa2_fwd_kernel":
-            assert a[4] == "false", (fam, a)  # PREFETCH = true (the round-1 pipeline) is not dispatched any more
-            linked.add(("fa2_fwd", int(a[0]), a[3] == "true"))
-        elif f == "fa2_fwd_v2_kernel":
-            linked.add(("fa2_fwd_v2", int(a[0]), int(a[1]), a[2] == "true"))
+        if f == "fa2_fwd_v2_kernel":  # 4th argument: option bits; 262144 (OPT_1STAGE) = the single-stage form `stages = 1` selects
+            linked.add(("fa2_fwd_v2", int(a[0]), int(a[1]), a[2] == "true", bool(int(a[3]) & 262144)))
         elif f == "fa2_fwd_dsplit_kernel":
             linked.add(("fa2_fwd_dsplit", int(a[5]) or int(a[0])))
         elif f == "fa2_fwd_m16_pair_kernel":
-            # fragment depth 2, scores scaled in fp32, no debug bits (131072 = the single-stage form `stages = 1` selects at D = 512)
-            assert a in (["2", "false", "false", "0"], ["2", "true", "false", "0"], ["2", "true", "false", "131072"]), a
-            linked.add(("fa2_fwd_m16", 512 if a[1] == "true" else 256))
-        elif f == "fa2_fwd_m16x_kernel":  # 7th argument: V given transposed ([B,H,D,N], the *_swizzle_qkv names)
-            linked.add(("fa2_fwd_m16x64r" if a[1] == "64" else "fa2_fwd_m16x", int(a[0]), a[6] == "true"))
+            # fragment depth 2, scores scaled in fp32, no debug bits (262144 = the single-stage form `stages = 1` selects: one burst per tile)
+            assert a[:3] in (["2", "false", "false"], ["2", "true", "false"]) and a[3] in ("0", "262144"), a
+            linked.add(("fa2_fwd_m16", 512 if a[1] == "true" else 256, a[3] == "262144"))
+        elif f == "fa2_fwd_m16x_kernel":  # 6th argument: option bits (32768 = single-stage form); 7th: V given transposed ([B,H,D,N], the *_swizzle_qkv names)
+            assert int(a[5]) & ~(32768 | (3 << 16)) == 5, a  # the shipped options: phase-A priority + split prologue
+            linked.add(("fa2_fwd_m16x64r" if a[1] == "64" else "fa2_fwd_m16x", int(a[0]), a[6] == "true", bool(int(a[5]) & 32768)))
         elif f in ("fa2_fwd_dring_kernel", "fa2_fwd_splitkv_kernel"):
             linked.add((f[:-len("_kernel")], int(a[0])))
         else:
@@ -70,13 +68,16 @@ def test_attention_kernels_in_the_product_library_are_exactly_the_plannable_ones
                             continue
                         fam = t.split("<")[0]
                         d = int(re.search(r"<D=(\d+)", t).group(1))
-                        if fam == "fa2_fwd":
-                            plannable.add((fam, d, vt))
-                        elif fam == "fa2_fwd_v2":
-                            plannable.add((fam, d, int(re.search(r"NW=(\d+)", t).group(1)), vt))
+                        one = "single stage" in t
+                        assert one == (stages == 1) or fam == "fa2_fwd_splitkv", t  # (the split-KV rung says load-then-compute in its template text)
+                        if fam == "fa2_fwd_v2":
+                            plannable.add((fam, d, int(re.search(r"NW=(\d+)", t).group(1)), vt, one))
                         elif fam in ("fa2_fwd_m16x", "fa2_fwd_m16x64r"):
                             assert ("V^T" in t) == vt, t
-                            plannable.add((fam, d, vt))
+                            plannable.add((fam, d, vt, one))
+                        elif fam == "fa2_fwd_m16":
+                            assert not vt, t
+                            plannable.add((fam, d, one))
                         else:
                             assert not vt, t
                             plannable.add((fam, d))
@@ -88,6 +89,7 @@ def test_one_wave_per_simd_hgemm_instantiations_are_exactly_the_plannable_ones(b
     from cuda_learn_notes_amd import _loader
     m = built.manifest
     linked = set()
+    linked_s = set()
     fams = set()
     for fam, a in kernel_handles(_loader.so_path("libcln_amd.so")):
         if fam.startswith("hgemm::"):
@@ -95,7 +97,17 @@ def test_one_wave_per_simd_hgemm_instantiations_are_exactly_the_plannable_ones(b
         if fam == "hgemm::hgemm_w4_kernel":
             assert a[1:4] == ["3", "26", "0"], a  # LDS epilogue with non-temporal C stores, the production schedule, no ablation
             linked.add((int(a[0]), int(a[4]), int(a[5]), a[6] == "true"))
-    assert fams == {"hgemm_w4_kernel", "hgemm_pp_kernel", "hgemm_pp32_kernel", "hgemm_ring_kernel", "hgemm_1stage_kernel", "hgemm_mfma_naive_kernel",
+        if fam == "hgemm::hgemm_w4s_kernel":  # <layout, ring depth, epilogue>: stages 3 / 4 / 5 of the 256x256 names (2 is the probe library's)
+            assert a[2] == "3" and a[1] in ("3", "4", "5"), a
+            linked_s.add((int(a[0]), int(a[1])))
+    assert linked_s == {(l, s) for l in (0, 1) for s in (3, 4, 5)}, sorted(linked_s)
+    for name, layout in (("hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem", "NN"), ("hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_tn_swizzle_x4", "TN"),
+                         ("hgemm_wmma_m16n16k16_mma4x4_warp4x4_stages_dsmem", "NN")):
+        for st in (3, 4, 5):
+            t = m.describe(name, (4096, 4096, 4096), st)
+            assert t.startswith("hgemm_w4s<256x256,ring of %d x 32-deep" % st) and t.endswith(layout + ">"), t
+            assert not m.describe(name, (4096, 4096, 32 * 2 * st - 64), st).startswith("hgemm_w4s"), st  # fewer than 2 S slots: another kernel
+    assert fams == {"hgemm_w4_kernel", "hgemm_w4s_kernel", "hgemm_pp_kernel", "hgemm_pp32_kernel", "hgemm_ring_kernel", "hgemm_1stage_kernel", "hgemm_mfma_naive_kernel",
                     "hgemm_valu_tile_kernel", "hgemm_naive_f16_kernel", "hgemm_sliced_k_f16_kernel"}, sorted(fams)
     plannable = set()
     rows = [("hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem", 0), ("hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_tn_swizzle_x4", 1),
