@@ -32,10 +32,16 @@ struct FaPlan {
   int nw = 0;          // waves per workgroup
   int bc = 0;          // keys per KV tile
   bool one_stage = false;       // stages = 1: the stage-2 kernel of the shape with every tile fetch waited for where it is issued
+  bool f32_scale = false;       // the *_acc_f32 names at D <= 128: scores scaled in fp32 (Q as loaded) instead of the fp16 pre-scaled Q
 };
 
-FaPlan fa2_plan(int family, bool vt, int B, int H, int N, int D, int stages, int max_d) {
+FaPlan fa2_plan(int family, bool vt, int B, int H, int N, int D, int stages, int max_d, bool acc32 = false) {
   FaPlan p;
+  // The reference's *_acc_f32 names accumulate both GEMMs in fp32 (flash_attn_mma_share_qkv_F32F16F16F32.cu:66) where the plain names accumulate
+  // in fp16: the precision rung of the ladder. Here every kernel accumulates in fp32; what the D <= 128 kernels round is Q * log2(e)/sqrt(d),
+  // once, to fp16 (2^-11 relative per score term: 4e-3 on O under keys amplified 4-6x, 5e-4 on N(0,1) inputs). The *_acc_f32 names run the
+  // same kernels with the scores scaled in fp32 instead (one v_fma_f32 per score: 2e-3 / 2e-4), 4-10 % slower (profiles/r04_fa_fscale_probe.log).
+  p.f32_scale = acc32 && !vt && family == FAM_SPLIT_Q && D <= 128;
   if (B <= 0 || H <= 0 || N <= 0 || D <= 0) return p.rc = CLN_ERR_BAD_ARG, p;
   if ((long long)B * H * (long long)(N / 32 + 1) > 0x7fffffffLL) return p.rc = CLN_ERR_UNSUPPORTED, p;  // grid size (x)
   if (D > max_d) return p.rc = CLN_ERR_UNSUPPORTED, p;  // "headdim not support!"
@@ -142,6 +148,10 @@ int fa2_run(const FaPlan& p, const void* q, const void* k, const void* v, void* 
     return fa2::launch_v2<DD, 2, VT, OPTT>(q, k, v, o, B, H, N, s);
 #define FA_V2(DD, OPTT, HAS8)                                                      \
   case DD:                                                                         \
+    if constexpr (!VT) {                                                           \
+      if (p.f32_scale && p.one_stage) { FA_V2_NW(DD, ((OPTT) & ~fa2::OPT_PRE) | fa2::OPT_1STAGE, HAS8) } \
+      if (p.f32_scale) { FA_V2_NW(DD, (OPTT) & ~fa2::OPT_PRE, HAS8) }              \
+    }                                                                              \
     if (p.one_stage) { FA_V2_NW(DD, (OPTT) | fa2::OPT_1STAGE, HAS8) }              \
     FA_V2_NW(DD, OPTT, HAS8)
       switch (D) {
@@ -156,9 +166,9 @@ int fa2_run(const FaPlan& p, const void* q, const void* k, const void* v, void* 
 #undef FA_V2_NW
       return CLN_ERR_UNSUPPORTED;
     case K_M16X64R:
-      return fa2::m16x_run(64, 64, VT, p.one_stage, q, k, v, o, B, H, N, s);
+      return fa2::m16x_run(64, 64, VT, p.one_stage, p.f32_scale, q, k, v, o, B, H, N, s);
     case K_M16:
-      if (D == 64 || D == 128) return fa2::m16x_run(D, 32, VT, p.one_stage, q, k, v, o, B, H, N, s);  // 128-key tiles; own compile unit
+      if (D == 64 || D == 128) return fa2::m16x_run(D, 32, VT, p.one_stage, p.f32_scale, q, k, v, o, B, H, N, s);  // 128-key tiles; own compile unit
       if constexpr (!VT) {
         constexpr int ONE = 262144;  // flash_attn_m16.cuh: the tile requested in one burst at the top of phase A and waited for there
         if (D == 256) return p.one_stage ? fa2::launch_m16_pair<2, false, false, ONE>(q, k, v, o, B, H, N, s)
@@ -183,16 +193,17 @@ int fa2_run(const FaPlan& p, const void* q, const void* k, const void* v, void* 
 
 template <bool VT>
 int fa2_dispatch(int family, const void* q, const void* k, const void* v, void* o, int B, int H, int N, int D,
-                 int stages, int max_d, hipStream_t s) {
+                 int stages, int max_d, bool acc32, hipStream_t s) {
   if (!q || !k || !v || !o) return CLN_ERR_BAD_ARG;
   if (!cln_aligned16(q) || !cln_aligned16(k) || !cln_aligned16(v) || !cln_aligned16(o)) return CLN_ERR_BAD_ARG;
-  const FaPlan p = fa2_plan(family, VT, B, H, N, D, stages, max_d);
+  const FaPlan p = fa2_plan(family, VT, B, H, N, D, stages, max_d, acc32);
   if (p.rc != CLN_OK) return p.rc;
   return fa2_run<VT>(p, q, k, v, o, B, H, N, D, s);
 }
 
-int fa2_describe(int family, bool vt, int B, int H, int N, int D, int stages, int max_d, char* buf, int len) {
-  const FaPlan p = fa2_plan(family, vt, B, H, N, D, stages, max_d);
+int fa2_describe(int family, bool vt, int B, int H, int N, int D, int stages, int max_d, bool acc32, char* buf, int len) {
+  const FaPlan p = fa2_plan(family, vt, B, H, N, D, stages, max_d, acc32);
+  const char* qs = p.f32_scale ? "fp32-scaled scores" : "pre-scaled Q";
   if (p.rc != CLN_OK) return p.rc;
   const char* st = p.one_stage ? " [single stage: every tile fetch waited for where it is issued]" : "";
   const char* vts = vt ? ",V^T" : "";
@@ -201,15 +212,15 @@ int fa2_describe(int family, bool vt, int B, int H, int N, int D, int stages, in
       return snprintf(buf, len, "fa2_fwd_splitkv<D=%d,%s> 4 waves share 32 rows, 128-key tiles split over the waves, "
                                 "cross-wave max via LDS", D, p.one_stage ? "load-then-compute" : "next K fragments prefetched into registers");
     case K_V2:
-      return snprintf(buf, len, "fa2_fwd_v2<D=%d,NW=%d,BC=64,%s%s%s> %d waves x 32 rows%s", D, p.nw, p.one_stage ? "load-then-compute" : "prefetch",
-                      D <= 128 ? ",pre-scaled Q" : "", vts, p.nw, st);
+      return snprintf(buf, len, "fa2_fwd_v2<D=%d,NW=%d,BC=64,%s%s%s%s> %d waves x 32 rows%s", D, p.nw, p.one_stage ? "load-then-compute" : "prefetch",
+                      D <= 128 ? "," : "", D <= 128 ? qs : "", vts, p.nw, st);
     case K_M16X64R:
-      return snprintf(buf, len, "fa2_fwd_m16x64r<D=64,BC=64,16x16x32 MFMA,pre-scaled Q,sum-checked softmax%s> 8 waves x 64 rows, two groups one "
-                                "phase apart, K/V fragments shared by 4 query blocks%s", vts, st);
+      return snprintf(buf, len, "fa2_fwd_m16x64r<D=64,BC=64,16x16x32 MFMA,%s,sum-checked softmax%s> 8 waves x 64 rows, two groups one "
+                                "phase apart, K/V fragments shared by 4 query blocks%s", qs, vts, st);
     case K_M16:
       if (D <= 128)
-        return snprintf(buf, len, "fa2_fwd_m16x<D=%d,BC=%d,16x16x32 MFMA,pre-scaled Q,sum-checked softmax%s> 8 waves x 32 rows, two groups "
-                                  "one phase apart%s", D, p.bc, vts, st);
+        return snprintf(buf, len, "fa2_fwd_m16x<D=%d,BC=%d,16x16x32 MFMA,%s,sum-checked softmax%s> 8 waves x 32 rows, two groups "
+                                  "one phase apart%s", D, p.bc, qs, vts, st);
       if (D == 512)
         return snprintf(buf, len, "fa2_fwd_m16<D=512,BC=32,16x16x32 MFMA,pairs of waves split d> 8 waves, 128 rows, two groups one phase apart%s", st);
       return snprintf(buf, len, "fa2_fwd_m16<D=%d,BC=%d,16x16x32 MFMA> 8 waves x 32 rows, two groups one phase apart%s", D, p.bc, st);
@@ -269,7 +280,7 @@ struct FaName {
 #define CLN_FA(name, FAM, VT, MAXD)                                                                       \
   CLN_API int name(const void* q, const void* k, const void* v, void* o, int B, int H, int N, int D,     \
                    int stages, void* stream) {                                                            \
-    return fa2_dispatch<VT>(FAM, q, k, v, o, B, H, N, D, stages, MAXD, (hipStream_t)stream);              \
+    return fa2_dispatch<VT>(FAM, q, k, v, o, B, H, N, D, stages, MAXD, strstr(#name, "_acc_f32") != nullptr, (hipStream_t)stream); \
   }
 CLN_FA_LIST(CLN_FA)
 
@@ -279,6 +290,6 @@ int cln_fa_describe(const char* name, int B, int H, int N, int D, int stages, ch
 #define CLN_FA_ROW(n, FAM, VT, MAXD) {#n, FAM, VT, MAXD},
   static const FaName table[] = {CLN_FA_LIST(CLN_FA_ROW)};
   for (const FaName& e : table)
-    if (strcmp(e.name, name) == 0) return fa2_describe(e.family, e.vt, B, H, N, D, stages, e.max_d, buf, len);
+    if (strcmp(e.name, name) == 0) return fa2_describe(e.family, e.vt, B, H, N, D, stages, e.max_d, strstr(e.name, "_acc_f32") != nullptr, buf, len);
   return CLN_ERR_BAD_ARG;
 }

@@ -58,6 +58,10 @@ enum : int {
   // burst's place in the iteration: 0 = top of phase A, 1 = end of phase A, 2 = top of phase B, 3 = end of phase B.
   M16X_ONE_STAGE = 32768,
   M16X_ONE_POS_SHIFT = 16,  // two bits
+  // scores scaled in fp32 (round 4; the reference's *_acc_f32 names): Q goes into the MFMAs as loaded, S^T accumulates from 0 and every score takes
+  // one v_fma_f32 (s * log2(e)/sqrt(d) - m) on its way into v_exp_f32 -- no fp16 rounding of Q * log2(e)/sqrt(d) (2^-11 relative per term, which
+  // amplified keys turn into 3.9e-3 on O where this form has 2e-3), 64 more VALU instructions per wave and 128-key tile at D = 64
+  M16X_FSCALE = 1 << 18,
   M16X_ONE_POS = 2           // the shipped position: top of phase B (the MFMA-only phase), 0.95-1.0x of stages = 2 (profiles/r04_fa_one_stage_probe.log)
 };
 
@@ -73,6 +77,7 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
   constexpr int DSTEPS = (NOPT / 2) * NDB;    // PV steps before the first P^T k-step that contains a deferred block
   constexpr int DRATE = (NDEF * NPAIR + DSTEPS - 1) / DSTEPS;
   static_assert(NDEF >= 1 && NOPT >= 2, "at least one P^T k-step must be complete at the end of phase A");
+  static_assert((OX & M16X_FSCALE) == 0 || (OX & M16X_LATE_CHECK) == 0, "the fp32-scaled form has no late-check variant");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -143,7 +148,9 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
 #pragma unroll
     for (int i = 0; i < G::PPW; ++i) dma_piece(0, 0, i);
   }
+  constexpr bool FS = (OX & M16X_FSCALE) != 0;
   auto scale_q = [&]() __attribute__((always_inline)) {
+    if constexpr (FS) return;  // Q as loaded: the scale is applied to the fp32 scores
     const half_t sc = (half_t)scale_log2e;
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb)
@@ -233,8 +240,10 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
     // item it of key block kb: query block it >> 1, registers (it & 1) * 2, + 1 -> k-slots of P^T step kb >> 1
     auto exp_item = [&](int kb, int it, float (&acc)[NQB]) __attribute__((always_inline)) {
       const int qb = it >> 1, r = (it & 1) * 2;
-      const float a0 = (OX & M16X_ABL_EXP) != 0 ? s[kb][qb][r] : __builtin_amdgcn_exp2f(s[kb][qb][r]);
-      const float a1 = (OX & M16X_ABL_EXP) != 0 ? s[kb][qb][r + 1] : __builtin_amdgcn_exp2f(s[kb][qb][r + 1]);
+      const float x0 = FS ? __builtin_fmaf(s[kb][qb][r], scale_log2e, -m_run[qb]) : s[kb][qb][r];
+      const float x1 = FS ? __builtin_fmaf(s[kb][qb][r + 1], scale_log2e, -m_run[qb]) : s[kb][qb][r + 1];
+      const float a0 = (OX & M16X_ABL_EXP) != 0 ? x0 : __builtin_amdgcn_exp2f(x0);
+      const float a1 = (OX & M16X_ABL_EXP) != 0 ? x1 : __builtin_amdgcn_exp2f(x1);
       acc[qb] += a0 + a1;
       const h2 a = __builtin_convertvector(f2{a0, a1}, h2);
       // an input-only empty asm is a chained node of the instruction selector: the item stays in the step it was
@@ -308,7 +317,7 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
           for (int kb = NOPT; kb < NKB; ++kb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kb][qb][r]);
-          bad |= mx > 14.0f;
+          bad |= (FS ? __builtin_fmaf(mx, scale_log2e, -m_run[qb]) : mx) > 14.0f;
         }
       }
       const bool first = j == 0;  // tile 0 has no reference yet: it adopts its true maximum
@@ -324,18 +333,21 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
           const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
           mx = fmaxf(__uint_as_float(s16[0]), __uint_as_float(s16[1]));
           const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-          const float d = fmaxf(__uint_as_float(s32[0]), __uint_as_float(s32[1]));  // relative to the running reference
+          float d = fmaxf(__uint_as_float(s32[0]), __uint_as_float(s32[1]));  // relative to the running reference
+          if constexpr (FS) d = __builtin_fmaf(d, scale_log2e, -m_run[qb]);      // (raw maximum -> scaled, relative)
           const float delta = first ? d : fmaxf(d, 0.f);
           const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-delta);
           m_run[qb] += delta;
           l_run[qb] *= alpha;
+          if constexpr (!FS) {  // (FS: the raw scores stay, exp_item subtracts the new m_run)
 #pragma unroll
-          for (int kb = 0; kb < NKB; ++kb)
+            for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) s[kb][qb][r] -= delta;
+              for (int r = 0; r < 4; ++r) s[kb][qb][r] -= delta;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) minit[qb][r] = -m_run[qb];
-          asm volatile("" : "+v"(minit[qb]));
+            for (int r = 0; r < 4; ++r) minit[qb][r] = -m_run[qb];
+            asm volatile("" : "+v"(minit[qb]));
+          }
 #pragma unroll
           for (int b = 0; b < NDB; ++b)
 #pragma unroll

@@ -13,9 +13,18 @@ namespace fa2 {
 // dims. 64 rows per wave (D = 64, 512-row workgroups, 64-key tiles; long sequences): NDEF = 1 of the 4 key blocks.
 // `one_stage` (the names' stages = 1): the same kernels with each tile requested in one burst and waited for where it is requested
 // (M16X_ONE_STAGE), bit-identical output.
-int m16x_run(int D, int rows_per_wave, bool vt, bool one_stage, const void* q, const void* k, const void* v, void* o, int B, int H, int N, hipStream_t s) {
+// `f32_scale` (the *_acc_f32 names, V as [B,H,N,D] only): the same kernels with Q as loaded and the scores scaled in fp32 (M16X_FSCALE).
+int m16x_run(int D, int rows_per_wave, bool vt, bool one_stage, bool f32_scale, const void* q, const void* k, const void* v, void* o, int B, int H, int N, hipStream_t s) {
   constexpr int OX = M16X_PRIO | M16X_SPLIT_PROLOGUE;
   constexpr int O1 = OX | M16X_ONE_STAGE | (M16X_ONE_POS << M16X_ONE_POS_SHIFT);
+  if (f32_scale) {
+    if (vt) return CLN_ERR_UNSUPPORTED;
+    constexpr int F = OX | M16X_FSCALE, F1 = O1 | M16X_FSCALE;
+    if (D == 64 && rows_per_wave == 32) return one_stage ? launch_m16x<64, 32, 128, 8, 4, F1>(q, k, v, o, B, H, N, s) : launch_m16x<64, 32, 128, 8, 4, F>(q, k, v, o, B, H, N, s);
+    if (D == 128 && rows_per_wave == 32) return one_stage ? launch_m16x<128, 32, 128, 4, 4, F1>(q, k, v, o, B, H, N, s) : launch_m16x<128, 32, 128, 4, 4, F>(q, k, v, o, B, H, N, s);
+    if (D == 64 && rows_per_wave == 64) return one_stage ? launch_m16x<64, 64, 64, 4, 1, F1>(q, k, v, o, B, H, N, s) : launch_m16x<64, 64, 64, 4, 1, F>(q, k, v, o, B, H, N, s);
+    return CLN_ERR_UNSUPPORTED;
+  }
   if (one_stage) {
     if (!vt) {
       if (D == 64 && rows_per_wave == 32) return launch_m16x<64, 32, 128, 8, 4, O1>(q, k, v, o, B, H, N, s);

@@ -16,6 +16,9 @@ TOL = 3e-3
 # 2^-11 per term and |delta s| grows with |k| (measured 3.9e-3 max on O where the unscaled kernel has 2e-3). Still inside
 # the reference's own --check tolerance (atol 1e-2, flash_attn_mma.py:421); N(0,1) inputs stay below TOL.
 TOL_AMPLIFIED_KEYS = 6e-3
+# The precision rung exists as it does in the reference: its plain names accumulate both GEMMs in fp16, its *_acc_f32 names in fp32
+# (flash_attn_mma_share_qkv_F32F16F16F32.cu:66). Here the *_acc_f32 names run the same kernels with the scores scaled in fp32
+# (Q as loaded): they are held to TOL on the amplified-key inputs as well (test_acc_f32_names_scale_the_scores_in_fp32).
 
 
 def seeded(seed, *shape):
@@ -234,6 +237,42 @@ def test_deferred_max_paths(fa, built, dev, oracle):
         o = run(fa, built, name, q, k, v, 2, dev)
         assert torch.isfinite(o).all()
         assert (o.double() - ref).abs().max().item() <= TOL_AMPLIFIED_KEYS, name
+
+
+@pytest.mark.parametrize("B,H,N,D", [(1, 48, 1024, 64), (1, 48, 1024, 128), (1, 128, 1024, 64), (2, 3, 1024, 64), (2, 3, 1024, 128), (2, 3, 384, 32), (2, 3, 384, 96)])
+def test_acc_f32_names_scale_the_scores_in_fp32(fa, built, dev, oracle, B, H, N, D):
+    """The reference's *_acc_f32 names (fp32 accumulation of both GEMMs, flash_attn_mma_share_qkv_F32F16F16F32.cu:66 -- the precise rung)
+    run the D <= 128 kernels with Q as loaded and the scores scaled in fp32: the rescale-regime inputs (keys amplified 3-5x, a
+    creeping maximum) stay inside TOL = 3e-3, where the plain names (fp16 pre-scaled Q) need 6e-3; large grids (fa2_fwd_m16x,
+    fa2_fwd_m16x64r) and small ones (fa2_fwd_v2), both `stages` values, bit-identical to each other."""
+    q, k, v = seeded(31, B, H, N, D), seeded(32, B, H, N, D), seeded(33, B, H, N, D)
+    if N == 1024:
+        ramp = torch.linspace(0.2, 1.6, N).view(N, 1)
+        k[0, 0] = (k[0, 0].float() * ramp).half()       # creeping max, never a jump
+        k[0, 0, 900] = q[0, 0, 5] * 3.0                 # late spike
+        k[0, 1, 10] = q[0, 1, 300] * 5.0                # early spike
+        k[0, H - 1, 1000] = q[0, H - 1, 1023] * 4.0
+    else:
+        k[0, 0, 300] = q[0, 0, 7] * 4.0
+    heads = sorted({0, 1, H - 1})
+    ref = oracle.attention_fp64(q[:, heads], k[:, heads], v[:, heads])
+    plain_err = None
+    for name in ("flash_attn_mma_stages_split_q_shared_qkv_acc_f32", "flash_attn_mma_stages_split_q_shared_kv_acc_f32",
+                 "flash_attn_mma_stages_split_q_tiling_qkv_acc_f32", "flash_attn_mma_stages_split_q_shared_qkv_acc_f32_rr",
+                 "flash_attn_mma_stages_split_q_shared_qkv"):
+        d = built.manifest.describe(name, (B, H, N, D), 2)
+        assert ("fp32-scaled scores" in d) == ("_acc_f32" in name), (name, d)
+        o2 = run(fa, built, name, q, k, v, 2, dev)
+        o1 = run(fa, built, name, q, k, v, 1, dev)
+        assert torch.equal(o1, o2), name
+        err = (o2[:, heads].double() - ref).abs().max().item()
+        assert torch.isfinite(o2).all()
+        if "_acc_f32" in name:
+            assert err <= TOL, (name, err)
+        else:
+            plain_err = err
+            assert err <= TOL_AMPLIFIED_KEYS, (name, err)
+    assert plain_err is not None
 
 
 @pytest.mark.parametrize("D,H", [(64, 48), (128, 48), (256, 48), (512, 2), (768, 2), (1024, 3), (320, 2), (384, 3), (640, 2)])

@@ -39,7 +39,8 @@ def test_attention_kernels_in_the_product_library_are_exactly_the_plannable_ones
             continue
         f = fam.split("::")[1]
         if f == "fa2_fwd_v2_kernel":  # 4th argument: option bits; 262144 (OPT_1STAGE) = the single-stage form `stages = 1` selects
-            linked.add(("fa2_fwd_v2", int(a[0]), int(a[1]), a[2] == "true", bool(int(a[3]) & 262144)))
+            # 16384 (OPT_PRE) = fp16 pre-scaled Q (D <= 128; absent: scores scaled in fp32 -- D = 256, and the *_acc_f32 names at D <= 128)
+            linked.add(("fa2_fwd_v2", int(a[0]), int(a[1]), a[2] == "true", bool(int(a[3]) & 262144), int(a[0]) <= 128 and not int(a[3]) & 16384))
         elif f == "fa2_fwd_dsplit_kernel":
             linked.add(("fa2_fwd_dsplit", int(a[5]) or int(a[0])))
         elif f == "fa2_fwd_m16_pair_kernel":
@@ -47,8 +48,8 @@ def test_attention_kernels_in_the_product_library_are_exactly_the_plannable_ones
             assert a[:3] in (["2", "false", "false"], ["2", "true", "false"]) and a[3] in ("0", "262144"), a
             linked.add(("fa2_fwd_m16", 512 if a[1] == "true" else 256, a[3] == "262144"))
         elif f == "fa2_fwd_m16x_kernel":  # 6th argument: option bits (32768 = single-stage form); 7th: V given transposed ([B,H,D,N], the *_swizzle_qkv names)
-            assert int(a[5]) & ~(32768 | (3 << 16)) == 5, a  # the shipped options: phase-A priority + split prologue
-            linked.add(("fa2_fwd_m16x64r" if a[1] == "64" else "fa2_fwd_m16x", int(a[0]), a[6] == "true", bool(int(a[5]) & 32768)))
+            assert int(a[5]) & ~(32768 | (3 << 16) | (1 << 18)) == 5, a  # the shipped options: phase-A priority + split prologue (1 << 18: fp32-scaled scores)
+            linked.add(("fa2_fwd_m16x64r" if a[1] == "64" else "fa2_fwd_m16x", int(a[0]), a[6] == "true", bool(int(a[5]) & 32768), bool(int(a[5]) & (1 << 18))))
         elif f in ("fa2_fwd_dring_kernel", "fa2_fwd_splitkv_kernel"):
             linked.add((f[:-len("_kernel")], int(a[0])))
         else:
@@ -56,7 +57,8 @@ def test_attention_kernels_in_the_product_library_are_exactly_the_plannable_ones
     plannable = set()
     names = [("flash_attn_mma_stages_split_kv", False), ("flash_attn_mma_stages_split_q_shared_qkv", False),
              ("flash_attn_mma_stages_split_q_shared_qkv_swizzle_qkv", True), ("flash_attn_mma_stages_split_q_tiling_qkv", False),
-             ("flash_attn_mma_stages_split_q_tiling_qk_swizzle_qkv", True)]
+             ("flash_attn_mma_stages_split_q_tiling_qk_swizzle_qkv", True), ("flash_attn_mma_stages_split_q_shared_qkv_acc_f32", False),
+             ("flash_attn_mma_stages_split_q_tiling_qkv_acc_f32", False)]
     for name, vt in names:
         for D in (32, 64, 96, 128, 256, 320, 384, 512, 640, 768, 1024):
             for (B, H) in ((1, 1), (1, 8), (4, 8), (1, 48), (2, 96)):
@@ -70,11 +72,13 @@ def test_attention_kernels_in_the_product_library_are_exactly_the_plannable_ones
                         d = int(re.search(r"<D=(\d+)", t).group(1))
                         one = "single stage" in t
                         assert one == (stages == 1) or fam == "fa2_fwd_splitkv", t  # (the split-KV rung says load-then-compute in its template text)
+                        f32s = "fp32-scaled scores" in t
+                        assert f32s == ("_acc_f32" in name and d <= 128), t
                         if fam == "fa2_fwd_v2":
-                            plannable.add((fam, d, int(re.search(r"NW=(\d+)", t).group(1)), vt, one))
+                            plannable.add((fam, d, int(re.search(r"NW=(\d+)", t).group(1)), vt, one, f32s))
                         elif fam in ("fa2_fwd_m16x", "fa2_fwd_m16x64r"):
                             assert ("V^T" in t) == vt, t
-                            plannable.add((fam, d, vt, one))
+                            plannable.add((fam, d, vt, one, f32s))
                         elif fam == "fa2_fwd_m16":
                             assert not vt, t
                             plannable.add((fam, d, one))
