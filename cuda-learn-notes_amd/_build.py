@@ -29,14 +29,15 @@ KERNEL_SOURCES = [
 VENDOR_SOURCES = ["hgemm_vendor.hip", "hgemm_vendor_lt.hip", "fa2_vendor_ck.hip"]  # the last: ck_tile FMHA instances (~1 min of hipcc)
 # a comparison row whose sources are the ROCm image's ck_tile headers: if they are missing or do not compile, the vendor
 # library is linked without it (the callers treat the row as absent) instead of failing the whole build
-OPTIONAL_SOURCES = {"fa2_vendor_ck.hip"}
+OPTIONAL_SOURCES = {"fa2_vendor_ck.hip", "hgemm_vendor_lt.hip"}  # (the hipBLASLt row too: an image without hipBLASLt still builds the product)
 # test-only library; it re-links the two ring compile units for the explicit (tile, BK, stages) hook
-PROBE_SOURCES = ["hgemm_probe.hip", "flash_attn_probe.hip", "flash_attn_m16x_probe.hip"]
+# (csrc/probe/: the probe compile units and the kernels that only they instantiate -- nothing under it is linked into libcln_amd.so)
+PROBE_SOURCES = ["probe/hgemm_probe.hip", "probe/flash_attn_probe.hip", "probe/flash_attn_m16x_probe.hip"]
 PROBE_SHARED = ["hgemm_ring_nn.hip", "hgemm_ring_tn.hip"]
 CFLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-ffp-contract=fast",
-          "-I" + CSRC]
+          "-I" + CSRC, "-I" + os.path.join(CSRC, "probe")]
 # per-file additions (the reason is stated at the top of each file)
-EXTRA_FLAGS = {"flash_attn_m16x.hip": ["-fno-slp-vectorize"], "flash_attn_m16x_probe.hip": ["-fno-slp-vectorize"],
+EXTRA_FLAGS = {"flash_attn_m16x.hip": ["-fno-slp-vectorize"], "probe/flash_attn_m16x_probe.hip": ["-fno-slp-vectorize"],
                "fa2_vendor_ck.hip": ["-I/opt/rocm/include", "-Wno-everything"]}
 
 
@@ -50,18 +51,19 @@ def hipcc():
 def _deps_digest():
     """Digest of every header/include file: any change rebuilds all objects."""
     h = hashlib.sha256()
-    for fn in sorted(os.listdir(CSRC)):
-        if fn.endswith((".h", ".cuh", ".inc")):
-            with open(os.path.join(CSRC, fn), "rb") as f:
-                h.update(fn.encode())
-                h.update(f.read())
+    for sub in ("", "probe"):
+        for fn in sorted(os.listdir(os.path.join(CSRC, sub))):
+            if fn.endswith((".h", ".cuh", ".inc")):
+                with open(os.path.join(CSRC, sub, fn), "rb") as f:
+                    h.update(fn.encode())
+                    h.update(f.read())
     h.update(" ".join(CFLAGS).encode())
     h.update(repr(sorted(EXTRA_FLAGS.items())).encode())
     return h.hexdigest()
 
 
 def _compile_one(src, hdr_digest, verbose):
-    obj = os.path.join(BUILD, src.replace(".hip", ".o"))
+    obj = os.path.join(BUILD, os.path.basename(src).replace(".hip", ".o"))
     stamp = obj + ".stamp"
     with open(os.path.join(CSRC, src), "rb") as f:
         digest = hashlib.sha256(f.read() + hdr_digest.encode()).hexdigest()
@@ -107,7 +109,8 @@ def build(verbose=False, force=False):
     if force or not os.path.exists(main_so) or any(objs[s][1] for s in KERNEL_SOURCES):
         _link([objs[s][0] for s in KERNEL_SOURCES], main_so, [], verbose)
     if force or not os.path.exists(vend_so) or any(objs[s][1] for s in VENDOR_SOURCES):
-        _link([objs[s][0] for s in VENDOR_SOURCES if objs[s][0] is not None], vend_so, ["-L/opt/rocm/lib", "-lrocblas", "-lhipblaslt"], verbose)
+        libs = ["-L/opt/rocm/lib", "-lrocblas"] + (["-lhipblaslt"] if objs["hgemm_vendor_lt.hip"][0] is not None else [])
+        _link([objs[s][0] for s in VENDOR_SOURCES if objs[s][0] is not None], vend_so, libs, verbose)
     if force or not os.path.exists(probe_so) or any(objs[s][1] for s in PROBE_SOURCES + PROBE_SHARED):
         _link([objs[s][0] for s in PROBE_SOURCES + PROBE_SHARED], probe_so, [], verbose)
     return main_so, vend_so, probe_so

@@ -12,7 +12,6 @@
 // Every name goes through ONE planner (fa2_plan) that picks the gfx950 kernel for (family, shape, stages); the same
 // plan is what cln_describe() prints, so the name -> kernel map in manifest.py is checked against the code
 // (tests/test_describe.py).
-#include "flash_attn.cuh"
 #include "flash_attn_large_d.cuh"
 #include "flash_attn_splitkv.cuh"
 #include "flash_attn_v2.cuh"
@@ -58,14 +57,14 @@ FaPlan fa2_plan(int family, bool vt, int B, int H, int N, int D, int stages, int
   // ---- stages = 1 (reference kStage = 1, flash_attn_mma_share_qkv.cu:711-762: a tile is requested, waited for, then used): at EVERY head
   // dim the stage-2 kernel of the shape in its single-stage form -- each tile requested in one burst and waited for where it is requested,
   // no request of a wave in flight while it computes; same LDS image, same arithmetic, bit-identical output (`one_stage`). Rounds 1-3 ran
-  // a separate 4-wave load-then-compute kernel (flash_attn.cuh) for D <= 256: 0.24-0.44x of stages = 2 (profiles/r03_fa_stage1_vs_stage2.log);
+  // a separate 4-wave load-then-compute kernel (probe/flash_attn.cuh) for D <= 256: 0.24-0.44x of stages = 2 (profiles/r03_fa_stage1_vs_stage2.log);
   // that kernel now lives in the probe library only.
   p.one_stage = stages == 1;
   if (small_d) {
     if (D == 64 && N % 512 == 0) {  // (both V layouts)
       // >= 512 query rows per CU, in (nearly) whole rounds of 256 workgroups: 64 query rows per wave -- every K / V fragment
       // feeds four 16x16x32 MFMAs (flash_attn_m16x.cuh with RPW = 64, 64-key tiles; round 2 ran the 32x32x16 form of
-      // flash_attn_dsplit2.cuh here): [1,48,8192,64] 1063 -> 1138 TF, [2,32,4096,64] 1032 -> 1094, [1,16,16384,64] 1076 -> 1152
+      // probe/flash_attn_dsplit2.cuh here): [1,48,8192,64] 1063 -> 1138 TF, [2,32,4096,64] 1032 -> 1094, [1,16,16384,64] 1076 -> 1152
       // (profiles/r03_fa_m16x_64rows_probe.log)
       const long long wgs = bh * (N / 512), rounds = (wgs + 255) / 256;
       if (wgs >= 256 && wgs * 100 >= rounds * 256 * 88) return p.kind = K_M16X64R, p.d_inst = 64, p.nw = 8, p.bc = 64, p;
@@ -75,7 +74,7 @@ FaPlan fa2_plan(int family, bool vt, int B, int H, int N, int D, int stages, int
       //  D = 64 / 128: ping-pong kernel on 16x16x32 MFMAs (the energy-cheaper matrix shape, +3.5-5 % at D = 64 and
       //                +5.5-6.5 % at D = 128 over the 32x32x16 form of flash_attn_dsplit.cuh, profiles/r02_fa_m16_probe.log)
       //                with the sum-checked optimistic softmax, phase-A priority and the split prologue of round 3
-      //                (flash_attn_m16x.cuh: +1-2.5 % over flash_attn_m16.cuh, profiles/r03_fa_m16x_probe.log). (The one-wave-per-SIMD kernel flash_attn_w4.cuh measured parity at
+      //                (flash_attn_m16x.cuh: +1-2.5 % over flash_attn_m16.cuh, profiles/r03_fa_m16x_probe.log). (The one-wave-per-SIMD kernel probe/flash_attn_w4.cuh measured parity at
       //                best and lives in the probe library only.)
       //  D = 256: two-group ping-pong kernel, 8 waves x 32 rows
       if (D == 64) return p.kind = K_M16, p.d_inst = 64, p.nw = 8, p.bc = 128, p;
@@ -104,7 +103,7 @@ FaPlan fa2_plan(int family, bool vt, int B, int H, int N, int D, int stages, int
   // ---- head dims above 256 ("fine-grained tiling" rungs, flash_attn_large_d.cuh). The reference's tiling kernels template
   // on kStage 1 / 2 (flash_attn_mma_tiling_qkv.cu:63, :189-223: with kStage = 1 a tile is loaded, waited for, then used).
   // stages = 1 here: the SAME d-split / ring kernels with every tile fetch waited for where it is issued, so no load runs
-  // under compute (`one_stage`); stages = 2: the pipelines. (Round 3's first form ran the 4-wave kernel of flash_attn.cuh
+  // under compute (`one_stage`); stages = 2: the pipelines. (Round 3's first form ran the 4-wave kernel of probe/flash_attn.cuh
   // with the output head dim sliced and S recomputed per slice: 94 TF at D = 768 / 1024, profiles/r03_fa_stage1_vs_stage2.log.)
   switch (D) {
     case 512:  // config C5: the d-split PAIR kernel on 16x16x32 MFMAs, scores scaled in fp32 (flash_attn_m16.cuh, round 3: +2.7 %

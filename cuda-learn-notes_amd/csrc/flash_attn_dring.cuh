@@ -3,7 +3,7 @@
 // head-dim switch goes up to d = 1024 (kernels/flash-attn/mma/basic/flash_attn_mma_tiling_qkv.cu:70, :852-870;
 // flash_attn_mma.py:436-506).
 //
-// Why a new kernel (the predecessor is flash_attn_dwide.cuh, 0.25-0.27 of the fp16 MFMA peak). At these head
+// Why a new kernel (the predecessor is probe/flash_attn_dwide.cuh, 0.25-0.27 of the fp16 MFMA peak). At these head
 // dims the register file holds 64 query rows per CU (O^T alone is 64 x 1024 fp32 = 256 KiB of the 512 KiB), so every 16 keys
 // cost 64 KiB of K + V through L2 -> LDS per 4.2 MFLOP: the kernel lives on how well that stream is hidden. The d-wide kernel
 // had ONE K tile and ONE V tile of 32 keys in the LDS (2 x 64 KiB): each was refilled during the single phase that did not

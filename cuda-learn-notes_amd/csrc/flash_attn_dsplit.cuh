@@ -1,6 +1,6 @@
 // FlashAttention-2 forward for head dim 512 (BASELINE config C5 = [1,32,4096,512]), "d-split ping-pong" form.
 // Reference rungs: kernels/flash-attn/mma/basic/flash_attn_mma_tiling_qkv.cu:70, :732 (and tiling_qk.cu:72): the
-// reference streams Q, K and V in 16-wide d slices through O(1) shared memory. flash_attn_bigd.cuh keeps Q and a
+// reference streams Q, K and V in 16-wide d slices through O(1) shared memory. probe/flash_attn_bigd.cuh keeps Q and a
 // 256-wide O^T slice in the register file of ONE wave per SIMD and pays for it with (a) S recomputed per output
 // slice (1.5x the MFMA work), (b) every LDS-DMA issue stall and the whole softmax exposed (nobody else on the SIMD).
 // This kernel splits the head dim across a PAIR of waves instead:
@@ -16,7 +16,8 @@
 //   * K tiles are fetched by group 0 and V tiles by group 1 (LDS-DMA, 8 x 1 KiB per wave per tile, interleaved with
 //     the QK^T MFMAs), double-buffered, same source-side XOR swizzles as the big-D kernel.
 #pragma once
-#include "flash_attn_bigd.cuh"
+#include "flash_attn_v2.cuh"
+#include "hgemm_mfma.cuh"  // glds16_asm, lds_addr_of, wait_vmcnt
 
 namespace fa2 {
 
@@ -42,7 +43,7 @@ struct GeoSplit {
                 "d-split kernel: DH = 256, 128 with 32- or 64-key tiles, 64 with 64- or 128-key tiles");
   // XOR swizzles of the 16-byte chunk index (LDS images are lane-linear, so the swizzle is applied to the DMA source
   // address and to the fragment read). Rows of >= 256 bytes: K chunk ^= row & 15, V chunk ^= (row & 3) << 2
-  // (flash_attn_bigd.cuh). 128-byte rows (D = 64): two rows span the 64 banks, so K uses (row >> 1) & 7 and V moves
+  // (probe/flash_attn_bigd.cuh). 128-byte rows (D = 64): two rows span the 64 banks, so K uses (row >> 1) & 7 and V moves
   // the 64-byte block by (row >> 1) & 1.
   static __device__ __forceinline__ int swz_k(int row) { return CPR >= 16 ? (row & 15) : ((row >> 1) & 7); }
   static __device__ __forceinline__ int swz_v(int row) { return CPR >= 16 ? ((row & 3) << 2) : (((row >> 1) & 1) << 2); }
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 
-  // Fragment offsets (see flash_attn_bigd.cuh for the swizzles); this wave reads d columns part*256 .. +256 of K
+  // Fragment offsets (see probe/flash_attn_bigd.cuh for the swizzles); this wave reads d columns part*256 .. +256 of K
   // (k-steps part*16 ..) and of V (output blocks part*8 ..): + part*512 bytes in both images. The swizzle only
   // touches bits 5..7 (K) / 6..7 (V) of the byte offset, so fragment i is (one lane constant) ^ (i << 5 | 6) plus a
   // compile-time immediate: two address registers instead of twelve -- the register file is full by design.

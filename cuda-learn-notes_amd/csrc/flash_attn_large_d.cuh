@@ -5,12 +5,10 @@
 // O^T in registers and the partial S^T tiles are summed through LDS):
 //   512        pairs of waves, two 4-wave groups one phase apart, K/V double-buffered   (flash_attn_dsplit.cuh)
 //   640, 768, 1024  quads of waves (D / 4 columns each), K / V through two-slot rings of 16-key tiles (flash_attn_dring.cuh,
-//              round 3; its predecessor flash_attn_dwide.cuh -- one 32-key K tile and one V tile, no prefetch, D = 640 padded
+//              round 3; its predecessor probe/flash_attn_dwide.cuh -- one 32-key K tile and one V tile, no prefetch, D = 640 padded
 //              to 768 -- lives on in the probe library)
 //   320, 384   the D = 512 kernel's LDS geometry, every loop over the real head dim (DREAL; round 2)
 #pragma once
-#include "flash_attn.cuh"
-#include "flash_attn_bigd.cuh"
 #include "flash_attn_dsplit.cuh"
 #include "flash_attn_dring.cuh"
 

@@ -15,7 +15,7 @@
 //   * K image: 128-byte rows, chunk ^ ((row >> 1) & 7); V image: chunk ^ (((row >> 1) & 3) << 1) (the 16 rows x 32 bytes
 //     of one transposing read cover all 64 banks twice); 256-byte rows (D = 128): chunk ^ (row & 15) / ((row & 7) << 1).
 // Template: D = 64 | 128; RPW = query rows per wave, 32 (256-row workgroups) or 64 (512-row workgroups: every K / V
-// fragment then feeds four MFMAs -- the long-sequence form, cf. flash_attn_dsplit2.cuh); BC = keys per tile.
+// fragment then feeds four MFMAs -- the long-sequence form, cf. probe/flash_attn_dsplit2.cuh); BC = keys per tile.
 #pragma once
 #include "flash_attn_dsplit.cuh"
 

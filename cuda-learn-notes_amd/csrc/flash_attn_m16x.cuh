@@ -27,7 +27,7 @@
 namespace fa2 {
 
 // OX bits. Production uses M16X_PRIO | M16X_SPLIT_PROLOGUE (= 5); everything from M16X_PRIO_STATIC up is instantiated only in the
-// probe library (flash_attn_m16x_probe.hip) and its measured effect is in profiles/r03_fa_c4_ablation_probe.log.
+// probe library (probe/flash_attn_m16x_probe.hip) and its measured effect is in profiles/r03_fa_c4_ablation_probe.log.
 enum : int {
   M16X_PRIO = 1,            // s_setprio 1 in phase A (VALU-dense), 0 in phase B
   M16X_PRIO_B = 2,          // the opposite flip

@@ -2,7 +2,7 @@
 // -fno-slp-vectorize (see _build.py EXTRA_FLAGS): hipcc's SLP pass pairs the per-score f32 row-sum adds of neighbouring
 // steps into v_pk_add_f32, which drags the exponentials of a whole phase behind its last MFMA and is slower than two
 // plain adds beside MFMAs (MI355X_MICROARCH.md, per-instruction constants). Linked into the product library
-// (and, as a dependency of nothing else, not into the probe library, which has its own unit flash_attn_m16x_probe.hip).
+// (and, as a dependency of nothing else, not into the probe library, which has its own unit probe/flash_attn_m16x_probe.hip).
 #include "flash_attn_m16x.cuh"
 #include "flash_attn_m16x_api.h"
 

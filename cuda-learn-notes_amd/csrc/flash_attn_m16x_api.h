@@ -1,4 +1,4 @@
-// Host-side entries of the compile units flash_attn_m16x.hip / flash_attn_m16x_probe.hip (built with their own flags, see _build.py).
+// Host-side entries of the compile units flash_attn_m16x.hip / probe/flash_attn_m16x_probe.hip (built with their own flags, see _build.py).
 #pragma once
 #include "common.h"
 namespace fa2 {

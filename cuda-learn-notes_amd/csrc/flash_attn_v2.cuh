@@ -1,6 +1,6 @@
 // FlashAttention-2 forward, second-generation gfx950 kernel (head dims 32..256).
 //
-// Same mathematics and register-level dataflow as flash_attn.cuh (swapped S^T = K Q^T so a lane
+// Same mathematics and register-level dataflow as probe/flash_attn.cuh (swapped S^T = K Q^T so a lane
 // owns one query row; P^T stays in registers as the B operand of O^T = V^T P^T; V fragments fetched
 // with ds_read_b64_tr_b16 in the kv order of the P registers), re-structured around what the first
 // GPU profile showed was missing:
@@ -44,7 +44,7 @@ struct Geo {
   static constexpr int BC = 64, BR = NW * 32, NT = NW * 64;
   static constexpr int KS = D * 2 + 16;  // K row stride: +16 B makes ds_read_b128 over 32 rows conflict-free
   static constexpr int VPAD = ((D * 2) % 128 == 64) ? 0 : 64;
-  static constexpr int VS = VT ? (BC * 2 + 8) : (D * 2 + VPAD);  // see flash_attn.cuh
+  static constexpr int VS = VT ? (BC * 2 + 8) : (D * 2 + VPAD);  // see probe/flash_attn.cuh
   static constexpr int K_BYTES = BC * KS;
   static constexpr int V_BYTES = VT ? D * VS : BC * VS;
   static constexpr int STAGE = (K_BYTES + V_BYTES + 15) / 16 * 16;

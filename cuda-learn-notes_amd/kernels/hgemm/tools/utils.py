@@ -42,8 +42,9 @@ def try_load_hgemm_library(force_build: bool = False, verbose: bool = False):
     """Prebuilt library if there is one, else (or with force_build) build from sources -- reference utils.py:116-132."""
     if not force_build:
         try:
-            hgemm = _pkg.hgemm_lib()
-            pretty_print_line("Import prebuilt libcln_amd.so (hgemm) done, use it!")
+            import toy_hgemm as hgemm  # the module name the reference imports (utils.py:120); toy_hgemm.py at the repository root
+            hgemm.hgemm_mma_m16n8k16_naive  # noqa: B018 -- first attribute access dlopens libcln_amd.so (LibraryMissing when not built)
+            pretty_print_line("Import toy_hgemm (prebuilt libcln_amd.so) done, use it!")
         except _loader.LibraryMissing:
             pretty_print_line("Can't load prebuilt libcln_amd.so, force build from source (hipcc --offload-arch=gfx950)")
             hgemm = build_from_sources(verbose=verbose)

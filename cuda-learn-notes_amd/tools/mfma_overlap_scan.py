@@ -35,6 +35,33 @@ def scan(text, sub=""):
     return out
 
 
+def scan_shared_object(so_path, workdir):
+    """The same scan over the gfx950 code objects INSIDE a built shared library (llvm-objdump --offloading + -d: seconds, no
+    recompilation): -> ([(mangled kernel name, instruction)], number of MFMA instructions seen)."""
+    import glob
+    import os
+    import shutil
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        objdump = shutil.which("llvm-objdump")
+    if not objdump:
+        raise RuntimeError("llvm-objdump not found")
+    os.makedirs(workdir, exist_ok=True)
+    local = os.path.join(workdir, os.path.basename(so_path))
+    shutil.copy(so_path, local)  # --offloading writes the extracted bundles next to its input
+    subprocess.run([objdump, "--offloading", local], check=True, capture_output=True, cwd=workdir)
+    out, n_mfma = [], 0
+    for co in sorted(glob.glob(local + ".*gfx950")):
+        dis = subprocess.run([objdump, "-d", co], check=True, capture_output=True, text=True).stdout
+        # objdump: "<addr> <_Zname>:" headers, "\tinsn operands // addr: encoding" lines -> the hipcc -S shape scan() reads
+        text = re.sub(r"^[0-9a-f]+ <(_Z\w+)>:", r"\1:", dis, flags=re.M)
+        text = re.sub(r"//.*$", "", text, flags=re.M)
+        n_mfma += text.count("v_mfma")
+        out += scan(text)
+    return out, n_mfma
+
+
 if __name__ == "__main__":
     res = scan(open(sys.argv[1]).read(), sys.argv[2] if len(sys.argv) > 2 else "")
     from collections import Counter

@@ -1,7 +1,7 @@
 """On-GPU probe of primitive semantics the kernels rely on (run on the GPU box; compiles a tiny HIP file).
 Prints, for ds_read_b64_tr_b16, which LDS element every (lane, j) receives when lane l supplies the
 address of row 4*(l>>4) + ((l&15)>>2), cols 4*(l&3)..+3 of a [16][16] half image -- the model used by
-read_nfrag (hgemm_mfma.cuh) and the V fragments (flash_attn.cuh) -- and checks the MFMA C/D layouts."""
+read_nfrag (hgemm_mfma.cuh) and the V fragments (probe/flash_attn.cuh) -- and checks the MFMA C/D layouts."""
 import ctypes
 import os
 import subprocess

@@ -134,7 +134,7 @@ def test_m16x_register_dataflow_reproduces_attention():
     assert np.abs(out - reference(q, k, v)).max() < 1e-9
 
 
-# ---------------------------------------------------------------- flash_attn_m32x.cuh: 32x32x16, the same images
+# ---------------------------------------------------------------- probe/flash_attn_m32x.cuh: 32x32x16, the same images
 def test_m32x_register_dataflow_reproduces_attention():
     q, k, v = inputs(2)
     kimg, vimg = image(k, swz_k), image(v, swz_v)

@@ -449,7 +449,7 @@ def test_stages_one_is_the_single_stage_form_of_the_same_kernel(fa, built, dev, 
         assert torch.equal(o1, o2), name
 
 
-# register-blocked kernel (flash_attn_rb.cuh) through the probe hook: (D, option-set ids of flash_attn_probe.hip)
+# register-blocked kernel (probe/flash_attn_rb.cuh) through the probe hook: (D, option-set ids of probe/flash_attn_probe.hip)
 RB_VARIANTS = {64: [400, 401, 402, 403, 404, 405, 406, 407, 408, 409, 420, 421, 422], 128: [400, 401, 405, 407, 408, 409, 420, 421]}
 # ping-pong kernel with OPT_PRE (pre-scaled Q, accumulators started at -m): option-set ids 500..
 PRE_VARIANTS = {64: [500, 501, 502, 503, 504, 505, 506, 507, 508, 509, 510, 511], 128: [500, 501, 504, 505, 508, 509], 256: [500, 504]}
@@ -546,7 +546,7 @@ def test_probe_variants_match_production(fa, built, dev, oracle):
 
 @pytest.mark.parametrize("D,abl", [(64, 600), (64, 608), (64, 601), (128, 600), (128, 602)])
 def test_one_wave_per_simd_attention_probe(built, dev, oracle, D, abl):
-    """flash_attn_w4.cuh (probe library): hand-placed one-wave-per-SIMD stream; random data, the creeping-max / late
+    """probe/flash_attn_w4.cuh (probe library): hand-placed one-wave-per-SIMD stream; random data, the creeping-max / late
     jump / early spike regimes (rescale decided in the PV phase, applied behind its last MFMA), several KV lengths."""
     from cuda_learn_notes_amd import host
     for (B, H, N) in ((1, 2, 256), (2, 3, 512), (1, 2, 1024)):
@@ -586,7 +586,7 @@ def test_attention_on_16x16x32_mfma_probe_forms(built, dev, oracle, D, abl, N):
 
 @pytest.mark.parametrize("abl", [950, 951, 953, 955])
 def test_one_wave_per_simd_attention_on_16x16x32_probe(built, dev, oracle, abl):
-    """flash_attn_m16s.cuh (probe library): the sum-checked kernel as a one-wave-per-SIMD stream, 4 waves x
+    """probe/flash_attn_m16s.cuh (probe library): the sum-checked kernel as a one-wave-per-SIMD stream, 4 waves x
     64 rows, asm MFMAs with S^T in VGPRs / O^T in AGPRs. Several tile counts, rescale regimes (the cold path), and 200
     repeated launches bit-identical (the form depends on hand-kept MFMA -> VALU distances)."""
     from cuda_learn_notes_amd import host
@@ -613,7 +613,7 @@ def test_one_wave_per_simd_attention_on_16x16x32_probe(built, dev, oracle, abl):
 
 @pytest.mark.parametrize("abl", [960, 961, 962, 889])
 def test_sum_checked_attention_on_32x32x16_probe(built, dev, oracle, abl):
-    """flash_attn_m32x.cuh (probe library): the two-group sum-checked D = 64 kernel rebuilt on v_mfma_f32_32x32x16_f16 (S^T in 32 x 32
+    """probe/flash_attn_m32x.cuh (probe library): the two-group sum-checked D = 64 kernel rebuilt on v_mfma_f32_32x32x16_f16 (S^T in 32 x 32
     blocks, key blocks interleaved in pairs, P^T k-steps in accumulator register order, V^T fragments as two transposing reads 8 key
     rows apart). Several tile counts incl. one tile, the rescale regime (cold path), 50 repeated launches bit-identical.
     889: the 16x16x32 kernel with the deferred blocks' overflow check moved into phase B (M16X_LATE_CHECK) -- key 1000 of the last head
@@ -642,7 +642,7 @@ def test_sum_checked_attention_on_32x32x16_probe(built, dev, oracle, abl):
 
 @pytest.mark.parametrize("abl", [710, 711])
 def test_key_split_attention_probe(built, dev, oracle, abl):
-    """flash_attn_dsplit2.cuh KVS = true (probe library): the two wave groups walk one half of the KV tiles each and merge
+    """probe/flash_attn_dsplit2.cuh KVS = true (probe library): the two wave groups walk one half of the KV tiles each and merge
     (O^T, m, l) through LDS. Random data; a dominant key only in the FIRST half, only in the SECOND half (the merge then
     scales one partner by ~2^-large), in both; several KV lengths incl. the minimum (one tile per group)."""
     from cuda_learn_notes_amd import host
@@ -661,7 +661,7 @@ def test_key_split_attention_probe(built, dev, oracle, abl):
 
 
 def test_pingpong_kernel_with_64_rows_per_wave(fa, built, dev, oracle):
-    """64 query rows per wave (flash_attn_m16x.cuh, RPW = 64; round 2: flash_attn_dsplit2.cuh) at D = 64, >= 256 workgroups of 512
+    """64 query rows per wave (flash_attn_m16x.cuh, RPW = 64; round 2: probe/flash_attn_dsplit2.cuh) at D = 64, >= 256 workgroups of 512
     rows in whole rounds: the planner must pick it for these
     shapes; random data plus the creeping-max / late-jump / early-spike regimes (rescale of BOTH row groups of a wave,
     only one of which grows), sampled heads against the fp64 oracle, and bit-repeatability."""

@@ -58,6 +58,12 @@ def test_inline_asm_mfma_stream_of_the_one_wave_per_simd_hgemm(tmp_path):
     for k in w4:
         assert k["agpr"] in (256, 192, 144, 128, 100) and k["spill"] == 0 and k["scratch"] == 0, k
         assert kr.asm_mfma_stream_check(text, k["name"]) == [], k["demangled"]
+    # the ring-of-slots form (hgemm_w4s.cuh, stages 3 / 4 / 5 of the 256x256 names): same inline-asm MFMAs, same rules
+    w4s = [k for k in kernels if "hgemm_w4s_kernel" in k["demangled"]]
+    assert len(w4s) == 6, [k["demangled"] for k in w4s]  # ring depth 3 / 4 / 5 x NN / TN
+    for k in w4s:
+        assert k["agpr"] == 256 and k["vgpr"] <= 512 and k["spill"] == 0 and k["scratch"] == 0, k
+        assert kr.asm_mfma_stream_check(text, k["name"]) == [], k["demangled"]
 
 
 def test_production_attention_kernels_use_the_16x16x32_matrix_shape(tmp_path):
@@ -106,3 +112,29 @@ def test_no_mfma_destination_on_its_operand_registers(src, tmp_path):
     assert text.count("v_mfma") > 0, src
     bad = scan.scan(text)
     assert not bad, [(n[:60], l) for n, l in bad[:6]]
+
+
+# kernels of the TEST-ONLY probe library that carry the pattern ON PURPOSE or whose results are garbage by design
+PROBE_OVERLAP_ALLOWED = (
+    "fa2_fwd_m16_pair_kernelILi2ELb1ELb0ELi32768E", "fa2_fwd_m16_pair_kernelILi2ELb0ELb0ELi32768E",  # DBG 32768 = the round-2 code without cln_mfma_keep (the bisect's positive control)
+    "fa2_fwd_dsplit_kernelILi64ELi1ELi2ELi147485E",  # row sums on the matrix pipe (OPT_SUMM probe, profiles/r02_fa_rowsum_on_mfma_probe.log): its ones-operand MFMA
+    "hgemm_m32_kernelILi0ELi1E", "hgemm_pp_kernelILi0ELi1E",  # EPI = 1: no-store timing ablations (nothing is written back)
+)
+
+
+def test_built_libraries_have_no_mfma_destination_on_operand_registers(built, tmp_path):
+    """the per-source scan above covers the product units only, yet the probe library's measurements and
+    bit-repeatability tests are the evidence behind the dispatch choices. This scans the code objects INSIDE the built
+    libraries (llvm-objdump of the shipped binaries, no recompilation): the product library must be clean; in the probe library
+    only the deliberate positive controls and the no-store ablations may carry the pattern."""
+    import mfma_overlap_scan as scan
+    from cuda_learn_notes_amd import _loader
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("llvm-objdump not available")
+    bad, n = scan.scan_shared_object(_loader.so_path("libcln_amd.so"), str(tmp_path / "product"))
+    assert n > 20000, n  # the scan saw the library's MFMAs
+    assert not bad, [(k[:70], l) for k, l in bad[:6]]
+    bad, n = scan.scan_shared_object(_loader.so_path("libcln_amd_probe.so"), str(tmp_path / "probe"))
+    assert n > 50000, n
+    stray = [(k[:90], l) for k, l in bad if not any(a in k for a in PROBE_OVERLAP_ALLOWED)]
+    assert not stray, stray[:6]
