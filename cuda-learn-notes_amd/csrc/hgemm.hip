@@ -47,11 +47,13 @@ int best_plan(int M, int N, int K) {
     return eff * util * (1.0 + 0.5 * (1.0 - util));
   };
   // Small problems are latency-bound (launch ramp + one L2 round trip per K tile), not throughput-bound: up to 640
-  // tiles of 64x64 (1536^2) the smallest tile wins because it puts a workgroup on every CU (1024^3: 6.8 us vs 9.1 us for
-  // 64x128 on half the CUs and 8.4 / 10.0 us for rocBLAS TN / NN; profiles/r02_hgemm_small_probe.log); from 2048^2 on the
-  // throughput model below takes over. The shortcut is for SHORT K only (measured up to 1536): a skinny, K-heavy problem
-  // (1600^2 x 16384) is throughput-bound and goes through the model (where the 160x160 form scores 0.88 against 0.44).
-  if (M % 64 == 0 && N % 64 == 0 && K % 64 == 0 && K <= 2048 && (long long)(M / 64) * (N / 64) <= 640) return PLAN_R64x64;
+  // tiles of 64x64 (1536^2, 1600^2) the smallest tile wins because it puts a workgroup on every CU (1024^3: 6.8 us vs 9.1 us for
+  // 64x128 on half the CUs and 8.4 / 10.0 us for rocBLAS TN / NN; profiles/r02_hgemm_small_probe.log); from 1792^2 on the
+  // throughput model below takes over. At EVERY K: round 3 had limited the shortcut to K <= 2048 on one unmeasured shape; measured in round 4
+  // (profiles/r04_hgemm_small_mn_long_k_probe.log, C-ABI timed) the 64x64 ring wins all of 1024^2 / 1152^2 / 1280^2 / 1536^2 / 1600^2 at
+  // K = 4096 ... 16384 by 7-27 % over what the model picked (1600^2 x 16384: 669 vs 593 TF for hgemm_w4<160x160>, 100 tiles on 256 CUs;
+  // 1280^2 x 4096: 434 vs 330) -- the model prices a tile against a FULL chip and these grids do not fill it.
+  if (M % 64 == 0 && N % 64 == 0 && K % 64 == 0 && (long long)(M / 64) * (N / 64) <= 640) return PLAN_R64x64;
   double best = -1.0;
   int plan = PLAN_R128;
   auto offer = [&](int p, double sc) {

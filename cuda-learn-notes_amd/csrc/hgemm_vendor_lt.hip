@@ -33,7 +33,15 @@ LtPlan* find_or_make(int layout, int M, int N, int K) {
   if (!g_lt && hipblasLtCreate(&g_lt) != HIPBLAS_STATUS_SUCCESS) return nullptr;
   LtPlan p;
   p.layout = layout, p.M = M, p.N = N, p.K = K;
-  if (hipblasLtMatmulDescCreate(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F) != HIPBLAS_STATUS_SUCCESS) return nullptr;
+  // every failure path below releases what this call created (nothing is cached on failure, so a retry must not leak again)
+  auto fail = [&]() -> LtPlan* {
+    if (p.la) hipblasLtMatrixLayoutDestroy(p.la);
+    if (p.lb) hipblasLtMatrixLayoutDestroy(p.lb);
+    if (p.lc) hipblasLtMatrixLayoutDestroy(p.lc);
+    if (p.desc) hipblasLtMatmulDescDestroy(p.desc);
+    return nullptr;
+  };
+  if (hipblasLtMatmulDescCreate(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F) != HIPBLAS_STATUS_SUCCESS) return p.desc = nullptr, fail();
   const int32_t op_b = layout ? HIPBLAS_OP_T : HIPBLAS_OP_N, op_a = HIPBLAS_OP_N;
   hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &op_b, sizeof(op_b));
   hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &op_a, sizeof(op_a));
@@ -42,22 +50,21 @@ LtPlan* find_or_make(int layout, int M, int N, int K) {
   else ok &= hipblasLtMatrixLayoutCreate(&p.la, HIP_R_16F, N, K, N) == HIPBLAS_STATUS_SUCCESS;
   ok &= hipblasLtMatrixLayoutCreate(&p.lb, HIP_R_16F, K, M, K) == HIPBLAS_STATUS_SUCCESS;
   ok &= hipblasLtMatrixLayoutCreate(&p.lc, HIP_R_16F, N, M, N) == HIPBLAS_STATUS_SUCCESS;
-  if (!ok) return nullptr;
+  if (!ok) return fail();
   hipblasLtMatmulPreference_t pref;
-  if (hipblasLtMatmulPreferenceCreate(&pref) != HIPBLAS_STATUS_SUCCESS) return nullptr;
+  if (hipblasLtMatmulPreferenceCreate(&pref) != HIPBLAS_STATUS_SUCCESS) return fail();
   const uint64_t max_ws = MAX_WS;
   hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &max_ws, sizeof(max_ws));
   hipblasLtMatmulHeuristicResult_t res[1];
   int got = 0;
   const hipblasStatus_t hs = hipblasLtMatmulAlgoGetHeuristic(g_lt, p.desc, p.la, p.lb, p.lc, p.lc, pref, 1, res, &got);
   hipblasLtMatmulPreferenceDestroy(pref);
-  if (hs != HIPBLAS_STATUS_SUCCESS || got < 1 || res[0].state != HIPBLAS_STATUS_SUCCESS) return nullptr;
+  if (hs != HIPBLAS_STATUS_SUCCESS || got < 1 || res[0].state != HIPBLAS_STATUS_SUCCESS) return fail();
   p.algo = res[0].algo, p.ws_bytes = res[0].workspaceSize;
-  if (p.ws_bytes > g_ws_bytes) {
-    if (g_ws) (void)hipFree(g_ws);
-    g_ws = nullptr, g_ws_bytes = 0;
-    if (hipMalloc(&g_ws, p.ws_bytes) != hipSuccess) return nullptr;
-    g_ws_bytes = p.ws_bytes;
+  if (p.ws_bytes > MAX_WS) return fail();
+  if (!g_ws) {  // ONE workspace of the preference's maximum, allocated once: earlier plans never see theirs freed under a queued matmul
+    if (hipMalloc(&g_ws, MAX_WS) != hipSuccess) return g_ws = nullptr, fail();
+    g_ws_bytes = MAX_WS;
   }
   g_plans.push_back(p);
   return &g_plans.back();

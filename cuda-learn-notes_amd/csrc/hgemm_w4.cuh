@@ -34,9 +34,11 @@ namespace hgemm {
 
 // Epilogue through LDS for a wave tile of FN x 16 columns (128 or 96): [64 rows][FN*32 + 16 B] wave-private region,
 // passes of up to 64 rows; a lane streams 16 bytes, one store instruction = 4 (5) rows x 256 (192) contiguous bytes.
-template <int FM, int FN, int NT = 0>  // NT (probe): 1 = non-temporal C stores, 2 = write-through (sc0 sc1)
+// NT: 1 = non-temporal C stores WHEN the launch-uniform `nt_ok` says the launch's footprint is large (see W4_NT_FOOTPRINT), 2 (probe) =
+// write-through (sc0 sc1), 3 (probe) = non-temporal unconditionally
+template <int FM, int FN, int NT = 0>
 __device__ __forceinline__ void store_wide_tile_via_lds(half_t* Cmat, int N, int row0, int col0, int lane, char* wave_lds,
-                                                        const f4 (&acc)[FM][FN]) {
+                                                        const f4 (&acc)[FM][FN], int nt_ok = 1) {
   static_assert(FN == 8 || FN == 6 || FN == 5 || FN == 4, "128-, 96-, 80- or 64-column wave tile");
   constexpr int RS = FN * 32 + 16;  // row stride in bytes
   constexpr int LPR = FN * 2;       // 16-byte lanes per row
@@ -62,7 +64,10 @@ __device__ __forceinline__ void store_wide_tile_via_lds(half_t* Cmat, int N, int
       if (it * RPI < rows && lane < RPI * LPR && r < rows) {
         const u4 v = *reinterpret_cast<const u4*>(wave_lds + r * RS + (lane % LPR) * 16);
         u4* dst = reinterpret_cast<u4*>(Cmat + (size_t)(row0 + h0 * 16 + r) * N + col0 + (lane % LPR) * 8);
-        if constexpr (NT == 1) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+        if constexpr (NT == 1) {  // (the nt form is inline asm: under a run-time flag hipcc would merge the two stores of the diamond into one plain store)
+          if (nt_ok) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+          else asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+        } else if constexpr (NT == 3) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
         else if constexpr (NT == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
         else *dst = v;
       }
@@ -180,7 +185,7 @@ __global__ __launch_bounds__(256, 1) void hgemm_w4_kernel(const half_t* __restri
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   int tm, tn;
-  tile_coords(blockIdx.x, gridDim.x, tiles_m, tiles_n, swizzle, band, tm, tn);
+  tile_coords(blockIdx.x, gridDim.x, tiles_m, tiles_n, swizzle & 1, band, tm, tn);  // bit 1 of `swizzle`: non-temporal C stores allowed (launcher)
   const int m0 = tm * BM, n0 = tn * BN;
 
   KFill<C, FM> fa;
@@ -342,7 +347,7 @@ __global__ __launch_bounds__(256, 1) void hgemm_w4_kernel(const half_t* __restri
     for (int j = 0; j < FN; ++j) asm volatile("" : "+a"(acc[i][j]));
   if constexpr (EPI >= 2) {  // EPI 3 / 4 (probe library): the same epilogue with non-temporal / write-through C stores
     // B1 of the last tile: every wave is past its last fragment read; no DMA is in flight
-    store_wide_tile_via_lds<FM, FN, EPI - 2>(Cmat, N, m0 + wm * C::WTM, n0 + wn * C::WTN, lane, smem + wave * (64 * (FN * 32 + 16)), acc);
+    store_wide_tile_via_lds<FM, FN, EPI - 2>(Cmat, N, m0 + wm * C::WTM, n0 + wn * C::WTN, lane, smem + wave * (64 * (FN * 32 + 16)), acc, swizzle >> 1);
   } else {  // measurement-only variant: keep the accumulators live, store (almost) nothing
     float s = 0.f;
 #pragma unroll
@@ -355,6 +360,12 @@ __global__ __launch_bounds__(256, 1) void hgemm_w4_kernel(const half_t* __restri
 
 // K the kernel's peeled structure covers: whole 64-wide tiles, >= 6 of them when their number is even, >= 7 when odd
 inline bool w4_k_ok(int K) { return K % 64 == 0 && K >= ((K / 64) & 1 ? 448 : 384); }
+// Non-temporal C stores keep the output from displacing the A / B panels other workgroups still read from L2 / MALL: +1.3-1.5 % at 4096^3
+// (100.7 MB of operands), +3.4-3.6 % at 8192^3 (profiles/r03_hgemm_c_store_probe.log). A SMALL problem's C is what the next kernel reads
+// (chained GEMMs) and fits the 256 MiB Infinity Cache next to A and B: there the streaming hint would push out exactly that data
+// (ADVICE r3), so the epilogue takes the hint only from the measured size on: footprint = 2 (MK + KN + MN) bytes >= 96 MB.
+constexpr long long W4_NT_FOOTPRINT = 96LL << 20;
+inline int w4_nt_ok(int M, int N, int K) { return 2LL * ((long long)M * K + (long long)K * N + (long long)M * N) >= W4_NT_FOOTPRINT ? 1 : 0; }
 
 template <int LAYOUT, int EPI = 2, int VAR = 0, int ABL = 0, int BM = 256, int BN = 256>
 int launch_w4(const void* a, const void* b, void* c, int M, int N, int K, int swizzle, int swizzle_stride,
@@ -372,7 +383,7 @@ int launch_w4(const void* a, const void* b, void* c, int M, int N, int K, int sw
       if (cln_ensure_lds(lds_attr_odd, reinterpret_cast<const void*>(&hgemm_w4_kernel<LAYOUT, EPI, VAR, ABL, BM, BN, true>), C::LDS_BYTES) != CLN_OK)
         return CLN_ERR_LAUNCH;
       CLN_LAUNCH((hgemm_w4_kernel<LAYOUT, EPI, VAR, ABL, BM, BN, true>), dim3(tiles_m * tiles_n), dim3(256), C::LDS_BYTES, stream,
-                 (const half_t*)a, (const half_t*)b, (half_t*)c, M, N, K, tiles_m, tiles_n, swizzle ? 1 : 0, band);
+                 (const half_t*)a, (const half_t*)b, (half_t*)c, M, N, K, tiles_m, tiles_n, (swizzle ? 1 : 0) | (w4_nt_ok(M, N, K) << 1), band);
       return cln_check_launch();
     }
   }
@@ -380,7 +391,7 @@ int launch_w4(const void* a, const void* b, void* c, int M, int N, int K, int sw
   if (cln_ensure_lds(lds_attr, reinterpret_cast<const void*>(&hgemm_w4_kernel<LAYOUT, EPI, VAR, ABL, BM, BN>), C::LDS_BYTES) != CLN_OK)
     return CLN_ERR_LAUNCH;
   CLN_LAUNCH((hgemm_w4_kernel<LAYOUT, EPI, VAR, ABL, BM, BN>), dim3(tiles_m * tiles_n), dim3(256), C::LDS_BYTES, stream,
-             (const half_t*)a, (const half_t*)b, (half_t*)c, M, N, K, tiles_m, tiles_n, swizzle ? 1 : 0, band);
+             (const half_t*)a, (const half_t*)b, (half_t*)c, M, N, K, tiles_m, tiles_n, (swizzle ? 1 : 0) | (w4_nt_ok(M, N, K) << 1), band);
   return cln_check_launch();
 }
 
