@@ -238,6 +238,15 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[kb2][r] = 0.f;
     }
+    // ABL 512 = the `stages = 1` form in ONE burst (round 4): the wave requests all its pieces of tile j + 1 here, at the top of phase A,
+    // and waits for them here -- no request of the wave in flight while it computes (ABL 256, round 3: a wait after every piece, 0.37x)
+    if constexpr ((ABL & 512) != 0) {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < G::PPW; ++i) dma_piece(jn, (j + 1) & 1, i);
+      hgemm::wait_vmcnt<0>();
+      __builtin_amdgcn_sched_barrier(0);
+    }
     {
       // MFMA t works on k-step t / BCB of key block t % BCB (consecutive MFMAs alternate accumulators at BCB = 2)
       h8 kf[PD];
@@ -250,7 +259,7 @@ __global__ __launch_bounds__(512, 1) void fa2_fwd_dsplit_kernel(const half_t* __
         else s[t % BCB] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[t % PD], qf[t / BCB], s[t % BCB], 0, 0, 0);
         cln_mfma_keep(s[t % BCB], kf[t % PD], qf[t / BCB]);  // destination disjoint from the operands (common.h)
         if (t + PD < NQK) kf[t % PD] = k_frag(t + PD);
-        if (!(ABL & 1) && (t % DSTEP) == DSTEP - 1 && t / DSTEP < G::PPW) {
+        if (!(ABL & 1) && !(ABL & 512) && (t % DSTEP) == DSTEP - 1 && t / DSTEP < G::PPW) {
           dma_piece(jn, (j + 1) & 1, t / DSTEP);
           // ABL 256 = the `stages = 1` form: every tile fetch is waited for where it is issued, no load runs under compute
           if constexpr ((ABL & 256) != 0) hgemm::wait_vmcnt<0>();

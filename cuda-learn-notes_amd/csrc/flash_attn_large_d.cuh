@@ -15,11 +15,11 @@
 namespace fa {
 inline int launch_fa2_large_d(const void* q, const void* k, const void* v, void* o, int B, int H, int N, int D,
                               hipStream_t s, bool one_stage = false) {
-  if (one_stage) {  // `stages = 1`: the same kernels with every tile fetch waited for where it is issued (no load under compute)
+  if (one_stage) {  // `stages = 1`: the same kernels with every tile request waited for where it is issued (no load under compute); d-split: one burst per tile
     constexpr int O1 = fa2::OPT_DEFAULT | fa2::OPT_1STAGE;
     switch (D) {
-      case 320: return fa2::launch_dsplit<512, 2, 1, fa2::OPT_DEFAULT, 256, 320>(q, k, v, o, B, H, N, s);
-      case 384: return fa2::launch_dsplit<512, 2, 1, fa2::OPT_DEFAULT, 256, 384>(q, k, v, o, B, H, N, s);
+      case 320: return fa2::launch_dsplit<512, 2, 1, fa2::OPT_DEFAULT, 512, 320>(q, k, v, o, B, H, N, s);
+      case 384: return fa2::launch_dsplit<512, 2, 1, fa2::OPT_DEFAULT, 512, 384>(q, k, v, o, B, H, N, s);
       case 640: return fa2::launch_dring<640, O1, false, 0, 2, 2>(q, k, v, o, B, H, N, s);
       case 768: return fa2::launch_dring<768, O1, false, 0, 2, 2>(q, k, v, o, B, H, N, s);
       case 1024: return fa2::launch_dring<1024, O1, true, 1>(q, k, v, o, B, H, N, s);

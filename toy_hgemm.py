@@ -8,12 +8,20 @@ _lib = None
 __all__ = [e.name for e in _pkg.manifest.ENTRIES if e.lib in ("hgemm", "hgemm_vendor")]
 
 
+_EXTRA = [e.name for e in _pkg.manifest.ENTRIES if e.lib == "hgemm_vendor_lt"]  # our own hipBLASLt comparison rows (cln_ prefix): not reference names
+_lt = None
+
+
 def __getattr__(name):
-    global _lib
+    global _lib, _lt
     if name in __all__:
         if _lib is None:
             _lib = _pkg.load("hgemm", "hgemm_vendor")
         return getattr(_lib, name)
+    if name in _EXTRA:
+        if _lt is None:
+            _lt = _pkg.load("hgemm_vendor_lt")
+        return getattr(_lt, name)
     raise AttributeError("module 'toy_hgemm' has no attribute %r" % name)
 
 
