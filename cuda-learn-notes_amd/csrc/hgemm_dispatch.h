@@ -20,9 +20,11 @@ int ring_exact_tn(int tile, int bk, int stages, const void* a, const void* b, vo
 inline void ring_pick(int BM, int BN, int K, int& S, int& BK) {
   // reference bindings fall back to 2 stages for an unknown count (hgemm_mma_stage.cu:2380-2454 default case)
   if (S < 2 || S > 5) S = 2;
-  // 128x128: a 64-deep ring of 3+ stages is 96+ KiB, ONE workgroup (4 waves) per CU instead of two -- 842 / 826 / 825 TF at stages 3 / 4 / 5
-  // against 1005 at stages 2 (4096^3); the 32-deep ring keeps two workgroups on a CU: 937 / 940 / 935 (profiles/r04_hgemm_ring_bk_stages_probe.log)
-  const bool keep_two_per_cu = BM == 128 && BN == 128 && S >= 3;
+  // The 4-wave tiles (128x128, 64x128, 64x64) run two or more workgroups per CU; a 64-deep ring that grows past 80 KiB leaves ONE: 128x128 at
+  // 3 / 4 / 5 stages 842 / 826 / 825 TF against 1005 at 2 (4096^3), 64x128 at 4 / 5 stages 630 / 615 against 787-832. The 32-deep ring of the
+  // same depth keeps two on the CU: 128x128 937 / 940 / 935, 64x128 645 / 627 at 2048^3 where the 64-deep one has 571 / 560
+  // (profiles/r04_hgemm_ring_bk_stages_probe.log).
+  const bool keep_two_per_cu = BM + BN <= 256 && S * (BM + BN) * 64 * 2 > 80 * 1024;
   if (K % 64 == 0 && !keep_two_per_cu && S * (BM + BN) * 64 * 2 <= 160 * 1024) {
     BK = 64;
     return;

@@ -7,9 +7,9 @@
 #   5. rocprofv3 kernel-trace of the bandwidth kernels (bw_prof_*)                         -> <tag>_bw_rocprof.json
 #   6. the re-authored reference scripts on the GPU (run_all_scripts.sh)                   -> <tag>_reference_style_scripts_on_gpu.log
 #   7. C++ harness                                                                         -> <tag>_hgemm_bench_cpp.log
-#   8. stages = 1 vs 2 of the attention names, the hipBLASLt row, the bit-repeatability stress, the ck_tile FMHA comparator
+#   8. (round 4: + the single-stage / ring-of-slots / fp32-scale probes and the back-to-back stress) stages = 1 vs 2 of the attention names, the hipBLASLt row, the bit-repeatability stress, the ck_tile FMHA comparator
 #      -> <tag>_fa_stage1_vs_stage2.log, <tag>_hipblaslt_probe.log, <tag>_determinism_stress.log, <tag>_fa_ck_tile_comparator.log
-TAG=${1:-r03}
+TAG=${1:-r04}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$REPO/gpurun_out; T=$REPO/cuda-learn-notes_amd/tools
 mkdir -p $OUT; cd $REPO; export PYTHONUNBUFFERED=1
 # a box whose GPU faults on the first launch (seen once in round 2: every later command then hangs to its timeout) must
@@ -17,17 +17,23 @@ mkdir -p $OUT; cd $REPO; export PYTHONUNBUFFERED=1
 timeout 120 python -m pytest tests/test_gpu_flash_attn.py -m gpu -x -q -k golden_fixture > $OUT/${TAG}_sanity.log 2>&1 || { echo "sanity launch failed"; tail -5 $OUT/${TAG}_sanity.log; exit 7; }
 timeout 1500 python -m pytest tests -m gpu -q --timeout 120 > $OUT/${TAG}_pytest_gpu.log 2>&1; RC=$?; echo "pytest rc=$RC"; tail -3 $OUT/${TAG}_pytest_gpu.log
 if [ $RC -gt 1 ]; then echo "pytest aborted"; exit 8; fi
-timeout 300 python bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_20steps.json 2> $OUT/${TAG}_bench_20steps.err; echo "bench20 rc=$?"
-timeout 300 python bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/${TAG}_bench_default.err; echo "bench rc=$?"
+timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_20steps.json 2> $OUT/${TAG}_bench_20steps.err; echo "bench20 rc=$?"
+timeout 600 python bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/${TAG}_bench_default.err; echo "bench rc=$?"
 timeout 900 bash $T/profile_round.sh $TAG > $OUT/${TAG}_profile_round.log 2>&1; echo "profile_round rc=$?"
 timeout 600 bash $T/fa_trace.sh $TAG > $OUT/${TAG}_fa_trace.log 2>&1; echo "fa_trace rc=$?"
 ( cd /tmp && export TMPDIR=/tmp && BW_PROF_ORDER=$OUT/bw_prof_order.json timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/bwprof -o bw -- python $T/bw_prof_target.py > $OUT/${TAG}_bw_prof.log 2>&1 )
 python $T/bw_prof_summary.py $(ls $OUT/bwprof/*kernel_trace.csv $OUT/bwprof/*/*kernel_trace.csv 2>/dev/null | head -1) $OUT/bw_prof_order.json $OUT/${TAG}_bw_rocprof.json > $OUT/${TAG}_bw_rocprof.txt 2>&1; echo "bw rc=$?"
 timeout 900 bash $T/run_all_scripts.sh > $OUT/${TAG}_reference_style_scripts_on_gpu.log 2>&1; echo "scripts rc=$?"
-timeout 300 $REPO/cuda-learn-notes_amd/harness/hgemm_bench 200 > $OUT/${TAG}_hgemm_bench_cpp.log 2>&1; echo "harness rc=$?"
+timeout 600 $REPO/cuda-learn-notes_amd/harness/hgemm_bench 200 > $OUT/${TAG}_hgemm_bench_cpp.log 2>&1; echo "harness rc=$?"
 timeout 200 python $T/fa_stage_probe.py 2>&1 | grep STAGE > $OUT/${TAG}_fa_stage1_vs_stage2.log; echo "stage probe rc=$?"
 timeout 200 python $T/vendor_lt_probe.py 2>&1 | grep "^LT" > $OUT/${TAG}_hipblaslt_probe.log; echo "hipblaslt rc=$?"
 timeout 400 python $T/determinism_stress.py 200 2>&1 | grep DET > $OUT/${TAG}_determinism_stress.log; echo "determinism rc=$?"
 timeout 300 python $T/fa_ck_probe.py 2>&1 | grep "^CK" > $OUT/${TAG}_fa_ck_tile_comparator.log; echo "ck_tile comparator rc=$?"
+# round 4: the single-stage attention forms, the ring-of-slots HGEMM, the fp32-scaled attention form, back-to-back launch stress
+timeout 300 python $T/fa_one_stage_probe.py 2>&1 | grep "^ONE" > $OUT/${TAG}_fa_one_stage_probe.log; echo "one-stage probe rc=$?"
+timeout 300 python $T/hg_w4s_probe.py 2>&1 | grep "^W4S" > $OUT/${TAG}_hgemm_w4s_probe.log; echo "w4s probe rc=$?"
+timeout 300 python $T/fa_fscale_probe.py 2>&1 | grep "^FSCALE" > $OUT/${TAG}_fa_fscale_probe.log; echo "fscale probe rc=$?"
+( NBUF=16 FORMS=stages=2,stages=1 timeout 300 python $T/fa_race_stress.py 1 32 4096 512 60; NBUF=16 FORMS=stages=2,stages=1 timeout 300 python $T/fa_race_stress.py 4 8 2048 64 100;
+  NBUF=16 FORMS=stages=2 timeout 300 python $T/fa_race_stress.py 2 32 4096 256 40 ) 2>&1 | grep "^RACE" > $OUT/${TAG}_fa_back_to_back_stress.log; echo "stress rc=$?"
 cut -c1-1500 $OUT/${TAG}_bench_20steps.json; echo; cat $OUT/${TAG}_fa_kernel_trace.csv; cat $OUT/${TAG}_bw_rocprof.txt
 ls -la $OUT/${TAG}_* | head -40

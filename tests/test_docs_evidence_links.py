@@ -12,7 +12,7 @@ PAT = re.compile(r"`(?:profiles/)?(r0\d_[A-Za-z0-9_.\-]+\.(?:log|json|csv|txt))`
 
 def test_cited_evidence_files_exist():
     cited = set()
-    for f in ("DESIGN.md", "README.md", "INTEGRATION.md", os.path.join("profiles", "README.md")):
+    for f in ("DESIGN.md", "DESIGN_LOG.md", "README.md", "INTEGRATION.md", os.path.join("profiles", "README.md")):
         cited |= set(PAT.findall(open(os.path.join(ROOT, f)).read()))
     assert len(cited) > 50
     missing = sorted(n for n in cited if not os.path.exists(os.path.join(ROOT, "profiles", n)))
@@ -26,7 +26,7 @@ def test_every_round_file_is_in_the_profiles_index():
     assert not unlisted, unlisted
 
 
-DOCS = ("DESIGN.md", "README.md", "INTEGRATION.md", os.path.join("profiles", "README.md"))
+DOCS = ("DESIGN.md", "DESIGN_LOG.md", "README.md", "INTEGRATION.md", os.path.join("profiles", "README.md"))
 TRACE = re.compile(r"`(?:profiles/)?(r0\d_(?:bench_kernel_stats|fa_kernel_trace)\.csv)`")
 MICROS = re.compile(r"(\d+(?:\.\d+)?)\s*µs")
 

@@ -225,6 +225,11 @@ def test_baseline_configs_full_matrix(hg, dev, size):
         err = (c.float() - truth).abs()
         bad = err > ATOL + RTOL * truth.abs()
         assert not bad.any().item(), (name, int(bad.sum().item()), err.max().item())
+        # config C3 names stages in {2, 3, 4} (hgemm.py:359-361): the ring-of-slots form of the same kernel, the whole matrix bit-identical
+        for st in (3, 4):
+            cs = torch.zeros(M, N, dtype=torch.half, device=dev)
+            getattr(hg, name)(a, bb, cs, st, True, stride)
+            assert torch.equal(cs, c), (name, st)
     del truth
 
 
