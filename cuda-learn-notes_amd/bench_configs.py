@@ -161,7 +161,7 @@ def bandwidth_rows(dev, orc, shapes=((4096, 4096), (8192, 8192)), cpu_shape=(409
                     sec, it = _cpu_time(lambda: cpu_op(xc, x2c))
                     row["cpu_baseline"] = {"value": round(nbytes / sec * 1e-9, 2), "unit": "GB/s", "cores": torch.get_num_threads(),
                                            "kind": "port", "sample": "torch op of the reference script on CPU, [%d,%d] %s, %d calls "
-                                                                    "(%.3f s each)" % (S, K, str(dtype).replace("torch.", ""), it, sec)}
+                                                                    "(%.3f ms each)" % (S, K, str(dtype).replace("torch.", ""), it, sec * 1e3)}
                 except Exception as e:  # noqa: BLE001
                     row["cpu_baseline"] = {"error": str(e)[:120]}
                 del xc, x2c

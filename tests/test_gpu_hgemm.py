@@ -336,7 +336,7 @@ def test_stages_3_4_5_are_the_ring_of_slots_form_of_the_one_wave_per_simd_kernel
     fn = getattr(hg, name)
     via_name = 0
     for (M, N, K) in ((256, 256, 384), (512, 256, 448), (256, 768, 512), (768, 512, 640), (256, 256, 704), (1024, 1024, 2048), (4096, 4096, 832),
-                      (3584, 4096, 448), (4096, 4096, 384)):
+                      (3584, 4096, 448), (4096, 4096, 384), (512, 512, 576), (256, 512, 896)):  # K / 32 mod 10 = 8 (576, 896): the last remainder of the S = 5 round
         a, b = seeded(370 + K, M, K), seeded(371 + K, K, N)
         bb = (as_col_major(b) if layout else b).to(dev)
         ad = a.to(dev)
