@@ -21,7 +21,7 @@ import torch.nn.functional as F
 
 __all__ = [
     "hgemm", "hgemm_fp16_path", "as_col_major", "make_block_swizzle_stride", "unfused_standard_attn",
-    "attention_fp64", "sdpa", "get_mha_tflops", "elementwise_add", "reduce_sum", "softmax_global",
+    "attention_fp64", "attention_reference_plain_arithmetic", "sdpa", "get_mha_tflops", "elementwise_add", "reduce_sum", "softmax_global",
     "softmax_per_token", "layer_norm_torch", "layer_norm_kernel", "rms_norm_torch", "rms_norm_kernel",
     "rope_torch", "rope_kernel", "fp8_to_float", "histogram", "embedding", "activation", "dot_prod", "gemv", "mat_transpose", "sgemm",
 ]
@@ -65,6 +65,37 @@ def unfused_standard_attn(q, k, v):
 def attention_fp64(q, k, v):
     """Full-tensor fp64 reference (cdna guide rule 26: independent high-precision reference)."""
     return unfused_standard_attn(q.double(), k.double(), v.double())
+
+
+def attention_reference_plain_arithmetic(q, k, v, Bc=64):
+    """The ARITHMETIC of the reference's plain (non-`_acc_f32`) attention kernels, one head ([N, D] fp16 tensors), emulated on the CPU:
+    kernels/flash-attn/mma/basic/flash_attn_mma_share_qkv.cu -- S = Q K^T through `mma.sync.m16n8k16.f16.f16.f16.f16`, i.e. the UNSCALED scores
+    accumulate in fp16 over d in 16-wide steps (:346 HMMA16816 into half R_S); softmax in fp32 on `half2float(S) * scale` (:431-470); P rounded
+    to fp16; P V through the same fp16-accumulating MMA inside a 64-key tile (:555); O kept in fp32 across tiles with the exp(m_old - m_new)
+    rescale (:585-596, kOStorageAccFloat32 = 1 for d < 256). Each 16-deep MMA step is modelled at its BEST: exact products, fp32 sum,
+    ONE rounding to fp16 per step. Used by tests/test_oracle_golden.py to place the plain names' tolerance: what the reference's own plain
+    arithmetic achieves on an input is the bar the plain names are held to (the `*_acc_f32` names are held to the tighter one)."""
+    N, D = q.shape
+    scale = 1.0 / math.sqrt(D)
+    S = torch.zeros(N, k.shape[0], dtype=torch.half)
+    for c in range(0, D, 16):
+        S = (S.float() + q[:, c:c + 16].float() @ k[:, c:c + 16].float().t()).half()
+    m = torch.full((N,), -float("inf"))
+    l = torch.zeros(N)
+    O = torch.zeros(N, v.shape[1])
+    for t in range(0, k.shape[0], Bc):
+        s = S[:, t:t + Bc].float() * scale
+        m_new = torch.maximum(m, s.max(dim=1).values)
+        p = torch.exp(s - m_new[:, None])
+        alpha = torch.exp(m - m_new)
+        ph = p.half()
+        acc = torch.zeros(N, v.shape[1], dtype=torch.half)
+        for c in range(0, Bc, 16):
+            acc = (acc.float() + ph[:, c:c + 16].float() @ v[t + c:t + c + 16].float()).half()
+        O = O * alpha[:, None] + acc.float()
+        l = l * alpha + p.sum(dim=1)
+        m = m_new
+    return (O / l[:, None]).half()
 
 
 def sdpa(q, k, v):

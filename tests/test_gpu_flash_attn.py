@@ -16,6 +16,8 @@ TOL = 3e-3
 # 2^-11 per term and |delta s| grows with |k| (measured 3.9e-3 max on O where the unscaled kernel has 2e-3). Still inside
 # the reference's own --check tolerance (atol 1e-2, flash_attn_mma.py:421); N(0,1) inputs stay below TOL.
 TOL_AMPLIFIED_KEYS = 6e-3
+# Why 6e-3 and not less: the reference's own plain arithmetic (fp16-accumulating MMAs), emulated at its best on these inputs, gives 3.5-4.0e-3
+# (tests/test_oracle_golden.py::test_plain_attention_names_are_held_to_the_reference_plain_arithmetic) -- 3e-3 is a bar it does not meet.
 # The precision rung exists as it does in the reference: its plain names accumulate both GEMMs in fp16, its *_acc_f32 names in fp32
 # (flash_attn_mma_share_qkv_F32F16F16F32.cu:66). Here the *_acc_f32 names run the same kernels with the scores scaled in fp32
 # (Q as loaded): they are held to TOL on the amplified-key inputs as well (test_acc_f32_names_scale_the_scores_in_fp32).

@@ -108,3 +108,31 @@ def test_kernel_restatement_of_layer_norm_is_tied_to_the_pinned_script_oracle(or
         yk, yt = oracle.layer_norm_kernel(x, g, b), oracle.layer_norm_torch(x, g, b)
         derived = b + (yt - b) * math.sqrt((K + 1e-5) / (K - 1))
         assert torch.allclose(yk, derived, atol=2e-6, rtol=1e-6), K
+
+
+def test_plain_attention_names_are_held_to_the_reference_plain_arithmetic(oracle):
+    """Where the 6e-3 of tests/test_gpu_flash_attn.py (TOL_AMPLIFIED_KEYS, plain names at D <= 128) comes from. The reference's plain
+    kernels accumulate Q K^T and P V in fp16 (mma.sync ... f16.f16.f16.f16, flash_attn_mma_share_qkv.cu:346, :555); emulated at their best
+    (oracle.attention_reference_plain_arithmetic) they reach 4e-4 on N(0,1) inputs -- the README's "< 1e-3" -- and 3.5-4.0e-3 on the
+    rescale-regime inputs of the GPU tests (keys amplified 3-5x, logits of +-40): ABOVE 3e-3, below 6e-3. So 3e-3 on those inputs is a bar
+    the reference's own plain arithmetic does not meet; the plain names here (fp32 accumulation, Q * log2(e)/sqrt(d) rounded to fp16 once:
+    2.7-4.3e-3 measured) are held to the bound that arithmetic class gives, the `*_acc_f32` names (the reference's precise rung) to 3e-3."""
+    TOL, TOL_AMPLIFIED_KEYS = 3e-3, 6e-3
+    B, H, N, D = 1, 3, 1024, 64
+    g = lambda s: torch.randn(B, H, N, D, generator=torch.Generator().manual_seed(s)).half()  # noqa: E731 -- seeded() of the GPU test
+    q, k, v = g(31), g(32), g(33)
+    ramp = torch.linspace(0.2, 1.6, N).view(N, 1)
+    k[0, 0] = (k[0, 0].float() * ramp).half()
+    k[0, 0, 900] = q[0, 0, 5] * 3.0
+    k[0, 1, 10] = q[0, 1, 300] * 5.0
+    k[0, H - 1, 1000] = q[0, H - 1, 1023] * 4.0
+    worst = 0.0
+    for h in range(H):
+        ref = oracle.attention_fp64(q[:, h:h + 1], k[:, h:h + 1], v[:, h:h + 1])[0, 0]
+        o = oracle.attention_reference_plain_arithmetic(q[0, h], k[0, h], v[0, h])
+        worst = max(worst, (o.double() - ref).abs().max().item())
+    assert TOL < worst <= TOL_AMPLIFIED_KEYS, worst
+    q, k, v = g(1), g(2), g(3)  # N(0,1): the plain arithmetic is well inside TOL (and the README's 1e-3)
+    ref = oracle.attention_fp64(q[:, :1], k[:, :1], v[:, :1])[0, 0]
+    err = (oracle.attention_reference_plain_arithmetic(q[0, 0], k[0, 0], v[0, 0]).double() - ref).abs().max().item()
+    assert err < 1e-3, err
