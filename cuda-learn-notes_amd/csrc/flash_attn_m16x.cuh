@@ -62,6 +62,10 @@ enum : int {
   // one v_fma_f32 (s * log2(e)/sqrt(d) - m) on its way into v_exp_f32 -- no fp16 rounding of Q * log2(e)/sqrt(d) (2^-11 relative per term, which
   // amplified keys turn into 3.9e-3 on O where this form has 2e-3), 64 more VALU instructions per wave and 128-key tile at D = 64
   M16X_FSCALE = 1 << 18,
+  // probe (round 4; the "one untested trade" of DESIGN_LOG 9.3): ROW SUMS ON THE MATRIX PIPE. l = sum of the fp16 P values, from one more MFMA per
+  // 32-key step and query block with an all-ones A operand (every row of its 16x16 result is the row-sum vector, so no cross-lane reduction at the
+  // end either); the 64 v_add_f32 per tile go, and the fp16-overflow check of the optimistic blocks becomes a running v_max3 of the exponents (<= 15).
+  M16X_MFMA_SUM = 1 << 19,
   M16X_ONE_POS = 2           // the shipped position: top of phase B (the MFMA-only phase), 0.95-1.0x of stages = 2 (profiles/r04_fa_one_stage_probe.log)
 };
 
@@ -78,6 +82,8 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
   constexpr int DRATE = (NDEF * NPAIR + DSTEPS - 1) / DSTEPS;
   static_assert(NDEF >= 1 && NOPT >= 2, "at least one P^T k-step must be complete at the end of phase A");
   static_assert((OX & M16X_FSCALE) == 0 || (OX & M16X_LATE_CHECK) == 0, "the fp32-scaled form has no late-check variant");
+  static_assert((OX & M16X_MFMA_SUM) == 0 || (OX & M16X_LATE_CHECK) == 0, "row sums on the matrix pipe: no late-check variant");
+  constexpr bool MS = (OX & M16X_MFMA_SUM) != 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -137,6 +143,12 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb) ot[b][qb] = f4{0.f, 0.f, 0.f, 0.f};
   float m_run[NQB], l_run[NQB];
+  f4 lacc[NQB];  // MS: the row sums, accumulated by the matrix pipe
+  h8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (half_t)1.0f;
+#pragma unroll
+  for (int qb = 0; qb < NQB; ++qb) lacc[qb] = f4{0.f, 0.f, 0.f, 0.f};
   f4 minit[NQB];
 #pragma unroll
   for (int qb = 0; qb < NQB; ++qb) {
@@ -227,7 +239,7 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
     h8 pf[NU][NQB];
     float psum[NQB];
 #pragma unroll
-    for (int qb = 0; qb < NQB; ++qb) psum[qb] = 0.f;
+    for (int qb = 0; qb < NQB; ++qb) psum[qb] = MS ? -1.0e30f : 0.f;  // MS: running maximum of the exponents instead of the partial row sum
     constexpr bool ONE = (OX & M16X_ONE_STAGE) != 0;
     constexpr int ONE_POS = (OX >> M16X_ONE_POS_SHIFT) & 3;
     auto fetch_whole_tile = [&]() __attribute__((always_inline)) {  // stages = 1: request, wait, (later) use
@@ -238,13 +250,15 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
       __builtin_amdgcn_sched_barrier(0);
     };
     // item it of key block kb: query block it >> 1, registers (it & 1) * 2, + 1 -> k-slots of P^T step kb >> 1
-    auto exp_item = [&](int kb, int it, float (&acc)[NQB]) __attribute__((always_inline)) {
+    auto exp_item = [&](int kb, int it, float (&acc)[NQB], bool track = true) __attribute__((always_inline)) {
       const int qb = it >> 1, r = (it & 1) * 2;
       const float x0 = FS ? __builtin_fmaf(s[kb][qb][r], scale_log2e, -m_run[qb]) : s[kb][qb][r];
       const float x1 = FS ? __builtin_fmaf(s[kb][qb][r + 1], scale_log2e, -m_run[qb]) : s[kb][qb][r + 1];
       const float a0 = (OX & M16X_ABL_EXP) != 0 ? x0 : __builtin_amdgcn_exp2f(x0);
       const float a1 = (OX & M16X_ABL_EXP) != 0 ? x1 : __builtin_amdgcn_exp2f(x1);
-      acc[qb] += a0 + a1;
+      if constexpr (MS) {
+        if (track) acc[qb] = fmaxf(fmaxf(acc[qb], x0), x1);  // v_max3_f32
+      } else acc[qb] += a0 + a1;
       const h2 a = __builtin_convertvector(f2{a0, a1}, h2);
       // an input-only empty asm is a chained node of the instruction selector: the item stays in the step it was
       // written in (without it hipcc sinks every exponential below the last MFMA of the phase)
@@ -310,7 +324,7 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
       bool bad = false;
 #pragma unroll
       for (int qb = 0; qb < NQB; ++qb) {
-        bad |= !(psum[qb] <= 32768.0f);
+        bad |= MS ? !(psum[qb] <= 15.0f) : !(psum[qb] <= 32768.0f);
         if constexpr ((OX & M16X_LATE_CHECK) == 0) {
           float mx = s[NOPT][qb][0];
 #pragma unroll
@@ -339,6 +353,10 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
           const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-delta);
           m_run[qb] += delta;
           l_run[qb] *= alpha;
+          if constexpr (MS) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lacc[qb][r] *= alpha;
+          }
           if constexpr (!FS) {  // (FS: the raw scores stay, exp_item subtracts the new m_run)
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb)
@@ -352,7 +370,7 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
           for (int b = 0; b < NDB; ++b)
 #pragma unroll
             for (int r = 0; r < 4; ++r) ot[b][qb][r] *= alpha;
-          psum[qb] = 0.f;
+          psum[qb] = MS ? -1.0e30f : 0.f;
         }
 #pragma unroll
         for (int kb = 0; kb < NOPT; ++kb)
@@ -360,7 +378,7 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
           for (int it = 0; it < NPAIR; ++it) exp_item(kb, it, psum);
       }
 #pragma unroll
-      for (int qb = 0; qb < NQB; ++qb) l_run[qb] += psum[qb];
+      for (int qb = 0; qb < NQB; ++qb) l_run[qb] += MS ? 0.f : psum[qb];
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
     if constexpr ((OX & M16X_ABL_BAR) == 0) __builtin_amdgcn_s_barrier();
@@ -434,19 +452,28 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
 #pragma unroll
           for (int i = 0; i < DRATE; ++i) {
             const int it = idx * DRATE + i;
-            if (i * NQB / DRATE == qi && it < NDEF * NPAIR) exp_item(NOPT + it / NPAIR, it % NPAIR, psum_d);
+            if (i * NQB / DRATE == qi && it < NDEF * NPAIR) exp_item(NOPT + it / NPAIR, it % NPAIR, psum_d, false);
           }
           __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if constexpr (MS) {
+        if (b == NDB - 1) {  // the last d-block of P^T step u: every P of the step is final -- its row sums, on the matrix pipe
+#pragma unroll
+          for (int qb = 0; qb < NQB; ++qb) {
+            lacc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pf[u][qb], lacc[qb], 0, 0, 0);
+            cln_mfma_keep(lacc[qb], ones, pf[u][qb]);
+          }
         }
       }
       if (idx + PD < NPV) vf[idx % PD] = v_frag(idx + PD);
       // deferred items at DRATE per step: all of them are done before the first P^T step that holds a deferred block
 #pragma unroll
-      for (int it = idx * DRATE; !FINE_B && it < (idx + 1) * DRATE && it < NDEF * NPAIR; ++it) exp_item(NOPT + it / NPAIR, it % NPAIR, psum_d);
+      for (int it = idx * DRATE; !FINE_B && it < (idx + 1) * DRATE && it < NDEF * NPAIR; ++it) exp_item(NOPT + it / NPAIR, it % NPAIR, psum_d, false);
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
-    for (int qb = 0; qb < NQB; ++qb) l_run[qb] += psum_d[qb];
+    for (int qb = 0; qb < NQB; ++qb) l_run[qb] += MS ? 0.f : psum_d[qb];
     if constexpr (ONE && ONE_POS == 3) fetch_whole_tile();
     hgemm::wait_vmcnt<0>();  // own DMA pieces of tile j+1 landed
     if constexpr ((OX & M16X_ABL_BAR) == 0) __builtin_amdgcn_s_barrier();
@@ -462,8 +489,8 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
   char* ob = smem + wave * (G::RPW * G::OS);
 #pragma unroll
   for (int qb = 0; qb < NQB; ++qb) {
-    float l_tot = l_run[qb];
-    {
+    float l_tot = MS ? lacc[qb][0] : l_run[qb];
+    if constexpr (!MS) {
       const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(l_tot), __float_as_uint(l_tot), false, false);
       l_tot = __uint_as_float(s16[0]) + __uint_as_float(s16[1]);
       const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_tot), __float_as_uint(l_tot), false, false);

@@ -25,9 +25,11 @@ def ref64(q, k, v):
     return out
 
 
-for shape, codes in (((4, 8, 2048, 64), ((853, "pre-scaled Q (shipped)"), (990, "fp32-scaled scores"))),
-                     ((4, 8, 2048, 128), ((853, "pre-scaled Q (shipped)"), (990, "fp32-scaled scores"))),
-                     ((1, 48, 8192, 64), ((925, "pre-scaled Q (shipped)"), (992, "fp32-scaled scores")))):
+MS = "row sums on the matrix pipe"
+for shape, codes in (((4, 8, 2048, 64), ((853, "pre-scaled Q (shipped)"), (990, "fp32-scaled scores"), (994, MS), (995, MS + " + fp32 scale"))),
+                     ((4, 8, 2048, 128), ((853, "pre-scaled Q (shipped)"), (990, "fp32-scaled scores"), (994, MS))),
+                     ((2, 24, 4096, 64), ((853, "pre-scaled Q (shipped)"), (994, MS))),
+                     ((1, 48, 8192, 64), ((925, "pre-scaled Q (shipped)"), (992, "fp32-scaled scores"), (996, MS)))):
     B, H, N, D = shape
     torch.manual_seed(0)
     q, k, v = (torch.randn(B, H, N, D, dtype=torch.half, device=dev) for _ in range(3))
@@ -49,5 +51,5 @@ for shape, codes in (((4, 8, 2048, 64), ((853, "pre-scaled Q (shipped)"), (990, 
         host.fa2_variant((8, 0, 0, code), qa, ka, v, o)
         torch.cuda.synchronize()
         e2 = (o.double() - r_amp).abs().max().item() if r_amp is not None else float("nan")
-        print("FSCALE %-20s %-26s %8.4f ms %7.1f TF  max|O - fp64|: N(0,1) %.2e, amplified keys %.2e" %
+        print("FSCALE %-20s %-42s %8.4f ms %7.1f TF  max|O - fp64|: N(0,1) %.2e, amplified keys %.2e" %
               (shape, tag, ms, bu.mha_flops_conventional(*shape) / ms * 1e-9, e1, e2), flush=True)
