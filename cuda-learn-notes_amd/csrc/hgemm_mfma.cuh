@@ -87,6 +87,31 @@ __device__ __forceinline__ void tile_coords(int bid, int nblk, int tiles_m, int 
   tn = b * band + (rem - tm * width);
 }
 
+// Walk for problems whose operands do NOT fit the 256 MiB Infinity Cache (round 4; 12544^3 ... 16384^3, the sizes the reference's README
+// quotes). With the walk above every XCD streams its OWN contiguous range of the logical order, so the eight XCDs sit in eight distant
+// N-bands at once and B (512 MB at 16384^3) is re-read from HBM in every round of tiles. Here the XCDs take the logical order in
+// INTERLEAVED chunks of 32 tiles (round r = logical tiles 256 r ... 256 r + 255, XCD x its tiles 32 x ... 32 x + 31): the 256 tiles in
+// flight are 256 CONSECUTIVE tiles of the band walk -- with the reference's band of 8 tile columns, 32 rows x 8 columns: the band's 8 B
+// panels stay in the cache for the whole band, every A panel is read once per band, and an XCD's chunk is a 4 x 8 sub-block (4 + 8 panels
+// per L2, the same fill as before). No padding: ragged tile counts only shorten the last round (its tiles go to the XCDs in launch
+// order). (A first form that walked padded 16 x 16 blocks lost 8-13 % on ragged grids -- 12544 = 49 tiles, 10240 = 40 --
+// and gained 2-3 % on exact ones: profiles/r04_hgemm_block_walk_probe.log.) Pure schedule change: results are bit-identical.
+__device__ __forceinline__ void tile_coords_interleaved(int bid, int nblk, int tiles_m, int tiles_n, int band, int& tm, int& tn) {
+  const int full = nblk & ~255;  // tiles in whole rounds of 256
+  int wg = bid;
+  if (bid < full) {
+    const int xcd = bid & 7, local = bid >> 3;
+    wg = ((local >> 5) << 8) + (xcd << 5) + (local & 31);
+  }
+  if (band <= 0 || band > tiles_n) band = tiles_n;
+  const int per_band = tiles_m * band;
+  const int b = wg / per_band;
+  const int rem = wg - b * per_band;
+  const int width = min(band, tiles_n - b * band);
+  tm = rem / width;
+  tn = b * band + (rem - tm * width);
+}
+
 // ---- tile configuration ------------------------------------------------------------------------
 template <int BM_, int BN_, int BK_, int WM_, int WN_, int STAGES_, int LAYOUT_>
 struct Cfg {

@@ -26,6 +26,7 @@
 // Versus the 128x64 wave tile: 32 fragment reads per 128 MFMAs instead of 48 (LDS bytes per flop -33 %), 2 barriers per
 // 128 MFMAs instead of 4 per 64, no slot in which a SIMD's matrix pipe waits for the partner wave's rendezvous.
 #pragma once
+#include <stdlib.h>
 #include <type_traits>
 
 #include "hgemm_mfma.cuh"
@@ -185,7 +186,11 @@ __global__ __launch_bounds__(256, 1) void hgemm_w4_kernel(const half_t* __restri
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   int tm, tn;
-  tile_coords(blockIdx.x, gridDim.x, tiles_m, tiles_n, swizzle & 1, band, tm, tn);  // bit 1 of `swizzle`: non-temporal C stores allowed (launcher)
+  if (swizzle & 4) {  // bit 2: operands larger than the Infinity Cache -- XCDs take the band walk in interleaved chunks (hgemm_mfma.cuh)
+    tile_coords_interleaved(blockIdx.x, gridDim.x, tiles_m, tiles_n, band, tm, tn);
+  } else {
+    tile_coords(blockIdx.x, gridDim.x, tiles_m, tiles_n, swizzle & 1, band, tm, tn);  // bit 1 of `swizzle`: non-temporal C stores allowed (launcher)
+  }
   const int m0 = tm * BM, n0 = tn * BN;
 
   KFill<C, FM> fa;
@@ -347,7 +352,7 @@ __global__ __launch_bounds__(256, 1) void hgemm_w4_kernel(const half_t* __restri
     for (int j = 0; j < FN; ++j) asm volatile("" : "+a"(acc[i][j]));
   if constexpr (EPI >= 2) {  // EPI 3 / 4 (probe library): the same epilogue with non-temporal / write-through C stores
     // B1 of the last tile: every wave is past its last fragment read; no DMA is in flight
-    store_wide_tile_via_lds<FM, FN, EPI - 2>(Cmat, N, m0 + wm * C::WTM, n0 + wn * C::WTN, lane, smem + wave * (64 * (FN * 32 + 16)), acc, swizzle >> 1);
+    store_wide_tile_via_lds<FM, FN, EPI - 2>(Cmat, N, m0 + wm * C::WTM, n0 + wn * C::WTN, lane, smem + wave * (64 * (FN * 32 + 16)), acc, (swizzle >> 1) & 1);
   } else {  // measurement-only variant: keep the accumulators live, store (almost) nothing
     float s = 0.f;
 #pragma unroll
@@ -366,6 +371,23 @@ inline bool w4_k_ok(int K) { return K % 64 == 0 && K >= ((K / 64) & 1 ? 448 : 38
 // (ADVICE r3), so the epilogue takes the hint only from the measured size on: footprint = 2 (MK + KN + MN) bytes >= 96 MB.
 constexpr long long W4_NT_FOOTPRINT = 96LL << 20;
 inline int w4_nt_ok(int M, int N, int K) { return 2LL * ((long long)M * K + (long long)K * N + (long long)M * N) >= W4_NT_FOOTPRINT ? 1 : 0; }
+// The interleaved-chunk walk (tile_coords_interleaved, hgemm_mfma.cuh) when block swizzle is requested and A + B are at least TWICE the 256 MiB
+// Infinity Cache: 12544^3 1378-1387 -> 1422-1432 TF (+3-4 %), 15360^3 1354-1360 -> 1412-1423 (+4-5 %), 16384^3 1456-1460 -> 1485-1495 (+2 %), NN;
+// 10240^3 (420 MB of operands) -1.5 ... 0 %, 8192^3 0 % -- profiles/r04_hgemm_block_walk_probe.log. Bit-identical results.
+constexpr long long W4_SB_OPERANDS = 512LL << 20;
+inline int w4_sb_walk(int M, int N, int K, int swizzle, int tiles) {
+  // $CLN_AMD_W4_BLOCK_WALK = 0 / 1 forces the walk off / on (for A/B measurements; read once); unset: by operand size
+  static const int forced = [] {
+    const char* e = getenv("CLN_AMD_W4_BLOCK_WALK");
+    return e ? (e[0] == '1' ? 1 : 0) : -1;
+  }();
+  if (!swizzle || tiles < 512) return 0;
+  if (forced >= 0) return forced;
+  return (tiles >= 1024 && 2LL * ((long long)M * K + (long long)K * N) >= W4_SB_OPERANDS) ? 1 : 0;
+}
+// kernel argument `swizzle`: bit 0 block swizzle, bit 1 non-temporal C stores, bit 2 the interleaved-chunk walk
+inline int w4_swizzle_arg(int M, int N, int K, int swizzle, int tiles) { return (swizzle ? 1 : 0) | (w4_nt_ok(M, N, K) << 1) | (w4_sb_walk(M, N, K, swizzle, tiles) << 2); }
+inline int w4_grid(int, int, int, int, int tiles_m, int tiles_n) { return tiles_m * tiles_n; }
 
 template <int LAYOUT, int EPI = 2, int VAR = 0, int ABL = 0, int BM = 256, int BN = 256>
 int launch_w4(const void* a, const void* b, void* c, int M, int N, int K, int swizzle, int swizzle_stride,
@@ -382,16 +404,16 @@ int launch_w4(const void* a, const void* b, void* c, int M, int N, int K, int sw
       static cln_lds_attr lds_attr_odd;  // per device, thread-safe (common.h)
       if (cln_ensure_lds(lds_attr_odd, reinterpret_cast<const void*>(&hgemm_w4_kernel<LAYOUT, EPI, VAR, ABL, BM, BN, true>), C::LDS_BYTES) != CLN_OK)
         return CLN_ERR_LAUNCH;
-      CLN_LAUNCH((hgemm_w4_kernel<LAYOUT, EPI, VAR, ABL, BM, BN, true>), dim3(tiles_m * tiles_n), dim3(256), C::LDS_BYTES, stream,
-                 (const half_t*)a, (const half_t*)b, (half_t*)c, M, N, K, tiles_m, tiles_n, (swizzle ? 1 : 0) | (w4_nt_ok(M, N, K) << 1), band);
+      CLN_LAUNCH((hgemm_w4_kernel<LAYOUT, EPI, VAR, ABL, BM, BN, true>), dim3(w4_grid(M, N, K, swizzle, tiles_m, tiles_n)), dim3(256), C::LDS_BYTES, stream,
+                 (const half_t*)a, (const half_t*)b, (half_t*)c, M, N, K, tiles_m, tiles_n, w4_swizzle_arg(M, N, K, swizzle, tiles_m * tiles_n), band);
       return cln_check_launch();
     }
   }
   static cln_lds_attr lds_attr;  // per device, thread-safe (common.h)
   if (cln_ensure_lds(lds_attr, reinterpret_cast<const void*>(&hgemm_w4_kernel<LAYOUT, EPI, VAR, ABL, BM, BN>), C::LDS_BYTES) != CLN_OK)
     return CLN_ERR_LAUNCH;
-  CLN_LAUNCH((hgemm_w4_kernel<LAYOUT, EPI, VAR, ABL, BM, BN>), dim3(tiles_m * tiles_n), dim3(256), C::LDS_BYTES, stream,
-             (const half_t*)a, (const half_t*)b, (half_t*)c, M, N, K, tiles_m, tiles_n, (swizzle ? 1 : 0) | (w4_nt_ok(M, N, K) << 1), band);
+  CLN_LAUNCH((hgemm_w4_kernel<LAYOUT, EPI, VAR, ABL, BM, BN>), dim3(w4_grid(M, N, K, swizzle, tiles_m, tiles_n)), dim3(256), C::LDS_BYTES, stream,
+             (const half_t*)a, (const half_t*)b, (half_t*)c, M, N, K, tiles_m, tiles_n, w4_swizzle_arg(M, N, K, swizzle, tiles_m * tiles_n), band);
   return cln_check_launch();
 }
 

@@ -55,7 +55,11 @@ __global__ __launch_bounds__(256, 1) void hgemm_w4s_kernel(const half_t* __restr
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   int tm, tn;
-  tile_coords(blockIdx.x, gridDim.x, tiles_m, tiles_n, swizzle & 1, band, tm, tn);  // bit 1 of `swizzle`: non-temporal C stores allowed (w4_nt_ok)
+  if (swizzle & 4) {  // bit 2: operands larger than the Infinity Cache -- XCDs take the band walk in interleaved chunks (hgemm_mfma.cuh)
+    tile_coords_interleaved(blockIdx.x, gridDim.x, tiles_m, tiles_n, band, tm, tn);
+  } else {
+    tile_coords(blockIdx.x, gridDim.x, tiles_m, tiles_n, swizzle & 1, band, tm, tn);  // bit 1 of `swizzle`: non-temporal C stores allowed (w4_nt_ok)
+  }
   const int m0 = tm * C::BM, n0 = tn * C::BN;
 
   KFill<C, AP> fa;
@@ -194,7 +198,7 @@ __global__ __launch_bounds__(256, 1) void hgemm_w4s_kernel(const half_t* __restr
   for (int i = 0; i < FM; ++i)
 #pragma unroll
     for (int j = 0; j < FN; ++j) asm volatile("" : "+a"(acc[i][j]));
-  store_wide_tile_via_lds<FM, FN, EPI - 2>(Cmat, N, m0 + wm * C::WTM, n0 + wn * C::WTN, lane, smem + wave * (64 * (FN * 32 + 16)), acc, swizzle >> 1);
+  store_wide_tile_via_lds<FM, FN, EPI - 2>(Cmat, N, m0 + wm * C::WTM, n0 + wn * C::WTN, lane, smem + wave * (64 * (FN * 32 + 16)), acc, (swizzle >> 1) & 1);
 }
 
 // K the structure covers: whole pairs of 32-deep slots, at least 2 S of them
@@ -208,8 +212,8 @@ int launch_w4s(const void* a, const void* b, void* c, int M, int N, int K, int s
   const int band = (swizzle && swizzle_stride >= C::BN) ? swizzle_stride / C::BN : tiles_n;
   static cln_lds_attr lds_attr;  // per device, thread-safe (common.h)
   if (cln_ensure_lds(lds_attr, reinterpret_cast<const void*>(&hgemm_w4s_kernel<LAYOUT, S, EPI>), C::LDS_BYTES) != CLN_OK) return CLN_ERR_LAUNCH;
-  CLN_LAUNCH((hgemm_w4s_kernel<LAYOUT, S, EPI>), dim3(tiles_m * tiles_n), dim3(256), C::LDS_BYTES, stream, (const half_t*)a, (const half_t*)b,
-             (half_t*)c, M, N, K, tiles_m, tiles_n, (swizzle ? 1 : 0) | (w4_nt_ok(M, N, K) << 1), band);
+  CLN_LAUNCH((hgemm_w4s_kernel<LAYOUT, S, EPI>), dim3(w4_grid(M, N, K, swizzle, tiles_m, tiles_n)), dim3(256), C::LDS_BYTES, stream, (const half_t*)a,
+             (const half_t*)b, (half_t*)c, M, N, K, tiles_m, tiles_n, w4_swizzle_arg(M, N, K, swizzle, tiles_m * tiles_n), band);
   return cln_check_launch();
 }
 

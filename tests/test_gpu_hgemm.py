@@ -257,6 +257,28 @@ def test_rectangular_and_large_shapes(hg, built, dev, M, N, K):
     assert torch.equal(ct, c)  # same k order, same fp32 accumulation: TN and NN agree bit for bit
 
 
+@pytest.mark.parametrize("M,N,K", [(8192, 8192, 16384), (8448, 8192, 16384)])
+def test_operands_past_the_infinity_cache_take_the_interleaved_walk(hg, dev, M, N, K):
+    """A + B >= 512 MB and >= 1024 tiles with block swizzle on: the XCDs take the band walk in interleaved chunks (csrc/hgemm_mfma.cuh
+    tile_coords_interleaved; the sizes of the reference README, 12544^3 ... 16384^3, run it). A pure schedule change: the result equals the
+    un-swizzled launch bit for bit (exact grid: 32 x 32 tiles; ragged: 33 x 32, a last round of 32 tiles), at stages 2 and 3, and sampled rows
+    match the fp32 product."""
+    torch.manual_seed(M + K)
+    a = torch.randn(M, K, dtype=torch.half, device=dev)
+    b = torch.randn(K, N, dtype=torch.half, device=dev)
+    rows = torch.unique(torch.cat([torch.arange(0, M, M // 24), torch.tensor([M - 1, M - 257])]))
+    truth = a[rows].float() @ b.float()
+    plain = torch.zeros(M, N, dtype=torch.half, device=dev)
+    hg.hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem(a, b, plain, 2, False, 1)
+    err = (plain[rows].float() - truth).abs()
+    assert (err <= ATOL + RTOL * truth.abs()).all(), err.max().item()
+    for stages in (2, 3):
+        for stride in (2048, 1792):
+            c = torch.zeros(M, N, dtype=torch.half, device=dev)
+            hg.hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem(a, b, c, stages, True, stride)
+            assert torch.equal(c, plain), (stages, stride)
+
+
 @pytest.mark.parametrize("layout", [0, 1])
 def test_probe_kernels_stay_correct(built, dev, layout):
     """Tuning hooks kept in the library as measured (slower) alternatives must stay bit-identical to the shipped

@@ -77,3 +77,43 @@ def test_bench_steady_state_check_is_bounded(built, monkeypatch):
     monkeypatch.setattr(bu.time, "time", lambda: t[0])
     hist = bu.settle(lambda: None, 20, tol=0.001, max_seconds=4.0)
     assert len(hist) == 4
+
+
+def test_interleaved_tile_walk_is_a_bijection_with_compact_xcd_chunks():
+    """Python model of csrc/hgemm_mfma.cuh tile_coords_interleaved (the walk of the one-wave-per-SIMD HGEMM when A + B exceed twice the
+    Infinity Cache): every workgroup index maps to a distinct tile for ragged and exact grids and any band; in every full round the 32 tiles
+    of an XCD are 32 CONSECUTIVE tiles of the band walk (a 4 x 8 sub-block when the band is 8 tile columns wide), and the 256 tiles of a
+    round are consecutive too (32 rows x 8 columns: 8 B panels shared by all XCDs)."""
+    def coords(bid, nblk, tiles_m, tiles_n, band):
+        full = nblk & ~255
+        wg = bid
+        if bid < full:
+            xcd, local = bid & 7, bid >> 3
+            wg = ((local >> 5) << 8) + (xcd << 5) + (local & 31)
+        if band <= 0 or band > tiles_n:
+            band = tiles_n
+        per_band = tiles_m * band
+        b = wg // per_band
+        rem = wg - b * per_band
+        width = min(band, tiles_n - b * band)
+        tm = rem // width
+        return wg, tm, b * band + (rem - tm * width)
+
+    for tiles_m, tiles_n, band in ((64, 64, 8), (49, 49, 12), (60, 60, 7), (33, 32, 8), (40, 40, 10), (17, 70, 8), (64, 64, 0), (5, 7, 3)):
+        nblk = tiles_m * tiles_n
+        seen = {}
+        for bid in range(nblk):
+            wg, tm, tn = coords(bid, nblk, tiles_m, tiles_n, band)
+            assert 0 <= tm < tiles_m and 0 <= tn < tiles_n, (tiles_m, tiles_n, band, bid)
+            assert (tm, tn) not in seen, (tiles_m, tiles_n, band, bid, seen[(tm, tn)])
+            seen[(tm, tn)] = bid
+        assert len(seen) == nblk
+        for r in range(nblk // 256):  # a full round: bids 256 r ... 256 r + 255 (the hardware places bid on XCD bid % 8)
+            wgs = sorted(coords(b, nblk, tiles_m, tiles_n, band)[0] for b in range(256 * r, 256 * r + 256))
+            assert wgs == list(range(256 * r, 256 * r + 256))
+            for x in range(8):
+                mine = sorted(coords(b, nblk, tiles_m, tiles_n, band)[0] for b in range(256 * r, 256 * r + 256) if b % 8 == x)
+                assert mine == list(range(256 * r + 32 * x, 256 * r + 32 * x + 32)), (r, x)
+    # band of 8 columns on an exact grid: an XCD's chunk is 4 rows x 8 columns
+    tiles = [coords(b, 4096, 64, 64, 8)[1:] for b in range(256) if b % 8 == 3]
+    assert len({t[0] for t in tiles}) == 4 and len({t[1] for t in tiles}) == 8
