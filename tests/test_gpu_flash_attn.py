@@ -753,3 +753,42 @@ def test_transposed_v_names_on_the_sum_checked_kernel(fa, built, dev, oracle, B,
         assert (o_vt[b:b + 1, h:h + 1].double() - ref).abs().max().item() <= TOL_AMPLIFIED_KEYS, (b, h)
     for other in ("flash_attn_mma_stages_split_q_shared_kv_swizzle_qkv", "flash_attn_mma_stages_split_q_tiling_qk_swizzle_qkv"):
         assert torch.equal(run(fa, built, other, q, k, v, 2, dev), o_vt), other
+
+
+def test_seeded_fuzz_over_shapes_names_and_stages(fa, built, dev):
+    """30 seeded random problems over the supported head dims, sequence lengths that are multiples of the kernels' row blocks, small and large
+    grids, plain / acc_f32 / transposed-V / tiling names: the output matches an fp32 attention computed on the GPU (itself within 1e-4 of the
+    fp64 oracle on its first head) to TOL, and stages = 1 equals stages = 2 bit for bit; the failure message names the kernel."""
+    import random
+    rng = random.Random(4)
+    dims = [32, 64, 96, 128, 256, 320, 384, 512, 640, 768, 1024]
+    seen = set()
+    for case in range(30):
+        D = rng.choice(dims)
+        if D <= 256:
+            name = rng.choice(["flash_attn_mma_stages_split_q_shared_qkv", "flash_attn_mma_stages_split_q_shared_kv_acc_f32",
+                               "flash_attn_mma_stages_split_q_tiling_qk", "flash_attn_mma_stages_split_q_shared_qkv_swizzle_qkv" if D in (64, 128) else
+                               "flash_attn_mma_stages_split_q_shared_kv", "flash_attn_mma_stages_split_q_shared_qkv_acc_f32_rr"])
+        else:
+            name = rng.choice(["flash_attn_mma_stages_split_q_tiling_qkv", "flash_attn_mma_stages_split_q_tiling_qk_acc_f32",
+                               "flash_attn_mma_stages_split_q_tiling_qkv_swizzle_q"])
+        B, H = rng.choice([(1, 2), (2, 3), (1, 8), (1, 48), (4, 8), (2, 96)])
+        N = 128 * rng.choice([1, 2, 3, 4, 6, 8, 16]) if D < 640 else 64 * rng.choice([2, 3, 4, 8, 13])
+        if case % 3 == 0 and D <= 256:  # a grid large enough for the two-group kernels (>= 192 workgroups of 256 rows / >= 256 of 512 rows)
+            B, H, N = rng.choice([(1, 48, 1024), (1, 128, 1024), (2, 48, 512)])
+        elif B * H * N * D > (1 << 27):
+            N = 256
+        q, k, v = (torch.randn(B, H, N, D, generator=torch.Generator().manual_seed(5000 + 3 * case + i)).half().to(dev) for i in range(3))
+        ref = torch.softmax((q.float() @ k.float().transpose(-2, -1)) / (D ** 0.5), dim=-1) @ v.float()
+        vv = v.transpose(-2, -1).contiguous() if name in built.manifest.FA_V_TRANSPOSED else v
+        what = built.manifest.describe(name, (B, H, N, D), 2)
+        seen.add(what.split("<")[0])
+        outs = []
+        for stages in (2, 1):
+            o = torch.zeros_like(q)
+            getattr(fa, name)(q, k, vv, o, stages)
+            err = (o.float() - ref).abs().max().item()
+            assert err <= TOL, (case, name, (B, H, N, D), stages, what, err)
+            outs.append(o)
+        assert torch.equal(outs[0], outs[1]), (case, name, (B, H, N, D), what)
+    assert len(seen) >= 5, seen

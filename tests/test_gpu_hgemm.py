@@ -476,3 +476,41 @@ def test_policy_sizes_that_run_the_192_tiles(hg, built, dev, size):
         fn(ad, bb, c, 2, True, 2048)
         err = (c[rows.to(dev)].cpu().float() - truth).abs()
         assert (err <= ATOL + RTOL * truth.abs()).all(), err.max().item()
+
+
+def test_seeded_fuzz_over_shapes_stages_and_swizzle(hg, built, dev):
+    """40 seeded random problems (M, N, K multiples of 64 up to 3072 / 3072 / 6144, stages 2-5, block swizzle on / off, stride from the
+    reference policy or a random band): whatever kernel the policy picks (cln_describe names it in the failure message), sampled rows match the
+    fp32 product, TN equals NN bit for bit, and every `stages` value of the same problem gives the same bits."""
+    import random
+    from cuda_learn_notes_amd.bench_utils import as_col_major, make_block_swizzle_stride
+    rng = random.Random(20260923)
+    nn_name = "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem"
+    nn, tn = getattr(hg, nn_name), hg.hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_tn_swizzle_x4
+    kinds = set()
+    for case in range(40):
+        if case % 3 == 0:  # large multiples of 256: the one-wave-per-SIMD kernels and their ring-of-slots / ping-pong siblings
+            M, N = 256 * rng.randint(8, 16), 256 * rng.randint(8, 16)
+        else:
+            M, N = 64 * rng.randint(1, 48), 64 * rng.randint(1, 48)
+        K = 64 * rng.choice([1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 13, 16, 20, 26, 32, 40, 64, 96])
+        stages, swz = rng.randint(2, 5), rng.random() < 0.7
+        stride = make_block_swizzle_stride(N, K) if rng.random() < 0.5 else 256 * rng.randint(1, 8)
+        what = built.manifest.describe(nn_name, (M, N, K), stages)
+        kinds.add(what.split("<")[0])
+        a, b = seeded(1000 + case, M, K), seeded(2000 + case, K, N)
+        ad, bd = a.to(dev), b.to(dev)
+        c = torch.zeros(M, N, dtype=torch.half, device=dev)
+        nn(ad, bd, c, stages, swz, stride)
+        rows = sorted({0, M - 1, M // 2, rng.randrange(M), rng.randrange(M)})
+        truth = a[rows].float() @ b.float()
+        err = (c[rows].cpu().float() - truth).abs()
+        assert (err <= ATOL + RTOL * truth.abs()).all(), (case, (M, N, K), stages, what, err.max().item())
+        ct = torch.zeros(M, N, dtype=torch.half, device=dev)
+        tn(ad, as_col_major(b).to(dev), ct, stages, swz, stride)
+        assert torch.equal(ct, c), (case, (M, N, K), stages, what)
+        other = 2 + (stages - 1) % 4  # another stage count of the same problem
+        co = torch.zeros(M, N, dtype=torch.half, device=dev)
+        nn(ad, bd, co, other, not swz, stride)
+        assert torch.equal(co, c), (case, (M, N, K), stages, other, what, built.manifest.describe(nn_name, (M, N, K), other))
+    assert len(kinds) >= 3, kinds  # the sample reached several kernel families
