@@ -18,4 +18,4 @@ for item in json.load(open(order)):
                 "frac_of_8TBps": round(item["bytes"] / avg / 8000.0, 3)})
 json.dump(res, open(out, "w"), indent=1)
 for r in res:
-    print("%-42s %8.2f us %8.1f GB/s (%.0f%% of 8 TB/s)" % (r["kernel"], r["avg_us"], r["achieved_GBps"], 100 * r["frac_of_8TBps"]))
+    print("%-58s %8.2f us %8.1f GB/s (%.0f%% of 8 TB/s)" % (r["kernel"], r["avg_us"], r["achieved_GBps"], 100 * r["frac_of_8TBps"]))
