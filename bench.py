@@ -273,11 +273,11 @@ def main():
         out["extras"] = extras
         out["cpu_baseline"] = cpu_baseline(a, b, M, N, K)
         # ---- every other BASELINE.json config and the bandwidth kernels, each with its roofline fraction and the
-        # reference's torch path on the host cores: cuda-learn-notes_amd/bench_configs.py. Released first: the operands above.
+        # reference's torch path on the host cores: bench_configs.py (repository root). Released first: the operands above.
         del a, b, c
         torch.cuda.empty_cache()
         if not args.no_configs:
-            from cuda_learn_notes_amd import bench_configs as bc
+            import bench_configs as bc  # repository root, beside this file
             orc = entry.load_oracle()  # cpu_baseline legs only
             cfg = {}
             for key, fn in (("c1_elementwise_add_f32", lambda: bc.config_c1(dev, orc)),

@@ -1,4 +1,5 @@
-"""Side rows of bench.py: every BASELINE.json config and the bandwidth kernels, each with its own roofline and the
+"""Side rows of bench.py (a module of the BENCH, at the repository root: it is the one place besides tests/ and smoke() that calls the oracle, for
+the cpu_baseline legs -- nothing under cuda-learn-notes_amd/ does): every BASELINE.json config and the bandwidth kernels, each with its own roofline and the
 reference's torch path on the host cores beside it.
 
   config C1  elementwise_add_f32 [2048,2048]: the kernel rows AND the torch-CPU row the config literally names
@@ -25,8 +26,8 @@ import time
 
 import torch
 
-from . import _loader, manifest
-from . import bench_utils as bu
+from cuda_learn_notes_amd import _loader, manifest  # (bench.py has imported the package: __graft_entry__.load_package())
+from cuda_learn_notes_amd import bench_utils as bu
 
 MALL_BYTES = 256 << 20
 ROTATE_FOOTPRINT = 4 * MALL_BYTES  # combined footprint of the rotating sets: nothing of set i survives until its next use
@@ -67,8 +68,10 @@ def _cpu_time(fn, budget_s=0.8, max_iters=50):
 
 # ----------------------------------------------------------------------------------------------------------------
 # bandwidth kernels
-def _bw_specs(orc):
-    """(kernel name, dtype, signature kind, algorithmic bytes per element, torch-CPU callable of the same op)"""
+def _bw_specs(orc=None):
+    """(kernel name, dtype, signature kind, algorithmic bytes per element, torch-CPU callable of the same op -- the reference
+    script's torch path as restated in oracle/, only ever called by bandwidth_rows' cpu_baseline leg; `orc` may be None for callers that
+    want the table without the CPU callables)"""
     f = ctypes.c_float
     return [
         ("elementwise_add_f32x4", torch.float32, "P3", 12, lambda x, x2: orc.elementwise_add(x, x2)),

@@ -103,10 +103,9 @@ run(calls)
 # Infinity Cache, so the traced kernel durations are HBM durations (the rows above re-use one buffer set: bench.py's `gbps_same_buffers`)
 del keep, calls
 torch.cuda.empty_cache()
-from cuda_learn_notes_amd import bench_configs as bc  # noqa: E402
-orc = entry.load_oracle()  # (only for the spec table's CPU callables, which are not called here)
+import bench_configs as bc  # noqa: E402  (repository root; only its kernel table and launch closures are used here, no CPU leg)
 zz = torch.zeros(4, dtype=torch.float32, device=dev)
-for name, dtype, kind, bpe, _cpu in bc._bw_specs(orc):
+for name, dtype, kind, bpe, _cpu in bc._bw_specs():
     fn = _loader.symbol(name)
     for (Sr, Kr) in ((4096, 4096), (8192, 8192)):
         nr = Sr * Kr

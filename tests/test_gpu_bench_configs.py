@@ -1,4 +1,4 @@
-"""GPU: the side rows of bench.py (cuda-learn-notes_amd/bench_configs.py) run and are well-formed -- every BASELINE config and the
+"""GPU: the side rows of bench.py (bench_configs.py at the repository root) run and are well-formed -- every BASELINE config and the
 bandwidth kernels reach the driver's JSON line through this code, so a regression here would silently drop them to `error` entries."""
 import pytest
 import torch
@@ -8,7 +8,12 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def bc(built):
-    from cuda_learn_notes_amd import bench_configs
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench_configs
     return bench_configs
 
 
