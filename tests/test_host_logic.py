@@ -41,6 +41,7 @@ def test_product_path_never_imports_oracle():
             if fn.endswith((".py", ".hip", ".cuh", ".h", ".inc")):
                 src = open(os.path.join(dp, fn)).read()
                 assert "import oracle" not in src and "from oracle" not in src, fn
+                assert "load_oracle" not in src, fn  # (the bench's cpu_baseline legs live at the repository root: bench.py, bench_configs.py)
                 assert "/root/reference" not in src, fn
 
 
