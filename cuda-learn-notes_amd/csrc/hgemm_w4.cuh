@@ -374,8 +374,8 @@ inline int w4_nt_ok(int M, int N, int K) { return 2LL * ((long long)M * K + (lon
 // The interleaved-chunk walk (tile_coords_interleaved, hgemm_mfma.cuh) when block swizzle is requested and A + B are at least TWICE the 256 MiB
 // Infinity Cache: 12544^3 1378-1387 -> 1422-1432 TF (+3-4 %), 15360^3 1354-1360 -> 1412-1423 (+4-5 %), 16384^3 1456-1460 -> 1485-1495 (+2 %), NN;
 // 10240^3 (420 MB of operands) -1.5 ... 0 %, 8192^3 0 % -- profiles/r04_hgemm_block_walk_probe.log. Bit-identical results.
-constexpr long long W4_SB_OPERANDS = 512LL << 20;
-inline int w4_sb_walk(int M, int N, int K, int swizzle, int tiles) {
+constexpr long long W4_INTERLEAVED_OPERANDS = 512LL << 20;
+inline int w4_interleaved_walk(int M, int N, int K, int swizzle, int tiles) {
   // $CLN_AMD_W4_BLOCK_WALK = 0 / 1 forces the walk off / on (for A/B measurements; read once); unset: by operand size
   static const int forced = [] {
     const char* e = getenv("CLN_AMD_W4_BLOCK_WALK");
@@ -383,10 +383,10 @@ inline int w4_sb_walk(int M, int N, int K, int swizzle, int tiles) {
   }();
   if (!swizzle || tiles < 512) return 0;
   if (forced >= 0) return forced;
-  return (tiles >= 1024 && 2LL * ((long long)M * K + (long long)K * N) >= W4_SB_OPERANDS) ? 1 : 0;
+  return (tiles >= 1024 && 2LL * ((long long)M * K + (long long)K * N) >= W4_INTERLEAVED_OPERANDS) ? 1 : 0;
 }
 // kernel argument `swizzle`: bit 0 block swizzle, bit 1 non-temporal C stores, bit 2 the interleaved-chunk walk
-inline int w4_swizzle_arg(int M, int N, int K, int swizzle, int tiles) { return (swizzle ? 1 : 0) | (w4_nt_ok(M, N, K) << 1) | (w4_sb_walk(M, N, K, swizzle, tiles) << 2); }
+inline int w4_swizzle_arg(int M, int N, int K, int swizzle, int tiles) { return (swizzle ? 1 : 0) | (w4_nt_ok(M, N, K) << 1) | (w4_interleaved_walk(M, N, K, swizzle, tiles) << 2); }
 inline int w4_grid(int, int, int, int, int tiles_m, int tiles_n) { return tiles_m * tiles_n; }
 
 template <int LAYOUT, int EPI = 2, int VAR = 0, int ABL = 0, int BM = 256, int BN = 256>
