@@ -20,8 +20,12 @@ int m16x_run(int D, int rows_per_wave, bool vt, bool one_stage, bool f32_scale, 
   if (f32_scale) {
     if (vt) return CLN_ERR_UNSUPPORTED;
     constexpr int F = OX | M16X_FSCALE, F1 = O1 | M16X_FSCALE;
-    if (D == 64 && rows_per_wave == 32) return one_stage ? launch_m16x<64, 32, 128, 8, 4, F1>(q, k, v, o, B, H, N, s) : launch_m16x<64, 32, 128, 8, 4, F>(q, k, v, o, B, H, N, s);
-    if (D == 128 && rows_per_wave == 32) return one_stage ? launch_m16x<128, 32, 128, 4, 4, F1>(q, k, v, o, B, H, N, s) : launch_m16x<128, 32, 128, 4, 4, F>(q, k, v, o, B, H, N, s);
+    // 32 rows per wave: the row sums come from the matrix pipe as well (M16X_MFMA_SUM: l is then the sum of the SAME fp16 P values the numerator
+    // uses) -- same speed as the fp32 scale alone, max-abs-error on amplified-key inputs 1.0e-3 instead of 1.6-2.0e-3 (profiles/r04_fa_fscale_probe.log);
+    // the 64-row form has no registers for the extra accumulators (623 vs 1013 TF) and keeps the VALU row sums
+    constexpr int FM = F | M16X_MFMA_SUM, FM1 = F1 | M16X_MFMA_SUM;
+    if (D == 64 && rows_per_wave == 32) return one_stage ? launch_m16x<64, 32, 128, 8, 4, FM1>(q, k, v, o, B, H, N, s) : launch_m16x<64, 32, 128, 8, 4, FM>(q, k, v, o, B, H, N, s);
+    if (D == 128 && rows_per_wave == 32) return one_stage ? launch_m16x<128, 32, 128, 4, 4, FM1>(q, k, v, o, B, H, N, s) : launch_m16x<128, 32, 128, 4, 4, FM>(q, k, v, o, B, H, N, s);
     if (D == 64 && rows_per_wave == 64) return one_stage ? launch_m16x<64, 64, 64, 4, 1, F1>(q, k, v, o, B, H, N, s) : launch_m16x<64, 64, 64, 4, 1, F>(q, k, v, o, B, H, N, s);
     return CLN_ERR_UNSUPPORTED;
   }

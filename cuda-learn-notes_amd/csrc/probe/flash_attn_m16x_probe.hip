@@ -42,8 +42,11 @@ int m16x_probe_run(int D, int code, const void* q, const void* k, const void* v,
   MX(64, 180, 64, 64, 4, 1, 32773) MX(64, 181, 64, 64, 4, 1, 98309) MX(64, 182, 64, 64, 4, 1, 163845) MX(64, 183, 64, 64, 4, 1, 229381)
   // 190 / 191: scores scaled in fp32 (M16X_FSCALE = 262144 on top of the shipped options 5): Q unscaled, one v_fma_f32 per score; 191 = its single-stage form
   MX(64, 190, 32, 128, 8, 4, 262149) MX(128, 190, 32, 128, 4, 4, 262149) MX(64, 192, 64, 64, 4, 1, 262149)
+  // 197 / 198 / 199: the fp32-scaled form with 5 / 6 / 3 of the 8 key blocks exponentiated in phase B (the shipped acc_f32 form: 4)
+  MX(64, 197, 32, 128, 8, 5, 262149) MX(64, 198, 32, 128, 8, 6, 262149) MX(64, 199, 32, 128, 8, 3, 262149)
+  MX(128, 197, 32, 128, 4, 5, 262149) MX(128, 198, 32, 128, 4, 6, 262149) MX(128, 199, 32, 128, 4, 3, 262149)
   // 194..: row sums on the matrix pipe (M16X_MFMA_SUM = 524288 on top of the shipped options 5); 195: + fp32-scaled scores
-  MX(64, 194, 32, 128, 8, 4, 524293) MX(128, 194, 32, 128, 4, 4, 524293) MX(64, 196, 64, 64, 4, 1, 524293) MX(64, 195, 32, 128, 8, 4, 786437)
+  MX(64, 194, 32, 128, 8, 4, 524293) MX(128, 194, 32, 128, 4, 4, 524293) MX(64, 196, 64, 64, 4, 1, 524293) MX(64, 195, 32, 128, 8, 4, 786437) MX(128, 195, 32, 128, 4, 4, 786437) MX(64, 193, 64, 64, 4, 1, 786437)
 #undef MX
   // 150 + id: the one-wave-per-SIMD form (flash_attn_m16s.cuh: 4 waves x 64 rows), <D, BC, PD, NDEF>
 #define MS(DD, CODE, BCC, PDD, NDEFF, FINEE) \

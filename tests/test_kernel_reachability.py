@@ -48,7 +48,9 @@ def test_attention_kernels_in_the_product_library_are_exactly_the_plannable_ones
             assert a[:3] in (["2", "false", "false"], ["2", "true", "false"]) and a[3] in ("0", "262144"), a
             linked.add(("fa2_fwd_m16", 512 if a[1] == "true" else 256, a[3] == "262144"))
         elif f == "fa2_fwd_m16x_kernel":  # 6th argument: option bits (32768 = single-stage form); 7th: V given transposed ([B,H,D,N], the *_swizzle_qkv names)
-            assert int(a[5]) & ~(32768 | (3 << 16) | (1 << 18)) == 5, a  # the shipped options: phase-A priority + split prologue (1 << 18: fp32-scaled scores)
+            # the shipped options: phase-A priority + split prologue (1 << 18: fp32-scaled scores; 1 << 19: row sums on the matrix pipe, with them at 32 rows per wave)
+            assert int(a[5]) & ~(32768 | (3 << 16) | (1 << 18) | (1 << 19)) == 5, a
+            assert bool(int(a[5]) & (1 << 19)) == (bool(int(a[5]) & (1 << 18)) and a[1] == "32"), a
             linked.add(("fa2_fwd_m16x64r" if a[1] == "64" else "fa2_fwd_m16x", int(a[0]), a[6] == "true", bool(int(a[5]) & 32768), bool(int(a[5]) & (1 << 18))))
         elif f in ("fa2_fwd_dring_kernel", "fa2_fwd_splitkv_kernel"):
             linked.add((f[:-len("_kernel")], int(a[0])))
