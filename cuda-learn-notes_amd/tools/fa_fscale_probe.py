@@ -31,7 +31,7 @@ for shape, codes in (((4, 8, 2048, 64), ((853, "pre-scaled Q (shipped)"), (990, 
                      ((4, 8, 2048, 128), ((853, "pre-scaled Q (shipped)"), (990, "fp32-scaled scores"), (994, MS), (995, MS + " + fp32 scale"),
                                            (999, "fp32-scaled, 3 blocks deferred"), (997, "fp32-scaled, 5 blocks deferred"), (998, "fp32-scaled, 6 blocks deferred"))),
                      ((2, 24, 4096, 64), ((853, "pre-scaled Q (shipped)"), (994, MS))),
-                     ((1, 48, 8192, 64), ((925, "pre-scaled Q (shipped)"), (992, "fp32-scaled scores"), (996, MS), (993, MS + " + fp32 scale")))):
+                     ((1, 48, 8192, 64), ((925, "pre-scaled Q (shipped)"), (992, "fp32-scaled scores"), (996, MS)))):
     B, H, N, D = shape
     torch.manual_seed(0)
     q, k, v = (torch.randn(B, H, N, D, dtype=torch.half, device=dev) for _ in range(3))

@@ -18,7 +18,8 @@ sys.path.insert(0, PKG)
 
 def compile_asm(src, out_s):
     import _build
-    cmd = [_build.hipcc()] + _build.CFLAGS + _build.EXTRA_FLAGS.get(os.path.basename(src), []) + ["--cuda-device-only", "-S", src, "-o", out_s]
+    rel = os.path.relpath(os.path.abspath(src), _build.CSRC).replace(os.sep, "/")  # EXTRA_FLAGS is keyed by the path under csrc/ ("probe/x.hip")
+    cmd = [_build.hipcc()] + _build.CFLAGS + _build.EXTRA_FLAGS.get(rel, _build.EXTRA_FLAGS.get(os.path.basename(src), [])) + ["--cuda-device-only", "-S", src, "-o", out_s]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc -S failed for %s:\n%s" % (src, r.stderr[-3000:]))

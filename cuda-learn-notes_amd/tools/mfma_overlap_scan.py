@@ -62,6 +62,32 @@ def scan_shared_object(so_path, workdir):
     return out, n_mfma
 
 
+def shared_object_spills(so_path, workdir):
+    """Kernel metadata of the gfx950 code objects inside a built shared library (llvm-readelf --notes): -> (number of kernels,
+    [(kernel name, vgpr spills, sgpr spills, scratch bytes)] for every kernel that spills or uses scratch)."""
+    import glob
+    import os
+    import shutil
+    import subprocess
+    objdump, readelf = "/opt/rocm/lib/llvm/bin/llvm-objdump", "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    os.makedirs(workdir, exist_ok=True)
+    local = os.path.join(workdir, os.path.basename(so_path))
+    shutil.copy(so_path, local)
+    subprocess.run([objdump, "--offloading", local], check=True, capture_output=True, cwd=workdir)
+    n, bad = 0, []
+    for co in sorted(glob.glob(local + ".*gfx950")):
+        notes = subprocess.run([readelf, "--notes", co], check=True, capture_output=True, text=True).stdout
+        for blk in notes.split("- .agpr_count")[1:] if "- .agpr_count" in notes else notes.split(".args:")[1:]:
+            name = re.search(r"\.name:\s+(\S+)", blk)
+            vs, ss, sc = (re.search(r"\.%s:\s+(\d+)" % k, blk) for k in ("vgpr_spill_count", "sgpr_spill_count", "private_segment_fixed_size"))
+            if not (name and vs and ss and sc):
+                continue
+            n += 1
+            if int(vs.group(1)) or int(ss.group(1)) or int(sc.group(1)):
+                bad.append((name.group(1), int(vs.group(1)), int(ss.group(1)), int(sc.group(1))))
+    return n, bad
+
+
 if __name__ == "__main__":
     res = scan(open(sys.argv[1]).read(), sys.argv[2] if len(sys.argv) > 2 else "")
     from collections import Counter

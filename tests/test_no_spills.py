@@ -138,3 +138,16 @@ def test_built_libraries_have_no_mfma_destination_on_operand_registers(built, tm
     assert n > 50000, n
     stray = [(k[:90], l) for k, l in bad if not any(a in k for a in PROBE_OVERLAP_ALLOWED)]
     assert not stray, stray[:6]
+
+
+def test_built_product_library_has_no_spilling_kernel_a_name_can_reach(built, tmp_path):
+    """The same property read from the SHIPPED binary (kernel metadata of the code objects inside libcln_amd.so, llvm-readelf): no kernel spills
+    or uses scratch except the probe-only 256x256-tile-on-4-waves ring instantiations that share an object file with the product rings."""
+    import mfma_overlap_scan as scan
+    from cuda_learn_notes_amd import _loader
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"):
+        pytest.skip("llvm-readelf not available")
+    n, bad = scan.shared_object_spills(_loader.so_path("libcln_amd.so"), str(tmp_path))
+    assert n > 400, n
+    stray = [b for b in bad if "CfgILi256ELi256ELi32ELi2ELi2E" not in b[0] and "CfgILi256ELi256ELi64ELi2ELi2E" not in b[0]]
+    assert not stray, stray
