@@ -66,6 +66,8 @@ def load_so(so_name):
     for e in manifest.ENTRIES:
         if manifest.SO_OF_LIB[e.lib] != so_name:
             continue
+        if e.lib in manifest.OPTIONAL_LIBS and not hasattr(lib, e.name):
+            continue  # an optional comparison row that this build does not carry (image without hipBLASLt / ck_tile headers)
         fn = getattr(lib, e.name)  # AttributeError here == ABI hole; let it propagate
         fn.argtypes = ARGTYPES[e.sig]
         fn.restype = c_int
@@ -87,3 +89,9 @@ def load_so(so_name):
 def symbol(name):
     e = manifest.BY_NAME[name]
     return getattr(load_so(manifest.SO_OF_LIB[e.lib]), name)
+
+
+def has_symbol(name):
+    """False only for an optional comparison row that the built vendor library does not carry."""
+    e = manifest.BY_NAME[name]
+    return hasattr(load_so(manifest.SO_OF_LIB[e.lib]), name)

@@ -370,6 +370,8 @@ def load_lib(*groups):
     ns = types.SimpleNamespace()
     for e in manifest.ENTRIES:
         if e.lib in groups:
+            if e.lib in manifest.OPTIONAL_LIBS and not _loader.has_symbol(e.name):
+                continue  # optional comparison row absent from this build: the attribute is simply not there (callers test with hasattr / try)
             setattr(ns, e.name, _MAKERS[e.sig](e.name))
     return ns
 

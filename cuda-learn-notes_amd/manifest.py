@@ -237,6 +237,8 @@ BY_NAME = {e.name: e for e in ENTRIES}
 assert len(BY_NAME) == len(ENTRIES), "duplicate exported name"
 
 # which shared object holds which lib group
+# comparison-row groups whose sources are optional at build time (_build.OPTIONAL_SOURCES): the vendor library may have been linked without them
+OPTIONAL_LIBS = ("hgemm_vendor_lt", "fa2_vendor_ck")
 SO_OF_LIB = {
     "hgemm": "libcln_amd.so", "flash_attn": "libcln_amd.so", "elementwise": "libcln_amd.so",
     "reduce": "libcln_amd.so", "softmax": "libcln_amd.so", "layer_norm": "libcln_amd.so",

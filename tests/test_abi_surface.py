@@ -111,3 +111,15 @@ def test_every_product_entry_point_refuses_null_pointers_without_touching_a_devi
         assert rc in (-1, -2), (e.name, rc)
         seen += 1
     assert seen >= 200
+
+
+def test_optional_comparison_rows_may_be_absent_from_the_vendor_library(built, monkeypatch):
+    """an image without hipBLASLt (or without the ck_tile headers) builds the vendor library without those rows; the Python side must then
+    load the hgemm module without them instead of failing on the missing symbol."""
+    from cuda_learn_notes_amd import _loader, host
+    real = _loader.has_symbol
+    monkeypatch.setattr(_loader, "has_symbol", lambda n: False if n.startswith("cln_hgemm_hipblaslt") else real(n))
+    lib = host.load_lib("hgemm", "hgemm_vendor", "hgemm_vendor_lt")
+    assert hasattr(lib, "hgemm_cublas_tensor_op_nn") and hasattr(lib, "hgemm_mma_m16n8k16_naive")
+    assert not hasattr(lib, "cln_hgemm_hipblaslt_nn")
+    assert set(built.manifest.OPTIONAL_LIBS) == {"hgemm_vendor_lt", "fa2_vendor_ck"}
