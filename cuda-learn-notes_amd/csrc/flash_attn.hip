@@ -69,8 +69,16 @@ FaPlan fa2_plan(int family, bool vt, int B, int H, int N, int D, int stages, int
       const long long wgs = bh * (N / 512), rounds = (wgs + 255) / 256;
       if (wgs >= 256 && wgs * 100 >= rounds * 256 * 88) return p.kind = K_M16X64R, p.d_inst = 64, p.nw = 8, p.bc = 64, p;
     }
-    if ((!vt || D == 64 || D == 128) && N % 256 == 0 && bh * (N / 256) >= 192) {  // D = 256: non-transposed V only
-      // enough 256-row workgroups to occupy most of the chip:
+    // 256-row workgroups of the two-group kernels against 128-row (4-wave) workgroups of the v2 kernel, by the number w of 256-row
+    // blocks (profiles/r04_fa_small_grid_probe.log; rounds 1-3 switched at w >= 192 for every head dim and fell to 2-wave workgroups below 128):
+    //  D = 128: the two-group kernel at every w (w = 32 ... 128: +4-12 % over 4-wave v2, 2x over the 2-wave form the old rule picked)
+    //  D = 64:  v2 with 4 waves while its 2w workgroups each get a CU of their own (w <= 128: 1.2x the two-group kernel),
+    //           the two-group kernel above (w = 160: +14-19 % over v2)
+    //  D = 256: (non-transposed V only) the two-group kernel at every w (w = 32 ... 160: 1.7-3.7x the 4-wave v2 kernel, which holds the
+    //           whole register file and one wave per SIMD)
+    const long long w256 = N % 256 == 0 ? bh * (N / 256) : 0;
+    const long long w_min = D == 64 ? 129 : 1;
+    if ((!vt || D == 64 || D == 128) && w256 >= w_min) {
       //  D = 64 / 128: ping-pong kernel on 16x16x32 MFMAs (the energy-cheaper matrix shape, +3.5-5 % at D = 64 and
       //                +5.5-6.5 % at D = 128 over the 32x32x16 form of flash_attn_dsplit.cuh, profiles/r02_fa_m16_probe.log)
       //                with the sum-checked optimistic softmax, phase-A priority and the split prologue of round 3
@@ -84,17 +92,20 @@ FaPlan fa2_plan(int family, bool vt, int B, int H, int N, int D, int stages, int
       // (profiles/r02_fa_m16_d256_probe.log, variant 544)
       if (D == 256) return p.kind = K_M16, p.d_inst = 256, p.nw = 8, p.bc = 32, p;
     }
-    // v2 kernel: the largest of 8 / 4 / 2 waves (x 32 query rows) that N allows AND that still gives every one of the
-    // 256 CUs a workgroup (measured [2,8,2048,64]: 534 TF with 4 waves x 256 workgroups vs 413 TF with 8 x 128)
     if (D == 256) {  // needs the whole register file (one wave per SIMD): 4 waves x 32 rows only
       if (N % 128 != 0) return p.rc = CLN_ERR_UNSUPPORTED, p;
       return p.kind = K_V2, p.d_inst = 256, p.nw = 4, p.bc = 64, p;
     }
+    // v2 kernel, 32 query rows per wave: 4 waves whenever N allows (2-wave workgroups stage every K / V tile for half the rows:
+    // 0.5-0.75x at every grid size measured); 8 waves (D = 32 / 96 only -- at D = 64 / 128 those shapes run the two-group kernel)
+    // once the 8-wave workgroups alone cover more than half the CUs at D = 96 (w > 128: +0-6 % over 4 waves; at w <= 128 every
+    // 4-wave workgroup has a CU of its own and 4 waves win by 1.15x), past a full round of them at D = 32 (4 waves lead by 2-6 % up to w = 256)
     int nw = 0;
     for (int cand : {8, 4, 2}) {
       if (N % (cand * 32) != 0) continue;
+      if (cand == 8 && (D == 64 || D == 128 || w256 <= (D == 32 ? 256 : 128))) continue;
       nw = cand;
-      if (bh * (N / (cand * 32)) >= 256) break;
+      break;
     }
     if (nw == 0) return p.rc = CLN_ERR_UNSUPPORTED, p;
     return p.kind = K_V2, p.d_inst = D, p.nw = nw, p.bc = 64, p;

@@ -186,6 +186,8 @@ CLN_API int cln_fa2_variant(int D, int nw, int vt, int opt, int abl, const void*
   if (D == 256 && abl == 500) return fa2::launch_dsplit<256, 1, 1, 15 | fa2::OPT_KPRE | fa2::OPT_PRE>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 256 && abl == 504) return fa2::launch_dsplit<256, 1, 1, 14 | fa2::OPT_KPRE | fa2::OPT_PRE>(q, k, v, o, B, H, N, (hipStream_t)stream);
   V2(64, 8, 16397, 0) V2(64, 4, 16397, 0) V2(64, 2, 16397, 0) V2(128, 8, 16399, 0) V2(128, 4, 16399, 0) V2(32, 8, 16397, 0) V2(96, 4, 16399, 0)
+  // small-grid sweep (tools/fa_small_grid_probe.py): every wave count of the product's v2 instantiations
+  V2(128, 2, 16399, 0) V2(32, 4, 16397, 0) V2(32, 2, 16397, 0) V2(96, 8, 16399, 0) V2(96, 2, 16399, 0) V2(256, 4, 15, 0)
   V2(64, 8, 16396, 0) V2(128, 8, 16398, 0)
   V2(64, 8, 13, 0) V2(64, 4, 13, 0) V2(64, 4, 77, 0) V2(128, 8, 15, 0) V2(128, 4, 15, 0) V2(128, 4, 79, 0)
   V2(64, 8, 13, 1) V2(64, 8, 13, 2) V2(64, 8, 13, 7) V2(128, 8, 15, 1) V2(128, 8, 15, 7)
