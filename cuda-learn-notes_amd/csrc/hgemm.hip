@@ -12,8 +12,12 @@
 #include "hgemm_mfma.cuh"
 #include "hgemm_w4.cuh"
 #include "hgemm_w4s.cuh"
+#include "hgemm_splitk.cuh"
 #include "hgemm_valu.cuh"
 #include <string.h>
+#include <math.h>
+#include <mutex>
+#include <vector>
 
 using namespace hgemm;
 
@@ -80,6 +84,88 @@ int best_plan(int M, int N, int K) {
   }
   return plan;
 }
+// ---- split-K (hgemm_splitk.cuh): few output tiles, long K ------------------------------------------------------------------------------
+// WHEN: K >= 4096 and M N <= 2048^2 (K >= 5120 above 1536^2). Measured over 28 shapes x every (tile, splits) candidate against the policy
+// above (profiles/r04_hgemm_splitk_probe.log): inside that region split-K wins by 1.09-6.7x (1024^2 x 16384: 310 -> 823 TF, 128 x 8192 x 8192:
+// 267 -> 541, 768^2 x 12288: 174 -> 513; rocBLAS TN 603 / 471 / 339); outside it loses or ties (2048^3 0.79x, 1024^2 x 2048 0.65x, 2048^2 x 4096
+// 0.97x, 2560^2 / 3072^2 x 8192 0.97x / 0.82x, 1536^2 x 3072 0.99x).
+// WHICH (tile, S): the minimum of a time model fitted to the same sweep (rms 7 %; its pick is the measured best at 27 of the 28 shapes, 7 % off at one):
+//   t = rounds x (K / (64 S) x tau + phi) + rho,   rounds = ceil(tiles S / 256)
+//   tau = 2 BM BN 64 flop / (eff x 5.86 TF), shortened by 0.34 (1 - fill) when fewer than 256 workgroups run (idle CUs: higher clocks, no contention);
+//         eff: 256x256 1.25 | 192x256 1.19 | 192x192 1.08 | 128x256 0.97 | 160x160 0.94 (a workgroup alone on its CU, no C epilogue through LDS)
+//   phi = 3.9 us x sqrt(BM BN / 256^2): launch ramp, prologue, partial store;   rho = 5.2 us + (4 S M N + 2 M N) bytes / 3.6 TB/s: the reduce launch
+// The workspace (S M N floats <= 256 MiB) is per stream, allocated on first use and only ever grown; under stream capture a launch that would
+// have to allocate takes the single-pass plan instead.
+struct SplitK {
+  int bm = 0, bn = 0, S = 0;
+};
+constexpr size_t SPLITK_WS_MAX = 256u << 20;
+SplitK splitk_plan(int M, int N, int K) {
+  SplitK best;
+  const double mn = (double)M * (double)N;
+  if (K < 4096 || K % 64 || mn > 2048.0 * 2048.0 || (mn > 1536.0 * 1536.0 && K < 5120)) return best;
+  static const struct { int bm, bn; double eff; } shapes[] = {{256, 256, 1.249}, {192, 256, 1.188}, {192, 192, 1.078}, {128, 256, 0.974}, {160, 160, 0.942}};
+  double t_best = 1e30;
+  for (const auto& sh : shapes) {
+    if (M % sh.bm || N % sh.bn) continue;
+    const long long tiles = (long long)(M / sh.bm) * (N / sh.bn);
+    for (int S = 2; S <= 32; ++S) {
+      if (!w4_splitk_ok(K, S) || tiles * S > 768 || (double)S * mn * 4.0 > (double)SPLITK_WS_MAX) continue;
+      const long long n = tiles * S, rounds = (n + 255) / 256;
+      const double fill = n >= 256 ? 1.0 : (double)n / 256.0;
+      const double tau = 2.0 * sh.bm * sh.bn * 64.0 / (5.86e6 * sh.eff) * (1.0 - 0.338 * (1.0 - fill));
+      const double t = rounds * ((double)(K / S / 64) * tau + 3.88 * sqrt(sh.bm * sh.bn / 65536.0)) + 5.18 + (4.0 * S * mn + 2.0 * mn) / 3.615e6;
+      if (t < t_best) t_best = t, best.bm = sh.bm, best.bn = sh.bn, best.S = S;
+    }
+  }
+  return best;
+}
+
+struct SplitKWs {
+  int dev;
+  hipStream_t stream;
+  float* p;
+  size_t bytes;
+};
+std::mutex g_splitk_mu;
+std::vector<SplitKWs> g_splitk_ws;
+// the stream's workspace, grown if needed; nullptr when it cannot be had (allocation failed, or the stream is being captured and the
+// workspace would have to be allocated now)
+float* splitk_workspace(hipStream_t stream, size_t bytes) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(g_splitk_mu);
+  SplitKWs* e = nullptr;
+  for (auto& w : g_splitk_ws)
+    if (w.dev == dev && w.stream == stream) e = &w;
+  if (e && e->bytes >= bytes) return e->p;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return (void)hipGetLastError(), nullptr;
+  size_t want = 16u << 20;
+  while (want < bytes) want <<= 1;
+  if (want > SPLITK_WS_MAX) want = SPLITK_WS_MAX;
+  if (e) {  // grow: launches queued on this stream may still use the old buffer
+    if (hipStreamSynchronize(stream) != hipSuccess) return nullptr;
+    (void)hipFree(e->p);
+    e->p = nullptr, e->bytes = 0;
+  } else {
+    g_splitk_ws.push_back({dev, stream, nullptr, 0});
+    e = &g_splitk_ws.back();
+  }
+  if (hipMalloc(&e->p, want) != hipSuccess) return (void)hipGetLastError(), e->p = nullptr, nullptr;
+  e->bytes = want;
+  return e->p;
+}
+template <int LAYOUT>
+int splitk_dispatch(const SplitK& sk, const void* a, const void* b, void* c, float* ws, int M, int N, int K, hipStream_t st) {
+  if (sk.bm == 256 && sk.bn == 256) return launch_w4_splitk<LAYOUT, 26, 256, 256>(a, b, c, ws, M, N, K, sk.S, st);
+  if (sk.bm == 192 && sk.bn == 256) return launch_w4_splitk<LAYOUT, 26, 192, 256>(a, b, c, ws, M, N, K, sk.S, st);
+  if (sk.bm == 192 && sk.bn == 192) return launch_w4_splitk<LAYOUT, 26, 192, 192>(a, b, c, ws, M, N, K, sk.S, st);
+  if (sk.bm == 128 && sk.bn == 256) return launch_w4_splitk<LAYOUT, 26, 128, 256>(a, b, c, ws, M, N, K, sk.S, st);
+  if (sk.bm == 160 && sk.bn == 160) return launch_w4_splitk<LAYOUT, 26, 160, 160>(a, b, c, ws, M, N, K, sk.S, st);
+  return CLN_ERR_UNSUPPORTED;
+}
+
 int plan_tile(int plan) {
   switch (plan) {
     case PLAN_R128x256: return T128x256;
@@ -104,6 +190,11 @@ constexpr int W4_PRODUCTION = 26;  // schedule 10 (one DMA piece per 8 MFMAs, ru
 template <int LAYOUT>
 int best_dispatch(const void* a, const void* b, void* c, int M, int N, int K, int stages, int swizzle, int stride,
                   hipStream_t st) {
+  const SplitK sk = splitk_plan(M, N, K);
+  if (sk.S >= 2) {  // few tiles, long K: K split over S workgroups per tile, fp32 partials, one reduce launch (`stages` ignored: one pipeline)
+    float* ws = splitk_workspace(st, (size_t)sk.S * M * N * sizeof(float));
+    if (ws) return splitk_dispatch<LAYOUT>(sk, a, b, c, ws, M, N, K, st);
+  }
   int plan = best_plan(M, N, K);
   if (plan == PLAN_W192) return launch_w4<LAYOUT, W4_EPILOGUE, W4_PRODUCTION, 0, 192, 192>(a, b, c, M, N, K, swizzle, stride, st);
   if (plan == PLAN_W192x256) return launch_w4<LAYOUT, W4_EPILOGUE, W4_PRODUCTION, 0, 192, 256>(a, b, c, M, N, K, swizzle, stride, st);
@@ -145,6 +236,10 @@ int describe_w4(int BM, int BN, int layout, char* buf, int len, bool stages_igno
 int describe_best(int layout, int M, int N, int K, int stages, char* buf, int len) {
   int plan = best_plan(M, N, K);
   const char* l = layout == TN ? "TN" : "NN";
+  const SplitK sk = splitk_plan(M, N, K);
+  if (sk.S >= 2)
+    return snprintf(buf, len, "hgemm_w4<%dx%dx64,4 waves,%dx%d wave tiles,cross-tile LDS-DMA,%s> split-K x %d (K %d per workgroup, fp32 partials in "
+                              "register layout) + hgemm_splitk_reduce [stages ignored: one pipeline]", sk.bm, sk.bn, sk.bm / 2, sk.bn / 2, l, sk.S, K / sk.S);
   if (plan == PLAN_W192) return describe_w4(192, 192, layout, buf, len, stages != 2);
   if (plan == PLAN_W192x256) return describe_w4(192, 256, layout, buf, len, stages != 2);
   if (plan == PLAN_W256x192) return describe_w4(256, 192, layout, buf, len, stages != 2);

@@ -1,0 +1,87 @@
+// Split-K for the one-wave-per-SIMD HGEMM (hgemm_w4.cuh): problems whose M x N gives far fewer tiles than the chip has CUs
+// but whose K is long (1024 x 1024 x 16384: 16 tiles of 256 x 256; 128 x 8192 x 8192: 32 tiles of 128 x 256).
+//
+// The reference has no such kernel (its sweep is M = N = K, hgemm.py:277-281); without it these shapes fall to the 64 x 64 ring
+// (a workgroup on every CU, but 0.44 of the big kernel's rate per CU and every operand byte fetched 4x as often):
+// profiles/r04_hgemm_rect_probe_before.log -- 0.59-0.9 of rocBLAS, which splits K itself.
+//
+//   launch 1: grid (tiles, S). Workgroup (t, s) runs the UNCHANGED hgemm_w4 main loop over K columns [s K/S, (s+1) K/S) of tile t
+//             (EPI 5: leading dimension != loop extent) and writes its 256 fp32 accumulators per lane as they lie in the registers:
+//             workspace [S][tiles][4 waves][FM x FN fragments][64 lanes] x 16 B -- every store instruction 1 KiB contiguous, no LDS pass.
+//   launch 2: hgemm_splitk_reduce -- one workgroup per (tile, wave, 16-row fragment row): sums the S partials in fp32 (ascending s),
+//             rounds ONCE to fp16, transposes the 16 x (BN/2) strip through LDS and writes whole 16-byte row segments of C.
+// Numerics: fp32 accumulation throughout, one rounding -- the same as the single-pass kernel up to the fp32 summation order.
+#pragma once
+#include "hgemm_w4.cuh"
+
+namespace hgemm {
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void hgemm_splitk_reduce_kernel(const float* __restrict__ ws, half_t* __restrict__ Cmat, int N, int tiles_n,
+                                                                  int tiles, int S) {
+  constexpr int FM = BM / 32, FN = BN / 32, WTM = BM / 2, WTN = BN / 2;
+  constexpr int RS = FN * 32 + 16;  // LDS row stride in bytes (16 rows of WTN halves + pad)
+  __shared__ __attribute__((aligned(16))) char strip[16 * RS];
+  const int i = blockIdx.x % FM, tw = blockIdx.x / FM, w = tw & 3, tile = tw >> 2;
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const size_t split_stride = (size_t)tiles * (BM * BN);
+  for (int j = wv; j < FN; j += 4) {
+    const float* p = ws + (size_t)tile * (BM * BN) + w * (WTM * WTN) + ((i * FN + j) * 64 + lane) * 4;
+    f4 s = *reinterpret_cast<const f4*>(p);
+    int ks = 1;
+    for (; ks + 3 < S; ks += 4) {  // four loads in flight; summed in ascending split order
+      const f4 v0 = *reinterpret_cast<const f4*>(p + (size_t)ks * split_stride);
+      const f4 v1 = *reinterpret_cast<const f4*>(p + (size_t)(ks + 1) * split_stride);
+      const f4 v2 = *reinterpret_cast<const f4*>(p + (size_t)(ks + 2) * split_stride);
+      const f4 v3 = *reinterpret_cast<const f4*>(p + (size_t)(ks + 3) * split_stride);
+      s = s + v0;
+      s = s + v1;
+      s = s + v2;
+      s = s + v3;
+    }
+    for (; ks < S; ++ks) s = s + *reinterpret_cast<const f4*>(p + (size_t)ks * split_stride);
+    // lane l of fragment (i, j) holds row l & 15, columns 16 j + 4 (l >> 4) ... + 3 (the layout store_wide_tile_via_lds reads)
+    const h4 o = {(half_t)s[0], (half_t)s[1], (half_t)s[2], (half_t)s[3]};
+    *reinterpret_cast<h4*>(strip + (lane & 15) * RS + (j * 16 + 4 * (lane >> 4)) * 2) = o;
+  }
+  __syncthreads();
+  constexpr int LPR = FN * 2;  // 16-byte pieces per row
+  if (threadIdx.x < 16 * LPR) {
+    const int r = threadIdx.x / LPR, c = threadIdx.x - r * LPR;
+    const u4 v = *reinterpret_cast<const u4*>(strip + r * RS + c * 16);
+    const size_t row = (size_t)tm * BM + (w >> 1) * WTM + i * 16 + r;
+    *reinterpret_cast<u4*>(Cmat + row * N + (size_t)tn * BN + (w & 1) * WTN + c * 8) = v;
+  }
+}
+
+// K / S must be a K the kernel's peeled structure covers (w4_k_ok); the workspace holds S * M * N floats
+inline bool w4_splitk_ok(int K, int S) { return S >= 2 && K % (64 * S) == 0 && w4_k_ok(K / S) && K / 64 < (1 << 22); }
+
+template <int LAYOUT, int VAR, int BM, int BN>
+int launch_w4_splitk(const void* a, const void* b, void* c, float* ws, int M, int N, int K, int S, hipStream_t stream) {
+  using C = W4Cfg<BM, BN, LAYOUT>;
+  if (M % BM || N % BN || !w4_splitk_ok(K, S) || ws == nullptr) return CLN_ERR_UNSUPPORTED;
+  const int tiles_m = M / BM, tiles_n = N / BN, tiles = tiles_m * tiles_n, Kl = K / S;
+  if (S > 65535) return CLN_ERR_UNSUPPORTED;
+  const int sw = (K / 64) << 8;  // no block swizzle (few tiles), plain stores; bits 8..: the leading dimension in units of 64
+  if ((Kl / 64) & 1) {
+    static cln_lds_attr lds_attr_odd;
+    if (cln_ensure_lds(lds_attr_odd, reinterpret_cast<const void*>(&hgemm_w4_kernel<LAYOUT, 5, VAR, 0, BM, BN, true>), C::LDS_BYTES) != CLN_OK)
+      return CLN_ERR_LAUNCH;
+    CLN_LAUNCH((hgemm_w4_kernel<LAYOUT, 5, VAR, 0, BM, BN, true>), dim3(tiles, S), dim3(256), C::LDS_BYTES, stream, (const half_t*)a, (const half_t*)b,
+               reinterpret_cast<half_t*>(ws), M, N, Kl, tiles_m, tiles_n, sw, tiles_n);
+  } else {
+    static cln_lds_attr lds_attr;
+    if (cln_ensure_lds(lds_attr, reinterpret_cast<const void*>(&hgemm_w4_kernel<LAYOUT, 5, VAR, 0, BM, BN>), C::LDS_BYTES) != CLN_OK)
+      return CLN_ERR_LAUNCH;
+    CLN_LAUNCH((hgemm_w4_kernel<LAYOUT, 5, VAR, 0, BM, BN>), dim3(tiles, S), dim3(256), C::LDS_BYTES, stream, (const half_t*)a, (const half_t*)b,
+               reinterpret_cast<half_t*>(ws), M, N, Kl, tiles_m, tiles_n, sw, tiles_n);
+  }
+  int rc = cln_check_launch();
+  if (rc != CLN_OK) return rc;
+  CLN_LAUNCH((hgemm_splitk_reduce_kernel<BM, BN>), dim3(tiles * 4 * (BM / 32)), dim3(256), 0, stream, (const float*)ws, (half_t*)c, N, tiles_n, tiles, S);
+  return cln_check_launch();
+}
+
+}  // namespace hgemm

@@ -193,15 +193,28 @@ __global__ __launch_bounds__(256, 1) void hgemm_w4_kernel(const half_t* __restri
   }
   const int m0 = tm * BM, n0 = tn * BN;
 
+  // EPI 5 (split-K, hgemm_splitk.cuh): this workgroup multiplies K columns [blockIdx.y * K, (blockIdx.y + 1) * K) of a problem whose leading
+  // dimension (the whole K) rides in bits 8.. of `swizzle` in units of 64; every other form: ld == K, k0 == 0 (compile-time: same code as before)
   KFill<C, FM> fa;
-  fa.init(K, wave, lane);
   KFill<C, FN> fbt;
   NFillW<C, FN> fbn;
-  if constexpr (LAYOUT == TN) fbt.init(K, wave, lane);
-  else fbn.init(N, wave, lane);
-  const char* a_src = reinterpret_cast<const char*>(A + (size_t)m0 * K);
-  const char* b_src = (LAYOUT == TN) ? reinterpret_cast<const char*>(B + (size_t)n0 * K)
-                                     : reinterpret_cast<const char*>(B + n0);
+  const char* a_src;
+  const char* b_src;
+  if constexpr (EPI == 5) {
+    const int ld = (swizzle >> 8) * 64;
+    const size_t k0 = (size_t)blockIdx.y * K;
+    fa.init(ld, wave, lane);
+    if constexpr (LAYOUT == TN) fbt.init(ld, wave, lane);
+    else fbn.init(N, wave, lane);
+    a_src = reinterpret_cast<const char*>(A + (size_t)m0 * ld + k0);
+    b_src = (LAYOUT == TN) ? reinterpret_cast<const char*>(B + (size_t)n0 * ld + k0) : reinterpret_cast<const char*>(B + k0 * N + n0);
+  } else {
+    fa.init(K, wave, lane);
+    if constexpr (LAYOUT == TN) fbt.init(K, wave, lane);
+    else fbn.init(N, wave, lane);
+    a_src = reinterpret_cast<const char*>(A + (size_t)m0 * K);
+    b_src = (LAYOUT == TN) ? reinterpret_cast<const char*>(B + (size_t)n0 * K) : reinterpret_cast<const char*>(B + n0);
+  }
   const size_t a_step = 128;
   const size_t b_step = (LAYOUT == TN) ? (size_t)128 : (size_t)64 * N * 2;
   const unsigned lds0 = lds_addr_of(smem);
@@ -350,7 +363,16 @@ __global__ __launch_bounds__(256, 1) void hgemm_w4_kernel(const half_t* __restri
   for (int i = 0; i < FM; ++i)
 #pragma unroll
     for (int j = 0; j < FN; ++j) asm volatile("" : "+a"(acc[i][j]));
-  if constexpr (EPI >= 2) {  // EPI 3 / 4 (probe library): the same epilogue with non-temporal / write-through C stores
+  if constexpr (EPI == 5) {
+    // split-K partial: the fp32 accumulators as they lie in the registers -- `Cmat` is the fp32 workspace, [split][tile][wave][fragment][lane] x 16 bytes,
+    // one store instruction = 1 KiB contiguous; the reduce kernel (hgemm_splitk.cuh) sums the splits and transposes through LDS
+    float* dst = reinterpret_cast<float*>(Cmat) + ((size_t)blockIdx.y * (tiles_m * tiles_n) + (size_t)tm * tiles_n + tn) * (BM * BN) +
+                 wave * (C::WTM * C::WTN) + lane * 4;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) *reinterpret_cast<f4*>(dst + (i * FN + j) * 256) = acc[i][j];
+  } else if constexpr (EPI >= 2) {  // EPI 3 / 4 (probe library): the same epilogue with non-temporal / write-through C stores
     // B1 of the last tile: every wave is past its last fragment read; no DMA is in flight
     store_wide_tile_via_lds<FM, FN, EPI - 2>(Cmat, N, m0 + wm * C::WTM, n0 + wn * C::WTN, lane, smem + wave * (64 * (FN * 32 + 16)), acc, (swizzle >> 1) & 1);
   } else {  // measurement-only variant: keep the accumulators live, store (almost) nothing

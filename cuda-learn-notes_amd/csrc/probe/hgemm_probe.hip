@@ -5,6 +5,7 @@
 #include "hgemm_mfma.cuh"
 #include "hgemm_w4.cuh"
 #include "hgemm_w4s.cuh"
+#include "hgemm_splitk.cuh"
 
 using namespace hgemm;
 
@@ -132,6 +133,18 @@ CLN_API int cln_hgemm_variant(int kind, int layout, int tile, int bk, int stages
       default: return CLN_ERR_BAD_ARG;
     }
 #undef W4S_CASE
+  }
+  if (kind == 17) {  // split-K over the one-wave-per-SIMD kernel (hgemm_splitk.cuh): `tile` = shape, `stages` = number of splits
+    static float* ws = nullptr;  // probe-only workspace: 512 MiB, allocated once
+    constexpr size_t WS_BYTES = 512u << 20;
+    if (!ws && hipMalloc(&ws, WS_BYTES) != hipSuccess) return ws = nullptr, CLN_ERR_LAUNCH;
+    if ((size_t)stages * M * N * 4 > WS_BYTES) return CLN_ERR_UNSUPPORTED;
+#define SK_SHAPE(TT, BMM, BNN)                                                                                              \
+  if (tile == TT) return layout == TN ? launch_w4_splitk<TN, 26, BMM, BNN>(a, b, c, ws, M, N, K, stages, stream)           \
+                                      : launch_w4_splitk<NN, 26, BMM, BNN>(a, b, c, ws, M, N, K, stages, stream);
+    SK_SHAPE(0, 256, 256) SK_SHAPE(1, 128, 256) SK_SHAPE(2, 256, 128) SK_SHAPE(3, 192, 256) SK_SHAPE(4, 192, 192) SK_SHAPE(5, 160, 160)
+#undef SK_SHAPE
+    return CLN_ERR_BAD_ARG;
   }
   if (kind == 6) return launch_pp<NN, 1, 4>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);  // 4-slot no-store probe
   if (kind == 7) {  // ablations of the 4-slot no-store probe; `stages` = ABL bits (results are garbage by design)

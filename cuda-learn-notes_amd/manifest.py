@@ -76,12 +76,12 @@ _add("hgemm", "G6", "mfma_ring<128x128,BK by stages,NN>",
      "hgemm_mma_m16n8k16_mma2x4_warp4x4_stages", "hgemm_mma_m16n8k16_mma2x4_warp4x4_stages_dsmem")
 _add("hgemm", "G6", "hgemm_w4<256x128> at stages=2 (K % 64 == 0, K >= 384 / 448 for an even / odd K / 64) | mfma_ring<256x128,8 waves,NN>", "hgemm_wmma_m16n16k16_mma4x2_warp4x4_stages_dsmem")
 _add("hgemm", "G6", "hgemm_w4<256x256> at stages=2 (K % 64 == 0, K >= 384 / 448 for an even / odd K / 64) | hgemm_w4s<256x256, ring of `stages` 32-deep slots> at stages 3 / 4 / 5 | mfma_ring<256x256,8 waves,NN>", "hgemm_wmma_m16n16k16_mma4x4_warp4x4_stages_dsmem")
-_add("hgemm", "G6", "best<NN>: tile shape by estimated CU utilisation x kernel efficiency (csrc/hgemm.hip best_plan): hgemm_w4<256x256x64, one wave per SIMD> (stages 2) / hgemm_w4s<256x256, ring of `stages` 32-deep K slots, one wave per SIMD> (stages 3 / 4 / 5; bit-identical) -- hgemm_pp<256x256x64> / hgemm_pp32<4x32 ring> (stages 4) when K is < 384 or has an odd number < 7 of 64-wide tiles | hgemm_pp<192x256x64> | mfma_ring<128x256> | <64x128> | <64x64> (small problems) | <128x128> (see DISPATCH_EXAMPLES)",
+_add("hgemm", "G6", "best<NN>: tile shape by estimated CU utilisation x kernel efficiency (csrc/hgemm.hip best_plan): hgemm_w4<256x256x64, one wave per SIMD> (stages 2) / hgemm_w4s<256x256, ring of `stages` 32-deep K slots, one wave per SIMD> (stages 3 / 4 / 5; bit-identical) -- hgemm_pp<256x256x64> / hgemm_pp32<4x32 ring> (stages 4) when K is < 384 or has an odd number < 7 of 64-wide tiles | hgemm_pp<192x256x64> | mfma_ring<128x256> | <64x128> | <64x64> (small problems) | <128x128> | split-K over hgemm_w4 + hgemm_splitk_reduce (K >= 4096 and M N <= 2048^2: few tiles, long K; fp32 partials in a library-owned per-stream workspace) (see DISPATCH_EXAMPLES)",
      "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem", "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_x4",
      "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_rr",
      "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_swizzle")
 _add("hgemm", "G6", "mfma_ring<128x128,TN>", "hgemm_mma_m16n8k16_mma2x4_warp4x4_stages_dsmem_tn")
-_add("hgemm", "G6", "best<TN>: hgemm_w4 / hgemm_w4s / hgemm_pp / hgemm_pp32 / mfma_ring as for NN (see DISPATCH_EXAMPLES)", "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_tn_swizzle_x4")
+_add("hgemm", "G6", "best<TN>: hgemm_w4 / hgemm_w4s / hgemm_pp / hgemm_pp32 / mfma_ring / split-K as for NN (see DISPATCH_EXAMPLES)", "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_tn_swizzle_x4")
 _add("hgemm", "G6", "hgemm_w4<128x256> at stages=2 (K % 64 == 0, K >= 384 / 448 for an even / odd K / 64) | mfma_ring<128x256,8 waves,TN>", "hgemm_mma_stages_block_swizzle_tn_cute")
 
 # ---------------------------------------------------------------- flash-attn (28 + 3)
@@ -276,6 +276,7 @@ def entries_of(lib):
 # dims = (M, N, K) for HGEMM names, (B, H, N, D) for flash-attn names. tests/test_describe.py asserts this table
 # against the built library on a CPU-only box, so a change of the dispatch policy that is not reflected here fails CI.
 _W4X2 = "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem"
+_SK = " (K %d per workgroup, fp32 partials in register layout) + hgemm_splitk_reduce [stages ignored: one pipeline]"
 _SQKV = "flash_attn_mma_stages_split_q_shared_qkv"
 _TQKV = "flash_attn_mma_stages_split_q_tiling_qkv"
 _IGN = " [stages ignored: one pipeline]"
@@ -309,6 +310,15 @@ DISPATCH_EXAMPLES = [
     (_W4X2, (1792, 1792, 1792), 2, "mfma_ring<64x128x64,4 waves,stages=2,NN>"),
     (_W4X2, (2048, 2048, 2048), 2, "mfma_ring<64x128x64,4 waves,stages=2,NN>"),
     (_W4X2, (1024, 1024, 1024), 2, "mfma_ring<64x64x64,4 waves,stages=2,NN>"),
+    # few output tiles, long K (K >= 4096, M N <= 2048^2): split-K over the same kernel, tile and number of splits from a fitted time model
+    (_W4X2, (1024, 1024, 16384), 2, "hgemm_w4<128x256x64,4 waves,64x128 wave tiles,cross-tile LDS-DMA,NN> split-K x 8" + _SK % 2048),
+    (_W4X2, (128, 8192, 8192), 3, "hgemm_w4<128x256x64,4 waves,64x128 wave tiles,cross-tile LDS-DMA,NN> split-K x 8" + _SK % 1024),
+    (_W4X2, (2048, 2048, 16384), 2, "hgemm_w4<256x256x64,4 waves,128x128 wave tiles,cross-tile LDS-DMA,NN> split-K x 4" + _SK % 4096),
+    (_W4X2, (768, 768, 12288), 2, "hgemm_w4<192x192x64,4 waves,96x96 wave tiles,cross-tile LDS-DMA,NN> split-K x 12" + _SK % 1024),
+    (_W4X2 + "_tn_swizzle_x4", (640, 5120, 5120), 2, "hgemm_w4<160x160x64,4 waves,80x80 wave tiles,cross-tile LDS-DMA,TN> split-K x 2" + _SK % 2560),
+    (_W4X2, (2048, 2048, 4096), 2, "mfma_ring<64x128x64,4 waves,stages=2,NN>"),      # M N > 1536^2 needs K >= 5120
+    (_W4X2, (1024, 1024, 2048), 2, "mfma_ring<64x64x64,4 waves,stages=2,NN>"),       # K < 4096: single pass
+    (_W4X2, (2560, 2560, 8192), 2, "hgemm_w4<160x160x64,4 waves,80x80 wave tiles,cross-tile LDS-DMA,LDS epilogue,NN>"),  # M N > 2048^2: single pass
     (_W4X2 + "_tn_swizzle_x4", (4096, 4096, 4096), 2, "hgemm_w4<256x256x64,4 waves,128x128 wave tiles,cross-tile LDS-DMA,LDS epilogue,TN>"),
     ("hgemm_mma_m16n8k16_mma2x4_warp4x4_stages_dsmem", (4096, 4096, 4096), 3, "mfma_ring<128x128x32,4 waves,stages=3,NN>"),
     ("hgemm_mma_m16n8k16_mma2x4_warp4x4_stages_dsmem", (4096, 4096, 4096), 5, "mfma_ring<128x128x32,4 waves,stages=5,NN>"),

@@ -32,6 +32,8 @@ timeout 300 python $T/fa_ck_probe.py 2>&1 | grep "^CK" > $OUT/${TAG}_fa_ck_tile_
 # round 4: the single-stage attention forms, the ring-of-slots HGEMM, the fp32-scaled attention form, back-to-back launch stress
 timeout 300 python $T/fa_one_stage_probe.py 2>&1 | grep "^ONE" > $OUT/${TAG}_fa_one_stage_probe.log; echo "one-stage probe rc=$?"
 timeout 300 python $T/hg_w4s_probe.py 2>&1 | grep "^W4S" > $OUT/${TAG}_hgemm_w4s_probe.log; echo "w4s probe rc=$?"
+timeout 400 python $T/hg_rect_probe.py squares 2>&1 | grep "^RECT" > $OUT/${TAG}_hgemm_reference_sweep.log; echo "reference sweep rc=$?"
+timeout 300 python $T/hg_rect_probe.py 2>&1 | grep "^RECT" > $OUT/${TAG}_hgemm_rect_probe.log; echo "rect probe rc=$?"
 timeout 300 python $T/fa_small_grid_probe.py 2>&1 | grep "^SMALLGRID" > $OUT/${TAG}_fa_small_grid_probe.log; echo "small grid probe rc=$?"
 timeout 300 python $T/fa_fscale_probe.py 2>&1 | grep "^FSCALE" > $OUT/${TAG}_fa_fscale_probe.log; echo "fscale probe rc=$?"
 ( NBUF=16 FORMS=stages=2,stages=1 timeout 300 python $T/fa_race_stress.py 1 32 4096 512 60; NBUF=16 FORMS=stages=2,stages=1 timeout 300 python $T/fa_race_stress.py 4 8 2048 64 100;

@@ -67,7 +67,7 @@ def test_hgemm_tile_policy_invariants_over_a_grid_of_shapes(built):
     nn = "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem"
     tn = "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_tn_swizzle_x4"
     sizes = [64, 128, 192, 256, 320, 384, 512, 640, 960, 1024, 1280, 1536, 1600, 1920, 2048, 2240, 2560, 3072, 3200, 4096, 4160, 4800]
-    ks = [64, 128, 320, 384, 448, 512, 576, 1024, 4096, 4160]
+    ks = [64, 128, 320, 384, 448, 512, 576, 1024, 4096, 4160, 8192]
     seen = set()
     for M in sizes:
         for N in sizes[::2] + [M]:
@@ -78,7 +78,13 @@ def test_hgemm_tile_policy_invariants_over_a_grid_of_shapes(built):
                     bm, bn = int(bm), int(bn)
                     assert M % bm == 0 and N % bn == 0, (M, N, K, t)
                     seen.add((fam, bm, bn))
-                    if fam == "hgemm_w4":
+                    if "split-K" in t:  # few tiles, long K (csrc/hgemm.hip splitk_plan): S whole slices, each a K the peeled structure covers
+                        S, kl = map(int, re.search(r"split-K x (\d+) \(K (\d+) per workgroup", t).groups())
+                        assert fam == "hgemm_w4" and 2 <= S <= 32 and kl * S == K and K >= 4096 and M * N <= 2048 * 2048, (M, N, K, t)
+                        assert kl % 64 == 0 and kl // 64 >= (7 if (kl // 64) & 1 else 6), (M, N, K, t)
+                        assert S * M * N * 4 <= 256 << 20 and "stages ignored" in t, (M, N, K, t)
+                        seen.add(("split-K", bm, bn))
+                    elif fam == "hgemm_w4":
                         nt = K // 64
                         assert K % 64 == 0 and nt >= (7 if nt & 1 else 6), (M, N, K, t)
                         assert not (bm == 256 and bn == 256 and stages != 2), (M, N, K, stages, t)
@@ -88,7 +94,7 @@ def test_hgemm_tile_policy_invariants_over_a_grid_of_shapes(built):
                     assert t2.replace(",TN>", ",NN>") == t and ",TN>" in t2, (t, t2)
     # the policy actually uses its repertoire on this grid
     for want in (("hgemm_w4", 256, 256), ("hgemm_w4", 160, 160), ("hgemm_w4", 192, 192), ("hgemm_w4", 128, 256),
-                 ("mfma_ring", 64, 64), ("hgemm_pp", 256, 256)):
+                 ("mfma_ring", 64, 64), ("hgemm_pp", 256, 256), ("split-K", 128, 256), ("split-K", 160, 160), ("split-K", 192, 192), ("split-K", 256, 256)):
         assert want in seen, (want, sorted(seen))
     # a shape no tile divides is refused, not mis-tiled
     with pytest.raises(ValueError):

@@ -514,3 +514,79 @@ def test_seeded_fuzz_over_shapes_stages_and_swizzle(hg, built, dev):
         nn(ad, bd, co, other, not swz, stride)
         assert torch.equal(co, c), (case, (M, N, K), stages, other, what, built.manifest.describe(nn_name, (M, N, K), other))
     assert len(kinds) >= 3, kinds  # the sample reached several kernel families
+
+
+SPLIT_K_SHAPES = [(1024, 1024, 16384), (128, 8192, 8192), (256, 4096, 4096), (768, 768, 12288), (640, 5120, 5120), (1536, 1536, 8192),
+                  (2048, 2048, 16384), (256, 256, 16384), (1024, 1024, 4160), (384, 768, 4480), (2048, 2048, 8960), (1536, 2048, 8192),
+                  (192, 256, 16384), (960, 960, 4480), (1344, 1344, 4480)]
+
+
+@pytest.mark.parametrize("M,N,K", SPLIT_K_SHAPES)
+def test_split_k_full_matrix(hg, built, dev, M, N, K):
+    """Few output tiles, long K (csrc/hgemm_splitk.cuh: K split over S workgroups per tile of the one-wave-per-SIMD kernel, fp32 partials in
+    register layout, one reduce launch): the FULL matrix against the fp32 product at every tile shape the plan uses (256x256, 192x256, 192x192,
+    128x256, 160x160), even and odd numbers of K tiles per split, S from 2 to 32; TN equals NN bit for bit; `stages` is ignored."""
+    from cuda_learn_notes_amd.bench_utils import as_col_major
+    name = "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem"
+    what = built.manifest.describe(name, (M, N, K), 2)
+    assert "split-K x " in what and "hgemm_splitk_reduce" in what, what
+    a, b = seeded(M + K, M, K), seeded(N + K, K, N)
+    ad, bd = a.to(dev), b.to(dev)
+    c = torch.full((M, N), float("nan"), dtype=torch.half, device=dev)
+    getattr(hg, name)(ad, bd, c, 2, True, 2048)
+    check(c, a, b)
+    ct = torch.full((M, N), float("nan"), dtype=torch.half, device=dev)
+    hg.hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_tn_swizzle_x4(ad, as_col_major(b).to(dev), ct, 4, False, 0)
+    assert torch.equal(ct, c), what
+
+
+def test_split_k_workspace_grows_and_is_per_stream(hg, built, dev):
+    """The fp32 workspace is owned by the library, one per stream, allocated on first use and grown on demand: a small problem, then a larger
+    one, then the small one again on the same stream, and two problems interleaved on two streams, all give the single-stream results."""
+    name = "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem"
+    fn = getattr(hg, name)
+    probs = []
+    for (M, N, K) in ((256, 256, 8192), (1024, 1024, 16384), (256, 512, 4096)):
+        a, b = seeded(M + 7, M, K).to(dev), seeded(N + 9, K, N).to(dev)
+        c = torch.zeros(M, N, dtype=torch.half, device=dev)
+        fn(a, b, c, 2, False, 0)
+        probs.append((a, b, c))
+    torch.cuda.synchronize()
+    for (a, b, c) in probs:
+        check(c, a.cpu(), b.cpu())
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for rnd in range(3):
+        for st, (a, b, c) in ((s1, probs[0]), (s2, probs[1]), (s1, probs[2]), (s2, probs[0])):
+            o = torch.zeros_like(c)
+            with torch.cuda.stream(st):
+                fn(a, b, o, 2, False, 0)
+            outs.append((o, c))
+    torch.cuda.synchronize()
+    for o, c in outs:
+        assert torch.equal(o, c)
+
+
+def test_split_k_under_stream_capture(hg, built, dev):
+    """A captured launch replays: the workspace the stream already owns is used inside a graph; a stream that owns none yet (allocation is not
+    allowed while capturing) takes the single-pass plan -- same result within the parity tolerance either way."""
+    name = "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem"
+    fn = getattr(hg, name)
+    M, N, K = 512, 512, 8192
+    a, b = seeded(3, M, K), seeded(4, K, N)
+    ad, bd = a.to(dev), b.to(dev)
+    for warm in (True, False):
+        st = torch.cuda.Stream()
+        c = torch.zeros(M, N, dtype=torch.half, device=dev)
+        with torch.cuda.stream(st):
+            if warm:
+                fn(ad, bd, c, 2, False, 0)  # the stream's workspace now exists
+                st.synchronize()
+                c.zero_()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=st):
+                fn(ad, bd, c, 2, False, 0)
+            g.replay()
+            g.replay()
+        torch.cuda.synchronize()
+        check(c, a, b)

@@ -96,13 +96,15 @@ def test_one_wave_per_simd_hgemm_instantiations_are_exactly_the_plannable_ones(b
     m = built.manifest
     linked = set()
     linked_s = set()
+    linked_k = set()  # split-K forms (csrc/hgemm_splitk.cuh)
     fams = set()
     for fam, a in kernel_handles(_loader.so_path("libcln_amd.so")):
         if fam.startswith("hgemm::"):
             fams.add(fam.split("::")[1])
         if fam == "hgemm::hgemm_w4_kernel":
-            assert a[1:4] == ["3", "26", "0"], a  # LDS epilogue with non-temporal C stores, the production schedule, no ablation
-            linked.add((int(a[0]), int(a[4]), int(a[5]), a[6] == "true"))
+            # LDS epilogue with non-temporal C stores (3) or the split-K partial store (5), the production schedule, no ablation
+            assert a[1] in ("3", "5") and a[2:4] == ["26", "0"], a
+            (linked_k if a[1] == "5" else linked).add((int(a[0]), int(a[4]), int(a[5]), a[6] == "true"))
         if fam == "hgemm::hgemm_w4s_kernel":  # <layout, ring depth, epilogue>: stages 3 / 4 / 5 of the 256x256 names (2 is the probe library's)
             assert a[2] == "3" and a[1] in ("3", "4", "5"), a
             linked_s.add((int(a[0]), int(a[1])))
@@ -113,9 +115,10 @@ def test_one_wave_per_simd_hgemm_instantiations_are_exactly_the_plannable_ones(b
             t = m.describe(name, (4096, 4096, 4096), st)
             assert t.startswith("hgemm_w4s<256x256,ring of %d x 32-deep" % st) and t.endswith(layout + ">"), t
             assert not m.describe(name, (4096, 4096, 32 * 2 * st - 64), st).startswith("hgemm_w4s"), st  # fewer than 2 S slots: another kernel
-    assert fams == {"hgemm_w4_kernel", "hgemm_w4s_kernel", "hgemm_pp_kernel", "hgemm_pp32_kernel", "hgemm_ring_kernel", "hgemm_1stage_kernel", "hgemm_mfma_naive_kernel",
+    assert fams == {"hgemm_w4_kernel", "hgemm_w4s_kernel", "hgemm_splitk_reduce_kernel", "hgemm_pp_kernel", "hgemm_pp32_kernel", "hgemm_ring_kernel", "hgemm_1stage_kernel", "hgemm_mfma_naive_kernel",
                     "hgemm_valu_tile_kernel", "hgemm_naive_f16_kernel", "hgemm_sliced_k_f16_kernel"}, sorted(fams)
     plannable = set()
+    plannable_k = set()
     rows = [("hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem", 0), ("hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_tn_swizzle_x4", 1),
             ("hgemm_wmma_m16n16k16_mma4x2_warp4x4_stages_dsmem", 0), ("hgemm_wmma_m16n16k16_mma4x4_warp4x4_stages_dsmem", 0),
             ("hgemm_mma_stages_block_swizzle_tn_cute", 1)]
@@ -123,13 +126,20 @@ def test_one_wave_per_simd_hgemm_instantiations_are_exactly_the_plannable_ones(b
     for name, layout in rows:
         for M in sizes:
             for N in sizes:
-                for K in (384, 448, 512, 4096, 4160):
+                for K in (384, 448, 512, 4096, 4160, 4480, 8192, 8960, 12288):
+                    if K > 4160 and M * N > 2048 * 2048:
+                        continue
                     try:
                         t = m.describe(name, (M, N, K), 2)
                     except ValueError:
                         continue
                     mm = re.match(r"hgemm_w4<(\d+)x(\d+)x64", t)
-                    if mm:
+                    sk = re.search(r"split-K x \d+ \(K (\d+) per workgroup", t)
+                    if mm and sk:
+                        plannable_k.add((layout, int(mm.group(1)), int(mm.group(2)), bool((int(sk.group(1)) // 64) & 1)))
+                    elif mm:
                         plannable.add((layout, int(mm.group(1)), int(mm.group(2)), bool((K // 64) & 1)))
     assert linked - plannable == set(), sorted(linked - plannable)
     assert plannable - linked == set(), sorted(plannable - linked)
+    assert linked_k - plannable_k == set(), sorted(linked_k - plannable_k)
+    assert plannable_k - linked_k == set(), sorted(plannable_k - linked_k)

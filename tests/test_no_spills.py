@@ -53,7 +53,10 @@ def test_inline_asm_mfma_stream_of_the_one_wave_per_simd_hgemm(tmp_path):
     import kernel_resources as kr
     kernels, s = kr.report(os.path.join(ROOT, "cuda-learn-notes_amd", "csrc", "hgemm.hip"), keep=str(tmp_path))
     w4 = [k for k in kernels if "hgemm_w4_kernel" in k["demangled"]]
-    assert len(w4) == 28, [k["demangled"] for k in w4]  # 256x256, 192x256, 256x192, 192x192, 128x256, 256x128, 160x160 tiles x NN / TN x even / odd K tile count
+    # 256x256, 192x256, 256x192, 192x192, 128x256, 256x128, 160x160 tiles x NN / TN x even / odd K tile count, plus the split-K forms (EPI 5: partial
+    # store instead of the LDS epilogue) of 256x256, 192x256, 192x192, 128x256, 160x160
+    assert len(w4) == 28 + 20, [k["demangled"] for k in w4]
+    assert sum("hgemm_w4_kernel<0, 5," in k["demangled"] or "hgemm_w4_kernel<1, 5," in k["demangled"] for k in w4) == 20
     text = open(s).read()
     for k in w4:
         assert k["agpr"] in (256, 192, 144, 128, 100) and k["spill"] == 0 and k["scratch"] == 0, k
