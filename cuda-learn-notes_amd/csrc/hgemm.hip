@@ -43,7 +43,7 @@ int check_args(const void* a, const void* b, const void* c, int M, int N, int K)
 // 1066 for the previous policy, rocBLAS TN 894 / 1185), w4 160x160 at 2560 / 3200 (1065-1126 / 1080 TF vs 1015-1039 for 128x256 and 857 for the 64x128 ring; rocBLAS TN 900-1006 / 915), w4 192x256 at 4608 / 6144 (1356 / 1502 vs
 // 1146 / 1266, rocBLAS TN 1216 / 1388), w4 256x256 at 3584 / 4096 / 7680 / 8192.
 enum BestPlan { PLAN_PP256 = 0, PLAN_PP192, PLAN_R128x256, PLAN_R64x128, PLAN_R128, PLAN_W256, PLAN_W192x256, PLAN_W256x192, PLAN_W192, PLAN_W128x256, PLAN_W256x128, PLAN_R64x64, PLAN_W160 };
-int best_plan(int M, int N, int K) {
+int best_plan(int M, int N, int K, double* best_score = nullptr) {
   auto score = [](long long tiles, int slots, double eff) {
     if (tiles <= 0) return 0.0;
     const long long rounds = (tiles + slots - 1) / slots;
@@ -57,6 +57,7 @@ int best_plan(int M, int N, int K) {
   // (profiles/r04_hgemm_small_mn_long_k_probe.log, C-ABI timed) the 64x64 ring wins all of 1024^2 / 1152^2 / 1280^2 / 1536^2 / 1600^2 at
   // K = 4096 ... 16384 by 7-27 % over what the model picked (1600^2 x 16384: 669 vs 593 TF for hgemm_w4<160x160>, 100 tiles on 256 CUs;
   // 1280^2 x 4096: 434 vs 330) -- the model prices a tile against a FULL chip and these grids do not fill it.
+  if (best_score) *best_score = 0.0;
   if (M % 64 == 0 && N % 64 == 0 && K % 64 == 0 && (long long)(M / 64) * (N / 64) <= 640) return PLAN_R64x64;
   double best = -1.0;
   int plan = PLAN_R128;
@@ -82,6 +83,7 @@ int best_plan(int M, int N, int K) {
     if (M % 192 == 0 && N % 256 == 0) offer(PLAN_W192x256, score((long long)(M / 192) * (N / 256), 256, 0.96));
     if (M % 256 == 0 && N % 256 == 0) offer(PLAN_W256, score((long long)(M / 256) * (N / 256), 256, 1.00));
   }
+  if (best_score) *best_score = best;
   return plan;
 }
 // ---- split-K (hgemm_splitk.cuh): few output tiles, long K ------------------------------------------------------------------------------
@@ -166,6 +168,53 @@ int splitk_dispatch(const SplitK& sk, const void* a, const void* b, void* c, flo
   return CLN_ERR_UNSUPPORTED;
 }
 
+// ---- tail split (hgemm_splitk.cuh launch_w4_tail_split): a count of 256 x 256 tiles just past whole rounds of 256 ---------------------------
+// 4352^3 = 289 tiles, 5888^3 = 529, 7168^3 = 784 (sizes of the reference's sweep): the last round runs 16-33 tiles on 256 CUs and still costs
+// 0.55-0.7 of a full one. The last r tile rows go to split-K (all CUs busy for K / S), rows above them fill whole rounds:
+// profiles/r04_hgemm_tail_probe.log -- 4352^3 1032 -> 1223 TF (rocBLAS TN 1188), 5888^3 1162 -> 1337, 7168^3 1270 -> 1438, 9216^3 1381 -> 1450;
+// it loses where another tile shape already fills the rounds (4608^3: 192 x 256 tiles 1308 vs 1228) or the tail is most of a round (5120^3, 8704^3).
+// Decision by time estimates: a full round of 256 x 256 tiles T = 1.42 us x K / 64 + 5 us (95 us at 4096^3, 182 us per round at 8192^3), a last
+// round of fraction f costs (0.55 + 0.45 f) T (measured 0.54-0.70 for f = 0.06-0.44), the split-K part by splitk_plan's model; taken when the
+// single-pass 256 x 256 score times t_single / t_tail beats best_plan's best score by 3 %.
+struct TailSplit {
+  int m_split = 0, S = 0;
+};
+TailSplit tail_plan(int M, int N, int K) {
+  TailSplit out;
+  if (M % 256 || N % 256 || !w4_k_ok(K)) return out;
+  const long long tm = M / 256, tn = N / 256, tiles = tm * tn;
+  if (tiles <= 256 || tiles % 256 == 0) return out;
+  const double T = 1.42 * (K / 64) + 5.0;
+  auto rounds_time = [&](long long n) {
+    const long long full = n / 256, rest = n % 256;
+    return T * ((double)full + (rest ? 0.55 + 0.45 * (double)rest / 256.0 : 0.0));
+  };
+  const double t_single = rounds_time(tiles);
+  double t_best = 1e30;
+  for (long long r = 1; r < tm && r * tn <= 256; ++r) {
+    const long long tiles_a = (tm - r) * tn, tiles_b = r * tn;
+    if (tiles_a < 224) break;  // the rows above must still (nearly) fill a round
+    for (int S = 2; S <= 8; ++S) {
+      if (!w4_splitk_ok(K, S) || tiles_b * S > 512 || (double)S * (double)(r * 256) * (double)N * 4.0 > (double)SPLITK_WS_MAX) continue;
+      const long long n = tiles_b * S, rounds = (n + 255) / 256;
+      const double fill = n >= 256 ? 1.0 : (double)n / 256.0;
+      const double tau = 2.0 * 256 * 256 * 64.0 / (5.86e6 * 1.249) * (1.0 - 0.338 * (1.0 - fill));
+      const double mn_b = (double)(r * 256) * (double)N;
+      const double t_b = rounds * ((double)(K / S / 64) * tau + 3.88) + 5.18 + (4.0 * S * mn_b + 2.0 * mn_b) / 3.615e6;
+      const double t = rounds_time(tiles_a) + t_b;
+      if (t < t_best) t_best = t, out.m_split = (int)((tm - r) * 256), out.S = S;
+    }
+  }
+  if (out.S == 0) return out;
+  double best_score = 0.0;
+  (void)best_plan(M, N, K, &best_score);
+  const long long rounds = (tiles + 255) / 256;
+  const double util = (double)tiles / (double)(rounds * 256);
+  const double score_tail = util * (1.0 + 0.5 * (1.0 - util)) * t_single / t_best;
+  if (score_tail < 1.03 * best_score) out = TailSplit();
+  return out;
+}
+
 int plan_tile(int plan) {
   switch (plan) {
     case PLAN_R128x256: return T128x256;
@@ -194,6 +243,11 @@ int best_dispatch(const void* a, const void* b, void* c, int M, int N, int K, in
   if (sk.S >= 2) {  // few tiles, long K: K split over S workgroups per tile, fp32 partials, one reduce launch (`stages` ignored: one pipeline)
     float* ws = splitk_workspace(st, (size_t)sk.S * M * N * sizeof(float));
     if (ws) return splitk_dispatch<LAYOUT>(sk, a, b, c, ws, M, N, K, st);
+  }
+  const TailSplit ts = tail_plan(M, N, K);
+  if (ts.S >= 2) {  // a few tiles past whole rounds: the last tile rows split over K (`stages` ignored)
+    float* ws = splitk_workspace(st, (size_t)ts.S * (M - ts.m_split) * N * sizeof(float));
+    if (ws) return launch_w4_tail_split<LAYOUT, W4_EPILOGUE, W4_PRODUCTION, 256, 256>(a, b, c, ws, M, N, K, ts.m_split, ts.S, swizzle, stride, st);
   }
   int plan = best_plan(M, N, K);
   if (plan == PLAN_W192) return launch_w4<LAYOUT, W4_EPILOGUE, W4_PRODUCTION, 0, 192, 192>(a, b, c, M, N, K, swizzle, stride, st);
@@ -240,6 +294,11 @@ int describe_best(int layout, int M, int N, int K, int stages, char* buf, int le
   if (sk.S >= 2)
     return snprintf(buf, len, "hgemm_w4<%dx%dx64,4 waves,%dx%d wave tiles,cross-tile LDS-DMA,%s> split-K x %d (K %d per workgroup, fp32 partials in "
                               "register layout) + hgemm_splitk_reduce [stages ignored: one pipeline]", sk.bm, sk.bn, sk.bm / 2, sk.bn / 2, l, sk.S, K / sk.S);
+  const TailSplit ts = tail_plan(M, N, K);
+  if (ts.S >= 2)
+    return snprintf(buf, len, "hgemm_w4<256x256x64,4 waves,128x128 wave tiles,cross-tile LDS-DMA,LDS epilogue,%s> on rows [0, %d) + the last %d tile rows as "
+                              "split-K x %d (K %d per workgroup) + hgemm_splitk_reduce [tail split; stages ignored: one pipeline]", l, ts.m_split,
+                    (M - ts.m_split) / 256, ts.S, K / ts.S);
   if (plan == PLAN_W192) return describe_w4(192, 192, layout, buf, len, stages != 2);
   if (plan == PLAN_W192x256) return describe_w4(192, 256, layout, buf, len, stages != 2);
   if (plan == PLAN_W256x192) return describe_w4(256, 192, layout, buf, len, stages != 2);

@@ -84,4 +84,19 @@ int launch_w4_splitk(const void* a, const void* b, void* c, float* ws, int M, in
   return cln_check_launch();
 }
 
+// Tail split (round 4): a tile count just past a whole number of rounds of 256 (4352^3: 289 tiles of 256 x 256, 5888^3: 529, 7168^3: 784) leaves the
+// last round almost empty. The output is cut along M: rows [0, m_split) -- whole rounds of tiles -- run the single-pass kernel, the remaining
+// tile rows run split-K so that they, too, spread over the chip. Both are the launchers above / in hgemm_w4.cuh on sub-matrices (row offsets
+// only: leading dimensions unchanged), back to back on the caller's stream.
+template <int LAYOUT, int EPI, int VAR, int BM, int BN>
+int launch_w4_tail_split(const void* a, const void* b, void* c, float* ws, int M, int N, int K, int m_split, int S, int swizzle, int swizzle_stride,
+                         hipStream_t stream) {
+  if (m_split <= 0 || m_split >= M || m_split % BM || (M - m_split) % BM) return CLN_ERR_UNSUPPORTED;
+  int rc = launch_w4<LAYOUT, EPI, VAR, 0, BM, BN>(a, b, c, m_split, N, K, swizzle, swizzle_stride, stream);
+  if (rc != CLN_OK) return rc;
+  const half_t* a2 = reinterpret_cast<const half_t*>(a) + (size_t)m_split * K;
+  half_t* c2 = reinterpret_cast<half_t*>(c) + (size_t)m_split * N;
+  return launch_w4_splitk<LAYOUT, VAR, BM, BN>(a2, b, c2, ws, M - m_split, N, K, S, stream);
+}
+
 }  // namespace hgemm

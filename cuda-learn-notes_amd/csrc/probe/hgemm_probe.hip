@@ -146,6 +146,15 @@ CLN_API int cln_hgemm_variant(int kind, int layout, int tile, int bk, int stages
 #undef SK_SHAPE
     return CLN_ERR_BAD_ARG;
   }
+  if (kind == 18) {  // tail split: `tile` = tile rows (of 256) given to split-K, `stages` = number of splits
+    static float* ws = nullptr;
+    constexpr size_t WS_BYTES = 512u << 20;
+    if (!ws && hipMalloc(&ws, WS_BYTES) != hipSuccess) return ws = nullptr, CLN_ERR_LAUNCH;
+    if ((size_t)stages * tile * 256 * N * 4 > WS_BYTES) return CLN_ERR_UNSUPPORTED;
+    const int m_split = M - tile * 256;
+    return layout == TN ? launch_w4_tail_split<TN, 3, 26, 256, 256>(a, b, c, ws, M, N, K, m_split, stages, swizzle, swizzle_stride, stream)
+                        : launch_w4_tail_split<NN, 3, 26, 256, 256>(a, b, c, ws, M, N, K, m_split, stages, swizzle, swizzle_stride, stream);
+  }
   if (kind == 6) return launch_pp<NN, 1, 4>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);  // 4-slot no-store probe
   if (kind == 7) {  // ablations of the 4-slot no-store probe; `stages` = ABL bits (results are garbage by design)
     switch (stages) {

@@ -76,7 +76,7 @@ _add("hgemm", "G6", "mfma_ring<128x128,BK by stages,NN>",
      "hgemm_mma_m16n8k16_mma2x4_warp4x4_stages", "hgemm_mma_m16n8k16_mma2x4_warp4x4_stages_dsmem")
 _add("hgemm", "G6", "hgemm_w4<256x128> at stages=2 (K % 64 == 0, K >= 384 / 448 for an even / odd K / 64) | mfma_ring<256x128,8 waves,NN>", "hgemm_wmma_m16n16k16_mma4x2_warp4x4_stages_dsmem")
 _add("hgemm", "G6", "hgemm_w4<256x256> at stages=2 (K % 64 == 0, K >= 384 / 448 for an even / odd K / 64) | hgemm_w4s<256x256, ring of `stages` 32-deep slots> at stages 3 / 4 / 5 | mfma_ring<256x256,8 waves,NN>", "hgemm_wmma_m16n16k16_mma4x4_warp4x4_stages_dsmem")
-_add("hgemm", "G6", "best<NN>: tile shape by estimated CU utilisation x kernel efficiency (csrc/hgemm.hip best_plan): hgemm_w4<256x256x64, one wave per SIMD> (stages 2) / hgemm_w4s<256x256, ring of `stages` 32-deep K slots, one wave per SIMD> (stages 3 / 4 / 5; bit-identical) -- hgemm_pp<256x256x64> / hgemm_pp32<4x32 ring> (stages 4) when K is < 384 or has an odd number < 7 of 64-wide tiles | hgemm_pp<192x256x64> | mfma_ring<128x256> | <64x128> | <64x64> (small problems) | <128x128> | split-K over hgemm_w4 + hgemm_splitk_reduce (K >= 4096 and M N <= 2048^2: few tiles, long K; fp32 partials in a library-owned per-stream workspace) (see DISPATCH_EXAMPLES)",
+_add("hgemm", "G6", "best<NN>: tile shape by estimated CU utilisation x kernel efficiency (csrc/hgemm.hip best_plan): hgemm_w4<256x256x64, one wave per SIMD> (stages 2) / hgemm_w4s<256x256, ring of `stages` 32-deep K slots, one wave per SIMD> (stages 3 / 4 / 5; bit-identical) -- hgemm_pp<256x256x64> / hgemm_pp32<4x32 ring> (stages 4) when K is < 384 or has an odd number < 7 of 64-wide tiles | hgemm_pp<192x256x64> | mfma_ring<128x256> | <64x128> | <64x64> (small problems) | <128x128> | split-K over hgemm_w4 + hgemm_splitk_reduce (K >= 4096 and M N <= 2048^2: few tiles, long K; fp32 partials in a library-owned per-stream workspace) | tail split (a few 256x256 tiles past whole rounds of 256: the last tile rows as split-K) (see DISPATCH_EXAMPLES)",
      "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem", "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_x4",
      "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_rr",
      "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_swizzle")
@@ -316,6 +316,10 @@ DISPATCH_EXAMPLES = [
     (_W4X2, (2048, 2048, 16384), 2, "hgemm_w4<256x256x64,4 waves,128x128 wave tiles,cross-tile LDS-DMA,NN> split-K x 4" + _SK % 4096),
     (_W4X2, (768, 768, 12288), 2, "hgemm_w4<192x192x64,4 waves,96x96 wave tiles,cross-tile LDS-DMA,NN> split-K x 12" + _SK % 1024),
     (_W4X2 + "_tn_swizzle_x4", (640, 5120, 5120), 2, "hgemm_w4<160x160x64,4 waves,80x80 wave tiles,cross-tile LDS-DMA,TN> split-K x 2" + _SK % 2560),
+    # a few 256 x 256 tiles past whole rounds of 256: rows that fill whole rounds single-pass, the last tile rows split over K
+    (_W4X2, (4352, 4352, 4352), 2, "hgemm_w4<256x256x64,4 waves,128x128 wave tiles,cross-tile LDS-DMA,LDS epilogue,NN> on rows [0, 3840) + the last 2 tile rows as split-K x 4 (K 1088 per workgroup) + hgemm_splitk_reduce [tail split; stages ignored: one pipeline]"),
+    (_W4X2 + "_tn_swizzle_x4", (7168, 7168, 7168), 4, "hgemm_w4<256x256x64,4 waves,128x128 wave tiles,cross-tile LDS-DMA,LDS epilogue,TN> on rows [0, 6912) + the last 1 tile rows as split-K x 7 (K 1024 per workgroup) + hgemm_splitk_reduce [tail split; stages ignored: one pipeline]"),
+    (_W4X2, (4608, 4608, 4608), 2, "hgemm_w4<192x256x64,4 waves,96x128 wave tiles,cross-tile LDS-DMA,LDS epilogue,NN>"),  # another tile shape already fills the rounds
     (_W4X2, (2048, 2048, 4096), 2, "mfma_ring<64x128x64,4 waves,stages=2,NN>"),      # M N > 1536^2 needs K >= 5120
     (_W4X2, (1024, 1024, 2048), 2, "mfma_ring<64x64x64,4 waves,stages=2,NN>"),       # K < 4096: single pass
     (_W4X2, (2560, 2560, 8192), 2, "hgemm_w4<160x160x64,4 waves,80x80 wave tiles,cross-tile LDS-DMA,LDS epilogue,NN>"),  # M N > 2048^2: single pass

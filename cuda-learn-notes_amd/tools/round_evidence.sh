@@ -33,6 +33,7 @@ timeout 300 python $T/fa_ck_probe.py 2>&1 | grep "^CK" > $OUT/${TAG}_fa_ck_tile_
 timeout 300 python $T/fa_one_stage_probe.py 2>&1 | grep "^ONE" > $OUT/${TAG}_fa_one_stage_probe.log; echo "one-stage probe rc=$?"
 timeout 300 python $T/hg_w4s_probe.py 2>&1 | grep "^W4S" > $OUT/${TAG}_hgemm_w4s_probe.log; echo "w4s probe rc=$?"
 timeout 400 python $T/hg_rect_probe.py squares 2>&1 | grep "^RECT" > $OUT/${TAG}_hgemm_reference_sweep.log; echo "reference sweep rc=$?"
+timeout 400 python $T/hg_tail_probe.py 4352 4864 5888 6400 7168 7424 8448 9216 9472 10240 11008 11776 13056 2>&1 | grep "^TAIL" > $OUT/${TAG}_hgemm_tail_probe_after.log; echo "tail probe rc=$?"
 timeout 300 python $T/hg_rect_probe.py 2>&1 | grep "^RECT" > $OUT/${TAG}_hgemm_rect_probe.log; echo "rect probe rc=$?"
 timeout 300 python $T/fa_small_grid_probe.py 2>&1 | grep "^SMALLGRID" > $OUT/${TAG}_fa_small_grid_probe.log; echo "small grid probe rc=$?"
 timeout 300 python $T/fa_fscale_probe.py 2>&1 | grep "^FSCALE" > $OUT/${TAG}_fa_fscale_probe.log; echo "fscale probe rc=$?"

@@ -66,7 +66,7 @@ def test_hgemm_tile_policy_invariants_over_a_grid_of_shapes(built):
     m = built.manifest
     nn = "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem"
     tn = "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_tn_swizzle_x4"
-    sizes = [64, 128, 192, 256, 320, 384, 512, 640, 960, 1024, 1280, 1536, 1600, 1920, 2048, 2240, 2560, 3072, 3200, 4096, 4160, 4800]
+    sizes = [64, 128, 192, 256, 320, 384, 512, 640, 960, 1024, 1280, 1536, 1600, 1920, 2048, 2240, 2560, 3072, 3200, 4096, 4160, 4352, 4800]
     ks = [64, 128, 320, 384, 448, 512, 576, 1024, 4096, 4160, 8192]
     seen = set()
     for M in sizes:
@@ -78,7 +78,11 @@ def test_hgemm_tile_policy_invariants_over_a_grid_of_shapes(built):
                     bm, bn = int(bm), int(bn)
                     assert M % bm == 0 and N % bn == 0, (M, N, K, t)
                     seen.add((fam, bm, bn))
-                    if "split-K" in t:  # few tiles, long K (csrc/hgemm.hip splitk_plan): S whole slices, each a K the peeled structure covers
+                    if "tail split" in t:  # a few 256 x 256 tiles past whole rounds (csrc/hgemm.hip tail_plan)
+                        m_split, rows_b, S, kl = map(int, re.search(r"on rows \[0, (\d+)\) \+ the last (\d+) tile rows as split-K x (\d+) \(K (\d+) per", t).groups())
+                        assert (bm, bn) == (256, 256) and m_split + 256 * rows_b == M and kl * S == K and (M // 256) * (N // 256) > 256, (M, N, K, t)
+                        seen.add(("tail", bm, bn))
+                    elif "split-K" in t:  # few tiles, long K (csrc/hgemm.hip splitk_plan): S whole slices, each a K the peeled structure covers
                         S, kl = map(int, re.search(r"split-K x (\d+) \(K (\d+) per workgroup", t).groups())
                         assert fam == "hgemm_w4" and 2 <= S <= 32 and kl * S == K and K >= 4096 and M * N <= 2048 * 2048, (M, N, K, t)
                         assert kl % 64 == 0 and kl // 64 >= (7 if (kl // 64) & 1 else 6), (M, N, K, t)
@@ -94,7 +98,7 @@ def test_hgemm_tile_policy_invariants_over_a_grid_of_shapes(built):
                     assert t2.replace(",TN>", ",NN>") == t and ",TN>" in t2, (t, t2)
     # the policy actually uses its repertoire on this grid
     for want in (("hgemm_w4", 256, 256), ("hgemm_w4", 160, 160), ("hgemm_w4", 192, 192), ("hgemm_w4", 128, 256),
-                 ("mfma_ring", 64, 64), ("hgemm_pp", 256, 256), ("split-K", 128, 256), ("split-K", 160, 160), ("split-K", 192, 192), ("split-K", 256, 256)):
+                 ("mfma_ring", 64, 64), ("hgemm_pp", 256, 256), ("split-K", 128, 256), ("split-K", 160, 160), ("split-K", 192, 192), ("split-K", 256, 256), ("tail", 256, 256)):
         assert want in seen, (want, sorted(seen))
     # a shape no tile divides is refused, not mis-tiled
     with pytest.raises(ValueError):

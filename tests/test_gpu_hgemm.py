@@ -590,3 +590,30 @@ def test_split_k_under_stream_capture(hg, built, dev):
             g.replay()
         torch.cuda.synchronize()
         check(c, a, b)
+
+
+@pytest.mark.parametrize("M,N,K", [(4352, 4352, 4352), (5888, 5888, 1792), (4096, 4352, 2048), (4864, 4864, 4864)])
+def test_tail_split_matches_the_fp32_product(hg, built, dev, M, N, K):
+    """A count of 256 x 256 tiles just past whole rounds of 256 (csrc/hgemm.hip tail_plan): the rows that fill whole rounds run the single-pass
+    kernel, the last tile rows run split-K; sampled rows from both regions and the seam against the fp32 product, TN equals NN bit for bit,
+    every `stages` value gives the same bits (the plan ignores it)."""
+    import re
+    from cuda_learn_notes_amd.bench_utils import as_col_major, make_block_swizzle_stride
+    name = "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem"
+    what = built.manifest.describe(name, (M, N, K), 2)
+    assert "tail split" in what, what
+    m_split = int(re.search(r"on rows \[0, (\d+)\)", what).group(1))
+    torch.manual_seed(M + N + K)
+    a = torch.randn(M, K, dtype=torch.half, device=dev)
+    b = torch.randn(K, N, dtype=torch.half, device=dev)
+    rows = torch.unique(torch.tensor([0, 255, m_split // 2, m_split - 1, m_split, m_split + 1, m_split + 255, (m_split + M) // 2, M - 256, M - 1]))
+    truth = a[rows].float() @ b.float()
+    stride = make_block_swizzle_stride(N, K)
+    c = torch.full((M, N), float("nan"), dtype=torch.half, device=dev)
+    getattr(hg, name)(a, b, c, 2, True, stride)
+    assert not torch.isnan(c).any()
+    err = (c[rows].float() - truth).abs()
+    assert (err <= ATOL + RTOL * truth.abs()).all(), (what, err.max().item())
+    ct = torch.zeros(M, N, dtype=torch.half, device=dev)
+    hg.hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_tn_swizzle_x4(a, as_col_major(b), ct, 3, False, 0)
+    assert torch.equal(ct, c), what
