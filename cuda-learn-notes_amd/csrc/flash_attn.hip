@@ -78,7 +78,9 @@ FaPlan fa2_plan(int family, bool vt, int B, int H, int N, int D, int stages, int
     //           whole register file and one wave per SIMD)
     const long long w256 = N % 256 == 0 ? bh * (N / 256) : 0;
     const long long w_min = D == 64 ? 129 : 1;
-    if ((!vt || D == 64 || D == 128) && w256 >= w_min) {
+    // (D = 64 with N = 256: one 256-row block per head and two 128-key tiles -- the two-group pipeline never reaches its steady state;
+    //  4-wave v2 leads by 5-19 % at every B H measured, profiles/r04_fa_short_n_probe.log)
+    if ((!vt || D == 64 || D == 128) && w256 >= w_min && !(D == 64 && N == 256)) {
       //  D = 64 / 128: ping-pong kernel on 16x16x32 MFMAs (the energy-cheaper matrix shape, +3.5-5 % at D = 64 and
       //                +5.5-6.5 % at D = 128 over the 32x32x16 form of flash_attn_dsplit.cuh, profiles/r02_fa_m16_probe.log)
       //                with the sum-checked optimistic softmax, phase-A priority and the split prologue of round 3

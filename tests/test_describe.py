@@ -126,7 +126,9 @@ def test_flash_attn_planner_invariants_over_a_grid_of_shapes(built):
                 rows = 128 if (fam, D) == ("fa2_fwd_m16", 512) else rows_per_wg[fam]  # the D = 512 pair form: 4 pairs x 32 rows
                 assert N % rows == 0 or fam == "fa2_fwd_v2", (B, H, N, D, t)
                 wgs256 = B * H * (N // 256) if N % 256 == 0 else 0
-                if D in (64, 128, 256) and wgs256 >= (129 if D == 64 else 1) and not (D == 64 and t.startswith("fa2_fwd_m16x64r")):
+                if D == 64 and N == 256:  # one row block per head, two key tiles: the 4-wave v2 kernel at every grid size
+                    assert fam == "fa2_fwd_v2" and "NW=4" in t, (B, H, N, D, t)
+                elif D in (64, 128, 256) and wgs256 >= (129 if D == 64 else 1) and not (D == 64 and t.startswith("fa2_fwd_m16x64r")):
                     assert fam == ("fa2_fwd_m16" if D == 256 else "fa2_fwd_m16x") and "16x16x32" in t, (B, H, N, D, t)
                 if fam == "fa2_fwd_v2":  # 4-wave workgroups whenever N allows; 8 only at D = 32 / 96 on large grids; never 2 when 4 divide N
                     nw = int(t.split("NW=")[1].split(",")[0])

@@ -733,7 +733,7 @@ def test_ck_tile_fmha_comparator_row_is_a_correct_attention(built, dev, oracle, 
 
 
 
-@pytest.mark.parametrize("B,H,N,D", [(2, 96, 256, 64), (1, 48, 1024, 64), (2, 96, 256, 128), (1, 48, 1024, 128), (4, 64, 512, 64), (1, 64, 2048, 64)])
+@pytest.mark.parametrize("B,H,N,D", [(2, 96, 768, 64), (1, 48, 1024, 64), (2, 96, 256, 128), (1, 48, 1024, 128), (4, 64, 512, 64), (1, 64, 2048, 64)])
 def test_transposed_v_names_on_the_sum_checked_kernel(fa, built, dev, oracle, B, H, N, D):
     """The three *_swizzle_qkv names that take V as [B,H,D,N] run the V^T form of fa2_fwd_m16x / fa2_fwd_m16x64r when the grid fills
     the chip (round 3; the 8-wave v2 kernel before): V^T tile image with the row swizzle of the K image, plain 8-byte fragment
