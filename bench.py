@@ -282,6 +282,7 @@ def main():
             cfg = {}
             for key, fn in (("c1_elementwise_add_f32", lambda: bc.config_c1(dev, orc)),
                             ("hgemm", lambda: bc.hgemm_config_rows(pkg, dev, orc)),
+                            ("hgemm_policy", lambda: bc.hgemm_policy_rows(pkg, dev)),
                             ("fa2_stages", lambda: bc.fa_stage_rows(pkg, dev)),
                             ("bandwidth", lambda: bc.bandwidth_rows(dev, orc))):
                 t0 = time.perf_counter()

@@ -331,6 +331,45 @@ def hgemm_config_rows(pkg, dev, orc, sizes=(4096, 8192), stage_list=(2, 3, 4)):
 
 # ----------------------------------------------------------------------------------------------------------------
 # attention: the `stages` knob at configs C4 / C5 (+ D = 128)
+def hgemm_policy_rows(pkg, dev, shapes=((1024, 1024, 16384), (128, 8192, 8192), (4352, 4352, 4352), (7168, 7168, 7168))):
+    """Shapes off the headline configs whose plan is a composition of launches (csrc/hgemm.hip splitk_plan / tail_plan): few tiles with long K
+    (split-K over the one-wave-per-SIMD kernel + a reduce launch) and tile counts just past whole rounds of 256 (tail split) -- the best-dispatch
+    NN name next to rocBLAS NN / TN, with the plan cln_describe names.  A check of sampled rows against the fp32 product rides along."""
+    hg = pkg.hgemm_lib()
+    nn = hg.hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem
+    out = {}
+    hg.init_cublas_handle()
+    for (M, N, K) in shapes:
+        a = torch.randn(M, K, dtype=torch.half, device=dev)
+        b = torch.randn(K, N, dtype=torch.half, device=dev)
+        c = torch.zeros(M, N, dtype=torch.half, device=dev)
+        bt = bu.as_col_major(b)
+        stride = bu.make_block_swizzle_stride(N, K)
+        flops = bu.hgemm_flops(M, N, K)
+        hint = flops / 1.0e15 * 1e3
+        row = {"flops": flops, "plan": manifest.describe(bu.HEADLINE_HGEMM_NAME, (M, N, K), 2)}
+        nn(a, b, c, 2, True, stride)
+        rows = torch.tensor(sorted({0, M // 2, M - 257 if M > 257 else 0, M - 1}), device=dev)
+        truth = a[rows].float() @ b.float()
+        err = (c[rows].float() - truth).abs()
+        row["sampled_rows_within_one_fp16_ulp"] = bool((err <= 2e-3 + 2 ** -10 * truth.abs()).all().item())
+        ms, it = _hgemm_ms(lambda: nn(a, b, c, 2, True, stride), hint)
+        row["nn_tflops"], row["ms"], row["launches"] = _tf(flops, ms), round(ms, 5), it
+        try:
+            ms, _ = _hgemm_ms(lambda: hg.hgemm_cublas_tensor_op_nn(a, b, c), hint)
+            row["rocblas_nn_tflops"] = _tf(flops, ms)
+            ms, _ = _hgemm_ms(lambda: hg.hgemm_cublas_tensor_op_tn(a, bt, c), hint)
+            row["rocblas_tn_tflops"] = _tf(flops, ms)
+            row["pct_of_rocblas_nn"] = round(100.0 * row["nn_tflops"] / row["rocblas_nn_tflops"], 1)
+        except Exception as e:  # noqa: BLE001 -- the vendor row is a comparison, never the product
+            row["rocblas_error"] = str(e)[:160]
+        out["%dx%dx%d" % (M, N, K)] = row
+        del a, b, c, bt
+        torch.cuda.empty_cache()
+    hg.destroy_cublas_handle()
+    return out
+
+
 def fa_stage_rows(pkg, dev):
     fa = pkg.flash_attn_lib()
     sq, tq = fa.flash_attn_mma_stages_split_q_shared_qkv, fa.flash_attn_mma_stages_split_q_tiling_qkv

@@ -53,6 +53,15 @@ def test_hgemm_rows_small(bc, built, dev, oracle):
     assert c2["cpu_baseline"]["kind"] == "port" and c2["max_abs_err_vs_cpu_fp16_matmul"] <= 0.25
 
 
+def test_hgemm_policy_rows(bc, built, dev):
+    r = bc.hgemm_policy_rows(built, dev, shapes=((512, 512, 8192), (4352, 4352, 4352)))
+    sk, tail = r["512x512x8192"], r["4352x4352x4352"]
+    assert "split-K x " in sk["plan"] and "tail split" in tail["plan"], (sk["plan"], tail["plan"])
+    for row in (sk, tail):
+        assert row["sampled_rows_within_one_fp16_ulp"] is True and 20.0 < row["nn_tflops"] < 2500.0, row
+        assert "rocblas_nn_tflops" in row and "pct_of_rocblas_nn" in row, row
+
+
 def test_fa_stage_rows(bc, built, dev):
     r = bc.fa_stage_rows(built, dev)
     for key, one_over_two in (("fa2_c4_d64", 0.8), ("fa2_d128", 0.8), ("fa2_c5_d512", 0.6)):
