@@ -39,16 +39,29 @@ def _check_dtype(t, dtype):
         raise RuntimeError("values must be %s" % _TH_NAME.get(dtype, str(dtype)))
 
 
+# The wrappers below run once per launch: for a 4-10 us kernel their cost IS the launch rate (profiles/r04_bw_rows_probe.log: 8.0 us per call
+# through torch.cuda.current_stream() and per-tensor device objects, 4 us for torch's own dispatcher). The raw getters of torch._C do the same
+# lookups without building Stream / device objects; they exist in every torch 2.x build (Triton's launcher uses them) -- the public API is
+# the fallback.
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+def _current_device():
+    return _raw_device() if _raw_device is not None else torch.cuda.current_device()
+
+
 def _check_dev(*ts):
     """Every tensor must be a contiguous HIP tensor on the CURRENT device: the launch goes to
     torch.cuda.current_stream() of the current device with raw data_ptr()s, so a tensor living on another GPU
     would be dereferenced from the wrong device (fault or silent peer access)."""
-    cur = torch.cuda.current_device() if ts and ts[0].is_cuda else -1
     for t in ts:
         if not t.is_cuda:
             raise RuntimeError("expected a GPU (HIP) tensor, got device=%s: the kernel library has no CPU path"
                                % t.device)
-        if t.device.index != cur:
+    cur = _current_device() if ts else -1
+    for t in ts:
+        if t.get_device() != cur:
             raise RuntimeError("tensor on %s but the current device is cuda:%d: wrap the call in "
                                "`with torch.cuda.device(tensor.device):`" % (t.device, cur))
         if not t.is_contiguous():
@@ -56,11 +69,14 @@ def _check_dev(*ts):
 
 
 def _check_shape(t, *shape):
-    if tuple(t.shape) != tuple(shape):
+    if t.shape != shape:  # torch.Size is a tuple
         raise RuntimeError("Tensor size mismatch!")
 
 
 def _stream():
+    """The raw hipStream_t of torch's current stream on the current device."""
+    if _raw_stream is not None:
+        return _raw_stream(_current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
