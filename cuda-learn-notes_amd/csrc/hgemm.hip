@@ -96,8 +96,8 @@ int best_plan(int M, int N, int K, double* best_score = nullptr) {
 //   tau = 2 BM BN 64 flop / (eff x 5.86 TF), shortened by 0.34 (1 - fill) when fewer than 256 workgroups run (idle CUs: higher clocks, no contention);
 //         eff: 256x256 1.25 | 192x256 1.19 | 192x192 1.08 | 128x256 0.97 | 160x160 0.94 (a workgroup alone on its CU, no C epilogue through LDS)
 //   phi = 3.9 us x sqrt(BM BN / 256^2): launch ramp, prologue, partial store;   rho = 5.2 us + (4 S M N + 2 M N) bytes / 3.6 TB/s: the reduce launch
-// The workspace (S M N floats <= 256 MiB) is per stream, allocated on first use and only ever grown; under stream capture a launch that would
-// have to allocate takes the single-pass plan instead.
+// The workspace (S M N floats <= 256 MiB) is per stream, allocated on first use and only ever grown (an outgrown buffer is retired, not freed);
+// under stream capture a launch that would have to allocate takes the single-pass plan instead.
 struct SplitK {
   int bm = 0, bn = 0, S = 0;
 };
@@ -131,6 +131,7 @@ struct SplitKWs {
 };
 std::mutex g_splitk_mu;
 std::vector<SplitKWs> g_splitk_ws;
+std::vector<float*> g_splitk_retired;  // outgrown buffers, kept until the process ends (see splitk_workspace)
 // the stream's workspace, grown if needed; nullptr when it cannot be had (allocation failed, or the stream is being captured and the
 // workspace would have to be allocated now)
 float* splitk_workspace(hipStream_t stream, size_t bytes) {
@@ -146,16 +147,17 @@ float* splitk_workspace(hipStream_t stream, size_t bytes) {
   size_t want = 16u << 20;
   while (want < bytes) want <<= 1;
   if (want > SPLITK_WS_MAX) want = SPLITK_WS_MAX;
-  if (e) {  // grow: launches queued on this stream may still use the old buffer
-    if (hipStreamSynchronize(stream) != hipSuccess) return nullptr;
-    (void)hipFree(e->p);
-    e->p = nullptr, e->bytes = 0;
+  float* fresh = nullptr;
+  if (hipMalloc(&fresh, want) != hipSuccess) return (void)hipGetLastError(), nullptr;
+  if (e) {
+    // grow: launches already queued on this stream (or a host thread that fetched the pointer a moment ago) still use the old buffer, so it is
+    // retired, not freed -- sizes double, so a stream holds less than twice its largest workspace in total (< 512 MiB), and nothing waits
+    g_splitk_retired.push_back(e->p);
   } else {
     g_splitk_ws.push_back({dev, stream, nullptr, 0});
     e = &g_splitk_ws.back();
   }
-  if (hipMalloc(&e->p, want) != hipSuccess) return (void)hipGetLastError(), e->p = nullptr, nullptr;
-  e->bytes = want;
+  e->p = fresh, e->bytes = want;
   return e->p;
 }
 template <int LAYOUT>
