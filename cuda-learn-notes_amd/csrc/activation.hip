@@ -15,24 +15,31 @@
 namespace {
 
 struct Relu { static __device__ __forceinline__ float f(float x) { return fmaxf(0.f, x); } };
+// 1 / d as ONE v_rcp_f32 (1 ulp) instead of the IEEE division sequence hipcc emits for `/` without fast-math (v_div_scale x2, v_rcp, 4-5 fma,
+// v_div_fmas, v_div_fixup: ~11 VALU per element -- at 8 halves per lane the f16x8 rungs of hardswish / sigmoid / swish became VALU-bound:
+// hardswish f16x8_pack 4096x2048 6.9 us vs relu 4.9 us and torch 4.8 us, profiles/r04_scripts_vs_torch_before.log). The reference builds with
+// --use_fast_math, i.e. the same approximation; all four stay within 9 % of the parity tolerance (2e-6 rel + 1e-6 abs against fp64).
+static __device__ __forceinline__ float rcp1(float d) { return __builtin_amdgcn_rcpf(d); }
 struct Sigmoid {
   static __device__ __forceinline__ float f(float x) {
     x = fminf(fmaxf(x, -88.3762626647949f), 88.3762626647949f);
-    return 1.0f / (1.0f + __expf(-x));
+    return rcp1(1.0f + __expf(-x));
   }
 };
 struct Gelu {
+  // tanh form (reference gelu.cu GELU_OPS, torch.nn.GELU("tanh")): 0.5 x (1 + tanh u) = x / (1 + e^(-2u)), u = sqrt(2/pi) (x + 0.044715 x^3) --
+  // one exponential and one reciprocal instead of tanhf's ~25-instruction expansion (f16x8_pack 4096^2: 15.5 us, VALU-bound, with tanhf)
   static __device__ __forceinline__ float f(float x) {
     x = fminf(fmaxf(x, -88.3762626647949f), 88.3762626647949f);
-    return 0.5f * x * (1.0f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    return x * rcp1(1.0f + __expf(-2.0f * u));
   }
 };
-struct Swish { static __device__ __forceinline__ float f(float x) { return x / (1.0f + __expf(-x)); } };
+struct Swish { static __device__ __forceinline__ float f(float x) { return x * rcp1(1.0f + __expf(-x)); } };
 struct Elu { static __device__ __forceinline__ float f(float x) { return x > 0.f ? x : (__expf(x) - 1.f); } };
 struct HardSwish {
-  static __device__ __forceinline__ float f(float x) {
-    return x >= 3.f ? x : (x <= -3.f ? 0.f : x * (x + 3.f) / 6.f);
-  }
+  // x relu6(x + 3) / 6 (hardswish.cu:12-13 thresholds +-3), branch-free: add, v_med3_f32, two multiplies
+  static __device__ __forceinline__ float f(float x) { return x * __builtin_amdgcn_fmed3f(x + 3.f, 0.f, 6.f) * (1.0f / 6.0f); }
 };
 struct HardShrink {
   static __device__ __forceinline__ float f(float x) { return (x > 0.5f || x < -0.5f) ? x : 0.f; }
