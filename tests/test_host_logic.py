@@ -118,3 +118,46 @@ def test_interleaved_tile_walk_is_a_bijection_with_compact_xcd_chunks():
     # band of 8 columns on an exact grid: an XCD's chunk is 4 rows x 8 columns
     tiles = [coords(b, 4096, 64, 64, 8)[1:] for b in range(256) if b % 8 == 3]
     assert len({t[0] for t in tiles}) == 4 and len({t[1] for t in tiles}) == 8
+
+
+def test_split_k_workspace_layout_and_reduce_mapping_cover_the_tile_exactly_once():
+    """Python model of csrc/hgemm_w4.cuh (EPI 5 partial store) + csrc/hgemm_splitk.cuh (hgemm_splitk_reduce_kernel): lane l of fragment (i, j) of
+    wave w holds row 16 i + (l & 15), columns 16 j + 4 (l >> 4) ... + 3 of the wave tile (the layout store_wide_tile_via_lds reads); the GEMM writes
+    those four floats at ((w FM FN + i FN + j) 64 + l) 4 of the tile's workspace block; reduce workgroup (tile, w, i) reads them back with the same
+    index, puts them into its 16 x WTN strip and writes 16-byte row segments. For every tile shape split-K uses: each workspace float lands on
+    exactly one element of C, every element of the tile is written exactly once, by a 16-byte-aligned 8-half store."""
+    import numpy as np
+    for BM, BN in ((256, 256), (192, 256), (192, 192), (128, 256), (160, 160)):
+        FM, FN, WTM, WTN = BM // 32, BN // 32, BM // 2, BN // 2
+        # the value each workspace slot would hold if the accumulators held their own (row, col) index
+        ws = np.full(BM * BN, -1, dtype=np.int64)
+        for w in range(4):
+            wm, wn = w >> 1, w & 1
+            for i in range(FM):
+                for j in range(FN):
+                    for l in range(64):
+                        for e in range(4):
+                            row, col = wm * WTM + i * 16 + (l & 15), wn * WTN + j * 16 + 4 * (l >> 4) + e
+                            slot = w * (WTM * WTN) + ((i * FN + j) * 64 + l) * 4 + e
+                            assert ws[slot] == -1
+                            ws[slot] = row * BN + col
+        assert (ws >= 0).all() and len(set(ws.tolist())) == BM * BN  # a bijection tile <-> workspace block
+        out = np.full((BM, BN), -1, dtype=np.int64)
+        RS, LPR = FN * 32 + 16, FN * 2
+        for w in range(4):
+            for i in range(FM):  # one reduce workgroup
+                strip = {}
+                for t in range(256):
+                    wv, lane = t >> 6, t & 63
+                    for j in range(wv, FN, 4):
+                        base = w * (WTM * WTN) + ((i * FN + j) * 64 + lane) * 4
+                        for e in range(4):
+                            strip[(lane & 15) * RS + (j * 16 + 4 * (lane >> 4) + e) * 2] = ws[base + e]
+                for t in range(16 * LPR):
+                    r, c = t // LPR, t % LPR
+                    row, col0 = (w >> 1) * WTM + i * 16 + r, (w & 1) * WTN + c * 8
+                    assert col0 % 8 == 0
+                    for e in range(8):
+                        assert out[row, col0 + e] == -1
+                        out[row, col0 + e] = strip[r * RS + c * 16 + e * 2]
+        assert (out == np.arange(BM * BN).reshape(BM, BN)).all(), (BM, BN)
