@@ -189,6 +189,9 @@ def _make_r1(name):
     return f
 
 
+_SOFTMAX_ONE_BLOCK_MAX = 65536  # == SOFTMAX_ONE_BLOCK_MAX in csrc/softmax.hip (tests/test_host_logic.py holds them equal)
+
+
 def _make_sg(name):
     fn = _loader.symbol(name)
 
@@ -197,7 +200,10 @@ def _make_sg(name):
         _check_dtype(y, torch.float32)
         _check_dev(x, y)
         _check_shape(y, *x.shape)
-        total = torch.zeros(1, dtype=torch.float32, device=x.device)  # reference softmax.cu:419
+        # reference softmax.cu:419 allocates the zeroed accumulator in the binding; up to _SOFTMAX_ONE_BLOCK_MAX elements ONE workgroup
+        # does both passes and overwrites it (csrc/softmax.hip SOFTMAX_ONE_BLOCK_MAX), so no fill kernel is launched for it
+        n = x.numel()
+        total = (torch.empty if n <= _SOFTMAX_ONE_BLOCK_MAX else torch.zeros)(1, dtype=torch.float32, device=x.device)
         _raise(name, fn(x.data_ptr(), y.data_ptr(), total.data_ptr(), x.numel(), _stream()))
     f.__name__ = name
     return f

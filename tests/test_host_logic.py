@@ -161,3 +161,11 @@ def test_split_k_workspace_layout_and_reduce_mapping_cover_the_tile_exactly_once
                         assert out[row, col0 + e] == -1
                         out[row, col0 + e] = strip[r * RS + c * 16 + e * 2]
         assert (out == np.arange(BM * BN).reshape(BM, BN)).all(), (BM, BN)
+
+
+def test_global_softmax_one_block_threshold_is_the_same_on_both_sides(built):
+    """host.py skips zeroing the accumulator where csrc/softmax.hip runs its single-workgroup form (which overwrites it)."""
+    import re
+    from cuda_learn_notes_amd import host
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cuda-learn-notes_amd", "csrc", "softmax.hip")).read()
+    assert int(re.search(r"SOFTMAX_ONE_BLOCK_MAX = (\d+);", src).group(1)) == host._SOFTMAX_ONE_BLOCK_MAX
