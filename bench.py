@@ -38,6 +38,7 @@ def parse():
     p.add_argument("--stages", type=int, default=2)
     p.add_argument("--prewarm", type=float, default=0.6, help="seconds of untimed back-to-back launches before warmup")
     p.add_argument("--no-extras", action="store_true", help="skip FA2 / rocBLAS / CPU baseline side measurements")
+    p.add_argument("--no-pmc", action="store_true", help="do not re-run the headline kernel under rocprofv3 --pmc for this box's counters (3 child passes, ~20 s)")
     p.add_argument("--no-configs", action="store_true", help="skip the per-config rows (C1, C2, 8192^3, stage sweeps, bandwidth kernels)")
     p.add_argument("--launch", choices=["graph", "eager"], default="eager",
                    help="how the K timed steps reach the GPU: K eager launches from Python (default: host enqueue 9.5 us per step against a "
@@ -276,6 +277,17 @@ def main():
             extras["fa2_error"] = str(e)[:300]
         out["extras"] = extras
         out["cpu_baseline"] = cpu_baseline(a, b, M, N, K)
+        # ---- counters from THIS box: the same kernel for a dozen launches under rocprofv3 --pmc, in child processes after the timed
+        # region; on any trouble the replayed values above stay and `pmc.status` says why
+        if M == 4096 and not args.no_pmc:
+            pmc = bu.collect_pmc_here(ROOT)
+            out["pmc"] = pmc
+            if pmc["traffic"] is not None:
+                roofline["traffic"] = round(pmc["traffic"])
+                roofline["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this run"
+                roofline["traffic_measured_in_this_run"] = True
+            if pmc["mfma_busy"] is not None:
+                roofline["mfma_busy"] = round(pmc["mfma_busy"], 4)
         # ---- every other BASELINE.json config and the bandwidth kernels, each with its roofline fraction and the
         # reference's torch path on the host cores: bench_configs.py (repository root). Released first: the operands above.
         del a, b, c

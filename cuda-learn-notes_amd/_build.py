@@ -4,6 +4,7 @@
   csrc/hgemm_vendor*.hip, fa2_vendor_ck.hip  ----------->  lib/libcln_amd_vendor.so  (comparison rows: rocBLAS, hipBLASLt, ck_tile FMHA)
   csrc/*_probe.hip  ------------------------------------>  lib/libcln_amd_probe.so   (TEST-ONLY: tuning hooks, ablation and
                                                            probe instantiations; nothing in the product path loads it)
+  csrc/pyext/cln_fastcall.c  --gcc-->  lib/_cln_fastcall*.so  (CPython vectorcall entries in front of the C-ABI; optional)
 
 Replaces the reference's JIT `torch.utils.cpp_extension.load(...)` at script import
 (kernels/hgemm/tools/utils.py:104-113, kernels/elementwise/elementwise.py:10-22).
@@ -24,7 +25,7 @@ LIBDIR = os.path.join(PKG_DIR, "lib")
 ARCH = "gfx950"
 KERNEL_SOURCES = [
     "elementwise.hip", "activation.hip", "blas1.hip", "indexing.hip", "reduce.hip", "softmax.hip", "norm.hip", "rope.hip",
-    "sgemm.hip", "hgemm.hip", "hgemm_ring_nn.hip", "hgemm_ring_tn.hip", "flash_attn.hip", "flash_attn_m16x.hip", "describe.hip",
+    "sgemm.hip", "stream_scratch.hip", "hgemm.hip", "hgemm_ring_nn.hip", "hgemm_ring_tn.hip", "flash_attn.hip", "flash_attn_m16x.hip", "describe.hip",
 ]
 VENDOR_SOURCES = ["hgemm_vendor.hip", "hgemm_vendor_lt.hip", "fa2_vendor_ck.hip"]  # the last: ck_tile FMHA instances (~1 min of hipcc)
 # a comparison row whose sources are the ROCm image's ck_tile headers: if they are missing or do not compile, the vendor
@@ -92,6 +93,34 @@ def _link(objs, out, extra, verbose):
         raise RuntimeError("link failed for %s:\n%s" % (out, r.stderr[-4000:]))
 
 
+def build_pyext(verbose=False, force=False):
+    """csrc/pyext/cln_fastcall.c --gcc--> lib/_cln_fastcall<EXT_SUFFIX>: the CPython entry in front of the C-ABI (vectorcall, no ctypes
+    marshalling, no torch headers). Optional: without a C compiler / Python.h the host layer keeps calling through ctypes."""
+    import sysconfig
+    src = os.path.join(CSRC, "pyext", "cln_fastcall.c")
+    out = os.path.join(LIBDIR, "_cln_fastcall" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+    stamp = os.path.join(BUILD, "cln_fastcall.stamp")
+    with open(src, "rb") as f:
+        digest = hashlib.sha256(f.read() + out.encode()).hexdigest()
+    if not force and os.path.exists(out) and os.path.exists(stamp) and open(stamp).read() == digest:
+        return out
+    cc = os.environ.get("CC") or shutil.which("gcc") or shutil.which("cc")
+    inc = sysconfig.get_paths().get("include")
+    if not cc or not inc or not os.path.exists(os.path.join(inc, "Python.h")):
+        print("warning: no C compiler / Python.h: building without the _cln_fastcall entry (host.py falls back to ctypes)", file=sys.stderr)
+        return None
+    cmd = [cc, "-O2", "-shared", "-fPIC", "-Wall", "-I" + inc, src, "-o", out]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        print("warning: _cln_fastcall did not compile, building without it (host.py falls back to ctypes):\n%s" % r.stderr[-800:], file=sys.stderr)
+        return None
+    with open(stamp, "w") as f:
+        f.write(digest)
+    return out
+
+
 def build(verbose=False, force=False):
     os.makedirs(BUILD, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
@@ -113,6 +142,7 @@ def build(verbose=False, force=False):
         _link([objs[s][0] for s in VENDOR_SOURCES if objs[s][0] is not None], vend_so, libs, verbose)
     if force or not os.path.exists(probe_so) or any(objs[s][1] for s in PROBE_SOURCES + PROBE_SHARED):
         _link([objs[s][0] for s in PROBE_SOURCES + PROBE_SHARED], probe_so, [], verbose)
+    build_pyext(verbose, force)
     return main_so, vend_so, probe_so
 
 

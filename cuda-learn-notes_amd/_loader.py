@@ -82,6 +82,11 @@ def load_so(so_name):
         fn = lib.cln_describe
         fn.argtypes = [ctypes.c_char_p, c_int, c_int, c_int, c_int, c_int, ctypes.c_char_p, c_int]
         fn.restype = c_int
+        # split-K workspace entry points (include/cln_amd.h, round 5)
+        lib.cln_hgemm_workspace_bytes.argtypes, lib.cln_hgemm_workspace_bytes.restype = [c_int, c_int, c_int], ctypes.c_size_t
+        lib.cln_hgemm_set_workspace.argtypes, lib.cln_hgemm_set_workspace.restype = [c_void_p, ctypes.c_size_t, c_void_p], c_int
+        lib.cln_release_workspaces.argtypes, lib.cln_release_workspaces.restype = [], ctypes.c_size_t
+        lib.cln_hgemm_workspace_held.argtypes, lib.cln_hgemm_workspace_held.restype = [], ctypes.c_size_t
     _cache[so_name] = lib
     return lib
 

@@ -235,3 +235,77 @@ def pmc_value(profiles_dir: str, stem: str, key: str, kernel_sub: str = ""):
         return (vals[-1], os.path.basename(files[-1])) if vals else (None, None)
     except Exception:
         return None, None
+
+
+def collect_pmc_here(root, timeout_s=45.0):
+    """Counters from THIS box for the headline kernel: the production 4096^3 HGEMM re-run for a dozen launches in rocprofv3
+    child processes, one per counter set -- FETCH_SIZE and WRITE_SIZE cannot share a pass, PMC never together with the sys / hip / hsa trace
+    domains (MI355X_MICROARCH.md, HBM / rocprofv3 section). Returns {"traffic": bytes per launch, "mfma_busy": fraction, "status": text,
+    "seconds": wall} with None for what could not be had; never raises (the caller falls back to the committed pass and says so)."""
+    import csv
+    import glob
+    import os
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    t0 = time.time()
+    out = {"traffic": None, "read_bytes": None, "write_bytes": None, "mfma_busy": None, "status": "ok", "seconds": 0.0}
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        out["status"] = "rocprofv3 not found"
+        return out
+    target = os.path.join(root, "cuda-learn-notes_amd", "tools", "prof_target.py")
+    # kind 14, variant 203 = the production schedule with the production epilogue (tools/profile_round.sh)
+    args = [sys_executable(), target, "hgemm", "14", "0", "1", "64", "203", "4096", "12"]
+    tmp = tempfile.mkdtemp(prefix="cln_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    vals = {}
+    try:
+        for tag, ctrs in (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("sq", ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"])):
+            left = timeout_s - (time.time() - t0)
+            if left < 5.0:
+                out["status"] = "time budget spent before pass %s" % tag
+                break
+            d = os.path.join(tmp, tag)
+            cmd = [exe, "--kernel-trace", "--output-format", "csv", "--pmc"] + ctrs + ["-d", d, "-o", "pmc", "--"] + args
+            p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                p.wait(timeout=left)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, signal.SIGKILL)  # exactly the process group started here
+                p.wait()
+                out["status"] = "pass %s timed out" % tag
+                break
+            if p.returncode != 0:
+                out["status"] = "pass %s: rocprofv3 exit %d" % (tag, p.returncode)
+                break
+            per = {}
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if "hgemm_w4_kernel" in r["Kernel_Name"]:
+                        per.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+            for c, v in per.items():
+                v = v[1:] if len(v) > 2 else v
+                vals[c] = sum(v) / len(v)
+        if "FETCH_SIZE" in vals:
+            out["read_bytes"] = 2.0 * vals["FETCH_SIZE"] * 1024  # gfx950: FETCH_SIZE (KiB) reads half of a wide coalesced stream (tools/pmc_summary.py)
+        if "WRITE_SIZE" in vals:
+            out["write_bytes"] = vals["WRITE_SIZE"] * 1024
+        if out["read_bytes"] is not None and out["write_bytes"] is not None:
+            out["traffic"] = out["read_bytes"] + out["write_bytes"]
+        if vals.get("GRBM_GUI_ACTIVE"):
+            out["mfma_busy"] = (vals.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / 1024.0) / (vals["GRBM_GUI_ACTIVE"] / 8.0)
+        if out["status"] == "ok" and (out["traffic"] is None or out["mfma_busy"] is None):
+            out["status"] = "counters missing from the rocprofv3 output"
+    except Exception as e:  # noqa: BLE001 -- a side measurement
+        out["status"] = "error: %s" % str(e)[:120]
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+        out["seconds"] = round(time.time() - t0, 1)
+    return out
+
+
+def sys_executable():
+    import sys
+    return sys.executable or "python3"

@@ -38,8 +38,13 @@ struct Gelu {
 struct Swish { static __device__ __forceinline__ float f(float x) { return x * rcp1(1.0f + __expf(-x)); } };
 struct Elu { static __device__ __forceinline__ float f(float x) { return x > 0.f ? x : (__expf(x) - 1.f); } };
 struct HardSwish {
-  // x relu6(x + 3) / 6 (hardswish.cu:12-13 thresholds +-3), branch-free: add, v_med3_f32, two multiplies
-  static __device__ __forceinline__ float f(float x) { return x * __builtin_amdgcn_fmed3f(x + 3.f, 0.f, 6.f) * (1.0f / 6.0f); }
+  // the reference's piecewise form (hardswish.cu:37-45: x >= 3 -> x, x <= -3 -> 0, else x (x + 3) / 6) as two selects over the middle branch.
+  // Round 4 shipped the branch-free x * med3(x + 3, 0, 6) / 6 (4 VALU): it returned NaN for x = -inf (-inf * 0), +inf instead of x above
+  // FLT_MAX / 6 and was 1 ulp off x for x >= 3 -- the selects cost 3 more VALU per element and keep the reference's edges.
+  static __device__ __forceinline__ float f(float x) {
+    const float mid = x * (x + 3.f) * (1.0f / 6.0f);
+    return x >= 3.f ? x : (x <= -3.f ? 0.f : mid);
+  }
 };
 struct HardShrink {
   static __device__ __forceinline__ float f(float x) { return (x > 0.5f || x < -0.5f) ? x : 0.f; }

@@ -14,6 +14,7 @@
 //      diagonal2d  -> write-coalesced kernel with the reference's diagonal block order
 //      *_shared_*  -> 64x64 tile through LDS, 16-byte accesses on BOTH sides; `bcf` pads the tile rows (+1)
 #include "common.h"
+#include "stream_scratch.h"
 
 namespace {
 
@@ -27,7 +28,7 @@ __device__ __forceinline__ float tof(half_t x) { return (float)x; }
 // ---- dot product ---------------------------------------------------------------------------------
 template <typename T, int VEC>
 __global__ __launch_bounds__(1024) void dot_kernel(const T* __restrict__ a, const T* __restrict__ b,
-                                                   float* __restrict__ y, long long n) {
+                                                   float* __restrict__ y, long long n, ClnScratch* sc) {
   __shared__ float scratch[16];
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   const long long nvec = n / VEC, stride = (long long)gridDim.x * 1024;
@@ -55,17 +56,20 @@ __global__ __launch_bounds__(1024) void dot_kernel(const T* __restrict__ a, cons
   if (threadIdx.x == 0) {
     float t = 0.f;
     for (int k = 0; k < 16; ++k) t += scratch[k];
-    atomicAdd(y, t);
+    if (sc) cln_scratch_finish<float>(sc, y, t, gridDim.x);  // the last block moves the total into y (stream_scratch.h): y need not be zeroed
+    else atomicAdd(y, t);
   }
 }
 template <typename T, int VEC>
 int launch_dot(const void* a, const void* b, void* y, long long n, hipStream_t st) {
   if (!a || !b || !y || n < 0) return CLN_ERR_BAD_ARG;
-  if (n == 0) return CLN_OK;
+  if (n == 0) return hipMemsetAsync(y, 0, sizeof(float), st) == hipSuccess ? CLN_OK : ((void)hipGetLastError(), CLN_ERR_LAUNCH);
   if (sizeof(T) * VEC >= 16 && (!cln_aligned16(a) || !cln_aligned16(b))) return CLN_ERR_BAD_ARG;
   long long g = (n / VEC + 1023) / 1024;
   const int grid = (int)(g < 1 ? 1 : (g > 256 ? 256 : g));
-  CLN_LAUNCH((dot_kernel<T, VEC>), dim3(grid), dim3(1024), 0, st, (const T*)a, (const T*)b, (float*)y, n);
+  ClnScratch* sc = cln_stream_scratch(st);
+  if (!sc && hipMemsetAsync(y, 0, sizeof(float), st) != hipSuccess) return (void)hipGetLastError(), CLN_ERR_LAUNCH;
+  CLN_LAUNCH((dot_kernel<T, VEC>), dim3(grid), dim3(1024), 0, st, (const T*)a, (const T*)b, (float*)y, n, sc);
   return cln_check_launch();
 }
 
@@ -201,7 +205,7 @@ int launch_tr(int kind, const void* x, void* y, int row, int col, hipStream_t st
 
 }  // namespace
 
-// (a, b, y fp32[1] zeroed, n, stream) -- reference `torch::Tensor dot_prod_*(Tensor a, Tensor b)`
+// (a, b, y fp32[1] -- overwritten with the dot product, need not be zeroed (round 5) --, n, stream) -- reference `torch::Tensor dot_prod_*(Tensor a, Tensor b)`
 #define CLN_DOT(name, T, VEC)                                                              \
   CLN_API int name(const void* a, const void* b, void* y, long long n, void* stream) {     \
     return launch_dot<T, VEC>(a, b, y, n, (hipStream_t)stream);                            \

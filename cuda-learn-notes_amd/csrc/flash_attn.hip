@@ -22,7 +22,7 @@
 namespace {
 
 enum FaFamily { FAM_SPLIT_KV = 0, FAM_SPLIT_Q = 1 };
-enum FaKind { K_NONE = 0, K_SPLITKV, K_V2, K_DSPLIT, K_DRING, K_M16X64R, K_M16 };
+enum FaKind { K_NONE = 0, K_SPLITKV, K_V2, K_DSPLIT, K_DW4, K_M16X64R, K_M16 };
 
 struct FaPlan {
   int rc = CLN_OK;     // CLN_ERR_* when the shape is not supported
@@ -126,12 +126,9 @@ FaPlan fa2_plan(int family, bool vt, int B, int H, int N, int D, int stages, int
     case 320: case 384:
       if (N % 128 != 0) return p.rc = CLN_ERR_UNSUPPORTED, p;
       return p.kind = K_DSPLIT, p.d_inst = 512, p.nw = 8, p.bc = 32, p;
-    case 640: case 768:
+    case 640: case 768: case 1024:  // round 5: one wave per SIMD, 64 rows per workgroup (flash_attn_dw4.cuh)
       if (N % 64 != 0) return p.rc = CLN_ERR_UNSUPPORTED, p;
-      return p.kind = K_DRING, p.d_inst = D, p.nw = 8, p.bc = 16, p;
-    case 1024:
-      if (N % 64 != 0) return p.rc = CLN_ERR_UNSUPPORTED, p;
-      return p.kind = K_DRING, p.d_inst = 1024, p.nw = 8, p.bc = 16, p;
+      return p.kind = K_DW4, p.d_inst = D, p.nw = 4, p.bc = 16, p;
     default: return p.rc = CLN_ERR_UNSUPPORTED, p;
   }
 }
@@ -196,7 +193,7 @@ int fa2_run(const FaPlan& p, const void* q, const void* k, const void* v, void* 
         return fa::launch_fa2_large_d(q, k, v, o, B, H, N, D, s, p.one_stage);
       }
       return CLN_ERR_UNSUPPORTED;
-    case K_DRING:
+    case K_DW4:
       if constexpr (!VT) return fa::launch_fa2_large_d(q, k, v, o, B, H, N, D, s, p.one_stage);
       return CLN_ERR_UNSUPPORTED;
     default: return CLN_ERR_UNSUPPORTED;
@@ -241,9 +238,9 @@ int fa2_describe(int family, bool vt, int B, int H, int N, int D, int stages, in
         return snprintf(buf, len, "fa2_fwd_dsplit<D=%d,NSP=2,BC=32,LDS geometry of D=%d> 8 waves, pairs split the real d evenly%s", D, p.d_inst, st);
       return snprintf(buf, len, "fa2_fwd_dsplit<D=%d,NSP=%d,BC=%d> 8 waves, two groups one phase apart%s", D,
                       D == 512 ? 2 : 1, p.bc, st);
-    case K_DRING:
-      return snprintf(buf, len, "fa2_fwd_dring<D=%d,BC=16,2-slot K/V rings%s> 8 waves, 4 split d (%d columns each), 64 rows%s", D,
-                      D == 1024 ? ",row groups one phase apart,phase-2 priority" : "", D / 4, st);
+    case K_DW4:
+      return snprintf(buf, len, "fa2_fwd_dw4<D=%d,BC=16,2-slot K/V rings,O^T in AGPRs> 4 waves (one per SIMD) split d (%d columns each), 64 rows, "
+                                "softmax once per row by its owner wave%s", D, D / 4, st);
     default: return CLN_ERR_UNSUPPORTED;
   }
 }

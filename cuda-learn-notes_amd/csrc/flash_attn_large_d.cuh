@@ -4,13 +4,15 @@
 // the head dim is split across the waves of a query-row group instead (each wave keeps its 256 columns of Q and of
 // O^T in registers and the partial S^T tiles are summed through LDS):
 //   512        pairs of waves, two 4-wave groups one phase apart, K/V double-buffered   (flash_attn_dsplit.cuh)
-//   640, 768, 1024  quads of waves (D / 4 columns each), K / V through two-slot rings of 16-key tiles (flash_attn_dring.cuh,
-//              round 3; its predecessor probe/flash_attn_dwide.cuh -- one 32-key K tile and one V tile, no prefetch, D = 640 padded
+//   640, 768, 1024  FOUR waves, one per SIMD, each with all 64 rows of a quarter of d, softmax once per row by the row's owner wave
+//              (flash_attn_dw4.cuh, round 5); before: quads of waves x 2 row groups, K / V through two-slot rings of 16-key tiles (flash_attn_dring.cuh,
+//              round 3, now probe-only); its predecessor probe/flash_attn_dwide.cuh -- one 32-key K tile and one V tile, no prefetch, D = 640 padded
 //              to 768 -- lives on in the probe library)
 //   320, 384   the D = 512 kernel's LDS geometry, every loop over the real head dim (DREAL; round 2)
 #pragma once
 #include "flash_attn_dsplit.cuh"
 #include "flash_attn_dring.cuh"
+#include "flash_attn_dw4.cuh"
 
 namespace fa {
 inline int launch_fa2_large_d(const void* q, const void* k, const void* v, void* o, int B, int H, int N, int D,
@@ -20,9 +22,9 @@ inline int launch_fa2_large_d(const void* q, const void* k, const void* v, void*
     switch (D) {
       case 320: return fa2::launch_dsplit<512, 2, 1, fa2::OPT_DEFAULT, 512, 320>(q, k, v, o, B, H, N, s);
       case 384: return fa2::launch_dsplit<512, 2, 1, fa2::OPT_DEFAULT, 512, 384>(q, k, v, o, B, H, N, s);
-      case 640: return fa2::launch_dring<640, O1, false, 0, 2, 2>(q, k, v, o, B, H, N, s);
-      case 768: return fa2::launch_dring<768, O1, false, 0, 2, 2>(q, k, v, o, B, H, N, s);
-      case 1024: return fa2::launch_dring<1024, O1, true, 1>(q, k, v, o, B, H, N, s);
+      case 640: return fa2::launch_dw4<640, fa2::DW4_1STAGE>(q, k, v, o, B, H, N, s);
+      case 768: return fa2::launch_dw4<768, fa2::DW4_1STAGE>(q, k, v, o, B, H, N, s);
+      case 1024: return fa2::launch_dw4<1024, fa2::DW4_1STAGE>(q, k, v, o, B, H, N, s);
       default: return CLN_ERR_UNSUPPORTED;
     }
   }
@@ -39,9 +41,11 @@ inline int launch_fa2_large_d(const void* q, const void* k, const void* v, void*
     // (lock-step measured 1-4 % faster at 640 / 768)
     // two K and two V fragments in flight at 640 / 768 (+5 % / +1.5 % over one; deeper: no gain; D = 1024 has no registers for it:
     // profiles/r03_fa_dring_prefetch_probe.log)
-    case 640: return fa2::launch_dring<640, fa2::OPT_DEFAULT, false, 0, 2, 2>(q, k, v, o, B, H, N, s);
-    case 768: return fa2::launch_dring<768, fa2::OPT_DEFAULT, false, 0, 2, 2>(q, k, v, o, B, H, N, s);
-    case 1024: return fa2::launch_dring<1024, fa2::OPT_DEFAULT, true, 1>(q, k, v, o, B, H, N, s);  // + phase-2 priority: +4.4 %
+    // round 5: the one-wave-per-SIMD kernel (flash_attn_dw4.cuh) -- [1,16,4096,D] 684 -> 765 / 751 -> 818 / 793 -> 912 TF, [1,8,8192,1024] 803 -> 928 on one box
+    // (profiles/r05_fa_dw4_probe.log); the 8-wave ring kernel above stays in the probe library (variants 1000..1216)
+    case 640: return fa2::launch_dw4<640>(q, k, v, o, B, H, N, s);
+    case 768: return fa2::launch_dw4<768>(q, k, v, o, B, H, N, s);
+    case 1024: return fa2::launch_dw4<1024>(q, k, v, o, B, H, N, s);
     default: return CLN_ERR_UNSUPPORTED;
   }
 }

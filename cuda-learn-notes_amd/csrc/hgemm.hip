@@ -14,6 +14,7 @@
 #include "hgemm_w4s.cuh"
 #include "hgemm_splitk.cuh"
 #include "hgemm_valu.cuh"
+#include "stream_scratch.h"
 #include <string.h>
 #include <math.h>
 #include <mutex>
@@ -102,8 +103,18 @@ struct SplitK {
   int bm = 0, bn = 0, S = 0;
 };
 constexpr size_t SPLITK_WS_MAX = 256u << 20;
+// $CLN_AMD_NO_SPLITK=1 (read once): every shape single-pass -- for callers that need eager, captured and workspace-less runs of one shape to be
+// bit-identical (the split forms differ from the single-pass kernel in the fp32 summation order)
+bool splitk_disabled() {
+  static const bool v = [] {
+    const char* e = getenv("CLN_AMD_NO_SPLITK");
+    return e && e[0] == '1';
+  }();
+  return v;
+}
 SplitK splitk_plan(int M, int N, int K) {
   SplitK best;
+  if (splitk_disabled()) return best;
   const double mn = (double)M * (double)N;
   if (K < 4096 || K % 64 || mn > 2048.0 * 2048.0 || (mn > 1536.0 * 1536.0 && K < 5120)) return best;
   static const struct { int bm, bn; double eff; } shapes[] = {{256, 256, 1.249}, {192, 256, 1.188}, {192, 192, 1.078}, {128, 256, 0.974}, {160, 160, 0.942}};
@@ -123,50 +134,110 @@ SplitK splitk_plan(int M, int N, int K) {
   return best;
 }
 
+// ---- split-K workspace (round 5: caller-visible, bounded, freeable) -------------------------------
+// One workspace per (device, stream): W4_TICKET_FLOATS zeroed arrival counters + the fp32 partials. Either the CALLER's
+// (cln_hgemm_set_workspace: the library never allocates for that stream; a shape whose workspace does not fit takes the single-pass plan) or
+// library-owned (allocated on first use, grown by doubling up to SPLITK_WS_MAX).
+//   * g_ws_mu is held from the lookup to the END of the launch sequence that uses the workspace (1-2 launches): two host threads calling hgemm
+//     on one stream can no longer interleave their partial / reduce launches (ctypes drops the GIL around the C call). On one
+//     stream the launches of consecutive calls run in order, so one workspace per stream is enough.
+//   * every use records an event; a buffer is freed only after its event has completed (growth, LRU eviction, cln_release_workspaces) -- the
+//     event stays valid after its stream is destroyed, so a process that cycles streams does not leak: at most SPLITK_OWNED_MAX library-owned
+//     workspaces exist at a time (least recently used evicted first).
+//   * under stream capture the library never allocates, frees or records: a stream without a workspace takes the single-pass plan, and a
+//     captured graph holds the pointer of the workspace it was captured with -- replay it on the capture stream (or give each graph its own
+//     region through cln_hgemm_set_workspace), include/cln_amd.h says so.
 struct SplitKWs {
-  int dev;
-  hipStream_t stream;
-  float* p;
-  size_t bytes;
-};
-std::mutex g_splitk_mu;
-std::vector<SplitKWs> g_splitk_ws;
-std::vector<float*> g_splitk_retired;  // outgrown buffers, kept until the process ends (see splitk_workspace)
-// the stream's workspace, grown if needed; nullptr when it cannot be had (allocation failed, or the stream is being captured and the
-// workspace would have to be allocated now)
-float* splitk_workspace(hipStream_t stream, size_t bytes) {
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  std::lock_guard<std::mutex> lock(g_splitk_mu);
-  SplitKWs* e = nullptr;
-  for (auto& w : g_splitk_ws)
-    if (w.dev == dev && w.stream == stream) e = &w;
-  if (e && e->bytes >= bytes) return e->p;
+  hipStream_t stream = nullptr;
+  float* p = nullptr;
+  size_t bytes = 0;
+  bool user = false;          // caller-owned region (cln_hgemm_set_workspace)
+  hipEvent_t ev = nullptr;    // completion of the last launch that used the region (library-owned only)
+  unsigned long long used = 0;
+};
+constexpr size_t SPLITK_OWNED_MAX = 8;
+std::mutex g_ws_mu;
+std::vector<SplitKWs> g_ws;
+unsigned long long g_ws_clock = 0;
+
+bool stream_capturing(hipStream_t stream) {
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return (void)hipGetLastError(), nullptr;
+  if (hipStreamIsCapturing(stream, &cs) != hipSuccess) return (void)hipGetLastError(), true;
+  return cs != hipStreamCaptureStatusNone;
+}
+void ws_free_entry(SplitKWs& w) {  // g_ws_mu held; library-owned entries only
+  if (w.ev) {
+    (void)hipEventSynchronize(w.ev);  // the launches that used the buffer are done (valid even if the stream is gone)
+    (void)hipEventDestroy(w.ev);
+  }
+  if (w.p) (void)hipFree(w.p);
+  (void)hipGetLastError();
+  w.p = nullptr, w.ev = nullptr, w.bytes = 0;
+}
+// g_ws_mu held. The stream's workspace with room for `bytes` (tickets included), or nullptr: caller-owned region too small, allocation
+// failed, or the stream is being captured and the workspace would have to be allocated now.
+SplitKWs* ws_acquire(hipStream_t stream, size_t bytes) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return (void)hipGetLastError(), nullptr;
+  SplitKWs* e = nullptr;
+  for (auto& w : g_ws)
+    if (w.dev == dev && w.stream == stream) e = &w;
+  if (e && e->user) return e->bytes >= bytes ? (e->used = ++g_ws_clock, e) : nullptr;
+  if (e && e->bytes >= bytes) return e->used = ++g_ws_clock, e;
+  if (bytes > SPLITK_WS_MAX + W4_TICKET_FLOATS * 4 || stream_capturing(stream)) return nullptr;
   size_t want = 16u << 20;
   while (want < bytes) want <<= 1;
-  if (want > SPLITK_WS_MAX) want = SPLITK_WS_MAX;
-  float* fresh = nullptr;
-  if (hipMalloc(&fresh, want) != hipSuccess) return (void)hipGetLastError(), nullptr;
   if (e) {
-    // grow: launches already queued on this stream (or a host thread that fetched the pointer a moment ago) still use the old buffer, so it is
-    // retired, not freed -- sizes double, so a stream holds less than twice its largest workspace in total (< 512 MiB), and nothing waits
-    g_splitk_retired.push_back(e->p);
+    ws_free_entry(*e);  // grow: waits for the stream's earlier split-K launches (rare: sizes double)
   } else {
-    g_splitk_ws.push_back({dev, stream, nullptr, 0});
-    e = &g_splitk_ws.back();
+    size_t owned = 0;
+    for (auto& w : g_ws) owned += w.user ? 0 : 1;
+    while (owned >= SPLITK_OWNED_MAX) {  // evict the least recently used library-owned workspace
+      size_t lru = g_ws.size();
+      for (size_t i = 0; i < g_ws.size(); ++i)
+        if (!g_ws[i].user && (lru == g_ws.size() || g_ws[i].used < g_ws[lru].used)) lru = i;
+      ws_free_entry(g_ws[lru]);
+      g_ws.erase(g_ws.begin() + lru);
+      --owned;
+    }
+    g_ws.push_back(SplitKWs());
+    e = &g_ws.back();
+    e->dev = dev, e->stream = stream;
   }
-  e->p = fresh, e->bytes = want;
-  return e->p;
+  float* fresh = nullptr;
+  if (hipMalloc(&fresh, want) != hipSuccess || hipMemsetAsync(fresh, 0, W4_TICKET_FLOATS * 4, stream) != hipSuccess) {
+    (void)hipGetLastError();
+    if (fresh) (void)hipFree(fresh);
+    for (size_t i = 0; i < g_ws.size(); ++i)
+      if (&g_ws[i] == e) { g_ws.erase(g_ws.begin() + i); break; }
+    return nullptr;
+  }
+  if (hipEventCreateWithFlags(&e->ev, hipEventDisableTiming) != hipSuccess) e->ev = nullptr, (void)hipGetLastError();
+  e->p = fresh, e->bytes = want, e->used = ++g_ws_clock;
+  return e;
+}
+void ws_mark_used(SplitKWs* e, hipStream_t stream) {  // g_ws_mu held, after the launches
+  if (e && !e->user && e->ev && !stream_capturing(stream)) (void)hipEventRecord(e->ev, stream), (void)hipGetLastError();
+}
+// splits up to which the ONE-launch form (EPI 6: the last-arriving workgroup of a tile reduces) is taken; above it the tile's reduction on one
+// CU costs more than the reduce launch it saves (profiles/r05_hgemm_splitk_fused_probe.log). $CLN_AMD_SPLITK_FUSED_MAX_S overrides (0 = never).
+int splitk_fused_max_s() {
+  static const int v = [] {
+    const char* e = getenv("CLN_AMD_SPLITK_FUSED_MAX_S");
+    return e ? atoi(e) : 4;
+  }();
+  return v;
 }
 template <int LAYOUT>
 int splitk_dispatch(const SplitK& sk, const void* a, const void* b, void* c, float* ws, int M, int N, int K, hipStream_t st) {
-  if (sk.bm == 256 && sk.bn == 256) return launch_w4_splitk<LAYOUT, 26, 256, 256>(a, b, c, ws, M, N, K, sk.S, st);
-  if (sk.bm == 192 && sk.bn == 256) return launch_w4_splitk<LAYOUT, 26, 192, 256>(a, b, c, ws, M, N, K, sk.S, st);
-  if (sk.bm == 192 && sk.bn == 192) return launch_w4_splitk<LAYOUT, 26, 192, 192>(a, b, c, ws, M, N, K, sk.S, st);
-  if (sk.bm == 128 && sk.bn == 256) return launch_w4_splitk<LAYOUT, 26, 128, 256>(a, b, c, ws, M, N, K, sk.S, st);
-  if (sk.bm == 160 && sk.bn == 160) return launch_w4_splitk<LAYOUT, 26, 160, 160>(a, b, c, ws, M, N, K, sk.S, st);
+  // `ws` = tickets + partials; the two-launch form uses the partial area only
+#define CLN_SK(BMM, BNN)                                                                                                        \
+  if (sk.bm == BMM && sk.bn == BNN)                                                                                             \
+    return sk.S <= splitk_fused_max_s() ? launch_w4_splitk_fused<LAYOUT, 26, BMM, BNN>(a, b, c, ws, M, N, K, sk.S, st)         \
+                                        : launch_w4_splitk<LAYOUT, 26, BMM, BNN>(a, b, c, ws + W4_TICKET_FLOATS, M, N, K, sk.S, st);
+  CLN_SK(256, 256) CLN_SK(192, 256) CLN_SK(192, 192) CLN_SK(128, 256) CLN_SK(160, 160)
+#undef CLN_SK
   return CLN_ERR_UNSUPPORTED;
 }
 
@@ -183,7 +254,7 @@ struct TailSplit {
 };
 TailSplit tail_plan(int M, int N, int K) {
   TailSplit out;
-  if (M % 256 || N % 256 || !w4_k_ok(K)) return out;
+  if (splitk_disabled() || M % 256 || N % 256 || !w4_k_ok(K)) return out;
   const long long tm = M / 256, tn = N / 256, tiles = tm * tn;
   if (tiles <= 256 || tiles % 256 == 0) return out;
   const double T = 1.42 * (K / 64) + 5.0;
@@ -242,14 +313,26 @@ template <int LAYOUT>
 int best_dispatch(const void* a, const void* b, void* c, int M, int N, int K, int stages, int swizzle, int stride,
                   hipStream_t st) {
   const SplitK sk = splitk_plan(M, N, K);
-  if (sk.S >= 2) {  // few tiles, long K: K split over S workgroups per tile, fp32 partials, one reduce launch (`stages` ignored: one pipeline)
-    float* ws = splitk_workspace(st, (size_t)sk.S * M * N * sizeof(float));
-    if (ws) return splitk_dispatch<LAYOUT>(sk, a, b, c, ws, M, N, K, st);
+  if (sk.S >= 2) {  // few tiles, long K: K split over S workgroups per tile, fp32 partials; S <= splitk_fused_max_s(): ONE launch (`stages` ignored: one pipeline)
+    std::lock_guard<std::mutex> lock(g_ws_mu);  // held across the launch(es): see the workspace notes above
+    SplitKWs* w = ws_acquire(st, w4_splitk_ws_bytes(M, N, sk.S));
+    if (w) {
+      const int rc = splitk_dispatch<LAYOUT>(sk, a, b, c, w->p, M, N, K, st);
+      ws_mark_used(w, st);
+      return rc;
+    }
   }
   const TailSplit ts = tail_plan(M, N, K);
   if (ts.S >= 2) {  // a few tiles past whole rounds: the last tile rows split over K (`stages` ignored)
-    float* ws = splitk_workspace(st, (size_t)ts.S * (M - ts.m_split) * N * sizeof(float));
-    if (ws) return launch_w4_tail_split<LAYOUT, W4_EPILOGUE, W4_PRODUCTION, 256, 256>(a, b, c, ws, M, N, K, ts.m_split, ts.S, swizzle, stride, st);
+    std::lock_guard<std::mutex> lock(g_ws_mu);
+    SplitKWs* w = ws_acquire(st, w4_splitk_ws_bytes(M - ts.m_split, N, ts.S));
+    if (w) {
+      const int rc = ts.S <= splitk_fused_max_s()
+                         ? launch_w4_tail_split<LAYOUT, W4_EPILOGUE, W4_PRODUCTION, 256, 256, true>(a, b, c, w->p, M, N, K, ts.m_split, ts.S, swizzle, stride, st)
+                         : launch_w4_tail_split<LAYOUT, W4_EPILOGUE, W4_PRODUCTION, 256, 256, false>(a, b, c, w->p + W4_TICKET_FLOATS, M, N, K, ts.m_split, ts.S, swizzle, stride, st);
+      ws_mark_used(w, st);
+      return rc;
+    }
   }
   int plan = best_plan(M, N, K);
   if (plan == PLAN_W192) return launch_w4<LAYOUT, W4_EPILOGUE, W4_PRODUCTION, 0, 192, 192>(a, b, c, M, N, K, swizzle, stride, st);
@@ -295,12 +378,13 @@ int describe_best(int layout, int M, int N, int K, int stages, char* buf, int le
   const SplitK sk = splitk_plan(M, N, K);
   if (sk.S >= 2)
     return snprintf(buf, len, "hgemm_w4<%dx%dx64,4 waves,%dx%d wave tiles,cross-tile LDS-DMA,%s> split-K x %d (K %d per workgroup, fp32 partials in "
-                              "register layout) + hgemm_splitk_reduce [stages ignored: one pipeline]", sk.bm, sk.bn, sk.bm / 2, sk.bn / 2, l, sk.S, K / sk.S);
+                              "register layout) + %s [stages ignored: one pipeline]", sk.bm, sk.bn, sk.bm / 2, sk.bn / 2, l, sk.S, K / sk.S,
+                    sk.S <= splitk_fused_max_s() ? "in-kernel fix-up by the last-arriving workgroup (one launch)" : "hgemm_splitk_reduce");
   const TailSplit ts = tail_plan(M, N, K);
   if (ts.S >= 2)
     return snprintf(buf, len, "hgemm_w4<256x256x64,4 waves,128x128 wave tiles,cross-tile LDS-DMA,LDS epilogue,%s> on rows [0, %d) + the last %d tile rows as "
-                              "split-K x %d (K %d per workgroup) + hgemm_splitk_reduce [tail split; stages ignored: one pipeline]", l, ts.m_split,
-                    (M - ts.m_split) / 256, ts.S, K / ts.S);
+                              "split-K x %d (K %d per workgroup) + %s [tail split; stages ignored: one pipeline]", l, ts.m_split,
+                    (M - ts.m_split) / 256, ts.S, K / ts.S, ts.S <= splitk_fused_max_s() ? "in-kernel fix-up" : "hgemm_splitk_reduce");
   if (plan == PLAN_W192) return describe_w4(192, 192, layout, buf, len, stages != 2);
   if (plan == PLAN_W192x256) return describe_w4(192, 256, layout, buf, len, stages != 2);
   if (plan == PLAN_W256x192) return describe_w4(256, 192, layout, buf, len, stages != 2);
@@ -440,6 +524,57 @@ CLN_G6(hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_tn_swizzle_x4,
 CLN_G6(hgemm_mma_stages_block_swizzle_tn_cute,
        ((N % 256 == 0) ? fixed_tile_dispatch<TN, 128, 256>(T128x256, a, b, c, M, N, K, stages, swizzle, swizzle_stride, stream)
                        : ring_dispatch_tn(T128, a, b, c, M, N, K, stages, swizzle, swizzle_stride, stream)))
+
+// ---- workspace entry points (include/cln_amd.h; not part of the reference surface: its bindings take only a, b, c --
+// kernels/hgemm/mma/basic/hgemm_mma_stage.cu:2380-2413 -- so the default stays library-owned, but it is bounded, visible and freeable)
+// bytes the split-K / tail-split plan of the best-dispatch names needs for (M, N, K); 0 = the shape runs single-pass and never touches a workspace
+CLN_API size_t cln_hgemm_workspace_bytes(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  const SplitK sk = splitk_plan(M, N, K);
+  if (sk.S >= 2) return w4_splitk_ws_bytes(M, N, sk.S);
+  const TailSplit ts = tail_plan(M, N, K);
+  if (ts.S >= 2) return w4_splitk_ws_bytes(M - ts.m_split, N, ts.S);
+  return 0;
+}
+// Caller-owned workspace for the launches on `stream` of the current device: `ptr` (device memory, 16-byte aligned, `bytes` long) replaces the
+// library-owned buffer until it is withdrawn with ptr = NULL. Its first 4 KiB (arrival counters) are zeroed ON THE STREAM by this call; the
+// caller keeps the region alive and untouched while launches that may use it are queued. A shape that needs more than `bytes` runs single-pass.
+CLN_API int cln_hgemm_set_workspace(void* ptr, size_t bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return (void)hipGetLastError(), CLN_ERR_LAUNCH;
+  if (ptr && (!cln_aligned16(ptr) || bytes < (size_t)W4_TICKET_FLOATS * 4 + 16)) return CLN_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> lock(g_ws_mu);
+  for (size_t i = 0; i < g_ws.size(); ++i)
+    if (g_ws[i].dev == dev && g_ws[i].stream == st) {
+      if (!g_ws[i].user) ws_free_entry(g_ws[i]);
+      g_ws.erase(g_ws.begin() + i);
+      break;
+    }
+  if (!ptr) return CLN_OK;
+  if (hipMemsetAsync(ptr, 0, W4_TICKET_FLOATS * 4, st) != hipSuccess) return (void)hipGetLastError(), CLN_ERR_LAUNCH;
+  SplitKWs w;
+  w.dev = dev, w.stream = st, w.p = (float*)ptr, w.bytes = bytes, w.user = true, w.used = ++g_ws_clock;
+  g_ws.push_back(w);
+  return CLN_OK;
+}
+// Frees every library-owned workspace (after the launches that used it have completed) and forgets the caller-owned ones. Returns the bytes freed.
+CLN_API size_t cln_release_workspaces(void) {
+  std::lock_guard<std::mutex> lock(g_ws_mu);
+  size_t freed = 0;
+  for (auto& w : g_ws)
+    if (!w.user) freed += w.bytes, ws_free_entry(w);
+  g_ws.clear();
+  return freed + cln_stream_scratch_release();  // + the scratch slabs of the scalar-result kernels (stream_scratch.h)
+}
+// bytes of library-owned workspace currently held by this process (all devices, all streams)
+CLN_API size_t cln_hgemm_workspace_held(void) {
+  std::lock_guard<std::mutex> lock(g_ws_mu);
+  size_t held = 0;
+  for (auto& w : g_ws)
+    if (!w.user) held += w.bytes;
+  return held;
+}
 
 // describe hook of this library group (see cln_describe in describe.hip): the kernel a G6 name runs for (M, N, K,
 // stages); CLN_ERR_BAD_ARG when `name` is not one of the run-time dispatched HGEMM names (every other HGEMM name is

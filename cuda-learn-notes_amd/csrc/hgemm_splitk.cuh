@@ -84,11 +84,39 @@ int launch_w4_splitk(const void* a, const void* b, void* c, float* ws, int M, in
   return cln_check_launch();
 }
 
+// ONE launch (round 5): the same grid with EPI 6 -- the last-arriving workgroup of a tile sums the partials and stores C
+// (hgemm_w4.cuh). `ws` = W4_TICKET_FLOATS zeroed tickets + S * M * N floats. The reduction of a tile runs on ONE CU instead of 4 * BM / 32
+// workgroups of the reduce kernel, so it pays while S is small (the reduce launch costs ~5 us; a CU sums ~1 MiB of partials in about that time):
+// the planner (hgemm.hip) takes this form up to SPLITK_FUSED_MAX_S splits and the two-launch form above it.
+inline size_t w4_splitk_ws_bytes(int M, int N, int S) { return (size_t)W4_TICKET_FLOATS * 4 + (size_t)S * M * N * sizeof(float); }
+template <int LAYOUT, int VAR, int BM, int BN>
+int launch_w4_splitk_fused(const void* a, const void* b, void* c, float* ws, int M, int N, int K, int S, hipStream_t stream) {
+  using C = W4Cfg<BM, BN, LAYOUT>;
+  if (M % BM || N % BN || !w4_splitk_ok(K, S) || ws == nullptr) return CLN_ERR_UNSUPPORTED;
+  const int tiles_m = M / BM, tiles_n = N / BN, tiles = tiles_m * tiles_n, Kl = K / S;
+  if (S > 65535 || tiles > W4_TICKET_FLOATS) return CLN_ERR_UNSUPPORTED;
+  const int sw = (K / 64) << 8;
+  if ((Kl / 64) & 1) {
+    static cln_lds_attr lds_attr_odd;
+    if (cln_ensure_lds(lds_attr_odd, reinterpret_cast<const void*>(&hgemm_w4_kernel<LAYOUT, 6, VAR, 0, BM, BN, true>), C::LDS_BYTES) != CLN_OK)
+      return CLN_ERR_LAUNCH;
+    CLN_LAUNCH((hgemm_w4_kernel<LAYOUT, 6, VAR, 0, BM, BN, true>), dim3(tiles, S), dim3(256), C::LDS_BYTES, stream, (const half_t*)a, (const half_t*)b,
+               (half_t*)c, M, N, Kl, tiles_m, tiles_n, sw, tiles_n, ws);
+  } else {
+    static cln_lds_attr lds_attr;
+    if (cln_ensure_lds(lds_attr, reinterpret_cast<const void*>(&hgemm_w4_kernel<LAYOUT, 6, VAR, 0, BM, BN>), C::LDS_BYTES) != CLN_OK)
+      return CLN_ERR_LAUNCH;
+    CLN_LAUNCH((hgemm_w4_kernel<LAYOUT, 6, VAR, 0, BM, BN>), dim3(tiles, S), dim3(256), C::LDS_BYTES, stream, (const half_t*)a, (const half_t*)b,
+               (half_t*)c, M, N, Kl, tiles_m, tiles_n, sw, tiles_n, ws);
+  }
+  return cln_check_launch();
+}
+
 // Tail split (round 4): a tile count just past a whole number of rounds of 256 (4352^3: 289 tiles of 256 x 256, 5888^3: 529, 7168^3: 784) leaves the
 // last round almost empty. The output is cut along M: rows [0, m_split) -- whole rounds of tiles -- run the single-pass kernel, the remaining
 // tile rows run split-K so that they, too, spread over the chip. Both are the launchers above / in hgemm_w4.cuh on sub-matrices (row offsets
 // only: leading dimensions unchanged), back to back on the caller's stream.
-template <int LAYOUT, int EPI, int VAR, int BM, int BN>
+template <int LAYOUT, int EPI, int VAR, int BM, int BN, bool FUSED = false>
 int launch_w4_tail_split(const void* a, const void* b, void* c, float* ws, int M, int N, int K, int m_split, int S, int swizzle, int swizzle_stride,
                          hipStream_t stream) {
   if (m_split <= 0 || m_split >= M || m_split % BM || (M - m_split) % BM) return CLN_ERR_UNSUPPORTED;
@@ -96,7 +124,8 @@ int launch_w4_tail_split(const void* a, const void* b, void* c, float* ws, int M
   if (rc != CLN_OK) return rc;
   const half_t* a2 = reinterpret_cast<const half_t*>(a) + (size_t)m_split * K;
   half_t* c2 = reinterpret_cast<half_t*>(c) + (size_t)m_split * N;
-  return launch_w4_splitk<LAYOUT, VAR, BM, BN>(a2, b, c2, ws, M - m_split, N, K, S, stream);
+  if constexpr (FUSED) return launch_w4_splitk_fused<LAYOUT, VAR, BM, BN>(a2, b, c2, ws, M - m_split, N, K, S, stream);  // `ws` = tickets + partials
+  else return launch_w4_splitk<LAYOUT, VAR, BM, BN>(a2, b, c2, ws, M - m_split, N, K, S, stream);
 }
 
 }  // namespace hgemm

@@ -161,14 +161,16 @@ struct W4Cfg {
                 "wave tiles of 128, 96, 80 or 64 rows / columns; enough MFMAs per K tile to hang the schedule on");
 };
 
+constexpr int W4_TICKET_FLOATS = 1024;  // split-K workspace header: one arrival counter per output tile (<= 768 workgroups per launch), 4 KiB
 // VAR: bits 0..3 = schedule number (256x256 only; other shapes take w4_sched_for), bit 4 = boustrophedon MFMA order
 // (B fragments walked back and forth, so only ONE operand changes between consecutive MFMAs: ~1 % less power).
 // ODD: K / 64 is odd (>= 7): one more whole tile between the loop over tile pairs and the two closing tiles.
 template <int LAYOUT, int EPI = 2, int VAR = 0, int ABL = 0, int BM = 256, int BN = 256, bool ODD = false>
 __global__ __launch_bounds__(256, 1) void hgemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ B,
                                                           half_t* __restrict__ Cmat, int M, int N, int K, int tiles_m,
-                                                          int tiles_n, int swizzle, int band) {
+                                                          int tiles_n, int swizzle, int band, float* __restrict__ ws = nullptr) {
   using C = W4Cfg<BM, BN, LAYOUT>;
+  constexpr bool SPLITK = EPI == 5 || EPI == 6;  // 5: partials only (+ the reduce launch, probe library); 6: partials + in-kernel fix-up by the last arriver
   constexpr int FM = C::FM, FN = C::FN, NR = C::NR, NP = C::NP, NM = C::NM;
   constexpr W4Sched S = (BM == 256 && BN == 256) ? w4_sched(VAR & 15) : w4_sched_for(FM, FN, (BM == 128 || BN == 128 || BM == 160) ? 2 : (BM == 192 && BN == 192) ? 4 : 5);
   constexpr bool SNAKE = (VAR >> 4) & 1;
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(256, 1) void hgemm_w4_kernel(const half_t* __restri
   NFillW<C, FN> fbn;
   const char* a_src;
   const char* b_src;
-  if constexpr (EPI == 5) {
+  if constexpr (SPLITK) {
     const int ld = (swizzle >> 8) * 64;
     const size_t k0 = (size_t)blockIdx.y * K;
     fa.init(ld, wave, lane);
@@ -363,15 +365,68 @@ __global__ __launch_bounds__(256, 1) void hgemm_w4_kernel(const half_t* __restri
   for (int i = 0; i < FM; ++i)
 #pragma unroll
     for (int j = 0; j < FN; ++j) asm volatile("" : "+a"(acc[i][j]));
-  if constexpr (EPI == 5) {
-    // split-K partial: the fp32 accumulators as they lie in the registers -- `Cmat` is the fp32 workspace, [split][tile][wave][fragment][lane] x 16 bytes,
-    // one store instruction = 1 KiB contiguous; the reduce kernel (hgemm_splitk.cuh) sums the splits and transposes through LDS
-    float* dst = reinterpret_cast<float*>(Cmat) + ((size_t)blockIdx.y * (tiles_m * tiles_n) + (size_t)tm * tiles_n + tn) * (BM * BN) +
-                 wave * (C::WTM * C::WTN) + lane * 4;
+  if constexpr (SPLITK) {
+    // split-K partial: the fp32 accumulators as they lie in the registers -- the fp32 workspace is [split][tile][wave][fragment][lane] x 16 bytes,
+    // one store instruction = 1 KiB contiguous. EPI 5: `Cmat` IS the workspace and the reduce kernel (hgemm_splitk.cuh) sums the splits.
+    // EPI 6 (round 5, ONE launch): `ws` = [1024 tickets][partials]; the workgroup that takes the LAST ticket of its tile sums the S partials in
+    // ascending split order (its own included: re-read from its own L2 -- the same order, hence the same bits, as the reduce kernel), rounds once
+    // and writes C through the ordinary LDS-staged epilogue. Tickets reset themselves: no memset between launches.
+    const int tile = tm * tiles_n + tn, tiles = tiles_m * tiles_n;
+    float* part = (EPI == 6 ? ws + W4_TICKET_FLOATS : reinterpret_cast<float*>(Cmat));
+    float* dst = part + ((size_t)blockIdx.y * tiles + tile) * (BM * BN) + wave * (C::WTM * C::WTN) + lane * 4;
+    if constexpr (EPI == 5) {
 #pragma unroll
-    for (int i = 0; i < FM; ++i)
+      for (int i = 0; i < FM; ++i)
 #pragma unroll
-      for (int j = 0; j < FN; ++j) *reinterpret_cast<f4*>(dst + (i * FN + j) * 256) = acc[i][j];
+        for (int j = 0; j < FN; ++j) *reinterpret_cast<f4*>(dst + (i * FN + j) * 256) = acc[i][j];
+    }
+    if constexpr (EPI == 6) {
+      // Visibility across the 8 XCD L2s WITHOUT fences: the partials are stored and loaded at AGENT scope (`sc1`: write-through to / coherent
+      // read from the memory side) and the ticket is an agent-scope atomic. A __threadfence() pair here -- what the first form of this epilogue
+      // did -- writes back AND INVALIDATES the whole L2 of the XCD while the other workgroups are still streaming A / B panels through it:
+      // measured +17-45 us per launch (profiles/r05_hgemm_splitk_fused_probe.log, first block).
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst + (i * FN + j) * 256), "v"(acc[i][j]) : "memory");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's partial has reached the memory side
+      const int S = gridDim.y;
+      int* last = reinterpret_cast<int*>(smem + C::LDS_BYTES - 16);  // beyond the four staging regions of the epilogue
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        unsigned* tk = reinterpret_cast<unsigned*>(ws) + tile;
+        const unsigned old = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int l = old == (unsigned)(S - 1);
+        if (l) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // all S have arrived: the ticket is ready for the next launch
+        *last = l;
+      }
+      __syncthreads();
+      if (*last == 0) return;
+      const float* src = part + (size_t)tile * (BM * BN) + wave * (C::WTM * C::WTN) + lane * 4;
+      const size_t split_stride = (size_t)tiles * (BM * BN);
+      // split-major in chunks of 2 fragment rows: 2 x FN agent-scope loads of one split in flight per lane, every element summed in ascending
+      // split order (this workgroup's own partial included, re-read: the same order -- hence the same bits -- as the reduce kernel)
+#pragma unroll
+      for (int i0 = 0; i0 < FM; i0 += 2) {
+        for (int ks = 0; ks < S; ++ks) {
+          const float* p = src + (size_t)ks * split_stride;
+          f4 t[2][FN];
+#pragma unroll
+          for (int i = i0; i < i0 + 2 && i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(t[i - i0][j]) : "v"(p + (i * FN + j) * 256) : "memory");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int i = i0; i < i0 + 2 && i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+              asm volatile("" : "+v"(t[i - i0][j]));  // (volatile: ordered behind the wait; the add below depends on it)
+              acc[i][j] = ks == 0 ? t[i - i0][j] : acc[i][j] + t[i - i0][j];
+            }
+        }
+      }
+      store_wide_tile_via_lds<FM, FN, 0>(Cmat, N, m0 + wm * C::WTM, n0 + wn * C::WTN, lane, smem + wave * (64 * (FN * 32 + 16)), acc, 0);
+    }
   } else if constexpr (EPI >= 2) {  // EPI 3 / 4 (probe library): the same epilogue with non-temporal / write-through C stores
     // B1 of the last tile: every wave is past its last fragment read; no DMA is in flight
     store_wide_tile_via_lds<FM, FN, EPI - 2>(Cmat, N, m0 + wm * C::WTM, n0 + wn * C::WTN, lane, smem + wave * (64 * (FN * 32 + 16)), acc, (swizzle >> 1) & 1);

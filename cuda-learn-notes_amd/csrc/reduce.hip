@@ -9,6 +9,7 @@
 // (e.g. f16x8_pack_f16 adds the 8 halves of a pack in fp16, block_all_reduce.cu:252-262);
 // everything across packs / lanes / waves is fp32 (int32 for i8), result y is fp32 / int32.
 #include "common.h"
+#include "stream_scratch.h"
 
 namespace {
 
@@ -127,7 +128,7 @@ struct alignas(sizeof(E) * VEC) Pack {
 // the grid is capped at the CU count -- 4096 small workgroups spent 50 us in that tail alone.
 template <typename PS, int VEC>
 __global__ __launch_bounds__(1024) void reduce_sum_kernel(const typename PS::elem* __restrict__ a,
-                                                          typename PS::out* __restrict__ y, long long n) {
+                                                          typename PS::out* __restrict__ y, long long n, ClnScratch* sc) {
   using E = typename PS::elem;
   using O = typename PS::out;
   __shared__ O scratch[16];
@@ -178,7 +179,10 @@ __global__ __launch_bounds__(1024) void reduce_sum_kernel(const typename PS::ele
     O t = (lane < 16) ? scratch[lane] : (O)0;
 #pragma unroll
     for (int m = 8; m >= 1; m >>= 1) t += __shfl_xor(t, m, 64);
-    if (lane == 0) atomicAdd(y, t);
+    if (lane == 0) {
+      if (sc) cln_scratch_finish<O>(sc, y, t, gridDim.x);  // the last block moves the total into y and re-zeroes the scratch (stream_scratch.h)
+      else atomicAdd(y, t);                                // no scratch slot (stream capture): y was zeroed on the stream by the launcher
+    }
   }
 }
 
@@ -187,19 +191,21 @@ int launch_reduce(const void* a, void* y, long long n, hipStream_t st) {
   using PS = PackSum<IN, ACC, VEC>;
   using E = typename PS::elem;
   if (!a || !y || n < 0) return CLN_ERR_BAD_ARG;
-  if (n == 0) return CLN_OK;
+  if (n == 0) return hipMemsetAsync(y, 0, sizeof(typename PS::out), st) == hipSuccess ? CLN_OK : ((void)hipGetLastError(), CLN_ERR_LAUNCH);
   if (!cln_aligned(a, sizeof(E) * VEC >= 16 ? 16 : sizeof(E) * VEC)) return CLN_ERR_BAD_ARG;
   long long g = (n / VEC + 1023) / 1024;
   const int grid = (int)(g < 1 ? 1 : (g > 256 ? 256 : g));
+  ClnScratch* sc = cln_stream_scratch(st);
+  if (!sc && hipMemsetAsync(y, 0, sizeof(typename PS::out), st) != hipSuccess) return (void)hipGetLastError(), CLN_ERR_LAUNCH;
   CLN_LAUNCH((reduce_sum_kernel<PS, VEC>), dim3(grid), dim3(1024), 0, st, (const E*)a,
-             (typename PS::out*)y, n);
+             (typename PS::out*)y, n, sc);
   return cln_check_launch();
 }
 
 }  // namespace
 
-// (a, y, n_elements, stream): y is a 1-element fp32 (int32 for i8) buffer the caller zeroed --
-// the reference binding allocates it with torch::zeros on cuda:0 (block_all_reduce.cu:737-738).
+// (a, y, n_elements, stream): y is a 1-element fp32 (int32 for i8) buffer that the launch OVERWRITES with the sum (round 5; before: the
+// caller had to zero it, as the reference binding does with torch::zeros on cuda:0, block_all_reduce.cu:737-738 -- a zeroed y still works).
 #define CLN_RED(name, IN, ACC, VEC)                                            \
   CLN_API int name(const void* a, void* y, long long n, void* stream) {        \
     return launch_reduce<IN, ACC, VEC>(a, y, n, (hipStream_t)stream);          \

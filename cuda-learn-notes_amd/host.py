@@ -80,6 +80,38 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# ---- the CPython entry in front of the C-ABI (csrc/pyext/cln_fastcall.c, round 5): argument checks, data_ptr()s, the raw stream and the C call
+# in one vectorcall, falling back to the pure-Python wrapper below on ANY failed check or non-zero status (so the error texts stay those of
+# this file). Absent module, CPU-only torch build or $CLN_AMD_NO_FASTCALL=1: the wrappers call through ctypes as before.
+def _load_fastcall():
+    if os.environ.get("CLN_AMD_NO_FASTCALL", "0") == "1" or _raw_device is None or _raw_stream is None:
+        return None
+    import glob
+    import importlib.util
+    for path in glob.glob(os.path.join(_loader.LIBDIR, "_cln_fastcall*.so")):
+        try:
+            spec = importlib.util.spec_from_file_location("_cln_fastcall", path)
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            mod.setup(_raw_device, _raw_stream)
+            return mod
+        except Exception:  # noqa: BLE001 -- an optional accelerator: any trouble means ctypes
+            continue
+    return None
+
+
+_fastcall = _load_fastcall()
+
+
+def _fast(kind, name, fn, slow, dtype, vt=False, out_dtype=None):
+    """`slow` wrapped by the vectorcall entry of kind `kind` (a key of _cln_fastcall.KINDS) when the extension is there."""
+    if _fastcall is None:
+        return slow
+    import ctypes
+    addr = ctypes.cast(fn, ctypes.c_void_p).value
+    return _fastcall.bind(addr, _fastcall.KINDS[kind], dtype, slow, name, int(bool(vt)), out_dtype)
+
+
 def _raise(name, rc, unsupported_msg=None):
     if rc == 0:
         return
@@ -104,7 +136,7 @@ def _make_g3(name, dtype=torch.float16):
         _raise(name, fn(a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, _stream()),
                "%s: M/N/K must be multiples of the block tile" % name)
     f.__name__ = name
-    return f
+    return _fast("G3", name, fn, f, dtype)
 
 
 def _make_g6(name, dtype=torch.float16):
@@ -123,7 +155,7 @@ def _make_g6(name, dtype=torch.float16):
                         int(swizzle_stride), _stream()),
                "%s: M/N/K must be multiples of the block tile" % name)
     f.__name__ = name
-    return f
+    return _fast("G6", name, fn, f, dtype)
 
 
 def _make_h0(name):
@@ -157,7 +189,7 @@ def _make_fa(name):
             raise RuntimeError("headdim not support!")
         _raise(name, rc)
     f.__name__ = name
-    return f
+    return _fast("FA", name, fn, f, torch.float16, vt=vt)
 
 
 def _make_p3(name):
@@ -172,7 +204,7 @@ def _make_p3(name):
         _check_shape(c, *a.shape)
         _raise(name, fn(a.data_ptr(), b.data_ptr(), c.data_ptr(), a.numel(), _stream()))
     f.__name__ = name
-    return f
+    return _fast("P3", name, fn, f, dtype)
 
 
 def _make_r1(name):
@@ -182,11 +214,13 @@ def _make_r1(name):
     def f(x):
         _check_dtype(x, in_dt)
         _check_dev(x)
-        y = torch.zeros(1, dtype=out_dt, device=x.device)  # reference allocates it in the binding
+        # the reference binding allocates a ZEROED result (block_all_reduce.cu:737-738) and its blocks add into it: two dispatches per call. Here the
+        # launch overwrites y (csrc/stream_scratch.h: the last block moves the total out of a self-resetting per-stream scratch word): no fill kernel
+        y = torch.empty(1, dtype=out_dt, device=x.device)
         _raise(name, fn(x.data_ptr(), y.data_ptr(), x.numel(), _stream()))
         return y
     f.__name__ = name
-    return f
+    return _fast("R1", name, fn, f, in_dt, out_dtype=out_dt)
 
 
 _SOFTMAX_ONE_BLOCK_MAX = 65536  # == SOFTMAX_ONE_BLOCK_MAX in csrc/softmax.hip (tests/test_host_logic.py holds them equal)
@@ -223,7 +257,7 @@ def _make_xy(name):
                "%s: unsupported H=%d (must be a multiple of the pack width and fit 8 packs x 1024 lanes)"
                % (name, H))
     f.__name__ = name
-    return f
+    return _fast("XY", name, fn, f, dtype)
 
 
 def _make_ln(name):
@@ -239,7 +273,7 @@ def _make_ln(name):
         _raise(name, fn(x.data_ptr(), y.data_ptr(), float(g), float(b), N, K, _stream()),
                "%s: unsupported K=%d" % (name, K))
     f.__name__ = name
-    return f
+    return _fast("LN", name, fn, f, dtype)
 
 
 def _make_rn(name):
@@ -254,7 +288,7 @@ def _make_rn(name):
         N, K = x.size(0), x.size(1)
         _raise(name, fn(x.data_ptr(), y.data_ptr(), float(g), N, K, _stream()), "%s: unsupported K=%d" % (name, K))
     f.__name__ = name
-    return f
+    return _fast("RN", name, fn, f, dtype)
 
 
 def _make_rp(name):
@@ -323,7 +357,7 @@ def _make_un(name):
         _check_shape(y, *x.shape)
         _raise(name, fn(x.data_ptr(), y.data_ptr(), x.numel(), _stream()))
     f.__name__ = name
-    return f
+    return _fast("UN", name, fn, f, dtype)
 
 
 def _make_d2(name):
@@ -335,11 +369,11 @@ def _make_d2(name):
         _check_dtype(b, dtype)
         _check_dev(a, b)
         _check_shape(b, *a.shape)
-        prod = torch.zeros(1, dtype=torch.float32, device=a.device)  # reference dot_product.cu:236-238
+        prod = torch.empty(1, dtype=torch.float32, device=a.device)  # reference dot_product.cu:236-238 zeroes it; here the launch overwrites it (stream_scratch.h)
         _raise(name, fn(a.data_ptr(), b.data_ptr(), prod.data_ptr(), a.numel(), _stream()))
         return prod
     f.__name__ = name
-    return f
+    return _fast("D2", name, fn, f, dtype, out_dtype=torch.float32)
 
 
 def _make_gv(name):
@@ -396,6 +430,42 @@ def load_lib(*groups):
                 continue  # optional comparison row absent from this build: the attribute is simply not there (callers test with hasattr / try)
             setattr(ns, e.name, _MAKERS[e.sig](e.name))
     return ns
+
+
+# ---- split-K workspace of the best-dispatch HGEMM names (include/cln_amd.h; not part of the reference surface) -----------------------------
+_user_workspaces = {}  # (device, raw stream) -> the torch tensor handed to the library: kept alive here until it is withdrawn
+
+
+def hgemm_workspace_bytes(M, N, K):
+    """Bytes of fp32 workspace the split-K / tail-split plan of (M, N, K) uses; 0 = the shape runs single-pass."""
+    return int(_loader.load_so("libcln_amd.so").cln_hgemm_workspace_bytes(int(M), int(N), int(K)))
+
+
+def hgemm_set_workspace(buf):
+    """Give the launches on torch's CURRENT stream a caller-owned workspace: `buf` is a contiguous GPU tensor (any dtype; e.g.
+    torch.empty(nbytes, dtype=torch.uint8, device="cuda") from torch's caching allocator, so its lifetime follows torch's stream semantics),
+    or None to go back to the library-owned one. The library zeroes the first 4 KiB on the stream; shapes that need more than the buffer
+    holds run single-pass."""
+    lib = _loader.load_so("libcln_amd.so")
+    key = (_current_device(), _stream())
+    if buf is None:
+        _raise("cln_hgemm_set_workspace", lib.cln_hgemm_set_workspace(None, 0, key[1]))
+        _user_workspaces.pop(key, None)
+        return
+    _check_dev(buf)
+    _raise("cln_hgemm_set_workspace", lib.cln_hgemm_set_workspace(buf.data_ptr(), buf.numel() * buf.element_size(), key[1]))
+    _user_workspaces[key] = buf
+
+
+def release_workspaces():
+    """Free every library-owned workspace / scratch slab (after the launches that use them have completed); returns the bytes freed."""
+    _user_workspaces.clear()
+    return int(_loader.load_so("libcln_amd.so").cln_release_workspaces())
+
+
+def hgemm_workspace_held():
+    """Bytes of library-owned split-K workspace this process currently holds."""
+    return int(_loader.load_so("libcln_amd.so").cln_hgemm_workspace_held())
 
 
 def hgemm_variant(kind, layout, tile, bk, stages, a, b, c, swizzle=0, swizzle_stride=1):

@@ -84,7 +84,7 @@ def main():
                " * passed as void* (NULL = default stream). Every function returns 0 on success or\n"
                " *   -1 bad argument, -2 unsupported shape, -3 HIP launch error, -4 vendor-library error.\n"
                " * Launches are asynchronous on `stream`; the callee never allocates or keeps pointers.\n"
-               " */\n#ifndef CLN_AMD_H\n#define CLN_AMD_H\n#ifdef __cplusplus\nextern \"C\" {\n#endif\n")
+               " */\n#ifndef CLN_AMD_H\n#define CLN_AMD_H\n#ifdef __cplusplus\nextern \"C\" {\n#endif\n#include <stddef.h>\n")
     out.append("#define CLN_OK 0\n#define CLN_ERR_BAD_ARG (-1)\n#define CLN_ERR_UNSUPPORTED (-2)\n"
                "#define CLN_ERR_LAUNCH (-3)\n#define CLN_ERR_VENDOR (-4)\n")
     for lib, doc in GROUPS:
@@ -98,6 +98,25 @@ def main():
                " * `impl` comment above). Host-only: no launch, no device access. The tuning / ablation hooks\n"
                " * (cln_hgemm_variant, cln_fa2_variant) live in the TEST-ONLY libcln_amd_probe.so and are not declared here. */")
     out.append("int cln_describe(const char* name, int d0, int d1, int d2, int d3, int stages, char* buf, int buflen);")
+    out.append("\n/* ---- split-K workspace of the best-dispatch HGEMM names (not part of the reference surface: the reference's bindings take\n"
+               " * only a, b, c -- kernels/hgemm/mma/basic/hgemm_mma_stage.cu:2380-2413 -- and never need one). Shapes with few output tiles and a\n"
+               " * long K (and the last tile rows of a tile count just past whole rounds of 256) are split over K; the fp32 partials live in ONE\n"
+               " * workspace per (device, stream): 4 KiB of arrival counters + S*M*N floats.\n"
+               " *   default         library-owned: allocated on first use (never during stream capture: such a launch runs single-pass), grown by\n"
+               " *                   doubling up to 256 MiB, at most 8 held per process (least recently used freed first, after its last launch has\n"
+               " *                   completed), all freed by cln_release_workspaces().\n"
+               " *   caller-owned    cln_hgemm_set_workspace(ptr, bytes, stream): the library never allocates for that stream; size it with\n"
+               " *                   cln_hgemm_workspace_bytes(M, N, K) (0 = the shape runs single-pass); a shape that needs more runs single-pass.\n"
+               " *                   The first 4 KiB are zeroed on `stream` by the call; keep the region alive and untouched while launches are queued.\n"
+               " * Threads: calls are serialised per process while a workspace is in use (the lock covers the 1-2 launches of a split-K call), so two\n"
+               " * host threads may call hgemm on one stream. Graphs: a captured launch holds the pointer of the workspace its capture stream had;\n"
+               " * replay the graph on the capture stream, or give every graph its own caller-owned region. A shape's result does not depend on\n"
+               " * whose workspace is used, but it differs in the last bit from the single-pass plan (fp32 summation order), so eager and captured\n"
+               " * runs of a split-K shape on a stream WITHOUT a workspace are not bit-identical ($CLN_AMD_NO_SPLITK=1 forces single-pass everywhere). */")
+    out.append("size_t cln_hgemm_workspace_bytes(int M, int N, int K);")
+    out.append("int cln_hgemm_set_workspace(void* ptr, size_t bytes, void* stream);")
+    out.append("size_t cln_release_workspaces(void);   /* returns the bytes freed */")
+    out.append("size_t cln_hgemm_workspace_held(void); /* library-owned bytes currently held */")
     out.append("\n#ifdef __cplusplus\n}\n#endif\n#endif /* CLN_AMD_H */\n")
     path = os.path.join(ROOT, "include", "cln_amd.h")
     os.makedirs(os.path.dirname(path), exist_ok=True)

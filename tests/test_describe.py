@@ -112,7 +112,7 @@ def test_flash_attn_planner_invariants_over_a_grid_of_shapes(built):
     row / key granularity divides N (a launcher would otherwise refuse at run time what describe promised)."""
     m = built.manifest
     tq, sq = "flash_attn_mma_stages_split_q_tiling_qkv", "flash_attn_mma_stages_split_q_shared_qkv"
-    rows_per_wg = {"fa2_fwd_m16": 256, "fa2_fwd_m16x": 256, "fa2_fwd_m16x64r": 512, "fa2_fwd_dsplit": 128, "fa2_fwd_dring": 64, "fa2_fwd_v2": 64}
+    rows_per_wg = {"fa2_fwd_m16": 256, "fa2_fwd_m16x": 256, "fa2_fwd_m16x64r": 512, "fa2_fwd_dsplit": 128, "fa2_fwd_dw4": 64, "fa2_fwd_v2": 64}
     fam_seen = set()
     for D in (32, 64, 96, 128, 256, 320, 384, 512, 640, 768, 1024):
         for (B, H) in ((1, 1), (1, 8), (4, 8), (1, 48), (2, 96), (1, 256)):
@@ -138,11 +138,11 @@ def test_flash_attn_planner_invariants_over_a_grid_of_shapes(built):
                 if D == 512:
                     assert fam == "fa2_fwd_m16" and "pairs of waves split d" in t, t
                 if D in (640, 768, 1024):
-                    assert fam == "fa2_fwd_dring", t
+                    assert fam == "fa2_fwd_dw4" and "one per SIMD" in t, t
                 if D <= 256:  # the shared-QKV name (max head dim 256) plans the same kernel
                     assert m.describe(sq, (B, H, N, D), 2) == t
     for want in (("fa2_fwd_m16x", 64), ("fa2_fwd_m16x", 128), ("fa2_fwd_m16", 256), ("fa2_fwd_m16x64r", 64), ("fa2_fwd_v2", 32),
-                 ("fa2_fwd_dsplit", 384), ("fa2_fwd_m16", 512), ("fa2_fwd_dring", 1024), ("fa2_fwd_dring", 640)):
+                 ("fa2_fwd_dsplit", 384), ("fa2_fwd_m16", 512), ("fa2_fwd_dw4", 1024), ("fa2_fwd_dw4", 640)):
         assert want in fam_seen, (want, sorted(fam_seen))
     with pytest.raises(ValueError):  # "headdim not support!" of the shared-QKV rung (MAX_HEADDIM_CFG: 256)
         m.describe(sq, (1, 32, 4096, 512), 2)

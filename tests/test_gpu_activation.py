@@ -46,6 +46,32 @@ def test_activation_extremes_are_finite(lib, dev):
         assert torch.isfinite(yh).all(), op
 
 
+def test_hardswish_edges_follow_the_reference_piecewise_form(lib, dev):
+    """hardswish.cu:37-45: x >= 3 -> x EXACTLY (also for +inf and values above FLT_MAX / 6), x <= -3 -> 0 (also for -inf), NaN stays NaN
+    (the branch-free x * med3(x + 3, 0, 6) / 6 gave NaN at -inf, +inf above 5.7e37 and 1 ulp off x for x >= 3)."""
+    inf = float("inf")
+    vals = [3.0, 3.0000002, 7.3, 1234.567, 1e38, 3.0e38, inf, -3.0, -3.0000002, -1e38, -inf, float("nan"), 0.0, -0.0, 1.0, -1.0]
+    x = torch.tensor(vals * 4, device=dev)
+    y = torch.full_like(x, 7.0)
+    for rung in ("f32", "f32x4"):
+        getattr(lib, "hardswish_" + rung)(x, y)
+        got = y.cpu()[:len(vals)]
+        for v, g in zip(vals, got.tolist()):
+            if v != v:
+                assert g != g
+            elif v >= 3.0:
+                assert g == torch.tensor(v, dtype=torch.float32).item(), (rung, v, g)
+            elif v <= -3.0:
+                assert g == 0.0, (rung, v, g)
+        assert abs(got[14].item() - 4.0 / 6.0) < 1e-6 and abs(got[15].item() + 2.0 / 6.0) < 1e-6
+    xh = torch.tensor([3.0, 100.0, 65504.0, inf, -3.0, -65504.0, -inf, 1.0] * 8, dtype=torch.half, device=dev)
+    yh = torch.full_like(xh, 7.0)
+    for rung in ("f16", "f16x2", "f16x8", "f16x8_pack"):
+        getattr(lib, "hardswish_" + rung)(xh, yh)
+        g = yh.cpu()[:8].tolist()
+        assert g[:4] == [3.0, 100.0, 65504.0, inf] and g[4:7] == [0.0, 0.0, 0.0] and abs(g[7] - 4.0 / 6.0) < 1e-3, (rung, g)
+
+
 def test_activation_dtype_error(lib, dev):
     x = torch.zeros(8, device=dev)
     with pytest.raises(RuntimeError, match="values must be torch::kHalf"):

@@ -299,3 +299,67 @@ def test_launches_past_the_mall_use_streaming_stores_and_give_the_same_bits(buil
     small = torch.zeros(2048, H, device=dev)
     lib.rope_f32x4_pack(x[:2048].contiguous(), small)  # 128 MB: plain path, same positions 0..2047
     assert torch.equal(out[:2048], small)
+
+
+# ------------------------------------------------------------------ scalar results without a zeroed output (round 5)
+def test_reduce_and_dot_overwrite_their_result(lib, built, dev, oracle):
+    """csrc/stream_scratch.h: the launch OVERWRITES y (the last block moves the total out of a self-resetting per-stream scratch word), so the
+    result tensor no longer has to be zeroed -- through the raw C-ABI with y pre-filled with garbage, repeatedly, on several streams at once,
+    and through the Python wrappers (which now hand out torch.empty results)."""
+    from cuda_learn_notes_amd import _loader, host
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1 << 20, generator=g)
+    xd = x.to(dev)
+    exact = oracle.reduce_sum(x)
+    raw = _loader.symbol("block_all_reduce_sum_f32x4_f32")
+    y = torch.full((1,), float("nan"), device=dev)
+    for _ in range(5):
+        y.fill_(float("nan"))
+        assert raw(xd.data_ptr(), y.data_ptr(), xd.numel(), host._stream()) == 0
+        assert abs(y.item() - exact) <= 1e-3 * max(1.0, abs(exact)) + 1e-2
+    xi = torch.randint(-128, 128, (1 << 20,), dtype=torch.int8, generator=g)
+    yi = torch.full((1,), 12345, dtype=torch.int32, device=dev)
+    assert _loader.symbol("block_all_reduce_sum_i8x16_pack_i32")(xi.to(dev).data_ptr(), yi.data_ptr(), xi.numel(), host._stream()) == 0
+    assert yi.item() == int(xi.to(torch.int64).sum().item())
+    # several streams at once: one scratch slot per stream
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    parts = [torch.randn(1 << 18, generator=g) for _ in range(4)]
+    res = []
+    for rep in range(6):
+        for st, p in zip(streams, parts):
+            with torch.cuda.stream(st):
+                res.append((lib.block_all_reduce_sum_f32x4_f32(p.to(dev, non_blocking=False)), p))
+    torch.cuda.synchronize()
+    for r, p in res:
+        e = oracle.reduce_sum(p)
+        assert abs(r.item() - e) <= 1e-3 * max(1.0, abs(e)) + 1e-2
+    # n == 0 still yields a zero
+    z = torch.full((1,), 3.0, device=dev)
+    assert raw(xd.data_ptr(), z.data_ptr(), 0, host._stream()) == 0
+    torch.cuda.synchronize()
+    assert z.item() == 0.0
+    # dot product: same scheme
+    d = built.load("dot_product")
+    a, b = torch.randn(1 << 18, generator=g), torch.randn(1 << 18, generator=g)
+    want = (a.double() * b.double()).sum().item()
+    for _ in range(3):
+        got = d.dot_prod_f32x4_f32(a.to(dev), b.to(dev))
+        assert abs(got.item() - want) <= 1e-3 * max(1.0, abs(want)) + 1e-2
+
+
+def test_reduce_under_stream_capture_takes_the_memset_path(lib, dev, oracle):
+    """No scratch slot may be allocated while a stream is being captured: a stream without one zeroes y with a memset node and adds into it
+    directly; replays give the same sum."""
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(1 << 18, generator=g)
+    xd = x.to(dev)
+    exact = oracle.reduce_sum(x)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=st):
+            y = lib.block_all_reduce_sum_f32x4_f32(xd)
+        for _ in range(3):
+            graph.replay()
+            st.synchronize()
+            assert abs(y.item() - exact) <= 1e-3 * max(1.0, abs(exact)) + 1e-2

@@ -1,6 +1,8 @@
 """GPU parity: every HGEMM entry point through the C-ABI vs the CPU oracle (fp32-accumulate product of
 the same fp16 inputs). Tolerance: the kernels accumulate in fp32 and round once to fp16, so the result
 must be within one fp16 ulp of the fp32 truth: rtol 2^-10 (plus atol 2e-3 for near-cancelled sums)."""
+import re
+
 import pytest
 import torch
 
@@ -529,7 +531,7 @@ def test_split_k_full_matrix(hg, built, dev, M, N, K):
     from cuda_learn_notes_amd.bench_utils import as_col_major
     name = "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem"
     what = built.manifest.describe(name, (M, N, K), 2)
-    assert "split-K x " in what and "hgemm_splitk_reduce" in what, what
+    assert "split-K x " in what and ("hgemm_splitk_reduce" in what or "in-kernel fix-up" in what), what
     a, b = seeded(M + K, M, K), seeded(N + K, K, N)
     ad, bd = a.to(dev), b.to(dev)
     c = torch.full((M, N), float("nan"), dtype=torch.half, device=dev)
@@ -617,3 +619,132 @@ def test_tail_split_matches_the_fp32_product(hg, built, dev, M, N, K):
     ct = torch.zeros(M, N, dtype=torch.half, device=dev)
     hg.hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_tn_swizzle_x4(a, as_col_major(b), ct, 3, False, 0)
     assert torch.equal(ct, c), what
+
+
+# ------------------------------------------------------------------ split-K workspace entry points (round 5)
+def _hip_runtime():
+    """torch's own HIP runtime (the one libcln_amd.so is bound to: _loader imports torch first), for raw stream handles."""
+    import ctypes
+    import glob
+    import os
+    cands = glob.glob(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so*"))
+    return ctypes.CDLL(cands[0]) if cands else ctypes.CDLL("libamdhip64.so")
+
+
+def test_workspace_entry_points_caller_owned_and_release(hg, built, dev):
+    """include/cln_amd.h workspace block: cln_hgemm_workspace_bytes says what a shape needs (0 for a single-pass shape), a caller-owned region
+    (a torch tensor from the caching allocator) gives the same bits as the library-owned one, a region that is too small makes the shape run
+    single-pass (still inside the parity tolerance), cln_release_workspaces frees what the library holds."""
+    from cuda_learn_notes_amd import host
+    name = "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem"
+    fn = getattr(hg, name)
+    assert host.hgemm_workspace_bytes(4096, 4096, 4096) == 0  # 256 tiles, one round: single pass
+    M, N, K = 1024, 1024, 16384
+    need = host.hgemm_workspace_bytes(M, N, K)
+    S = int(re.search(r"split-K x (\d+)", built.manifest.describe(name, (M, N, K), 2)).group(1))
+    assert need == 4096 + S * M * N * 4
+    assert host.hgemm_workspace_bytes(4352, 4352, 4352) > 0  # tail split
+    a, b = seeded(21, M, K), seeded(22, K, N)
+    ad, bd = a.to(dev), b.to(dev)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        host.release_workspaces()
+        assert host.hgemm_workspace_held() == 0
+        c_lib = torch.zeros(M, N, dtype=torch.half, device=dev)
+        fn(ad, bd, c_lib, 2, False, 0)
+        st.synchronize()
+        held = host.hgemm_workspace_held()
+        assert held >= need and held <= 2 * max(need, 16 << 20)
+        buf = torch.empty(need, dtype=torch.uint8, device=dev)
+        buf.fill_(0xAB)  # garbage: the library zeroes the ticket header itself
+        host.hgemm_set_workspace(buf)
+        assert host.hgemm_workspace_held() == 0  # the stream's library-owned buffer went away with the hand-over
+        c_usr = torch.zeros(M, N, dtype=torch.half, device=dev)
+        for _ in range(3):  # self-resetting tickets: repeated launches on the same region
+            c_usr.zero_()
+            fn(ad, bd, c_usr, 2, False, 0)
+        st.synchronize()
+        assert torch.equal(c_usr, c_lib)
+        assert host.hgemm_workspace_held() == 0  # the library did not allocate behind the caller's back
+        small = torch.empty(8192, dtype=torch.uint8, device=dev)
+        host.hgemm_set_workspace(small)  # too small for this shape: single-pass plan
+        c_sp = torch.zeros(M, N, dtype=torch.half, device=dev)
+        fn(ad, bd, c_sp, 2, False, 0)
+        st.synchronize()
+        assert host.hgemm_workspace_held() == 0
+        host.hgemm_set_workspace(None)
+        fn(ad, bd, c_usr, 2, False, 0)  # library-owned again
+        st.synchronize()
+        assert torch.equal(c_usr, c_lib) and host.hgemm_workspace_held() > 0
+    check(c_lib, a, b)
+    check(c_sp, a, b)
+    assert host.release_workspaces() > 0 and host.hgemm_workspace_held() == 0
+
+
+def test_workspace_does_not_leak_over_many_streams(hg, built, dev):
+    """a process that cycles streams must not pin a workspace per stream for ever. 300 raw HIP streams, each created,
+    used for one split-K launch and destroyed: the library never holds more than 8 workspaces (least recently used freed once its last launch has
+    completed -- the completion event outlives the stream), every result is right."""
+    import ctypes
+    from cuda_learn_notes_amd import _loader, host
+    hip = _hip_runtime()
+    hip.hipStreamCreate.argtypes, hip.hipStreamCreate.restype = [ctypes.POINTER(ctypes.c_void_p)], ctypes.c_int
+    hip.hipStreamDestroy.argtypes, hip.hipStreamDestroy.restype = [ctypes.c_void_p], ctypes.c_int
+    hip.hipStreamSynchronize.argtypes, hip.hipStreamSynchronize.restype = [ctypes.c_void_p], ctypes.c_int
+    raw = _loader.symbol("hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem")
+    M, N, K = 256, 256, 8192
+    assert host.hgemm_workspace_bytes(M, N, K) > 0
+    a, b = seeded(31, M, K), seeded(32, K, N)
+    ad, bd = a.to(dev), b.to(dev)
+    ref = torch.zeros(M, N, dtype=torch.half, device=dev)
+    getattr(hg, "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem")(ad, bd, ref, 2, False, 0)
+    torch.cuda.synchronize()
+    check(ref, a, b)
+    host.release_workspaces()
+    peak = 0
+    outs = [torch.zeros(M, N, dtype=torch.half, device=dev) for _ in range(4)]
+    for i in range(300):
+        s = ctypes.c_void_p()
+        assert hip.hipStreamCreate(ctypes.byref(s)) == 0
+        c = outs[i % 4]
+        assert raw(ad.data_ptr(), bd.data_ptr(), c.data_ptr(), M, N, K, 2, 0, 0, s) == 0
+        if i % 4 == 3:
+            assert hip.hipStreamSynchronize(s) == 0
+            assert torch.equal(c, ref), i
+        peak = max(peak, host.hgemm_workspace_held())
+        if i % 2 == 0:  # half of the streams are destroyed while their launch may still be queued
+            assert hip.hipStreamDestroy(s) == 0
+    torch.cuda.synchronize()
+    assert 0 < peak <= 8 * (16 << 20), peak
+    assert host.release_workspaces() <= 8 * (16 << 20) + (64 * 256) * 2 and host.hgemm_workspace_held() == 0
+
+
+def test_two_host_threads_on_one_stream_get_their_own_results(hg, built, dev):
+    """ctypes drops the GIL around the C call, so two threads can be inside hgemm on the same stream; the workspace lock
+    covers each call's whole launch sequence, so the partial / reduce launches of two calls never interleave."""
+    import threading
+    name = "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem"
+    fn = getattr(hg, name)
+    probs = []
+    for seed, (M, N, K) in enumerate(((512, 512, 8192), (256, 256, 16384))):  # both split-K, S above and below the one-launch limit
+        a, b = seeded(40 + seed, M, K).to(dev), seeded(50 + seed, K, N).to(dev)
+        ref = torch.zeros(M, N, dtype=torch.half, device=dev)
+        fn(a, b, ref, 2, False, 0)
+        probs.append((a, b, ref))
+    torch.cuda.synchronize()
+    outs = [[], []]
+    st = torch.cuda.Stream()
+
+    def work(i):
+        a, b, ref = probs[i]
+        with torch.cuda.stream(st):
+            for _ in range(40):
+                o = torch.zeros_like(ref)
+                fn(a, b, o, 2, False, 0)
+                outs[i].append(o)
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    torch.cuda.synchronize()
+    for i in range(2):
+        assert len(outs[i]) == 40 and all(torch.equal(o, probs[i][2]) for o in outs[i])

@@ -52,8 +52,11 @@ def test_attention_kernels_in_the_product_library_are_exactly_the_plannable_ones
             assert int(a[5]) & ~(32768 | (3 << 16) | (1 << 18) | (1 << 19)) == 5, a
             assert bool(int(a[5]) & (1 << 19)) == (bool(int(a[5]) & (1 << 18)) and a[1] == "32"), a
             linked.add(("fa2_fwd_m16x64r" if a[1] == "64" else "fa2_fwd_m16x", int(a[0]), a[6] == "true", bool(int(a[5]) & 32768), bool(int(a[5]) & (1 << 18))))
-        elif f in ("fa2_fwd_dring_kernel", "fa2_fwd_splitkv_kernel"):
+        elif f == "fa2_fwd_splitkv_kernel":
             linked.add((f[:-len("_kernel")], int(a[0])))
+        elif f == "fa2_fwd_dw4_kernel":  # <D, option bits (1 = the single-stage form), K / V fragments in flight>: round 5, head dims 640 / 768 / 1024
+            assert a[1] in ("0", "1") and a[2:] == ["2", "2"], a
+            linked.add(("fa2_fwd_dw4", int(a[0]), a[1] == "1"))
         else:
             raise AssertionError("attention kernel family the planner does not know: %s<%s>" % (fam, ", ".join(a)))
     plannable = set()
@@ -81,7 +84,7 @@ def test_attention_kernels_in_the_product_library_are_exactly_the_plannable_ones
                         elif fam in ("fa2_fwd_m16x", "fa2_fwd_m16x64r"):
                             assert ("V^T" in t) == vt, t
                             plannable.add((fam, d, vt, one, f32s))
-                        elif fam == "fa2_fwd_m16":
+                        elif fam in ("fa2_fwd_m16", "fa2_fwd_dw4"):
                             assert not vt, t
                             plannable.add((fam, d, one))
                         else:
@@ -97,14 +100,19 @@ def test_one_wave_per_simd_hgemm_instantiations_are_exactly_the_plannable_ones(b
     linked = set()
     linked_s = set()
     linked_k = set()  # split-K forms (csrc/hgemm_splitk.cuh)
+    linked_k6 = set()  # their one-launch twins
     fams = set()
     for fam, a in kernel_handles(_loader.so_path("libcln_amd.so")):
         if fam.startswith("hgemm::"):
             fams.add(fam.split("::")[1])
         if fam == "hgemm::hgemm_w4_kernel":
             # LDS epilogue with non-temporal C stores (3) or the split-K partial store (5), the production schedule, no ablation
-            assert a[1] in ("3", "5") and a[2:4] == ["26", "0"], a
-            (linked_k if a[1] == "5" else linked).add((int(a[0]), int(a[4]), int(a[5]), a[6] == "true"))
+            # (6, round 5: the split-K form whose last-arriving workgroup reduces in the same launch -- instantiated for the same shapes as 5)
+            assert a[1] in ("3", "5", "6") and a[2:4] == ["26", "0"], a
+            if a[1] != "6":
+                (linked_k if a[1] == "5" else linked).add((int(a[0]), int(a[4]), int(a[5]), a[6] == "true"))
+            else:
+                linked_k6.add((int(a[0]), int(a[4]), int(a[5]), a[6] == "true"))
         if fam == "hgemm::hgemm_w4s_kernel":  # <layout, ring depth, epilogue>: stages 3 / 4 / 5 of the 256x256 names (2 is the probe library's)
             assert a[2] == "3" and a[1] in ("3", "4", "5"), a
             linked_s.add((int(a[0]), int(a[1])))
@@ -143,3 +151,4 @@ def test_one_wave_per_simd_hgemm_instantiations_are_exactly_the_plannable_ones(b
     assert plannable - linked == set(), sorted(plannable - linked)
     assert linked_k - plannable_k == set(), sorted(linked_k - plannable_k)
     assert plannable_k - linked_k == set(), sorted(plannable_k - linked_k)
+    assert linked_k6 == linked_k, sorted(linked_k6 ^ linked_k)  # the one-launch form exists for exactly the shapes of the two-launch form

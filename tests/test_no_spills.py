@@ -42,7 +42,7 @@ def test_production_attention_instantiations_are_in_the_report(tmp_path):
     # single-stage form (`stages = 1`); the [B,H,N,D] ones also with the scores scaled in fp32 (the *_acc_f32 names)
     assert len(kernels_x) == 18, [k["demangled"] for k in kernels_x]
     for want in ("fa2_fwd_dsplit_kernel<512, 2, 1,", "fa2_fwd_m16x_kernel<64, 32, 128, 8, 4, 5, false>", "fa2_fwd_m16x_kernel<128, 32, 128, 4, 4, 5, false>", "fa2_fwd_m16x_kernel<128, 32, 128, 4, 4, 5, true>", "fa2_fwd_m16_pair_kernel<2, false, false, 0>", "fa2_fwd_m16_pair_kernel<2, true, false, 0>",
-                 "fa2_fwd_v2_kernel<128, 2, true", "fa2_fwd_splitkv_kernel<64, true>", "fa2_fwd_dring_kernel<1024, 15, true, 1, 1, 1>", "fa2_fwd_dring_kernel<640, 15, false, 0, 2, 2>", "fa2_fwd_m16x_kernel<64, 64, 64, 4, 1, 5, false>"):
+                 "fa2_fwd_v2_kernel<128, 2, true", "fa2_fwd_splitkv_kernel<64, true>", "fa2_fwd_dw4_kernel<1024, 0, 2, 2>", "fa2_fwd_dw4_kernel<640, 1, 2, 2>", "fa2_fwd_m16x_kernel<64, 64, 64, 4, 1, 5, false>"):
         assert any(want in n for n in names), want
 
 
@@ -55,8 +55,11 @@ def test_inline_asm_mfma_stream_of_the_one_wave_per_simd_hgemm(tmp_path):
     w4 = [k for k in kernels if "hgemm_w4_kernel" in k["demangled"]]
     # 256x256, 192x256, 256x192, 192x192, 128x256, 256x128, 160x160 tiles x NN / TN x even / odd K tile count, plus the split-K forms (EPI 5: partial
     # store instead of the LDS epilogue) of 256x256, 192x256, 192x192, 128x256, 160x160
-    assert len(w4) == 28 + 20, [k["demangled"] for k in w4]
-    assert sum("hgemm_w4_kernel<0, 5," in k["demangled"] or "hgemm_w4_kernel<1, 5," in k["demangled"] for k in w4) == 20
+    # (round 5) ... each split-K form twice: EPI 6 = partials + in-kernel fix-up by the last-arriving workgroup (one launch, up to 4 splits),
+    # EPI 5 = partials only, summed by the reduce launch (more splits)
+    assert len(w4) == 28 + 20 + 20, [k["demangled"] for k in w4]
+    for epi in (5, 6):
+        assert sum(("hgemm_w4_kernel<0, %d," % epi) in k["demangled"] or ("hgemm_w4_kernel<1, %d," % epi) in k["demangled"] for k in w4) == 20
     text = open(s).read()
     for k in w4:
         assert k["agpr"] in (256, 192, 144, 128, 100) and k["spill"] == 0 and k["scratch"] == 0, k
