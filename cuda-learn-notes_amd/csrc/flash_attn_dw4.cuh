@@ -49,7 +49,11 @@ struct GeoDW4 {
   static_assert(LDS_BYTES <= 160 * 1024 && (ROW / 16) % 16 == 0, "LDS / swizzle range");
 };
 
-enum : int { DW4_1STAGE = 1, DW4_NO_DEFER = 2, DW4_ABL_DMA = 4, DW4_ABL_SOFTMAX = 8 };  // the last two: probe ablations (garbage results)
+// DW4_CARRY: the last MFMA group of a phase (operands already in registers) is issued AFTER the barrier, under the LDS round trips the next phase
+// starts with. DW4_M0WALK: the pieces of a tile request walk M0 (2 instructions per piece instead of 4). DW4_SPREAD: the softmax in four sections
+// behind four MFMA groups instead of two. (DW4_ABL_*: probe ablations, garbage results.)
+enum : int { DW4_1STAGE = 1, DW4_NO_DEFER = 2, DW4_ABL_DMA = 4, DW4_ABL_SOFTMAX = 8, DW4_CARRY = 16, DW4_M0WALK = 32, DW4_SPREAD = 64,
+              DW4_DEFAULT = DW4_CARRY | DW4_M0WALK | DW4_SPREAD };
 
 template <int D, int OPT = 0, int KPF = 2, int VPF = 2>
 __global__ __launch_bounds__(256, 1) void fa2_fwd_dw4_kernel(const half_t* __restrict__ Q, const half_t* __restrict__ K,
@@ -101,9 +105,26 @@ __global__ __launch_bounds__(256, 1) void fa2_fwd_dw4_kernel(const half_t* __res
     // M0 is ours for the whole kernel (no other instruction of it reads M0): no save / restore around the request
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(is_v ? v_voff[i] : k_voff[i]), "s"(src), "s"(dst) : "memory", "m0");
   };
+  // DW4_M0WALK: piece 0 of a tile request sets M0, every piece leaves it 4 KiB further (this wave's next destination): the pieces of ONE
+  // request must be issued in order 0, 1, ... and nothing else may touch M0 between them (nothing else in this kernel uses M0)
+  auto piece_w = [&](bool is_v, int t, int i) __attribute__((always_inline)) {
+    if constexpr ((OPT & DW4_ABL_DMA) != 0) return;
+    if constexpr ((OPT & DW4_M0WALK) == 0) {
+      piece(is_v, t, i);
+    } else {
+      const char* src = (is_v ? Vh : Kh) + (size_t)clampt(t) * G::TILE;
+      const unsigned voff = is_v ? v_voff[i] : k_voff[i];
+      if (i == 0) {
+        const unsigned dst = lds0 + (is_v ? 2 * G::TILE : 0) + (t & 1) * G::TILE + (unsigned)wave * 1024u;
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\ts_add_u32 m0, m0, 0x1000" ::"v"(voff), "s"(src), "s"(dst) : "memory", "m0", "scc");
+      } else {
+        asm volatile("global_load_lds_dwordx4 %0, %1\n\ts_add_u32 m0, m0, 0x1000" ::"v"(voff), "s"(src) : "memory", "m0", "scc");
+      }
+    }
+  };
   auto req_tile = [&](bool is_v, int t) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < PPW; ++i) piece(is_v, t, i);
+    for (int i = 0; i < PPW; ++i) piece_w(is_v, t, i);
   };
 
   // ---- Q fragments (B operand of S^T = K Q^T on 16x16x32): query 16*rb + i16, d = part*DH + 32*ks + 8*g4 .. +7
@@ -175,8 +196,23 @@ __global__ __launch_bounds__(256, 1) void fa2_fwd_dw4_kernel(const half_t* __res
   const char* ax_r = smem + G::AX + l31 * 4;                  // + rb * 128
 
   f4 s[4];
+  constexpr bool CARRY = (OPT & DW4_CARRY) != 0;
+  h8 kf_carry;  // DW4_CARRY: the K fragment of the last k-step, read before the barrier that ends phase A, multiplied after it
   // S^T partial of tile t (in K slot t & 1) over this wave's quarter of d: 4 row blocks x NKS k-steps, KPF fragments in flight.
-  // `hook(ks)` runs after the four MFMAs of k-step ks (DMA pieces, softmax sections).
+  // `hook(ks)` runs after the four MFMAs of k-step ks (DMA pieces, softmax sections). With DW4_CARRY the last k-step is left to qk_finish().
+  auto qk_group = [&](int ks, const h8& kfr) __attribute__((always_inline)) {
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+      // inline asm with the accumulator tied to ONE VGPR tuple (early-clobber on the first k-step): left to the builtin, hipcc parks the
+      // four partial tiles in AGPRs beside O^T and copies them out after every MFMA (s_nop 7 + 4 v_accvgpr_read per MFMA)
+      // (s_nop 1 in front of a group: a VGPR written by a VALU instruction needs two wait states before an MFMA reads it as A / B, and hipcc's
+      // hazard pass does not see into inline asm -- the fragments normally come straight from LDS reads, but register copies it inserts are VALU)
+      if (ks == 0 && rb == 0) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(s[rb]) : "v"(kfr), "v"(qf[rb][0]));
+      else if (ks == 0) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(s[rb]) : "v"(kfr), "v"(qf[rb][0]));
+      else if (rb == 0) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(s[rb]) : "v"(kfr), "v"(qf[rb][ks]));
+      else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(s[rb]) : "v"(kfr), "v"(qf[rb][ks]));
+    }
+  };
   auto qk_tile = [&](int slot, auto&& hook) __attribute__((always_inline)) {
     const char* kb = smem + slot * G::TILE;
     constexpr int KD = KPF < NKS ? KPF : NKS;
@@ -186,16 +222,20 @@ __global__ __launch_bounds__(256, 1) void fa2_fwd_dw4_kernel(const half_t* __res
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
-#pragma unroll
-      for (int rb = 0; rb < 4; ++rb) {
-        // inline asm with the accumulator tied to ONE VGPR tuple (early-clobber on the first k-step): left to the builtin, hipcc parks the
-        // four partial tiles in AGPRs beside O^T and copies them out after every MFMA (s_nop 7 + 4 v_accvgpr_read per MFMA)
-        if (ks == 0) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(s[rb]) : "v"(kf[0]), "v"(qf[rb][0]));
-        else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(s[rb]) : "v"(kf[ks % KD]), "v"(qf[rb][ks]));
+      if (CARRY && ks == NKS - 1) {
+        kf_carry = kf[ks % KD];
+      } else {
+        qk_group(ks, kf[ks % KD]);
+        if (ks + KD < NKS) kf[ks % KD] = *reinterpret_cast<const h8*>(kb + k_addr(ks + KD));
+        __builtin_amdgcn_sched_barrier(0);  // the hook's VALU work goes BEHIND the four MFMAs (into their shadow), not in front of them
       }
-      if (ks + KD < NKS) kf[ks % KD] = *reinterpret_cast<const h8*>(kb + k_addr(ks + KD));
-      __builtin_amdgcn_sched_barrier(0);  // the hook's VALU work goes BEHIND the four MFMAs (into their shadow), not in front of them
       hook(ks);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  auto qk_finish = [&]() __attribute__((always_inline)) {
+    if constexpr (CARRY) {
+      qk_group(NKS - 1, kf_carry);
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -216,11 +256,27 @@ __global__ __launch_bounds__(256, 1) void fa2_fwd_dw4_kernel(const half_t* __res
   qk_tile(0, [&](int) {});
   __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the fragment reads of K slot 0 are done
   DW4_BARRIER();
+  qk_finish();
   req_tile(false, 2);
   if constexpr ((OPT & DW4_1STAGE) != 0) hgemm::wait_vmcnt<0>();
   write_partials();
   __builtin_amdgcn_s_waitcnt(0xC07F);
   DW4_BARRIER();
+
+  // DW4_CARRY: the PV MFMAs of the last d block of a tile (V fragment and both P fragments already in registers) are issued after the barrier
+  // that ends phase B, at the head of the next phase A. Zero fragments before the first tile: the carried MFMAs then add nothing.
+  h8 vf_carry, pf_carry[2];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) vf_carry[e] = (half_t)0.f, pf_carry[0][e] = (half_t)0.f, pf_carry[1][e] = (half_t)0.f;
+  auto pv_finish = [&]() __attribute__((always_inline)) {
+    if constexpr (CARRY) {
+      // (s_nop 1: see qk_group -- before the first tile the carried fragments are zeros written by v_mov right here; without the pad the first
+      // MFMA read stale registers: NaN at D = 640 / 768, profiles/r05_fa_dw4_probe.log)
+      asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(ot[0][NDB - 1]) : "v"(vf_carry), "v"(pf_carry[0]));
+      asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(ot[1][NDB - 1]) : "v"(vf_carry), "v"(pf_carry[1]));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
 
   for (int j = 0; j < T; ++j) {
     // ================= phase A: softmax of tile j by the row owners + S^T partial of tile j+1; V(j+1) requested
@@ -228,38 +284,55 @@ __global__ __launch_bounds__(256, 1) void fa2_fwd_dw4_kernel(const half_t* __res
       f4 ap[4];  // the four d-parts' partials of this wave's 16 rows (summed in part order by every owner: the order is fixed)
 #pragma unroll
       for (int p = 0; p < 4; ++p) ap[p] = *reinterpret_cast<const f4*>(sx_r + p * 4096);
+      pv_finish();  // (tile j-1's last d block: runs under the LDS round trip of the reads above and of the first K fragments)
       f4 a;
       float p4[4];
-      float alpha = 1.f;
+      float alpha = 1.f, mx = 0.f;
+      constexpr bool SPREAD = (OPT & DW4_SPREAD) != 0;
+      // softmax sections: behind the MFMA groups of k-steps 0, 1 (two sections) or 0 .. 3 (DW4_SPREAD: at most ~10 VALU per 64-clock group)
+      auto sec_max_lane = [&]() __attribute__((always_inline)) {
+        a = (ap[0] + ap[1]) + (ap[2] + ap[3]);
+        mx = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]));  // row maximum over the 16 keys of the tile: 4 in the lane ...
+      };
+      auto sec_max_row = [&]() __attribute__((always_inline)) {  // ... then the four g4 lanes of the row
+        const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+        mx = fmaxf(__uint_as_float(s16[0]), __uint_as_float(s16[1]));
+        const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+        mx = fmaxf(__uint_as_float(s32[0]), __uint_as_float(s32[1]));
+        const float mxs = mx * scale_log2e;
+        bool grow;
+        if constexpr ((OPT & DW4_NO_DEFER) != 0) grow = mxs > m_run;
+        else grow = (mxs - m_run) > 8.0f;
+        const float m_new = grow ? mxs : m_run;
+        alpha = grow ? __builtin_amdgcn_exp2f(m_run - m_new) : 1.f;
+        m_run = m_new;
+        l_run *= alpha;
+        if (j == 0) alpha = 1.f;  // O and l are still zero: nothing to rescale
+      };
+      auto sec_exp = [&]() __attribute__((always_inline)) {
+        const float nm = -m_run;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) p4[e] = __builtin_amdgcn_exp2f(fmaf(a[e], scale_log2e, nm));
+      };
+      auto sec_publish = [&]() __attribute__((always_inline)) {
+        l_run += (p4[0] + p4[1]) + (p4[2] + p4[3]);
+        const h2 lo = __builtin_convertvector(f2{p4[0], p4[1]}, h2), hh = __builtin_convertvector(f2{p4[2], p4[3]}, h2);
+        *reinterpret_cast<h4*>(px_w) = h4{lo[0], lo[1], hh[0], hh[1]};
+        *reinterpret_cast<float*>(ax_w) = alpha;
+      };
       qk_tile((j + 1) & 1, [&](int ks) __attribute__((always_inline)) {
         if constexpr ((OPT & DW4_1STAGE) == 0) {
-          if (ks < PPW) piece(true, j + 1, ks);
+          if (ks < PPW) piece_w(true, j + 1, ks);
         }
         if constexpr ((OPT & DW4_ABL_SOFTMAX) != 0) return;
-        if (ks == 0) {  // row maximum over the 16 keys of the tile: 4 in the lane, then the four g4 lanes of the row
-          a = (ap[0] + ap[1]) + (ap[2] + ap[3]);
-          float mx = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]));
-          const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-          mx = fmaxf(__uint_as_float(s16[0]), __uint_as_float(s16[1]));
-          const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-          mx = fmaxf(__uint_as_float(s32[0]), __uint_as_float(s32[1]));
-          const float mxs = mx * scale_log2e;
-          bool grow;
-          if constexpr ((OPT & DW4_NO_DEFER) != 0) grow = mxs > m_run;
-          else grow = (mxs - m_run) > 8.0f;
-          const float m_new = grow ? mxs : m_run;
-          alpha = grow ? __builtin_amdgcn_exp2f(m_run - m_new) : 1.f;
-          m_run = m_new;
-          l_run *= alpha;
-          if (j == 0) alpha = 1.f;  // O and l are still zero: nothing to rescale
-        } else if (ks == 1) {
-          const float nm = -m_run;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) p4[e] = __builtin_amdgcn_exp2f(fmaf(a[e], scale_log2e, nm));
-          l_run += (p4[0] + p4[1]) + (p4[2] + p4[3]);
-          const h2 lo = __builtin_convertvector(f2{p4[0], p4[1]}, h2), hh = __builtin_convertvector(f2{p4[2], p4[3]}, h2);
-          *reinterpret_cast<h4*>(px_w) = h4{lo[0], lo[1], hh[0], hh[1]};
-          *reinterpret_cast<float*>(ax_w) = alpha;
+        if constexpr (SPREAD) {
+          if (ks == 0) sec_max_lane();
+          else if (ks == 1) sec_max_row();
+          else if (ks == 2) sec_exp();
+          else if (ks == 3) sec_publish();
+        } else {
+          if (ks == 0) sec_max_lane(), sec_max_row();
+          else if (ks == 1) sec_exp(), sec_publish();
         }
       });
     }
@@ -285,6 +358,7 @@ __global__ __launch_bounds__(256, 1) void fa2_fwd_dw4_kernel(const half_t* __res
       h8 vf[VD];
 #pragma unroll
       for (int i = 0; i < VD; ++i) vf[i] = rd_v(i);
+      qk_finish();  // (tile j+1's last k-step: runs under the LDS round trip of the reads above)
       if constexpr ((OPT & DW4_1STAGE) != 0) {  // `stages = 1`: both tile requests of the step in ONE burst, waited for right here --
         req_tile(false, j + 3);                 // no request of the wave is in flight while it computes (the V slot of tile j+1 has been
         req_tile(true, j + 1);                  // free since the barrier before last: same LDS images, same arithmetic, bit-identical)
@@ -307,13 +381,16 @@ __global__ __launch_bounds__(256, 1) void fa2_fwd_dw4_kernel(const half_t* __res
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int b = 0; b < NDB; ++b) {
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-          asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(ot[rb][b]) : "v"(vf[b % VD]), "v"(pf[rb]));
-        if (b + VD < NDB) vf[b % VD] = rd_v(b + VD);
+        if (CARRY && b == NDB - 1) {
+          vf_carry = vf[b % VD], pf_carry[0] = pf[0], pf_carry[1] = pf[1];
+        } else {
+          asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(ot[0][b]) : "v"(vf[b % VD]), "v"(pf[0]));  // (pad: P fragments are assembled by v_mov)
+          asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(ot[1][b]) : "v"(vf[b % VD]), "v"(pf[1]));
+          if (b + VD < NDB) vf[b % VD] = rd_v(b + VD);
+        }
         if (b == 0) write_partials();
         if constexpr ((OPT & DW4_1STAGE) == 0) {
-          if (b < PPW) piece(false, j + 3, b);
+          if (b < PPW) piece_w(false, j + 3, b);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -322,6 +399,7 @@ __global__ __launch_bounds__(256, 1) void fa2_fwd_dw4_kernel(const half_t* __res
     if constexpr ((OPT & (DW4_1STAGE | DW4_ABL_DMA)) == 0) hgemm::wait_vmcnt<2 * PPW>();  // K(j+2) has landed
     DW4_BARRIER();
   }
+  pv_finish();  // the last tile's last d block
   hgemm::wait_vmcnt<0>();  // the dead refills of the last tiles: nothing may land in the staging area below
   // ---- epilogue: row sums to LDS, O = O^T / l staged through LDS in two passes of 32 rows per wave
   {

@@ -220,12 +220,15 @@ SplitKWs* ws_acquire(hipStream_t stream, size_t bytes) {
 void ws_mark_used(SplitKWs* e, hipStream_t stream) {  // g_ws_mu held, after the launches
   if (e && !e->user && e->ev && !stream_capturing(stream)) (void)hipEventRecord(e->ev, stream), (void)hipGetLastError();
 }
-// splits up to which the ONE-launch form (EPI 6: the last-arriving workgroup of a tile reduces) is taken; above it the tile's reduction on one
-// CU costs more than the reduce launch it saves (profiles/r05_hgemm_splitk_fused_probe.log). $CLN_AMD_SPLITK_FUSED_MAX_S overrides (0 = never).
+// splits up to which the ONE-launch form (EPI 6: the last-arriving workgroup of a tile reduces) is taken. Measured (profiles/r05_hgemm_splitk_fused_probe.log,
+// every shape of the round-4 split-K / tail probes under 0 = never, the default, 64 = always): at 2 splits one launch is 1-4 % faster than partial +
+// reduce launch (512 x 8192^2 68.1 -> 67.3 us, 2048^2 x 8192 70.6 -> 70.1, 640 x 5120^2 43.4 -> 41.9); at 4 splits the tile's reduction on ONE CU
+// (1 MiB of partials at one CU's load rate) costs 3-5 us more than the reduce launch it saves (256 x 4096^2 23.4 -> 26.6 us, 4352^3 138.9 -> 149.6),
+// at 8 and more 5-6 us more. $CLN_AMD_SPLITK_FUSED_MAX_S overrides (0 = never).
 int splitk_fused_max_s() {
   static const int v = [] {
     const char* e = getenv("CLN_AMD_SPLITK_FUSED_MAX_S");
-    return e ? atoi(e) : 4;
+    return e ? atoi(e) : 2;
   }();
   return v;
 }
@@ -307,6 +310,9 @@ int plan_tile(int plan) {
 // EPI 3: C through the wave-private LDS staging, then NON-TEMPORAL 16-byte stores -- the output does not displace the A / B panels the other
 // workgroups (and, back to back, the next launch) still read from L2 / MALL: +1.3-1.5 % at 4096^3, +3.4-3.6 % at 8192^3 over plain stores,
 // same bits (profiles/r03_hgemm_c_store_probe.log; write-through `sc0 sc1` stores: +1.4 % / -0.2 %)
+// (The persistent tile walk -- hgemm_w4.cuh EPI 7: one workgroup per CU walks its tiles, the next tile's first K tiles requested before the C store --
+// was built and measured in round 5: 8192^3 NN 1549 -> 1539 / TN 1550 -> 1557 TF, 8960^3 1465 -> 1436 / 1466 -> 1464, 10240^3 1469 -> 1475 / 1470 -> 1488,
+// 16384^3 1491 -> 1483, bit-identical: +-1 %, inside the box noise. It lives in the probe library, kind 19; profiles/r05_hgemm_persist_probe.log.)
 constexpr int W4_EPILOGUE = 3;
 constexpr int W4_PRODUCTION = 26;  // schedule 10 (one DMA piece per 8 MFMAs, running on into the next tile), boustrophedon MFMA order
 template <int LAYOUT>

@@ -87,7 +87,7 @@ int launch_w4_splitk(const void* a, const void* b, void* c, float* ws, int M, in
 // ONE launch (round 5): the same grid with EPI 6 -- the last-arriving workgroup of a tile sums the partials and stores C
 // (hgemm_w4.cuh). `ws` = W4_TICKET_FLOATS zeroed tickets + S * M * N floats. The reduction of a tile runs on ONE CU instead of 4 * BM / 32
 // workgroups of the reduce kernel, so it pays while S is small (the reduce launch costs ~5 us; a CU sums ~1 MiB of partials in about that time):
-// the planner (hgemm.hip) takes this form up to SPLITK_FUSED_MAX_S splits and the two-launch form above it.
+// the planner (hgemm.hip splitk_fused_max_s) takes this form at 2 splits and the two-launch form above: measurements there.
 inline size_t w4_splitk_ws_bytes(int M, int N, int S) { return (size_t)W4_TICKET_FLOATS * 4 + (size_t)S * M * N * sizeof(float); }
 template <int LAYOUT, int VAR, int BM, int BN>
 int launch_w4_splitk_fused(const void* a, const void* b, void* c, float* ws, int M, int N, int K, int S, hipStream_t stream) {

@@ -76,6 +76,33 @@ __device__ __forceinline__ void store_wide_tile_via_lds(half_t* Cmat, int N, int
   }
 }
 
+// The same epilogue in passes of ONE 16-row fragment row: 16 x (FN * 32 + 16) bytes of wave-private LDS (4.25 KiB at FN = 8) instead of 64 rows -- for
+// the persistent form (EPI 7), whose ring already holds the next tile's first K tiles while C is stored. Same stores, same order within a row block.
+template <int FM, int FN>
+__device__ __forceinline__ void store_wide_tile_via_lds_rows16(half_t* Cmat, int N, int row0, int col0, int lane, char* wave_lds, const f4 (&acc)[FM][FN],
+                                                               int nt_ok) {
+  static_assert(FN == 8, "128-column wave tile");
+  constexpr int RS = FN * 32 + 16, LPR = FN * 2, RPI = 64 / LPR;
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const f4 v = acc[i][j];
+      h4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+      *reinterpret_cast<h4*>(wave_lds + (lane & 15) * RS + (j * 16 + 4 * (lane >> 4)) * 2) = o;
+    }
+#pragma unroll
+    for (int it = 0; it < 16 / RPI; ++it) {
+      const int r = it * RPI + lane / LPR;
+      const u4 v = *reinterpret_cast<const u4*>(wave_lds + r * RS + (lane % LPR) * 16);
+      u4* dst = reinterpret_cast<u4*>(Cmat + (size_t)(row0 + i * 16 + r) * N + col0 + (lane % LPR) * 8);
+      if (nt_ok) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+      else asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads of this pass precede the writes of the next (same wave-private rows)
+  }
+}
+
 // Compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>). A `#pragma unroll` loop of 128
 // iterations whose body carries every hook exceeds LLVM's pragma-unroll size cap before the hooks are folded away and
 // is then left rolled (accumulators indexed dynamically -> scratch memory).
@@ -187,13 +214,23 @@ __global__ __launch_bounds__(256, 1) void hgemm_w4_kernel(const half_t* __restri
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 1, wn = wave & 1;
+  // EPI 7 (round 5): PERSISTENT tile walk -- the launch has one workgroup per CU and workgroup b runs the tiles b, b + G, b + 2G, ...
+  // of the same logical order (G = gridDim.x, a multiple of 8: the XCD of tile b + rG is the XCD of b). Before the C store of a tile the
+  // first two K tiles of the NEXT tile are requested into the ring (every wave is past its last fragment read), and the epilogue stages through
+  // 17 KiB BESIDE the ring in passes of one 16-row fragment row: the next tile's prologue latency, and the launch of a fresh workgroup, hide under the store.
+  constexpr bool PERSIST = EPI == 7;
+  const int n_tiles = tiles_m * tiles_n;
   int tm, tn;
-  if (swizzle & 4) {  // bit 2: operands larger than the Infinity Cache -- XCDs take the band walk in interleaved chunks (hgemm_mfma.cuh)
-    tile_coords_interleaved(blockIdx.x, gridDim.x, tiles_m, tiles_n, band, tm, tn);
-  } else {
-    tile_coords(blockIdx.x, gridDim.x, tiles_m, tiles_n, swizzle & 1, band, tm, tn);  // bit 1 of `swizzle`: non-temporal C stores allowed (launcher)
-  }
-  const int m0 = tm * BM, n0 = tn * BN;
+  auto coords = [&](int vb, int& tm_, int& tn_) {
+    if (swizzle & 4) {  // bit 2: operands larger than the Infinity Cache -- XCDs take the band walk in interleaved chunks (hgemm_mfma.cuh)
+      tile_coords_interleaved(vb, PERSIST ? n_tiles : (int)gridDim.x, tiles_m, tiles_n, band, tm_, tn_);
+    } else {
+      tile_coords(vb, PERSIST ? n_tiles : (int)gridDim.x, tiles_m, tiles_n, swizzle & 1, band, tm_, tn_);  // bit 1 of `swizzle`: non-temporal C stores allowed (launcher)
+    }
+  };
+  int vb = blockIdx.x;
+  coords(vb, tm, tn);
+  int m0 = tm * BM, n0 = tn * BN;
 
   // EPI 5 (split-K, hgemm_splitk.cuh): this workgroup multiplies K columns [blockIdx.y * K, (blockIdx.y + 1) * K) of a problem whose leading
   // dimension (the whole K) rides in bits 8.. of `swizzle` in units of 64; every other form: ld == K, k0 == 0 (compile-time: same code as before)
@@ -249,6 +286,9 @@ __global__ __launch_bounds__(256, 1) void hgemm_w4_kernel(const half_t* __restri
   };
 
   f4 acc[FM][FN];
+  h8 af[2][FM], bf[2][FN];
+  bool prefetched = false;  // PERSIST: this tile's first two K tiles were requested before the previous tile's C store
+  for (;;) {  // one pass unless PERSIST
 #pragma unroll
   for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -261,7 +301,6 @@ __global__ __launch_bounds__(256, 1) void hgemm_w4_kernel(const half_t* __restri
 #pragma unroll
     for (int j = 0; j < FN; ++j) asm volatile("" : "+a"(acc[i][j]));
   asm volatile("s_nop 7");
-  h8 af[2][FM], bf[2][FN];
 
   // fragment read op r of k-step kk: r = 0 -> A fragment 0, 1..FN -> B fragments, FN+1.. -> A fragments 1..FM-1
   // (the MFMA order is A-fragment-major: the first FN MFMAs of a k-step need A0 and every B fragment).
@@ -320,13 +359,24 @@ __global__ __launch_bounds__(256, 1) void hgemm_w4_kernel(const half_t* __restri
 
   const int nt = K / 64;
   // prologue: tiles 0 and 1 in flight, tile 0 landed, its k-step 0 fragments in registers
+  auto prologue_requests = [&]() {
 #pragma unroll
-  for (int p = 0; p < NP; ++p) piece(p, lds0);
-  advance();
+    for (int p = 0; p < NP; ++p) piece(p, lds0);
+    advance();
 #pragma unroll
-  for (int p = 0; p < NP; ++p) piece(p, lds0 + C::STAGE_BYTES);
-  advance();
-  wait_vmcnt<NP>();
+    for (int p = 0; p < NP; ++p) piece(p, lds0 + C::STAGE_BYTES);
+    advance();
+  };
+  constexpr int C_STORES = FM * FN / 2;  // global stores per lane of one C epilogue (FM x FN x 16 rows x 32 B / 1 KiB per wave-instruction ... / 64 lanes)
+  if (PERSIST && prefetched) {
+    // both K tiles were requested BEFORE the previous tile's C stores (vmcnt completes in issue order on gfx9, loads and stores alike): once at most
+    // the C_STORES younger stores are outstanding, every piece has landed -- the stores themselves are not waited for
+    static_assert(C_STORES < 64, "vmcnt is a 6-bit field");
+    wait_vmcnt<C_STORES>();
+  } else {
+    prologue_requests();
+    wait_vmcnt<NP>();
+  }
   W4_BARRIER();
 #pragma unroll
   for (int r = 0; r < NR; ++r) read_op(smem, 0, r);
@@ -388,7 +438,9 @@ __global__ __launch_bounds__(256, 1) void hgemm_w4_kernel(const half_t* __restri
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < FN; ++j) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst + (i * FN + j) * 256), "v"(acc[i][j]) : "memory");
+        for (int j = 0; j < FN; ++j) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst + (i * FN + j) * 256), "v"(acc[i][j]) : "memory");  // (s_nop: the data
+          // registers are a temporary copy of AGPRs that hipcc re-uses for the next copy at once -- a store of more than 8 bytes needs one wait state
+          // before its data VGPRs are overwritten, and the hazard pass does not see into inline asm: without it the partials were corrupted)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's partial has reached the memory side
       const int S = gridDim.y;
       int* last = reinterpret_cast<int*>(smem + C::LDS_BYTES - 16);  // beyond the four staging regions of the epilogue
@@ -427,6 +479,25 @@ __global__ __launch_bounds__(256, 1) void hgemm_w4_kernel(const half_t* __restri
       }
       store_wide_tile_via_lds<FM, FN, 0>(Cmat, N, m0 + wm * C::WTM, n0 + wn * C::WTN, lane, smem + wave * (64 * (FN * 32 + 16)), acc, 0);
     }
+  } else if constexpr (PERSIST) {
+    // B1 of the last K tile: every wave is past its last fragment read, no DMA is in flight -> both ring buffers are free for the NEXT tile's prologue,
+    // requested here, before this tile's C leaves through the staging rows beside the ring
+    const int nvb = vb + (int)gridDim.x;
+    const bool more = nvb < n_tiles;
+    const int row0 = m0 + wm * C::WTM, col0 = n0 + wn * C::WTN;
+    if (more) {
+      coords(nvb, tm, tn);
+      m0 = tm * BM, n0 = tn * BN;
+      a_src = reinterpret_cast<const char*>(A + (size_t)m0 * K);
+      b_src = (LAYOUT == TN) ? reinterpret_cast<const char*>(B + (size_t)n0 * K) : reinterpret_cast<const char*>(B + n0);
+      prologue_requests();
+    }
+    // (lane id recomputed here: the epilogue's lane-derived addresses are invariant over the tile loop and would otherwise be hoisted above it and
+    // carried -- spilled -- through the K loop, whose register file is full)
+    store_wide_tile_via_lds_rows16<FM, FN>(Cmat, N, row0, col0, cln_fresh_lane(), smem + C::LDS_BYTES + wave * (16 * (FN * 32 + 16)), acc, (swizzle >> 1) & 1);
+    if (!more) break;
+    vb = nvb, prefetched = true;
+    continue;
   } else if constexpr (EPI >= 2) {  // EPI 3 / 4 (probe library): the same epilogue with non-temporal / write-through C stores
     // B1 of the last tile: every wave is past its last fragment read; no DMA is in flight
     store_wide_tile_via_lds<FM, FN, EPI - 2>(Cmat, N, m0 + wm * C::WTM, n0 + wn * C::WTN, lane, smem + wave * (64 * (FN * 32 + 16)), acc, (swizzle >> 1) & 1);
@@ -438,6 +509,8 @@ __global__ __launch_bounds__(256, 1) void hgemm_w4_kernel(const half_t* __restri
       for (int j = 0; j < FN; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
     if (s == 123.456f) Cmat[(size_t)m0 * N + n0] = (half_t)s;
   }
+  break;
+  }  // for (;;)
 }
 
 // K the kernel's peeled structure covers: whole 64-wide tiles, >= 6 of them when their number is even, >= 7 when odd
@@ -491,6 +564,41 @@ int launch_w4(const void* a, const void* b, void* c, int M, int N, int K, int sw
     return CLN_ERR_LAUNCH;
   CLN_LAUNCH((hgemm_w4_kernel<LAYOUT, EPI, VAR, ABL, BM, BN>), dim3(w4_grid(M, N, K, swizzle, tiles_m, tiles_n)), dim3(256), C::LDS_BYTES, stream,
              (const half_t*)a, (const half_t*)b, (half_t*)c, M, N, K, tiles_m, tiles_n, w4_swizzle_arg(M, N, K, swizzle, tiles_m * tiles_n), band);
+  return cln_check_launch();
+}
+
+// Persistent form (EPI 7, see the kernel): one workgroup per CU walks the tiles b, b + G, ... -- for launches of MORE tiles than CUs.
+inline int w4_cu_count() {
+  static const int n = [] {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    (void)hipGetLastError();
+    return cus > 0 ? cus & ~7 : 256;  // a multiple of 8: tile b + r G stays on the XCD of tile b
+  }();
+  return n;
+}
+template <int LAYOUT, int VAR = 26>
+int launch_w4_persist(const void* a, const void* b, void* c, int M, int N, int K, int swizzle, int swizzle_stride, hipStream_t stream) {
+  constexpr int BM = 256, BN = 256, EPI = 7;
+  using C = W4Cfg<BM, BN, LAYOUT>;
+  constexpr int LDS = C::LDS_BYTES + 4 * 16 * (C::FN * 32 + 16);
+  static_assert(LDS <= 160 * 1024, "ring + epilogue staging rows");
+  const bool odd = (K / 64) & 1;
+  if (M % BM || N % BN || !w4_k_ok(K)) return CLN_ERR_UNSUPPORTED;
+  const int tiles_m = M / BM, tiles_n = N / BN, tiles = tiles_m * tiles_n;
+  const int band = (swizzle && swizzle_stride >= BN) ? swizzle_stride / BN : tiles_n;
+  const int grid = tiles < w4_cu_count() ? tiles : w4_cu_count();
+  if (odd) {
+    static cln_lds_attr lds_attr_odd;
+    if (cln_ensure_lds(lds_attr_odd, reinterpret_cast<const void*>(&hgemm_w4_kernel<LAYOUT, EPI, VAR, 0, BM, BN, true>), LDS) != CLN_OK) return CLN_ERR_LAUNCH;
+    CLN_LAUNCH((hgemm_w4_kernel<LAYOUT, EPI, VAR, 0, BM, BN, true>), dim3(grid), dim3(256), LDS, stream, (const half_t*)a, (const half_t*)b, (half_t*)c, M, N, K,
+               tiles_m, tiles_n, w4_swizzle_arg(M, N, K, swizzle, tiles), band);
+  } else {
+    static cln_lds_attr lds_attr;
+    if (cln_ensure_lds(lds_attr, reinterpret_cast<const void*>(&hgemm_w4_kernel<LAYOUT, EPI, VAR, 0, BM, BN>), LDS) != CLN_OK) return CLN_ERR_LAUNCH;
+    CLN_LAUNCH((hgemm_w4_kernel<LAYOUT, EPI, VAR, 0, BM, BN>), dim3(grid), dim3(256), LDS, stream, (const half_t*)a, (const half_t*)b, (half_t*)c, M, N, K,
+               tiles_m, tiles_n, w4_swizzle_arg(M, N, K, swizzle, tiles), band);
+  }
   return cln_check_launch();
 }
 

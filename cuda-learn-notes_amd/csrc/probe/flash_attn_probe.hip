@@ -164,15 +164,19 @@ CLN_API int cln_fa2_variant(int D, int nw, int vt, int opt, int abl, const void*
   // 800.. = the sum-checked optimistic softmax form (flash_attn_m16x.cuh, its own compile unit): abl = 800 + code,
   //         code = 16 * (NDEF - 1) + OX (OX: 1 = phase-A priority, 4 = split prologue); 860.. = prefetch depth 4; 880.. = 64 rows per wave
   if (abl >= 800 && abl < 1000 && D <= 128) return fa2::m16x_probe_run(D, abl - 800, q, k, v, o, B, H, N, (hipStream_t)stream);
-  // 1300 + opt = the one-wave-per-SIMD kernel for head dims 640 / 768 / 1024 (flash_attn_dw4.cuh, round 5); opt: 1 = `stages = 1` form, 2 = running
-  // maximum raised on every growth (drives the AGPR rescale path on every tile), 4 = no K / V DMA after the prologue, 8 = no softmax (4, 8: garbage results);
-  // 1400 + 10 * KPF + VPF = K / V fragments in flight
+  // 1300 + opt = the one-wave-per-SIMD kernel for head dims 640 / 768 / 1024 (flash_attn_dw4.cuh, round 5); opt bits: 1 = `stages = 1` form, 2 = running
+  // maximum raised on every growth (drives the AGPR rescale path on every tile), 4 = no K / V DMA after the prologue, 8 = no softmax (4, 8: garbage results),
+  // 16 = last MFMA group of a phase carried across the barrier, 32 = M0-walking tile requests, 64 = softmax in four sections (112 = production);
+  // 1500 + 10 * KPF + VPF = K / V fragments in flight (on the production options)
 #define DW4(DD, OPTV) if (D == DD && abl == 1300 + OPTV) return fa2::launch_dw4<DD, OPTV>(q, k, v, o, B, H, N, (hipStream_t)stream);
   DW4(640, 0) DW4(768, 0) DW4(1024, 0) DW4(640, 1) DW4(768, 1) DW4(1024, 1) DW4(640, 2) DW4(768, 2) DW4(1024, 2)
-  DW4(1024, 4) DW4(1024, 8) DW4(1024, 12) DW4(768, 4) DW4(768, 8) DW4(768, 12)
+  DW4(1024, 4) DW4(1024, 116) DW4(768, 4) DW4(768, 116)
+  DW4(640, 16) DW4(768, 16) DW4(1024, 16) DW4(640, 32) DW4(768, 32) DW4(1024, 32) DW4(640, 64) DW4(768, 64) DW4(1024, 64)
+  DW4(640, 48) DW4(768, 48) DW4(1024, 48) DW4(640, 112) DW4(768, 112) DW4(1024, 112) DW4(640, 113) DW4(768, 113) DW4(1024, 113)
+  DW4(640, 114) DW4(768, 114) DW4(1024, 114) DW4(640, 96) DW4(768, 96) DW4(1024, 96)
 #undef DW4
-#define DW4P(DD, KP, VP) if (D == DD && abl == 1400 + 10 * KP + VP) return fa2::launch_dw4<DD, 0, KP, VP>(q, k, v, o, B, H, N, (hipStream_t)stream);
-  DW4P(1024, 1, 1) DW4P(1024, 3, 3) DW4P(1024, 4, 4) DW4P(1024, 4, 2) DW4P(1024, 2, 4) DW4P(768, 1, 1) DW4P(768, 3, 3) DW4P(768, 4, 4) DW4P(640, 3, 3) DW4P(640, 1, 1)
+#define DW4P(DD, KP, VP) if (D == DD && abl == 1500 + 10 * KP + VP) return fa2::launch_dw4<DD, fa2::DW4_DEFAULT, KP, VP>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  DW4P(1024, 1, 1) DW4P(1024, 3, 3) DW4P(1024, 4, 2) DW4P(768, 1, 1) DW4P(768, 3, 3) DW4P(640, 3, 3) DW4P(640, 1, 1)
 #undef DW4P
   // 1000 = the ring kernel for head dims 640 / 768 / 1024 (flash_attn_dring.cuh), row groups one phase apart; 1001 = lock-step
   if (D == 640 && abl == 1000) return fa2::launch_dring<640, fa2::OPT_DEFAULT>(q, k, v, o, B, H, N, (hipStream_t)stream);

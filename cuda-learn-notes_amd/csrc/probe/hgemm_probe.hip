@@ -155,6 +155,9 @@ CLN_API int cln_hgemm_variant(int kind, int layout, int tile, int bk, int stages
     return layout == TN ? launch_w4_tail_split<TN, 3, 26, 256, 256>(a, b, c, ws, M, N, K, m_split, stages, swizzle, swizzle_stride, stream)
                         : launch_w4_tail_split<NN, 3, 26, 256, 256>(a, b, c, ws, M, N, K, m_split, stages, swizzle, swizzle_stride, stream);
   }
+  // 19 = the persistent tile walk of the one-wave-per-SIMD kernel (hgemm_w4.cuh EPI 7, round 5): one workgroup per CU walks its tiles, the next tile's
+  // prologue requested before the C store. Measured +-1 % against one workgroup per tile (profiles/r05_hgemm_persist_probe.log): not in the product.
+  if (kind == 19) return layout == TN ? launch_w4_persist<TN>(a, b, c, M, N, K, swizzle, swizzle_stride, stream) : launch_w4_persist<NN>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);
   if (kind == 6) return launch_pp<NN, 1, 4>(a, b, c, M, N, K, swizzle, swizzle_stride, stream);  // 4-slot no-store probe
   if (kind == 7) {  // ablations of the 4-slot no-store probe; `stages` = ABL bits (results are garbage by design)
     switch (stages) {

@@ -179,10 +179,8 @@ __global__ __launch_bounds__(1024) void reduce_sum_kernel(const typename PS::ele
     O t = (lane < 16) ? scratch[lane] : (O)0;
 #pragma unroll
     for (int m = 8; m >= 1; m >>= 1) t += __shfl_xor(t, m, 64);
-    if (lane == 0) {
-      if (sc) cln_scratch_finish<O>(sc, y, t, gridDim.x);  // the last block moves the total into y and re-zeroes the scratch (stream_scratch.h)
-      else atomicAdd(y, t);                                // no scratch slot (stream capture): y was zeroed on the stream by the launcher
-    }
+    if (sc) cln_scratch_finish<O>(sc, y, t, gridDim.x, lane);  // the block that completes the launch moves the total into y and re-zeroes the scratch (stream_scratch.h)
+    else if (lane == 0) atomicAdd(y, t);                       // no scratch slot (stream capture): y was zeroed on the stream by the launcher
   }
 }
 

@@ -4,7 +4,7 @@
 // kernels add one atomic per block into it: every call is TWO dispatches (fill + kernel), 8.4 us of host time against torch.sum's 4.
 // Here the blocks add into a library-owned, zero-initialised scratch word; the block that takes the LAST ticket moves the total into y
 // (overwriting it -- y no longer has to be zeroed) and leaves sum and ticket at zero for the next launch: one dispatch, no fill.
-//   * one 256-byte slot per (device, stream): launches on one stream run in order, so they can share it; 64 slots per device, the least
+//   * one 4-KiB slot per (device, stream): launches on one stream run in order, so they can share it; 64 slots per device, the least
 //     recently used one re-assigned after a hipDeviceSynchronize() when a 65th stream shows up (a process that cycles streams never leaks);
 //   * nullptr when the slot cannot be had without touching the device (first use or eviction while the stream is being captured, allocation
 //     failure): the caller then zeroes y on the stream (a memset node under capture) and the kernel adds into y directly, as before;
@@ -12,30 +12,51 @@
 #pragma once
 #include "common.h"
 
+// One slot: EIGHT partial sums and tickets, each on its own 128-byte line (a block uses set blockIdx & 7 = its XCD), and one top ticket. All of a
+// launch's blocks hammering ONE word serialise at ~12 ns per atomic (MI355X_MICROARCH.md "fanin": 256 blocks = 3 us of tail); eight sets of 32 take 0.4 us.
 struct ClnScratch {
-  float sum;            // fp32 or int32 bits
-  unsigned pad0[31];
-  unsigned ticket;      // blocks arrived
-  unsigned pad1[31];
+  struct { float sum; unsigned pad[31]; } part[8];        // fp32 or int32 bits
+  struct { unsigned ticket; unsigned pad[31]; } arrive[8];  // blocks of the set that have added their partial
+  unsigned top;                                           // sets whose last block has arrived
+  unsigned pad[511];
 };
-static_assert(sizeof(ClnScratch) == 256, "one slot = 256 bytes");
+static_assert(sizeof(ClnScratch) == 4096, "one slot = 4 KiB");
 
 ClnScratch* cln_stream_scratch(hipStream_t stream);
 size_t cln_stream_scratch_release();  // frees every slab (cln_release_workspaces); returns the bytes freed
 
 #if defined(__HIPCC__)
-// Device side: `t` is this block's partial (one thread per block calls it). Returns nothing; the last block writes *y.
+// Device side, called by the WHOLE first wave of a block; `t` is the block's partial (valid in lane 0). The block that completes the launch
+// moves the total into *y and leaves every word of the slot at zero.
+//   lane 0: partial added to the set's sum with a RETURNING atomic -- the add has been performed at the point of coherence once its value is
+//           back, only then is the set's ticket taken (no release fence: a fence writes back and invalidates the XCD's L2, per block);
+//           the last block of a set takes the top ticket; the block that takes the last top ticket knows every set is complete
+//   lanes 0..7 of that block: one exchange each (all in flight together) collects and re-zeroes the eight sums
 template <typename O>
-__device__ __forceinline__ void cln_scratch_finish(ClnScratch* sc, O* y, O t, unsigned nblocks) {
-  O* sum = reinterpret_cast<O*>(&sc->sum);
-  O old = __hip_atomic_fetch_add(sum, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  // the add has been PERFORMED at the point of coherence once its return value is here; only then is the ticket taken -- no L2 write-back /
-  // invalidate (what a release fence would cost every block), just one returning atomic
-  asm volatile("" : "+v"(old)::"memory");
-  const unsigned tk = __hip_atomic_fetch_add(&sc->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (tk == nblocks - 1) {  // every other block's add precedes its ticket, all tickets precede this one
-    *y = __hip_atomic_exchange(sum, (O)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&sc->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ void cln_scratch_finish(ClnScratch* sc, O* y, O t, unsigned nblocks, int lane) {
+  int last = 0;
+  if (lane == 0) {
+    const unsigned g = blockIdx.x & 7u, in_set = (nblocks - g + 7u) >> 3, sets = nblocks < 8u ? nblocks : 8u;
+    O old = __hip_atomic_fetch_add(reinterpret_cast<O*>(&sc->part[g].sum), t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" : "+v"(old)::"memory");
+    unsigned tk = __hip_atomic_fetch_add(&sc->arrive[g].ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tk == in_set - 1) {
+      __hip_atomic_store(&sc->arrive[g].ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("" : "+v"(tk)::"memory");
+      const unsigned tt = __hip_atomic_fetch_add(&sc->top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tt == sets - 1) {
+        __hip_atomic_store(&sc->top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = 1;
+      }
+    }
+  }
+  last = __shfl(last, 0, 64);
+  if (last) {  // wave-uniform
+    O v = (O)0;
+    if (lane < 8) v = __hip_atomic_exchange(reinterpret_cast<O*>(&sc->part[lane].sum), (O)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int m = 4; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    if (lane == 0) *y = v;
   }
 }
 #endif

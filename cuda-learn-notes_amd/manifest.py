@@ -76,7 +76,7 @@ _add("hgemm", "G6", "mfma_ring<128x128,BK by stages,NN>",
      "hgemm_mma_m16n8k16_mma2x4_warp4x4_stages", "hgemm_mma_m16n8k16_mma2x4_warp4x4_stages_dsmem")
 _add("hgemm", "G6", "hgemm_w4<256x128> at stages=2 (K % 64 == 0, K >= 384 / 448 for an even / odd K / 64) | mfma_ring<256x128,8 waves,NN>", "hgemm_wmma_m16n16k16_mma4x2_warp4x4_stages_dsmem")
 _add("hgemm", "G6", "hgemm_w4<256x256> at stages=2 (K % 64 == 0, K >= 384 / 448 for an even / odd K / 64) | hgemm_w4s<256x256, ring of `stages` 32-deep slots> at stages 3 / 4 / 5 | mfma_ring<256x256,8 waves,NN>", "hgemm_wmma_m16n16k16_mma4x4_warp4x4_stages_dsmem")
-_add("hgemm", "G6", "best<NN>: tile shape by estimated CU utilisation x kernel efficiency (csrc/hgemm.hip best_plan): hgemm_w4<256x256x64, one wave per SIMD> (stages 2) / hgemm_w4s<256x256, ring of `stages` 32-deep K slots, one wave per SIMD> (stages 3 / 4 / 5; bit-identical) -- hgemm_pp<256x256x64> / hgemm_pp32<4x32 ring> (stages 4) when K is < 384 or has an odd number < 7 of 64-wide tiles | hgemm_pp<192x256x64> | mfma_ring<128x256> | <64x128> | <64x64> (small problems) | <128x128> | split-K over hgemm_w4, reduced in the same launch by the last-arriving workgroup of a tile up to 4 splits and by hgemm_splitk_reduce above (K >= 4096 and M N <= 2048^2: few tiles, long K; fp32 partials in a per-stream workspace: library-owned, bounded and freeable, or the caller's -- cln_hgemm_set_workspace) | tail split (a few 256x256 tiles past whole rounds of 256: the last tile rows as split-K) (see DISPATCH_EXAMPLES)",
+_add("hgemm", "G6", "best<NN>: tile shape by estimated CU utilisation x kernel efficiency (csrc/hgemm.hip best_plan): hgemm_w4<256x256x64, one wave per SIMD> (stages 2) / hgemm_w4s<256x256, ring of `stages` 32-deep K slots, one wave per SIMD> (stages 3 / 4 / 5; bit-identical) -- hgemm_pp<256x256x64> / hgemm_pp32<4x32 ring> (stages 4) when K is < 384 or has an odd number < 7 of 64-wide tiles | hgemm_pp<192x256x64> | mfma_ring<128x256> | <64x128> | <64x64> (small problems) | <128x128> | split-K over hgemm_w4, reduced in the same launch by the last-arriving workgroup of a tile at 2 splits and by hgemm_splitk_reduce above (K >= 4096 and M N <= 2048^2: few tiles, long K; fp32 partials in a per-stream workspace: library-owned, bounded and freeable, or the caller's -- cln_hgemm_set_workspace) | tail split (a few 256x256 tiles past whole rounds of 256: the last tile rows as split-K) (see DISPATCH_EXAMPLES)",
      "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem", "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_x4",
      "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_rr",
      "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem_swizzle")
@@ -276,8 +276,8 @@ def entries_of(lib):
 # dims = (M, N, K) for HGEMM names, (B, H, N, D) for flash-attn names. tests/test_describe.py asserts this table
 # against the built library on a CPU-only box, so a change of the dispatch policy that is not reflected here fails CI.
 _W4X2 = "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem"
-_SK = " (K %d per workgroup, fp32 partials in register layout) + hgemm_splitk_reduce [stages ignored: one pipeline]"  # more than 4 splits: the reduce launch
-_SKF = " (K %d per workgroup, fp32 partials in register layout) + in-kernel fix-up by the last-arriving workgroup (one launch) [stages ignored: one pipeline]"  # <= 4 splits (round 5)
+_SK = " (K %d per workgroup, fp32 partials in register layout) + hgemm_splitk_reduce [stages ignored: one pipeline]"  # more than 2 splits: the reduce launch
+_SKF = " (K %d per workgroup, fp32 partials in register layout) + in-kernel fix-up by the last-arriving workgroup (one launch) [stages ignored: one pipeline]"  # 2 splits (round 5)
 _SQKV = "flash_attn_mma_stages_split_q_shared_qkv"
 _TQKV = "flash_attn_mma_stages_split_q_tiling_qkv"
 _IGN = " [stages ignored: one pipeline]"
@@ -314,11 +314,11 @@ DISPATCH_EXAMPLES = [
     # few output tiles, long K (K >= 4096, M N <= 2048^2): split-K over the same kernel, tile and number of splits from a fitted time model
     (_W4X2, (1024, 1024, 16384), 2, "hgemm_w4<128x256x64,4 waves,64x128 wave tiles,cross-tile LDS-DMA,NN> split-K x 8" + _SK % 2048),
     (_W4X2, (128, 8192, 8192), 3, "hgemm_w4<128x256x64,4 waves,64x128 wave tiles,cross-tile LDS-DMA,NN> split-K x 8" + _SK % 1024),
-    (_W4X2, (2048, 2048, 16384), 2, "hgemm_w4<256x256x64,4 waves,128x128 wave tiles,cross-tile LDS-DMA,NN> split-K x 4" + _SKF % 4096),
+    (_W4X2, (2048, 2048, 16384), 2, "hgemm_w4<256x256x64,4 waves,128x128 wave tiles,cross-tile LDS-DMA,NN> split-K x 4" + _SK % 4096),
     (_W4X2, (768, 768, 12288), 2, "hgemm_w4<192x192x64,4 waves,96x96 wave tiles,cross-tile LDS-DMA,NN> split-K x 12" + _SK % 1024),
     (_W4X2 + "_tn_swizzle_x4", (640, 5120, 5120), 2, "hgemm_w4<160x160x64,4 waves,80x80 wave tiles,cross-tile LDS-DMA,TN> split-K x 2" + _SKF % 2560),
     # a few 256 x 256 tiles past whole rounds of 256: rows that fill whole rounds single-pass, the last tile rows split over K
-    (_W4X2, (4352, 4352, 4352), 2, "hgemm_w4<256x256x64,4 waves,128x128 wave tiles,cross-tile LDS-DMA,LDS epilogue,NN> on rows [0, 3840) + the last 2 tile rows as split-K x 4 (K 1088 per workgroup) + in-kernel fix-up [tail split; stages ignored: one pipeline]"),
+    (_W4X2, (4352, 4352, 4352), 2, "hgemm_w4<256x256x64,4 waves,128x128 wave tiles,cross-tile LDS-DMA,LDS epilogue,NN> on rows [0, 3840) + the last 2 tile rows as split-K x 4 (K 1088 per workgroup) + hgemm_splitk_reduce [tail split; stages ignored: one pipeline]"),
     (_W4X2 + "_tn_swizzle_x4", (7168, 7168, 7168), 4, "hgemm_w4<256x256x64,4 waves,128x128 wave tiles,cross-tile LDS-DMA,LDS epilogue,TN> on rows [0, 6912) + the last 1 tile rows as split-K x 7 (K 1024 per workgroup) + hgemm_splitk_reduce [tail split; stages ignored: one pipeline]"),
     (_W4X2, (4608, 4608, 4608), 2, "hgemm_w4<192x256x64,4 waves,96x128 wave tiles,cross-tile LDS-DMA,LDS epilogue,NN>"),  # another tile shape already fills the rounds
     (_W4X2, (2048, 2048, 4096), 2, "mfma_ring<64x128x64,4 waves,stages=2,NN>"),      # M N > 1536^2 needs K >= 5120

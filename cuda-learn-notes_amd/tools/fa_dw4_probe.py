@@ -45,14 +45,19 @@ for (B, H, N, D) in [(1, 2, 512, 640), (1, 2, 512, 768), (1, 2, 512, 1024), (1, 
     for name, kk in (("randn", k), ("growing keys", k * torch.linspace(0.2, 6.0, N, device=dev).view(1, 1, N, 1).half())):
         ref = ref_attn(q, kk, v)
         check("%s %s production" % ((B, H, N, D), name), lambda: prod(q, kk, v, o, 2), o, ref)
-        for abl in (1300, 1301, 1302):
+        for abl in (1300, 1301, 1302, 1316, 1332, 1364, 1348, 1396, 1412, 1413, 1414):
             check("%s %s dw4 %d" % ((B, H, N, D), name, abl), lambda: host.fa2_variant((4, 0, 0, abl), q, kk, v, o), o, ref)
     # bit-identity of the `stages = 1` form
     o1, o2 = torch.zeros_like(q), torch.zeros_like(q)
     host.fa2_variant((4, 0, 0, 1300), q, k, v, o1)
     host.fa2_variant((4, 0, 0, 1301), q, k, v, o2)
+    o3, o4, o5 = torch.zeros_like(q), torch.zeros_like(q), torch.zeros_like(q)
+    host.fa2_variant((4, 0, 0, 1412), q, k, v, o3)
+    host.fa2_variant((4, 0, 0, 1413), q, k, v, o4)
+    prod(q, k, v, o5, 1)
     torch.cuda.synchronize()
-    print("BIT %s stages 1 == 2: %s" % ((B, H, N, D), torch.equal(o1, o2)), flush=True)
+    print("BIT %s stages 1 == 2: %s; production options (carry / M0 walk / spread) == plain: %s; their stages 1 == 2: %s; production name stages 1: %s"
+          % ((B, H, N, D), torch.equal(o1, o2), torch.equal(o3, o1), torch.equal(o4, o3), torch.equal(o5, o3)), flush=True)
 
 # ---- timing
 shapes = [(1, 16, 4096, 640), (1, 16, 4096, 768), (1, 16, 4096, 1024)] + ([] if quick else [(1, 8, 8192, 1024), (2, 16, 2048, 768)])
@@ -62,10 +67,10 @@ for (B, H, N, D) in shapes:
     o = torch.zeros_like(q)
     fl = bu.mha_flops_conventional(B, H, N, D)
     cands = [("production stages 2", lambda: prod(q, k, v, o, 2)), ("production stages 1", lambda: prod(q, k, v, o, 1))]
-    codes = [1300, 1301, 1302]
+    codes = [1300, 1301, 1316, 1332, 1364, 1348, 1396, 1412, 1413]
     if D in (768, 1024):
-        codes += [1304, 1308, 1312]
-    codes += {1024: [1411, 1433, 1444, 1442, 1424], 768: [1411, 1433, 1444], 640: [1411, 1433]}[D]
+        codes += [1304, 1416]
+    codes += {1024: [1511, 1533, 1542], 768: [1511, 1533], 640: [1511, 1533]}[D]
     for abl in codes:
         cands.append(("dw4 %d" % abl, (lambda a: lambda: host.fa2_variant((4, 0, 0, a), q, k, v, o))(abl)))
     for rnd in range(2):

@@ -23,3 +23,17 @@ print("HOSTOV torch.softmax(out=)               %.2f us/call"%host_rate(lambda: 
 print("HOSTOV _stream()                         %.2f us/call"%host_rate(host._stream))
 print("HOSTOV torch.cuda.current_stream().cuda_stream %.2f us/call"%host_rate(lambda: torch.cuda.current_stream().cuda_stream))
 print("HOSTOV _check_dev(3 tensors)             %.2f us/call"%host_rate(lambda: host._check_dev(a,b,c)))
+# round 5: the CPython entry (csrc/pyext/cln_fastcall.c) against the pure-Python wrapper it falls back to (ctypes), and the scalar-result kernels
+# without the zero-fill dispatch (csrc/stream_scratch.h)
+print("HOSTOV fastcall module loaded            %s" % (host._fastcall is not None))
+slow_add = getattr(ew.elementwise_add_f32, "__wrapped__", None)
+if slow_add is not None:
+    print("HOSTOV pure-Python wrapper (ctypes) add  %.2f us/call" % host_rate(lambda: slow_add(a, b, c)))
+rd = pkg.load("reduce"); xr = torch.randn(4096, device=dev)
+print("HOSTOV block_all_reduce_sum_f32x4_f32    %.2f us/call" % host_rate(lambda: rd.block_all_reduce_sum_f32x4_f32(xr), 10000))
+print("HOSTOV torch.sum                         %.2f us/call" % host_rate(lambda: torch.sum(xr), 10000))
+nm = pkg.load("rms_norm"); xh = torch.randn(64, 1024, device=dev).half(); oh = torch.zeros_like(xh)
+print("HOSTOV rms_norm_f16x8_pack_f32           %.2f us/call" % host_rate(lambda: nm.rms_norm_f16x8_pack_f32(xh, oh, 1.0)))
+hgl = pkg.hgemm_lib(); A = torch.randn(256, 256, device=dev).half(); C = torch.zeros_like(A)
+print("HOSTOV hgemm G6 wrapper 256^3            %.2f us/call" % host_rate(lambda: hgl.hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem(A, A, C, 2, False, 0), 10000))
+print("HOSTOV torch.matmul(out=) 256^3          %.2f us/call" % host_rate(lambda: torch.matmul(A, A, out=C), 10000))

@@ -9,7 +9,7 @@
 #   7. C++ harness                                                                         -> <tag>_hgemm_bench_cpp.log
 #   8. (round 4: + the single-stage / ring-of-slots / fp32-scale probes and the back-to-back stress) stages = 1 vs 2 of the attention names, the hipBLASLt row, the bit-repeatability stress, the ck_tile FMHA comparator
 #      -> <tag>_fa_stage1_vs_stage2.log, <tag>_hipblaslt_probe.log, <tag>_determinism_stress.log, <tag>_fa_ck_tile_comparator.log
-TAG=${1:-r04}
+TAG=${1:-r05}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$REPO/gpurun_out; T=$REPO/cuda-learn-notes_amd/tools
 mkdir -p $OUT; cd $REPO; export PYTHONUNBUFFERED=1
 # a box whose GPU faults on the first launch (seen once in round 2: every later command then hangs to its timeout) must
@@ -17,8 +17,11 @@ mkdir -p $OUT; cd $REPO; export PYTHONUNBUFFERED=1
 timeout 120 python -m pytest tests/test_gpu_flash_attn.py -m gpu -x -q -k golden_fixture > $OUT/${TAG}_sanity.log 2>&1 || { echo "sanity launch failed"; tail -5 $OUT/${TAG}_sanity.log; exit 7; }
 timeout 1500 python -m pytest tests -m gpu -q --timeout 120 > $OUT/${TAG}_pytest_gpu.log 2>&1; RC=$?; echo "pytest rc=$RC"; tail -3 $OUT/${TAG}_pytest_gpu.log
 if [ $RC -gt 1 ]; then echo "pytest aborted"; exit 8; fi
-timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_20steps.json 2> $OUT/${TAG}_bench_20steps.err; echo "bench20 rc=$?"
-timeout 600 python bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/${TAG}_bench_default.err; echo "bench rc=$?"
+# (round 5: stdout = one short row per kernel, then the compact headline object as the LAST line; the full result is bench_detail.json)
+timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_20steps.log 2> $OUT/${TAG}_bench_20steps.err; echo "bench20 rc=$?"
+tail -1 $OUT/${TAG}_bench_20steps.log > $OUT/${TAG}_bench_20steps.json; cp $OUT/bench_detail.json $OUT/${TAG}_bench_detail_20steps.json
+timeout 600 python bench.py > $OUT/${TAG}_bench_default.log 2> $OUT/${TAG}_bench_default.err; echo "bench rc=$?"
+tail -1 $OUT/${TAG}_bench_default.log > $OUT/${TAG}_bench_default.json; cp $OUT/bench_detail.json $OUT/${TAG}_bench_detail_default.json
 timeout 900 bash $T/profile_round.sh $TAG > $OUT/${TAG}_profile_round.log 2>&1; echo "profile_round rc=$?"
 timeout 600 bash $T/fa_trace.sh $TAG > $OUT/${TAG}_fa_trace.log 2>&1; echo "fa_trace rc=$?"
 ( cd /tmp && export TMPDIR=/tmp && BW_PROF_ORDER=$OUT/bw_prof_order.json timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/bwprof -o bw -- python $T/bw_prof_target.py > $OUT/${TAG}_bw_prof.log 2>&1 )
@@ -39,5 +42,23 @@ timeout 300 python $T/fa_small_grid_probe.py 2>&1 | grep "^SMALLGRID" > $OUT/${T
 timeout 300 python $T/fa_fscale_probe.py 2>&1 | grep "^FSCALE" > $OUT/${TAG}_fa_fscale_probe.log; echo "fscale probe rc=$?"
 ( NBUF=16 FORMS=stages=2,stages=1 timeout 300 python $T/fa_race_stress.py 1 32 4096 512 60; NBUF=16 FORMS=stages=2,stages=1 timeout 300 python $T/fa_race_stress.py 4 8 2048 64 100;
   NBUF=16 FORMS=stages=2 timeout 300 python $T/fa_race_stress.py 2 32 4096 256 40 ) 2>&1 | grep "^RACE" > $OUT/${TAG}_fa_back_to_back_stress.log; echo "stress rc=$?"
+# round 5: the one-wave-per-SIMD attention kernel for D = 640 / 768 / 1024 against the round-4 ring kernel (timing + LDS / fabric counters), the
+# one-launch split-K form under 0 / default / 64 splits, the host cost of a call through the CPython entry, every script against its torch row
+timeout 400 python $T/fa_dw4_probe.py 2>&1 | grep "^CHK\|^BIT\|^FA" > $OUT/${TAG}_fa_dw4_probe.log; echo "dw4 probe rc=$?"
+rm -f $OUT/${TAG}_hgemm_splitk_fused_probe_final.log
+for s in 0 2 64; do CLN_AMD_SPLITK_FUSED_MAX_S=$s timeout 200 python $T/hg_splitk_fused_probe.py 2>&1 | grep "^SKF" >> $OUT/${TAG}_hgemm_splitk_fused_probe_final.log; done; echo "fused split-K probe rc=$?"
+timeout 120 python $T/host_overhead_probe.py 2>&1 | grep "^HOSTOV" > $OUT/${TAG}_host_call_overhead_final.log; echo "host overhead rc=$?"
+timeout 900 python $T/scripts_vs_torch.py 2>&1 | grep "^SVT" > $OUT/${TAG}_scripts_vs_torch.log; echo "scripts vs torch rc=$?"
+( cd /tmp && export TMPDIR=/tmp
+  P1="SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE"
+  for D in 1024 768; do
+    for abl in 1412 1000; do  # 1412 = the production options of flash_attn_dw4.cuh, 1000 = flash_attn_dring.cuh (round 3 / 4 production)
+      for pass in sq fetch write; do
+        case $pass in sq) C="$P1";; fetch) C="FETCH_SIZE";; write) C="WRITE_SIZE";; esac
+        timeout 120 rocprofv3 --kernel-trace --output-format csv --pmc $C -d $OUT/pmc_bigd_${D}_${abl}_$pass -o pmc -- python $T/prof_target.py fa2 $D 4 0 $abl 1 16 4096 6 > $OUT/pmc_bigd_${D}_${abl}_$pass.log 2>&1
+      done
+      python $T/pmc_summary.py fa2_fwd $OUT/${TAG}_pmc_fa_d${D}_$([ $abl = 1412 ] && echo dw4 || echo dring).json $OUT/pmc_bigd_${D}_${abl}_sq $OUT/pmc_bigd_${D}_${abl}_fetch $OUT/pmc_bigd_${D}_${abl}_write > /dev/null
+    done
+  done ); echo "big-D pmc rc=$?"
 cut -c1-1500 $OUT/${TAG}_bench_20steps.json; echo; cat $OUT/${TAG}_fa_kernel_trace.csv; cat $OUT/${TAG}_bw_rocprof.txt
 ls -la $OUT/${TAG}_* | head -40

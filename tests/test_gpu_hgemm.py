@@ -560,8 +560,8 @@ def test_split_k_workspace_grows_and_is_per_stream(hg, built, dev):
     outs = []
     for rnd in range(3):
         for st, (a, b, c) in ((s1, probs[0]), (s2, probs[1]), (s1, probs[2]), (s2, probs[0])):
-            o = torch.zeros_like(c)
             with torch.cuda.stream(st):
+                o = torch.zeros_like(c)  # (filled on the stream that runs the launch: a fill on another stream races with it)
                 fn(a, b, o, 2, False, 0)
             outs.append((o, c))
     torch.cuda.synchronize()
@@ -716,7 +716,7 @@ def test_workspace_does_not_leak_over_many_streams(hg, built, dev):
             assert hip.hipStreamDestroy(s) == 0
     torch.cuda.synchronize()
     assert 0 < peak <= 8 * (16 << 20), peak
-    assert host.release_workspaces() <= 8 * (16 << 20) + (64 * 256) * 2 and host.hgemm_workspace_held() == 0
+    assert host.release_workspaces() <= 8 * (16 << 20) + (64 * 4096) * 2 and host.hgemm_workspace_held() == 0
 
 
 def test_two_host_threads_on_one_stream_get_their_own_results(hg, built, dev):

@@ -55,8 +55,9 @@ def test_attention_kernels_in_the_product_library_are_exactly_the_plannable_ones
         elif f == "fa2_fwd_splitkv_kernel":
             linked.add((f[:-len("_kernel")], int(a[0])))
         elif f == "fa2_fwd_dw4_kernel":  # <D, option bits (1 = the single-stage form), K / V fragments in flight>: round 5, head dims 640 / 768 / 1024
-            assert a[1] in ("0", "1") and a[2:] == ["2", "2"], a
-            linked.add(("fa2_fwd_dw4", int(a[0]), a[1] == "1"))
+            # 112 = last MFMA group carried across the barrier + M0-walking tile requests + softmax in four sections
+            assert a[1] in ("112", "113") and a[2:] == ["2", "2"], a
+            linked.add(("fa2_fwd_dw4", int(a[0]), a[1] == "113"))
         else:
             raise AssertionError("attention kernel family the planner does not know: %s<%s>" % (fam, ", ".join(a)))
     plannable = set()

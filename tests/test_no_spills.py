@@ -42,7 +42,7 @@ def test_production_attention_instantiations_are_in_the_report(tmp_path):
     # single-stage form (`stages = 1`); the [B,H,N,D] ones also with the scores scaled in fp32 (the *_acc_f32 names)
     assert len(kernels_x) == 18, [k["demangled"] for k in kernels_x]
     for want in ("fa2_fwd_dsplit_kernel<512, 2, 1,", "fa2_fwd_m16x_kernel<64, 32, 128, 8, 4, 5, false>", "fa2_fwd_m16x_kernel<128, 32, 128, 4, 4, 5, false>", "fa2_fwd_m16x_kernel<128, 32, 128, 4, 4, 5, true>", "fa2_fwd_m16_pair_kernel<2, false, false, 0>", "fa2_fwd_m16_pair_kernel<2, true, false, 0>",
-                 "fa2_fwd_v2_kernel<128, 2, true", "fa2_fwd_splitkv_kernel<64, true>", "fa2_fwd_dw4_kernel<1024, 0, 2, 2>", "fa2_fwd_dw4_kernel<640, 1, 2, 2>", "fa2_fwd_m16x_kernel<64, 64, 64, 4, 1, 5, false>"):
+                 "fa2_fwd_v2_kernel<128, 2, true", "fa2_fwd_splitkv_kernel<64, true>", "fa2_fwd_dw4_kernel<1024, 112, 2, 2>", "fa2_fwd_dw4_kernel<640, 113, 2, 2>", "fa2_fwd_m16x_kernel<64, 64, 64, 4, 1, 5, false>"):
         assert any(want in n for n in names), want
 
 
