@@ -22,9 +22,9 @@ inline int launch_fa2_large_d(const void* q, const void* k, const void* v, void*
     switch (D) {
       case 320: return fa2::launch_dsplit<512, 2, 1, fa2::OPT_DEFAULT, 512, 320>(q, k, v, o, B, H, N, s);
       case 384: return fa2::launch_dsplit<512, 2, 1, fa2::OPT_DEFAULT, 512, 384>(q, k, v, o, B, H, N, s);
-      case 640: return fa2::launch_dw4<640, fa2::DW4_DEFAULT | fa2::DW4_1STAGE>(q, k, v, o, B, H, N, s);
-      case 768: return fa2::launch_dw4<768, fa2::DW4_DEFAULT | fa2::DW4_1STAGE>(q, k, v, o, B, H, N, s);
-      case 1024: return fa2::launch_dw4<1024, fa2::DW4_DEFAULT | fa2::DW4_1STAGE>(q, k, v, o, B, H, N, s);
+      case 640: return fa2::launch_dw4<640, fa2::DW4_CARRY | fa2::DW4_UNROLL2 | fa2::DW4_1STAGE>(q, k, v, o, B, H, N, s);
+      case 768: return fa2::launch_dw4<768, fa2::DW4_DEFAULT | fa2::DW4_UNROLL2 | fa2::DW4_1STAGE>(q, k, v, o, B, H, N, s);
+      case 1024: return fa2::launch_dw4<1024, fa2::DW4_DEFAULT | fa2::DW4_UNROLL2 | fa2::DW4_1STAGE>(q, k, v, o, B, H, N, s);
       default: return CLN_ERR_UNSUPPORTED;
     }
   }
@@ -43,9 +43,9 @@ inline int launch_fa2_large_d(const void* q, const void* k, const void* v, void*
     // profiles/r03_fa_dring_prefetch_probe.log)
     // round 5: the one-wave-per-SIMD kernel (flash_attn_dw4.cuh) -- [1,16,4096,D] 684 -> 765 / 751 -> 818 / 793 -> 912 TF, [1,8,8192,1024] 803 -> 928 on one box
     // (profiles/r05_fa_dw4_probe.log); the 8-wave ring kernel above stays in the probe library (variants 1000..1216)
-    case 640: return fa2::launch_dw4<640, fa2::DW4_DEFAULT>(q, k, v, o, B, H, N, s);
-    case 768: return fa2::launch_dw4<768, fa2::DW4_DEFAULT>(q, k, v, o, B, H, N, s);
-    case 1024: return fa2::launch_dw4<1024, fa2::DW4_DEFAULT>(q, k, v, o, B, H, N, s);
+    case 640: return fa2::launch_dw4<640, fa2::DW4_CARRY | fa2::DW4_UNROLL2>(q, k, v, o, B, H, N, s);
+    case 768: return fa2::launch_dw4<768, fa2::DW4_DEFAULT | fa2::DW4_UNROLL2>(q, k, v, o, B, H, N, s);
+    case 1024: return fa2::launch_dw4<1024, fa2::DW4_DEFAULT | fa2::DW4_UNROLL2>(q, k, v, o, B, H, N, s);
     default: return CLN_ERR_UNSUPPORTED;
   }
 }

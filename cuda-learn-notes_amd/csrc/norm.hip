@@ -20,9 +20,9 @@ namespace {
 // everywhere -> identical result, no broadcast hop). Each scratch array is written once per kernel, so no
 // protecting barrier is needed; layer-norm keeps the reference kernels' two-pass mean / variance
 // (layer_norm.cu:53-110) and therefore uses two scratch arrays and two barriers.
-__device__ __forceinline__ float row_sum(float v, float* scratch) {
+__device__ __forceinline__ float row_sum(float v, float* scratch, int rpw) {
   v = wave_sum(v);
-  const int nw = blockDim.x >> 6;
+  const int nw = rpw > 1 ? 1 : (int)(blockDim.x >> 6);  // wave-per-row groups (rowwise.cuh rows_per_wg): the row is one wave
   if (nw > 1) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (lane == 0) scratch[w] = v;
@@ -34,21 +34,22 @@ __device__ __forceinline__ float row_sum(float v, float* scratch) {
 }
 
 template <typename T, int VEC, int MAXV>
-__global__ void layer_norm_kernel(const T* __restrict__ x, T* __restrict__ y, float g, float b, int K, int stream_nt) {
+__global__ void layer_norm_kernel(const T* __restrict__ x, T* __restrict__ y, float g, float b, int K, int stream_nt, int rpw) {
   __shared__ float scratch[2][16];
-  const size_t off = (size_t)blockIdx.x * K;
+  const RowPos rp = row_pos(rpw);
+  const size_t off = rp.row * K;
   RowRegs<T, VEC, MAXV> r;
-  r.load(x + off, K, 0.f);
+  r.load(x + off, K, 0.f, rp.tid, rp.tpr);
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i)
 #pragma unroll
     for (int e = 0; e < VEC; ++e) s += r.x[i][e];
-  const float mean = row_sum(s, scratch[0]) / (float)K;
+  const float mean = row_sum(s, scratch[0], rpw) / (float)K;
   float v = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
-    const int col = (i * blockDim.x + threadIdx.x) * VEC;
+    const int col = (i * rp.tpr + rp.tid) * VEC;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
       const float d = (col < K) ? (r.x[i][e] - mean) : 0.f;
@@ -56,31 +57,32 @@ __global__ void layer_norm_kernel(const T* __restrict__ x, T* __restrict__ y, fl
       v += d * d;
     }
   }
-  const float a = rsqrtf(row_sum(v, scratch[1]) / ((float)K + 1e-5f)) * g;
+  const float a = rsqrtf(row_sum(v, scratch[1], rpw) / ((float)K + 1e-5f)) * g;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i)
 #pragma unroll
     for (int e = 0; e < VEC; ++e) r.x[i][e] = fmaf(r.x[i][e], a, b);
-  r.store(y + off, K, stream_nt);
+  r.store(y + off, K, stream_nt, rp.tid, rp.tpr);
 }
 
 template <typename T, int VEC, int MAXV>
-__global__ void rms_norm_kernel(const T* __restrict__ x, T* __restrict__ y, float g, int K, int stream_nt) {
+__global__ void rms_norm_kernel(const T* __restrict__ x, T* __restrict__ y, float g, int K, int stream_nt, int rpw) {
   __shared__ float scratch[16];
-  const size_t off = (size_t)blockIdx.x * K;
+  const RowPos rp = row_pos(rpw);
+  const size_t off = rp.row * K;
   RowRegs<T, VEC, MAXV> r;
-  r.load(x + off, K, 0.f);
+  r.load(x + off, K, 0.f, rp.tid, rp.tpr);
   float v = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i)
 #pragma unroll
     for (int e = 0; e < VEC; ++e) v += r.x[i][e] * r.x[i][e];
-  const float a = rsqrtf(row_sum(v, scratch) / (float)K + 1e-5f) * g;
+  const float a = rsqrtf(row_sum(v, scratch, rpw) / (float)K + 1e-5f) * g;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i)
 #pragma unroll
     for (int e = 0; e < VEC; ++e) r.x[i][e] = r.x[i][e] * a;
-  r.store(y + off, K, stream_nt);
+  r.store(y + off, K, stream_nt, rp.tid, rp.tpr);
 }
 
 template <typename T, int VEC>
@@ -88,9 +90,9 @@ int launch_ln(const void* x, void* y, float g, float b, int N, int K, hipStream_
   if (!x || !y || N <= 0 || K <= 0) return CLN_ERR_BAD_ARG;
   if (!cln_aligned(x, sizeof(T) * VEC) || !cln_aligned(y, sizeof(T) * VEC)) return CLN_ERR_BAD_ARG;
   if (K % VEC) return CLN_ERR_UNSUPPORTED;
-  const int nt = row_threads(K, VEC), vpt = vecs_per_thread(K, VEC, nt);
+  const int nt = row_threads(K, VEC), vpt = vecs_per_thread(K, VEC, nt), rpw = rows_per_wg(nt, N);
 #define CALL(MV)                                                                                              \
-  CLN_LAUNCH((layer_norm_kernel<T, VEC, MV>), dim3(N), dim3(nt), 0, st, (const T*)x, (T*)y, g, b, K, cln_stream_nt(2LL * N * K * (long long)sizeof(T)))
+  CLN_LAUNCH((layer_norm_kernel<T, VEC, MV>), dim3(N / rpw), dim3(nt * rpw), 0, st, (const T*)x, (T*)y, g, b, K, cln_stream_nt(2LL * N * K * (long long)sizeof(T)), rpw)
   ROWWISE_DISPATCH_MAXV(vpt, CALL);
 #undef CALL
   return cln_check_launch();
@@ -100,9 +102,9 @@ int launch_rms(const void* x, void* y, float g, int N, int K, hipStream_t st) {
   if (!x || !y || N <= 0 || K <= 0) return CLN_ERR_BAD_ARG;
   if (!cln_aligned(x, sizeof(T) * VEC) || !cln_aligned(y, sizeof(T) * VEC)) return CLN_ERR_BAD_ARG;
   if (K % VEC) return CLN_ERR_UNSUPPORTED;
-  const int nt = row_threads(K, VEC), vpt = vecs_per_thread(K, VEC, nt);
+  const int nt = row_threads(K, VEC), vpt = vecs_per_thread(K, VEC, nt), rpw = rows_per_wg(nt, N);
 #define CALL(MV) \
-  CLN_LAUNCH((rms_norm_kernel<T, VEC, MV>), dim3(N), dim3(nt), 0, st, (const T*)x, (T*)y, g, K, cln_stream_nt(2LL * N * K * (long long)sizeof(T)))
+  CLN_LAUNCH((rms_norm_kernel<T, VEC, MV>), dim3(N / rpw), dim3(nt * rpw), 0, st, (const T*)x, (T*)y, g, K, cln_stream_nt(2LL * N * K * (long long)sizeof(T)), rpw)
   ROWWISE_DISPATCH_MAXV(vpt, CALL);
 #undef CALL
   return cln_check_launch();

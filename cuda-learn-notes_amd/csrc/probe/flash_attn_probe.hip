@@ -14,6 +14,7 @@
 #include "flash_attn_m16x_api.h"
 #include "flash_attn_dring.cuh"
 #include "flash_attn_dw4.cuh"
+#include "flash_attn_dw4b.cuh"
 #include <type_traits>
 
 #define V3(DD, NWW, OPTT) \
@@ -171,12 +172,23 @@ CLN_API int cln_fa2_variant(int D, int nw, int vt, int opt, int abl, const void*
 #define DW4(DD, OPTV) if (D == DD && abl == 1300 + OPTV) return fa2::launch_dw4<DD, OPTV>(q, k, v, o, B, H, N, (hipStream_t)stream);
   DW4(640, 0) DW4(768, 0) DW4(1024, 0) DW4(640, 1) DW4(768, 1) DW4(1024, 1) DW4(640, 2) DW4(768, 2) DW4(1024, 2)
   DW4(1024, 4) DW4(1024, 116) DW4(768, 4) DW4(768, 116)
-  DW4(640, 16) DW4(768, 16) DW4(1024, 16) DW4(640, 32) DW4(768, 32) DW4(1024, 32) DW4(640, 64) DW4(768, 64) DW4(1024, 64)
+  DW4(640, 16) DW4(640, 17) DW4(768, 16) DW4(1024, 16) DW4(640, 32) DW4(768, 32) DW4(1024, 32) DW4(640, 64) DW4(768, 64) DW4(1024, 64)
   DW4(640, 48) DW4(768, 48) DW4(1024, 48) DW4(640, 112) DW4(768, 112) DW4(1024, 112) DW4(640, 113) DW4(768, 113) DW4(1024, 113)
   DW4(640, 114) DW4(768, 114) DW4(1024, 114) DW4(640, 96) DW4(768, 96) DW4(1024, 96)
+  // + 128 = two tiles per loop iteration (compile-time ring-slot parity)
+  DW4(640, 144) DW4(640, 145) DW4(640, 240) DW4(768, 240) DW4(768, 241) DW4(1024, 240) DW4(1024, 241) DW4(768, 176) DW4(1024, 176) DW4(640, 128) DW4(768, 128) DW4(1024, 128)
+  // D = 512 (config C5) on the same kernel with 128 rows per workgroup (GeoDW4<512, 2>)
+  DW4(512, 0) DW4(512, 1) DW4(512, 2) DW4(512, 16) DW4(512, 48) DW4(512, 112) DW4(512, 113) DW4(512, 114) DW4(512, 4) DW4(512, 116)
 #undef DW4
+  // 1600 + opt = the one-barrier-per-tile form for D = 640 / 768 (flash_attn_dw4b.cuh); opt bits 1 / 2 / 4 / 8 as above
+#define DW4B(DD, OPTV) if (D == DD && abl == 1600 + OPTV) return fa2::launch_dw4b<DD, OPTV>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  DW4B(640, 0) DW4B(768, 0) DW4B(640, 1) DW4B(768, 1) DW4B(640, 2) DW4B(768, 2) DW4B(640, 4) DW4B(768, 4)
+#undef DW4B
+#define DW4BP(DD, KP, VP) if (D == DD && abl == 1700 + 10 * KP + VP) return fa2::launch_dw4b<DD, 0, KP, VP>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  DW4BP(640, 3, 3) DW4BP(768, 3, 3) DW4BP(640, 1, 1) DW4BP(768, 1, 1) DW4BP(768, 4, 2)
+#undef DW4BP
 #define DW4P(DD, KP, VP) if (D == DD && abl == 1500 + 10 * KP + VP) return fa2::launch_dw4<DD, fa2::DW4_DEFAULT, KP, VP>(q, k, v, o, B, H, N, (hipStream_t)stream);
-  DW4P(1024, 1, 1) DW4P(1024, 3, 3) DW4P(1024, 4, 2) DW4P(768, 1, 1) DW4P(768, 3, 3) DW4P(640, 3, 3) DW4P(640, 1, 1)
+  DW4P(1024, 1, 1) DW4P(1024, 3, 3) DW4P(1024, 4, 2) DW4P(768, 1, 1) DW4P(768, 3, 3) DW4P(640, 3, 3) DW4P(640, 1, 1) DW4P(512, 1, 1) DW4P(512, 4, 4) DW4P(512, 4, 2)
 #undef DW4P
   // 1000 = the ring kernel for head dims 640 / 768 / 1024 (flash_attn_dring.cuh), row groups one phase apart; 1001 = lock-step
   if (D == 640 && abl == 1000) return fa2::launch_dring<640, fa2::OPT_DEFAULT>(q, k, v, o, B, H, N, (hipStream_t)stream);

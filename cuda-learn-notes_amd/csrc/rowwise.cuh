@@ -3,6 +3,7 @@
 // write per element), per-lane access width fixed by the rung name (VEC * sizeof(T) bytes).
 #pragma once
 #include "common.h"
+#include <stdlib.h>
 
 namespace rowwise {
 
@@ -32,15 +33,47 @@ inline int row_threads(int K, int VEC) {
   return nt;
 }
 inline int vecs_per_thread(int K, int VEC, int nt) { return (K / VEC + nt - 1) / nt; }
+constexpr int ROWS_PER_WG_DEFAULT = 1;  // measured: 1 / 2 / 4 rows per workgroup within 1 % of each other at 4096^2 ... 8192^2, 8 slower (profiles/r05_bw_rows_per_wg_probe.log)
+
+// Rows per workgroup (round 5). A row that fits ONE wave (row_threads == 64: up to 4096 fp16 / 2048 fp32 elements at 8 packs per lane)
+// needs no LDS and no barrier, so several such rows can share a workgroup: 4096 one-wave workgroups become 1024 of four waves. Built to test whether
+// the workgroup count is the 4-5 us fixed cost of the 10-15 us launches at 4096^2: it is NOT -- f16 softmax / layer-norm / rms-norm
+// 14.3 / 14.1 / 14.1 us at 1 row per workgroup, 14.6 / 13.8 / 13.9 at 4, 16.9 / 16.5 / 16.2 at 8 -- so the default stays one row per workgroup;
+// $CLN_AMD_ROWS_PER_WG = 2 / 4 / 8 / 16 selects the grouped form (read once).
+inline int rows_per_wg(int nt, int rows) {
+  static const int forced = [] {
+    const char* e = getenv("CLN_AMD_ROWS_PER_WG");
+    const int v = e ? atoi(e) : 0;
+    return (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) ? v : 0;
+  }();
+  if (nt != 64) return 1;
+  int r = forced ? forced : ROWS_PER_WG_DEFAULT;
+  while (r > 1 && rows % r) r >>= 1;  // whole workgroups only: no row guard in the kernels
+  return r;
+}
+// position of this thread in its row group: TPR threads per row, row = first row of the workgroup + group index
+struct RowPos {
+  int tid, tpr;
+  size_t row;
+};
+__device__ __forceinline__ RowPos row_pos(int rpw) {
+  RowPos p;
+  if (rpw == 1) {
+    p.tid = threadIdx.x, p.tpr = blockDim.x, p.row = blockIdx.x;
+  } else {  // wave-per-row groups
+    p.tid = threadIdx.x & 63, p.tpr = 64, p.row = (size_t)blockIdx.x * rpw + (threadIdx.x >> 6);
+  }
+  return p;
+}
 
 // Register-resident row: MAXV packs of VEC elements per thread, as fp32.
 template <typename T, int VEC, int MAXV>
 struct RowRegs {
   float x[MAXV][VEC];
-  __device__ __forceinline__ void load(const T* row, int K, float fill) {
+  __device__ __forceinline__ void load(const T* row, int K, float fill, int tid = threadIdx.x, int tpr = blockDim.x) {
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-      const int col = (i * blockDim.x + threadIdx.x) * VEC;
+      const int col = (i * tpr + tid) * VEC;
       if (col < K) {
         const Pack<T, VEC> p = *reinterpret_cast<const Pack<T, VEC>*>(row + col);
 #pragma unroll
@@ -51,10 +84,10 @@ struct RowRegs {
       }
     }
   }
-  __device__ __forceinline__ void store(T* row, int K, int nt = 0) const {
+  __device__ __forceinline__ void store(T* row, int K, int nt = 0, int tid = threadIdx.x, int tpr = blockDim.x) const {
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-      const int col = (i * blockDim.x + threadIdx.x) * VEC;
+      const int col = (i * tpr + tid) * VEC;
       if (col < K) {
         Pack<T, VEC> p;
 #pragma unroll

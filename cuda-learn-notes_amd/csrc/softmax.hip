@@ -92,12 +92,17 @@ int launch_global(const void* x, void* y, void* total, long long n, hipStream_t 
   return cln_check_launch();
 }
 
+// row reductions: a row of one wave (wave-per-row groups, rpw > 1, or a 64-thread workgroup) stays inside the wave; larger rows go through LDS
+__device__ __forceinline__ float row_sum_g(float v, float* scratch, int rpw) { return rpw > 1 ? wave_sum(v) : block_sum_rt(v, scratch); }
+__device__ __forceinline__ float row_max_g(float v, float* scratch, int rpw) { return rpw > 1 ? wave_max(v) : block_max_rt(v, scratch); }
+
 template <typename T, int VEC, int MAXV, int MODE>
-__global__ void softmax_row_kernel(const T* __restrict__ x, T* __restrict__ y, int H, int stream_nt) {
+__global__ void softmax_row_kernel(const T* __restrict__ x, T* __restrict__ y, int H, int stream_nt, int rpw) {
   __shared__ float scratch[16];
-  const size_t off = (size_t)blockIdx.x * H;
+  const RowPos rp = row_pos(rpw);
+  const size_t off = rp.row * H;
   RowRegs<T, VEC, MAXV> r;
-  r.load(x + off, H, -INFINITY);
+  r.load(x + off, H, -INFINITY, rp.tid, rp.tpr);
   float m = 0.f, d = 0.f;
   if constexpr (MODE == UNSAFE) {
 #pragma unroll
@@ -107,14 +112,14 @@ __global__ void softmax_row_kernel(const T* __restrict__ x, T* __restrict__ y, i
         r.x[i][e] = __expf(r.x[i][e]);
         d += r.x[i][e];
       }
-    d = block_sum_rt(d, scratch);
+    d = row_sum_g(d, scratch, rpw);
   } else if constexpr (MODE == SAFE) {
     m = -INFINITY;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i)
 #pragma unroll
       for (int e = 0; e < VEC; ++e) m = fmaxf(m, r.x[i][e]);
-    m = block_max_rt(m, scratch);
+    m = row_max_g(m, scratch, rpw);
 #pragma unroll
     for (int i = 0; i < MAXV; ++i)
 #pragma unroll
@@ -122,7 +127,7 @@ __global__ void softmax_row_kernel(const T* __restrict__ x, T* __restrict__ y, i
         r.x[i][e] = __expf(r.x[i][e] - m);
         d += r.x[i][e];
       }
-    d = block_sum_rt(d, scratch);
+    d = row_sum_g(d, scratch, rpw);
   } else {
     // online normaliser: per-thread (m, d), then one max-reduction and one rescaled sum-reduction
     m = -INFINITY;
@@ -136,8 +141,8 @@ __global__ void softmax_row_kernel(const T* __restrict__ x, T* __restrict__ y, i
         m = mn;
       }
     if (m == -INFINITY) d = 0.f;
-    const float mg = block_max_rt(m, scratch);
-    d = block_sum_rt((m == -INFINITY) ? 0.f : d * __expf(m - mg), scratch);
+    const float mg = row_max_g(m, scratch, rpw);
+    d = row_sum_g((m == -INFINITY) ? 0.f : d * __expf(m - mg), scratch, rpw);
     m = mg;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i)
@@ -149,7 +154,7 @@ __global__ void softmax_row_kernel(const T* __restrict__ x, T* __restrict__ y, i
   for (int i = 0; i < MAXV; ++i)
 #pragma unroll
     for (int e = 0; e < VEC; ++e) r.x[i][e] *= inv;
-  r.store(y + off, H, stream_nt);
+  r.store(y + off, H, stream_nt, rp.tid, rp.tpr);
 }
 
 template <typename T, int VEC, int MODE>
@@ -157,9 +162,9 @@ int launch_rows(const void* x, void* y, int S, int H, hipStream_t st) {
   if (!x || !y || S <= 0 || H <= 0) return CLN_ERR_BAD_ARG;
   if (!cln_aligned(x, sizeof(T) * VEC) || !cln_aligned(y, sizeof(T) * VEC)) return CLN_ERR_BAD_ARG;
   if (H % VEC) return CLN_ERR_UNSUPPORTED;
-  const int nt = row_threads(H, VEC), vpt = vecs_per_thread(H, VEC, nt);
+  const int nt = row_threads(H, VEC), vpt = vecs_per_thread(H, VEC, nt), rpw = rows_per_wg(nt, S);
 #define CALL(MV) \
-  CLN_LAUNCH((softmax_row_kernel<T, VEC, MV, MODE>), dim3(S), dim3(nt), 0, st, (const T*)x, (T*)y, H, cln_stream_nt(2LL * S * H * (long long)sizeof(T)))
+  CLN_LAUNCH((softmax_row_kernel<T, VEC, MV, MODE>), dim3(S / rpw), dim3(nt * rpw), 0, st, (const T*)x, (T*)y, H, cln_stream_nt(2LL * S * H * (long long)sizeof(T)), rpw)
   ROWWISE_DISPATCH_MAXV(vpt, CALL);
 #undef CALL
   return cln_check_launch();

@@ -38,14 +38,14 @@ def check(tag, fn, o, ref):
 
 # ---- correctness: random inputs, and keys whose scale GROWS along the sequence (the running maximum rises by > 8 in the log2 domain
 # many times: the deferred form must take its rescale path)
-for (B, H, N, D) in [(1, 2, 512, 640), (1, 2, 512, 768), (1, 2, 512, 1024), (1, 8, 2048, 1024)]:
+for (B, H, N, D) in [(1, 2, 512, 512), (1, 3, 1152, 512), (1, 2, 512, 640), (1, 2, 64, 640), (1, 3, 1088, 768), (1, 2, 512, 768), (1, 2, 512, 1024), (1, 8, 2048, 1024)]:
     torch.manual_seed(0)
     q, k, v = (torch.randn(B, H, N, D, dtype=torch.half, device=dev) for _ in range(3))
     o = torch.zeros_like(q)
     for name, kk in (("randn", k), ("growing keys", k * torch.linspace(0.2, 6.0, N, device=dev).view(1, 1, N, 1).half())):
         ref = ref_attn(q, kk, v)
         check("%s %s production" % ((B, H, N, D), name), lambda: prod(q, kk, v, o, 2), o, ref)
-        for abl in (1300, 1301, 1302, 1316, 1332, 1364, 1348, 1396, 1412, 1413, 1414):
+        for abl in (1300, 1301, 1302, 1316, 1332, 1364, 1348, 1396, 1412, 1413, 1414) + ((1600, 1601, 1602) if D in (640, 768) else ()):
             check("%s %s dw4 %d" % ((B, H, N, D), name, abl), lambda: host.fa2_variant((4, 0, 0, abl), q, kk, v, o), o, ref)
     # bit-identity of the `stages = 1` form
     o1, o2 = torch.zeros_like(q), torch.zeros_like(q)
@@ -55,12 +55,25 @@ for (B, H, N, D) in [(1, 2, 512, 640), (1, 2, 512, 768), (1, 2, 512, 1024), (1, 
     host.fa2_variant((4, 0, 0, 1412), q, k, v, o3)
     host.fa2_variant((4, 0, 0, 1413), q, k, v, o4)
     prod(q, k, v, o5, 1)
+    if D >= 640:  # two tiles per loop iteration: same arithmetic, same bits
+        u = {640: 1444, 768: 1540, 1024: 1540}[D]
+        o8, o9 = torch.zeros_like(q), torch.zeros_like(q)
+        host.fa2_variant((4, 0, 0, u), q, k, v, o8)
+        host.fa2_variant((4, 0, 0, u + 1), q, k, v, o9)
+        torch.cuda.synchronize()
+        print("BIT %s unrolled-by-2 form == plain: %s; its stages 1 == 2: %s" % ((B, H, N, D), torch.equal(o8, o1), torch.equal(o9, o8)), flush=True)
+    if D in (640, 768):  # the one-barrier-per-tile form: same arithmetic, same bits
+        o6, o7 = torch.zeros_like(q), torch.zeros_like(q)
+        host.fa2_variant((4, 0, 0, 1600), q, k, v, o6)
+        host.fa2_variant((4, 0, 0, 1601), q, k, v, o7)
+        torch.cuda.synchronize()
+        print("BIT %s one-barrier form == two-barrier form: %s; its stages 1 == 2: %s" % ((B, H, N, D), torch.equal(o6, o1), torch.equal(o7, o6)), flush=True)
     torch.cuda.synchronize()
     print("BIT %s stages 1 == 2: %s; production options (carry / M0 walk / spread) == plain: %s; their stages 1 == 2: %s; production name stages 1: %s"
           % ((B, H, N, D), torch.equal(o1, o2), torch.equal(o3, o1), torch.equal(o4, o3), torch.equal(o5, o3)), flush=True)
 
 # ---- timing
-shapes = [(1, 16, 4096, 640), (1, 16, 4096, 768), (1, 16, 4096, 1024)] + ([] if quick else [(1, 8, 8192, 1024), (2, 16, 2048, 768)])
+shapes = [(1, 32, 4096, 512), (1, 16, 4096, 640), (1, 16, 4096, 768), (1, 16, 4096, 1024)] + ([] if quick else [(1, 8, 8192, 1024), (2, 16, 2048, 768), (4, 8, 2048, 512)])
 for (B, H, N, D) in shapes:
     torch.manual_seed(0)
     q, k, v = (torch.randn(B, H, N, D, dtype=torch.half, device=dev) for _ in range(3))
@@ -70,7 +83,12 @@ for (B, H, N, D) in shapes:
     codes = [1300, 1301, 1316, 1332, 1364, 1348, 1396, 1412, 1413]
     if D in (768, 1024):
         codes += [1304, 1416]
-    codes += {1024: [1511, 1533, 1542], 768: [1511, 1533], 640: [1511, 1533]}[D]
+    codes += {1024: [1511, 1533, 1542], 768: [1511, 1533], 640: [1511, 1533], 512: [1304, 1416, 1511, 1544, 1542]}[D]
+    if D == 512:
+        codes = [c for c in codes if c not in (1332, 1364, 1396)]
+    if D in (640, 768):
+        codes += [1600, 1601, 1604]
+    codes += {640: [1444, 1445, 1540, 1428], 768: [1540, 1541, 1476, 1428], 1024: [1540, 1541, 1476, 1428]}.get(D, [])  # + 128: two tiles per iteration
     for abl in codes:
         cands.append(("dw4 %d" % abl, (lambda a: lambda: host.fa2_variant((4, 0, 0, a), q, k, v, o))(abl)))
     for rnd in range(2):

@@ -115,6 +115,43 @@ def asm_mfma_stream_check(asm_text, mangled_name):
     return problems
 
 
+def asm_mfma_operand_hazards(asm_text, mangled_name):
+    """For a kernel whose MFMAs are inline asm (csrc/flash_attn_dw4.cuh, flash_attn_dw4b.cuh): a VGPR written by a VALU instruction needs TWO wait states
+    before an MFMA reads it as A / B operand, and hipcc's hazard pass does not look into inline asm. Walks every basic block: for each v_mfma, the
+    instructions of the two wait states before it (an `s_nop N` counts N + 1 states, every other instruction one) must not be VALU writes of its A / B
+    registers. Returns the offending (VALU instruction, MFMA) pairs."""
+    m = re.search(r"^%s:" % re.escape(mangled_name), asm_text, re.M)
+    if not m:
+        return ["kernel not found: " + mangled_name]
+    body = asm_text[m.end():asm_text.index("s_endpgm", m.end())]
+    ins = []
+    for ln in body.split("\n"):
+        i = ln.split(";")[0].strip()
+        if not i or i.startswith("."):
+            continue
+        ins.append(i)
+    problems = []
+    for k, i in enumerate(ins):
+        if not i.startswith("v_mfma"):
+            continue
+        ops = i.split(None, 1)[1].split(", ")
+        ab = _vregs(ops[1]) | _vregs(ops[2])
+        states, j = 0, k - 1
+        while j >= 0 and states < 2:
+            p = ins[j]
+            if p.endswith(":"):
+                break  # block boundary: predecessors not followed (the pads of the kernels sit inside the block of their MFMAs)
+            if p.startswith("s_nop"):
+                states += int(p.split()[1]) + 1
+            else:
+                if p.startswith("v_") and not p.startswith("v_mfma") and not p.startswith("v_accvgpr"):
+                    if _vregs(p.split(None, 1)[1].split(",")[0]) & ab:
+                        problems.append((p, i))
+                states += 1
+            j -= 1
+    return problems
+
+
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     keep = None

@@ -42,7 +42,7 @@ def test_production_attention_instantiations_are_in_the_report(tmp_path):
     # single-stage form (`stages = 1`); the [B,H,N,D] ones also with the scores scaled in fp32 (the *_acc_f32 names)
     assert len(kernels_x) == 18, [k["demangled"] for k in kernels_x]
     for want in ("fa2_fwd_dsplit_kernel<512, 2, 1,", "fa2_fwd_m16x_kernel<64, 32, 128, 8, 4, 5, false>", "fa2_fwd_m16x_kernel<128, 32, 128, 4, 4, 5, false>", "fa2_fwd_m16x_kernel<128, 32, 128, 4, 4, 5, true>", "fa2_fwd_m16_pair_kernel<2, false, false, 0>", "fa2_fwd_m16_pair_kernel<2, true, false, 0>",
-                 "fa2_fwd_v2_kernel<128, 2, true", "fa2_fwd_splitkv_kernel<64, true>", "fa2_fwd_dw4_kernel<1024, 112, 2, 2>", "fa2_fwd_dw4_kernel<640, 113, 2, 2>", "fa2_fwd_m16x_kernel<64, 64, 64, 4, 1, 5, false>"):
+                 "fa2_fwd_v2_kernel<128, 2, true", "fa2_fwd_splitkv_kernel<64, true>", "fa2_fwd_dw4_kernel<1024, 240, 2, 2>", "fa2_fwd_dw4_kernel<640, 145, 2, 2>", "fa2_fwd_m16x_kernel<64, 64, 64, 4, 1, 5, false>"):
         assert any(want in n for n in names), want
 
 
@@ -157,3 +157,18 @@ def test_built_product_library_has_no_spilling_kernel_a_name_can_reach(built, tm
     assert n > 400, n
     stray = [b for b in bad if "CfgILi256ELi256ELi32ELi2ELi2E" not in b[0] and "CfgILi256ELi256ELi64ELi2ELi2E" not in b[0]]
     assert not stray, stray
+
+
+def test_inline_asm_mfmas_of_the_large_head_dim_attention_kernel_never_read_a_fresh_valu_result(tmp_path):
+    """csrc/flash_attn_dw4.cuh issues every MFMA from inline asm (O^T tied to AGPRs, S^T to one VGPR tuple): the two wait states a VALU-written A / B
+    operand needs are then the kernel's own business. Round 5 shipped a pad in front of the FIRST MFMA of a group only and hipcc scheduled the register
+    copy of the second row block's P fragment between the two MFMAs of the group: one 32 x 32 tile of O wrong on the GPU
+    (profiles/r05_fa_dw4_unroll2_debug.log). Operands are now pinned + padded once per phase; this scan of the code object holds every MFMA to it."""
+    import kernel_resources as kr
+    kernels, s = kr.report(os.path.join(ROOT, "cuda-learn-notes_amd", "csrc", "flash_attn.hip"), keep=str(tmp_path))
+    text = open(s).read()
+    dw4 = [k for k in kernels if "fa2_fwd_dw4_kernel" in k["demangled"]]
+    assert len(dw4) == 6, [k["demangled"] for k in dw4]  # D = 640 / 768 / 1024 x stages 2 / 1
+    for k in dw4:
+        assert k["spill"] == 0 and k["scratch"] == 0 and k["agpr"] in (160, 192, 256), k
+        assert kr.asm_mfma_operand_hazards(text, k["name"]) == [], k["demangled"]
