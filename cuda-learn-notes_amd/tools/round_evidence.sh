@@ -44,20 +44,20 @@ timeout 300 python $T/fa_fscale_probe.py 2>&1 | grep "^FSCALE" > $OUT/${TAG}_fa_
   NBUF=16 FORMS=stages=2 timeout 300 python $T/fa_race_stress.py 2 32 4096 256 40 ) 2>&1 | grep "^RACE" > $OUT/${TAG}_fa_back_to_back_stress.log; echo "stress rc=$?"
 # round 5: the one-wave-per-SIMD attention kernel for D = 640 / 768 / 1024 against the round-4 ring kernel (timing + LDS / fabric counters), the
 # one-launch split-K form under 0 / default / 64 splits, the host cost of a call through the CPython entry, every script against its torch row
-timeout 400 python $T/fa_dw4_probe.py 2>&1 | grep "^CHK\|^BIT\|^FA" > $OUT/${TAG}_fa_dw4_probe.log; echo "dw4 probe rc=$?"
-rm -f $OUT/${TAG}_hgemm_splitk_fused_probe_final.log
-for s in 0 2 64; do CLN_AMD_SPLITK_FUSED_MAX_S=$s timeout 200 python $T/hg_splitk_fused_probe.py 2>&1 | grep "^SKF" >> $OUT/${TAG}_hgemm_splitk_fused_probe_final.log; done; echo "fused split-K probe rc=$?"
+timeout 400 python $T/fa_dw4_probe.py 2>&1 | grep "^CHK\|^BIT\|^FA" > $OUT/${TAG}_fa_dw4_probe_final.log; echo "dw4 probe rc=$?"
+rm -f $OUT/${TAG}_hgemm_splitk_fused_probe_evidence.log
+for s in 0 2 64; do CLN_AMD_SPLITK_FUSED_MAX_S=$s timeout 200 python $T/hg_splitk_fused_probe.py 2>&1 | grep "^SKF" >> $OUT/${TAG}_hgemm_splitk_fused_probe_evidence.log; done; echo "fused split-K probe rc=$?"
 timeout 120 python $T/host_overhead_probe.py 2>&1 | grep "^HOSTOV" > $OUT/${TAG}_host_call_overhead_final.log; echo "host overhead rc=$?"
 timeout 900 python $T/scripts_vs_torch.py 2>&1 | grep "^SVT" > $OUT/${TAG}_scripts_vs_torch.log; echo "scripts vs torch rc=$?"
 ( cd /tmp && export TMPDIR=/tmp
   P1="SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE"
   for D in 1024 768; do
-    for abl in 1412 1000; do  # 1412 = the production options of flash_attn_dw4.cuh, 1000 = flash_attn_dring.cuh (round 3 / 4 production)
+    for abl in 1540 1000; do  # 1540 = the production options of flash_attn_dw4.cuh (carry / M0 walk / spread / two tiles per iteration), 1000 = flash_attn_dring.cuh (round 3 / 4 production)
       for pass in sq fetch write; do
         case $pass in sq) C="$P1";; fetch) C="FETCH_SIZE";; write) C="WRITE_SIZE";; esac
         timeout 120 rocprofv3 --kernel-trace --output-format csv --pmc $C -d $OUT/pmc_bigd_${D}_${abl}_$pass -o pmc -- python $T/prof_target.py fa2 $D 4 0 $abl 1 16 4096 6 > $OUT/pmc_bigd_${D}_${abl}_$pass.log 2>&1
       done
-      python $T/pmc_summary.py fa2_fwd $OUT/${TAG}_pmc_fa_d${D}_$([ $abl = 1412 ] && echo dw4 || echo dring).json $OUT/pmc_bigd_${D}_${abl}_sq $OUT/pmc_bigd_${D}_${abl}_fetch $OUT/pmc_bigd_${D}_${abl}_write > /dev/null
+      python $T/pmc_summary.py fa2_fwd $OUT/${TAG}_pmc_fa_d${D}_$([ $abl = 1540 ] && echo dw4 || echo dring).json $OUT/pmc_bigd_${D}_${abl}_sq $OUT/pmc_bigd_${D}_${abl}_fetch $OUT/pmc_bigd_${D}_${abl}_write > /dev/null
     done
   done ); echo "big-D pmc rc=$?"
 cut -c1-1500 $OUT/${TAG}_bench_20steps.json; echo; cat $OUT/${TAG}_fa_kernel_trace.csv; cat $OUT/${TAG}_bw_rocprof.txt
