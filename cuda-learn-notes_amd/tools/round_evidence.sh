@@ -10,8 +10,12 @@
 #   8. (round 4: + the single-stage / ring-of-slots / fp32-scale probes and the back-to-back stress) stages = 1 vs 2 of the attention names, the hipBLASLt row, the bit-repeatability stress, the ck_tile FMHA comparator
 #      -> <tag>_fa_stage1_vs_stage2.log, <tag>_hipblaslt_probe.log, <tag>_determinism_stress.log, <tag>_fa_ck_tile_comparator.log
 TAG=${1:-r05}
+# second argument: which parts (round 5: the GPU budget of a round no longer fits everything in one call) -- "core" = 1-7 + the round-5 probes,
+# "repeat" = the round-4 probe set of item 8 on the final tree, "all" (default) = both
+PARTS=${2:-all}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$REPO/gpurun_out; T=$REPO/cuda-learn-notes_amd/tools
 mkdir -p $OUT; cd $REPO; export PYTHONUNBUFFERED=1
+if [ "$PARTS" != repeat ]; then
 # a box whose GPU faults on the first launch (seen once in round 2: every later command then hangs to its timeout) must
 # not burn the budget: one golden test first, and stop if the suite aborts
 timeout 120 python -m pytest tests/test_gpu_flash_attn.py -m gpu -x -q -k golden_fixture > $OUT/${TAG}_sanity.log 2>&1 || { echo "sanity launch failed"; tail -5 $OUT/${TAG}_sanity.log; exit 7; }
@@ -28,20 +32,6 @@ timeout 600 bash $T/fa_trace.sh $TAG > $OUT/${TAG}_fa_trace.log 2>&1; echo "fa_t
 python $T/bw_prof_summary.py $(ls $OUT/bwprof/*kernel_trace.csv $OUT/bwprof/*/*kernel_trace.csv 2>/dev/null | head -1) $OUT/bw_prof_order.json $OUT/${TAG}_bw_rocprof.json > $OUT/${TAG}_bw_rocprof.txt 2>&1; echo "bw rc=$?"
 timeout 900 bash $T/run_all_scripts.sh > $OUT/${TAG}_reference_style_scripts_on_gpu.log 2>&1; echo "scripts rc=$?"
 timeout 600 $REPO/cuda-learn-notes_amd/harness/hgemm_bench 200 > $OUT/${TAG}_hgemm_bench_cpp.log 2>&1; echo "harness rc=$?"
-timeout 200 python $T/fa_stage_probe.py 2>&1 | grep STAGE > $OUT/${TAG}_fa_stage1_vs_stage2.log; echo "stage probe rc=$?"
-timeout 200 python $T/vendor_lt_probe.py 2>&1 | grep "^LT" > $OUT/${TAG}_hipblaslt_probe.log; echo "hipblaslt rc=$?"
-timeout 400 python $T/determinism_stress.py 200 2>&1 | grep DET > $OUT/${TAG}_determinism_stress.log; echo "determinism rc=$?"
-timeout 300 python $T/fa_ck_probe.py 2>&1 | grep "^CK" > $OUT/${TAG}_fa_ck_tile_comparator.log; echo "ck_tile comparator rc=$?"
-# round 4: the single-stage attention forms, the ring-of-slots HGEMM, the fp32-scaled attention form, back-to-back launch stress
-timeout 300 python $T/fa_one_stage_probe.py 2>&1 | grep "^ONE" > $OUT/${TAG}_fa_one_stage_probe.log; echo "one-stage probe rc=$?"
-timeout 300 python $T/hg_w4s_probe.py 2>&1 | grep "^W4S" > $OUT/${TAG}_hgemm_w4s_probe.log; echo "w4s probe rc=$?"
-timeout 400 python $T/hg_rect_probe.py squares 2>&1 | grep "^RECT" > $OUT/${TAG}_hgemm_reference_sweep.log; echo "reference sweep rc=$?"
-timeout 400 python $T/hg_tail_probe.py 4352 4864 5888 6400 7168 7424 8448 9216 9472 10240 11008 11776 13056 2>&1 | grep "^TAIL" > $OUT/${TAG}_hgemm_tail_probe_after.log; echo "tail probe rc=$?"
-timeout 300 python $T/hg_rect_probe.py 2>&1 | grep "^RECT" > $OUT/${TAG}_hgemm_rect_probe.log; echo "rect probe rc=$?"
-timeout 300 python $T/fa_small_grid_probe.py 2>&1 | grep "^SMALLGRID" > $OUT/${TAG}_fa_small_grid_probe.log; echo "small grid probe rc=$?"
-timeout 300 python $T/fa_fscale_probe.py 2>&1 | grep "^FSCALE" > $OUT/${TAG}_fa_fscale_probe.log; echo "fscale probe rc=$?"
-( NBUF=16 FORMS=stages=2,stages=1 timeout 300 python $T/fa_race_stress.py 1 32 4096 512 60; NBUF=16 FORMS=stages=2,stages=1 timeout 300 python $T/fa_race_stress.py 4 8 2048 64 100;
-  NBUF=16 FORMS=stages=2 timeout 300 python $T/fa_race_stress.py 2 32 4096 256 40 ) 2>&1 | grep "^RACE" > $OUT/${TAG}_fa_back_to_back_stress.log; echo "stress rc=$?"
 # round 5: the one-wave-per-SIMD attention kernel for D = 640 / 768 / 1024 against the round-4 ring kernel (timing + LDS / fabric counters), the
 # one-launch split-K form under 0 / default / 64 splits, the host cost of a call through the CPython entry, every script against its torch row
 timeout 400 python $T/fa_dw4_probe.py 2>&1 | grep "^CHK\|^BIT\|^FA" > $OUT/${TAG}_fa_dw4_probe_final.log; echo "dw4 probe rc=$?"
@@ -60,5 +50,22 @@ timeout 900 python $T/scripts_vs_torch.py 2>&1 | grep "^SVT" > $OUT/${TAG}_scrip
       python $T/pmc_summary.py fa2_fwd $OUT/${TAG}_pmc_fa_d${D}_$([ $abl = 1540 ] && echo dw4 || echo dring).json $OUT/pmc_bigd_${D}_${abl}_sq $OUT/pmc_bigd_${D}_${abl}_fetch $OUT/pmc_bigd_${D}_${abl}_write > /dev/null
     done
   done ); echo "big-D pmc rc=$?"
+fi
+if [ "$PARTS" != core ]; then
+timeout 200 python $T/fa_stage_probe.py 2>&1 | grep STAGE > $OUT/${TAG}_fa_stage1_vs_stage2.log; echo "stage probe rc=$?"
+timeout 200 python $T/vendor_lt_probe.py 2>&1 | grep "^LT" > $OUT/${TAG}_hipblaslt_probe.log; echo "hipblaslt rc=$?"
+timeout 400 python $T/determinism_stress.py 200 2>&1 | grep DET > $OUT/${TAG}_determinism_stress.log; echo "determinism rc=$?"
+timeout 300 python $T/fa_ck_probe.py 2>&1 | grep "^CK" > $OUT/${TAG}_fa_ck_tile_comparator.log; echo "ck_tile comparator rc=$?"
+# round 4: the single-stage attention forms, the ring-of-slots HGEMM, the fp32-scaled attention form, back-to-back launch stress
+timeout 300 python $T/fa_one_stage_probe.py 2>&1 | grep "^ONE" > $OUT/${TAG}_fa_one_stage_probe.log; echo "one-stage probe rc=$?"
+timeout 300 python $T/hg_w4s_probe.py 2>&1 | grep "^W4S" > $OUT/${TAG}_hgemm_w4s_probe.log; echo "w4s probe rc=$?"
+timeout 400 python $T/hg_rect_probe.py squares 2>&1 | grep "^RECT" > $OUT/${TAG}_hgemm_reference_sweep.log; echo "reference sweep rc=$?"
+timeout 400 python $T/hg_tail_probe.py 4352 4864 5888 6400 7168 7424 8448 9216 9472 10240 11008 11776 13056 2>&1 | grep "^TAIL" > $OUT/${TAG}_hgemm_tail_probe_after.log; echo "tail probe rc=$?"
+timeout 300 python $T/hg_rect_probe.py 2>&1 | grep "^RECT" > $OUT/${TAG}_hgemm_rect_probe.log; echo "rect probe rc=$?"
+timeout 300 python $T/fa_small_grid_probe.py 2>&1 | grep "^SMALLGRID" > $OUT/${TAG}_fa_small_grid_probe.log; echo "small grid probe rc=$?"
+timeout 300 python $T/fa_fscale_probe.py 2>&1 | grep "^FSCALE" > $OUT/${TAG}_fa_fscale_probe.log; echo "fscale probe rc=$?"
+( NBUF=16 FORMS=stages=2,stages=1 timeout 300 python $T/fa_race_stress.py 1 32 4096 512 60; NBUF=16 FORMS=stages=2,stages=1 timeout 300 python $T/fa_race_stress.py 4 8 2048 64 100;
+  NBUF=16 FORMS=stages=2 timeout 300 python $T/fa_race_stress.py 2 32 4096 256 40 ) 2>&1 | grep "^RACE" > $OUT/${TAG}_fa_back_to_back_stress.log; echo "stress rc=$?"
+fi
 cut -c1-1500 $OUT/${TAG}_bench_20steps.json; echo; cat $OUT/${TAG}_fa_kernel_trace.csv; cat $OUT/${TAG}_bw_rocprof.txt
 ls -la $OUT/${TAG}_* | head -40
