@@ -415,7 +415,7 @@ def detail_rows(out):
             elif any(k in node for k in ("gbps", "tflops", "us_per_launch", "ms")) and not any(isinstance(v, (dict, list)) and v and k != "shape" and k != "mnk" for k, v in node.items() if k not in ("cpu_baseline", "roofline")):
                 name = node.get("kernel") or node.get("name") or node.get("tag") or ""
                 bits = []
-                for k in ("shape", "mnk", "dtype", "stages", "swizzle", "us_per_launch", "ms", "gbps", "frac_of_8TBs", "tflops", "frac", "frac_of_peak", "pct_of_rocblas"):
+                for k in ("shape", "mnk", "dtype", "stages", "swizzle", "us_per_launch", "us_64_row_launch", "ms", "gbps", "frac_of_8TBs", "tflops", "frac", "frac_of_peak", "pct_of_rocblas"):
                     if k in node:
                         bits.append("%s=%s" % (k, node[k]))
                 add(prefix + ":" + str(name)[:60], " ".join(bits))

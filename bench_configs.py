@@ -162,6 +162,10 @@ def bandwidth_rows(dev, orc, shapes=((4096, 4096), (8192, 8192)), cpu_shape=(409
                 continue
             ms, launches = _region_ms(calls, 3 * nsets)
             ms_same, _ = _region_ms(calls[:1], 50)
+            # the same kernel on 64 rows of the first set (1/64 .. 1/128 of the bytes), back to back: what one launch of this kernel costs on this box
+            # before a byte of HBM traffic counts -- dispatch-to-dispatch interval + grid ramp; the 4096^2 rows are 2-4 of these long
+            tiny = _bw_call(fn, kind, pool[0][:64], pool[1][:64] if n_in == 2 else None, pool[n_in][:64] if n_out else None, z, 64, K)
+            ms_tiny = _region_ms([tiny], 200, prewarm_s=0.05, target_ms=10.0)[0] if tiny() == 0 else None
             nbytes = bpe * n
             gbps = nbytes / ms * 1e-6
             row = {"kernel": name, "shape": [S, K], "dtype": "f16" if esz == 2 else "f32",
@@ -170,7 +174,8 @@ def bandwidth_rows(dev, orc, shapes=((4096, 4096), (8192, 8192)), cpu_shape=(409
                    "frac_of_measured_copy_6290": round(gbps / 6290.0, 4),
                    "rotating_sets": int(nsets), "rotating_footprint_MB": round(nsets * set_bytes / 1e6, 1),
                    "gbps_same_buffers": round(nbytes / ms_same * 1e-6, 1),
-                   "same_buffers_fit_infinity_cache": bool(set_bytes < MALL_BYTES)}
+                   "same_buffers_fit_infinity_cache": bool(set_bytes < MALL_BYTES),
+                   "us_64_row_launch": None if ms_tiny is None else round(ms_tiny * 1e3, 3)}
             if (S, K) == tuple(cpu_shape):
                 xc = torch.randn(S, K, generator=g).to(dtype)
                 x2c = torch.randn(S, K, generator=g).to(dtype)

@@ -57,8 +57,14 @@ struct GeoDW4 {
 // DW4_UNROLL2: two tiles per loop iteration, so that the ring-slot parity of every LDS address is a compile-time constant (fragment addresses become
 // register + immediate: no per-fragment address arithmetic) and the hazard pads in front of MFMA groups whose operands come straight from LDS go away --
 // the kernel is ISSUE-bound: one wave per SIMD issues ~1 instruction per 4-5 clocks and a 16-key step carried 213 instructions for 36 MFMAs at D = 768.
+// DW4_SKEW4 / DW4_SKEW8 (probe, negative result): after every barrier of the loop wave w idles w * 4 (8) wait states = 16 (32) clocks, so that the four
+// waves' LDS-DMA requests -- issued at the same point of the same instruction stream -- reach the CU's one address unit a piece-time apart instead of
+// together. Bit-identical; -2 % (D = 1024) ... -4 % (D = 768): the idling costs what it was meant to save, request collisions are NOT what the 45 % of
+// wave cycles spent waiting to issue (profiles/r05_pmc_fa_d1024_dw4.json) are made of (profiles/r05_fa_dw4_skew_probe.log). A zero-idle form -- four copies
+// of the loop, one per wave index, each placing its request behind MFMA w of a group -- was written too: hipcc then no longer keeps O^T in one AGPR
+// block (80 / 240 spilled registers at D = 768 / 1024), not measured.
 enum : int { DW4_1STAGE = 1, DW4_NO_DEFER = 2, DW4_ABL_DMA = 4, DW4_ABL_SOFTMAX = 8, DW4_CARRY = 16, DW4_M0WALK = 32, DW4_SPREAD = 64, DW4_UNROLL2 = 128,
-              DW4_DEFAULT = DW4_CARRY | DW4_M0WALK | DW4_SPREAD };
+              DW4_SKEW4 = 256, DW4_SKEW8 = 512, DW4_DEFAULT = DW4_CARRY | DW4_M0WALK | DW4_SPREAD };
 
 template <int D, int OPT = 0, int KPF = 2, int VPF = 2>
 __global__ __launch_bounds__(256, 1) void fa2_fwd_dw4_kernel(const half_t* __restrict__ Q, const half_t* __restrict__ K,
@@ -270,6 +276,14 @@ __global__ __launch_bounds__(256, 1) void fa2_fwd_dw4_kernel(const half_t* __res
     __builtin_amdgcn_s_barrier();  \
     asm volatile("" ::: "memory"); \
   } while (0)
+  auto skew = [&]() __attribute__((always_inline)) {
+    if constexpr ((OPT & (DW4_SKEW4 | DW4_SKEW8)) != 0) {
+      constexpr int WS = (OPT & DW4_SKEW8) != 0 ? 7 : 3;  // s_nop n = n + 1 wait states of 4 clocks
+      if (wave >= 1) asm volatile("s_nop %0" ::"n"(WS));
+      if (wave >= 2) asm volatile("s_nop %0" ::"n"(WS));
+      if (wave >= 3) asm volatile("s_nop %0" ::"n"(WS));
+    }
+  };
 
   // ---- prologue: S(0), K(2) requested into the slot S(0) has just left
   qk_tile(0, [&](int) {});
@@ -381,6 +395,7 @@ __global__ __launch_bounds__(256, 1) void fa2_fwd_dw4_kernel(const half_t* __res
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): P / alpha are in LDS, the K fragment reads are done
     if constexpr ((OPT & (DW4_1STAGE | DW4_ABL_DMA)) == 0) hgemm::wait_vmcnt<2 * PPW>();  // V(j) has landed
     DW4_BARRIER();
+    skew();
 
     // ================= phase B: O^T += V^T P^T of tile j; the partial S^T of tile j+1 published, K(j+3) requested
     {
@@ -455,6 +470,7 @@ __global__ __launch_bounds__(256, 1) void fa2_fwd_dw4_kernel(const half_t* __res
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the partials are in LDS, the V fragment reads are done
     if constexpr ((OPT & (DW4_1STAGE | DW4_ABL_DMA)) == 0) hgemm::wait_vmcnt<2 * PPW>();  // K(j+2) has landed
     DW4_BARRIER();
+    skew();
   };
   if constexpr (U2) {  // T = N / 16 is a multiple of 4 (N % 64 == 0, launcher)
     for (int j = 0; j < T; j += 2) {

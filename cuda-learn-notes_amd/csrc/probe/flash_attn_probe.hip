@@ -177,6 +177,9 @@ CLN_API int cln_fa2_variant(int D, int nw, int vt, int opt, int abl, const void*
   DW4(640, 114) DW4(768, 114) DW4(1024, 114) DW4(640, 96) DW4(768, 96) DW4(1024, 96)
   // + 128 = two tiles per loop iteration (compile-time ring-slot parity)
   DW4(640, 144) DW4(640, 145) DW4(640, 240) DW4(768, 240) DW4(768, 241) DW4(1024, 240) DW4(1024, 241) DW4(768, 176) DW4(1024, 176) DW4(640, 128) DW4(768, 128) DW4(1024, 128)
+  // + 256 / 512 = wave w idles 16 w / 32 w clocks after every loop barrier (DW4_SKEW4 / DW4_SKEW8) on the production options
+  DW4(640, 400) DW4(640, 656) DW4(768, 496) DW4(768, 752) DW4(1024, 496) DW4(1024, 752)
+  // + 1024 = one loop copy per wave index, the LDS-DMA request of a group behind MFMA w of the group (DW4_STAG)
   // D = 512 (config C5) on the same kernel with 128 rows per workgroup (GeoDW4<512, 2>)
   DW4(512, 0) DW4(512, 1) DW4(512, 2) DW4(512, 16) DW4(512, 48) DW4(512, 112) DW4(512, 113) DW4(512, 114) DW4(512, 4) DW4(512, 116)
 #undef DW4
@@ -190,6 +193,10 @@ CLN_API int cln_fa2_variant(int D, int nw, int vt, int opt, int abl, const void*
 #define DW4P(DD, KP, VP) if (D == DD && abl == 1500 + 10 * KP + VP) return fa2::launch_dw4<DD, fa2::DW4_DEFAULT, KP, VP>(q, k, v, o, B, H, N, (hipStream_t)stream);
   DW4P(1024, 1, 1) DW4P(1024, 3, 3) DW4P(1024, 4, 2) DW4P(768, 1, 1) DW4P(768, 3, 3) DW4P(640, 3, 3) DW4P(640, 1, 1) DW4P(512, 1, 1) DW4P(512, 4, 4) DW4P(512, 4, 2)
 #undef DW4P
+  // 2100 + 10 * KPF + VPF: the same sweep on the two-tiles-per-iteration form (the production options of each head dim)
+#define DW4PU(DD, OO, KP, VP) if (D == DD && abl == 2100 + 10 * KP + VP) return fa2::launch_dw4<DD, OO, KP, VP>(q, k, v, o, B, H, N, (hipStream_t)stream);
+  DW4PU(640, 144, 3, 3) DW4PU(640, 144, 4, 4) DW4PU(640, 144, 3, 2) DW4PU(768, 240, 3, 3) DW4PU(768, 240, 4, 4) DW4PU(768, 240, 3, 2) DW4PU(768, 240, 2, 3)
+#undef DW4PU
   // 1000 = the ring kernel for head dims 640 / 768 / 1024 (flash_attn_dring.cuh), row groups one phase apart; 1001 = lock-step
   if (D == 640 && abl == 1000) return fa2::launch_dring<640, fa2::OPT_DEFAULT>(q, k, v, o, B, H, N, (hipStream_t)stream);
   if (D == 768 && abl == 1000) return fa2::launch_dring<768, fa2::OPT_DEFAULT>(q, k, v, o, B, H, N, (hipStream_t)stream);

@@ -391,3 +391,17 @@ def describe(name, dims, stages=2):
     if rc < 0:
         raise ValueError("%s: shape %s not supported (status %d)" % (name, tuple(dims), rc))
     return buf.value.decode()
+
+
+def stages_honoured(name, dims, stages=2):
+    """True when `stages` selects the pipeline depth of the kernel `name` runs for `dims`, False when the plan has one pipeline and
+    the value is ignored (cln_stages_honoured; the text of describe() then carries "stages ignored"). Same errors as describe()."""
+    from . import _loader
+    lib = _loader.load_so("libcln_amd.so")
+    d = list(dims) + [0] * (4 - len(dims))
+    rc = lib.cln_stages_honoured(name.encode(), d[0], d[1], d[2], d[3], int(stages))
+    if rc == -1:
+        raise LookupError("%s is bound to one kernel: see manifest.BY_NAME[name].impl" % name)
+    if rc < 0:
+        raise ValueError("%s: shape %s not supported (status %d)" % (name, tuple(dims), rc))
+    return bool(rc)

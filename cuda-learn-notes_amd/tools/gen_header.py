@@ -98,6 +98,10 @@ def main():
                " * `impl` comment above). Host-only: no launch, no device access. The tuning / ablation hooks\n"
                " * (cln_hgemm_variant, cln_fa2_variant) live in the TEST-ONLY libcln_amd_probe.so and are not declared here. */")
     out.append("int cln_describe(const char* name, int d0, int d1, int d2, int d3, int stages, char* buf, int buflen);")
+    out.append("/* 1 = `stages` selects the pipeline depth of the kernel this (name, shape) runs; 0 = the plan has one pipeline and the value is ignored\n"
+               " * (cln_describe's text then says \"stages ignored\": the 192 / 160 / 128-wide one-wave-per-SIMD HGEMM tiles, split-K and tail-split plans);\n"
+               " * < 0 = cln_describe's status. For callers that sweep `stages` as the reference scripts do (kernels/hgemm/hgemm.py:359-361). */")
+    out.append("int cln_stages_honoured(const char* name, int d0, int d1, int d2, int d3, int stages);")
     out.append("\n/* ---- split-K workspace of the best-dispatch HGEMM names (not part of the reference surface: the reference's bindings take\n"
                " * only a, b, c -- kernels/hgemm/mma/basic/hgemm_mma_stage.cu:2380-2413 -- and never need one). Shapes with few output tiles and a\n"
                " * long K (and the last tile rows of a tile count just past whole rounds of 256) are split over K; the fp32 partials live in ONE\n"

@@ -52,11 +52,35 @@ def parse(asm_text):
     return out
 
 
+def _asm_cached(src):
+    """The assembly of `src` under build/asm_cache/, keyed by the digest of the source, of every header under csrc/ and of the flags (the key
+    _build.py stamps its objects with): several tests read the same 100-second compile of hgemm.hip -- one compile per tree state, not one per test."""
+    import hashlib
+    import _build
+    with open(src, "rb") as f:
+        digest = hashlib.sha256(f.read() + _build._deps_digest().encode() + b"-S").hexdigest()[:24]
+    cache = os.path.join(_build.BUILD, "asm_cache")
+    os.makedirs(cache, exist_ok=True)
+    out = os.path.join(cache, "%s.%s.s" % (os.path.basename(src).replace(".hip", ""), digest))
+    if not os.path.exists(out):
+        for old in os.listdir(cache):  # one entry per source: a stale digest of the same file goes
+            if old.startswith(os.path.basename(src).replace(".hip", "") + "."):
+                os.remove(os.path.join(cache, old))
+        tmp = out + ".tmp%d" % os.getpid()
+        compile_asm(src, tmp)
+        os.replace(tmp, out)
+    return out
+
+
 def report(src, keep=None):
-    d = keep or tempfile.mkdtemp(prefix="cln_asm_")
-    os.makedirs(d, exist_ok=True)
-    s = os.path.join(d, os.path.basename(src).replace(".hip", ".s"))
-    compile_asm(src, s)
+    """(kernels, path of the .s). `keep` = directory that receives a copy of the assembly for reading; the compile itself is cached."""
+    cached = _asm_cached(os.path.abspath(src))
+    s = cached
+    if keep:
+        import shutil
+        os.makedirs(keep, exist_ok=True)
+        s = os.path.join(keep, os.path.basename(src).replace(".hip", ".s"))
+        shutil.copyfile(cached, s)
     return parse(open(s).read()), s
 
 

@@ -39,7 +39,7 @@ def test_header_declares_manifest_and_libs_export_it(built):
     hdr = open(os.path.join(ROOT, "include", "cln_amd.h")).read()
     declared = re.findall(r"^int (\w+)\(", hdr, flags=re.M)
     assert len(declared) == len(set(declared))
-    names = {e.name for e in built.manifest.ENTRIES} | {"cln_describe", "cln_hgemm_set_workspace"}
+    names = {e.name for e in built.manifest.ENTRIES} | {"cln_describe", "cln_stages_honoured", "cln_hgemm_set_workspace"}
     assert set(declared) == names
     from cuda_learn_notes_amd import _loader
     main = ctypes.CDLL(_loader.so_path("libcln_amd.so"))
@@ -47,7 +47,7 @@ def test_header_declares_manifest_and_libs_export_it(built):
     for e in built.manifest.ENTRIES:
         lib = vend if built.manifest.SO_OF_LIB[e.lib] == "libcln_amd_vendor.so" else main
         assert hasattr(lib, e.name), e.name
-    assert hasattr(main, "cln_describe")
+    assert hasattr(main, "cln_describe") and hasattr(main, "cln_stages_honoured")
     # the split-K workspace entry points (round 5): declared in the header and exported
     ws_api = re.findall(r"^(?:size_t|int) (cln_\w*workspace\w*)\(", hdr, flags=re.M)
     assert sorted(ws_api) == ["cln_hgemm_set_workspace", "cln_hgemm_workspace_bytes", "cln_hgemm_workspace_held", "cln_release_workspaces"]

@@ -94,6 +94,7 @@ def test_hgemm_tile_policy_invariants_over_a_grid_of_shapes(built):
                         assert not (bm == 256 and bn == 256 and stages != 2), (M, N, K, stages, t)
                         if (bm, bn) != (256, 256):  # the other tile forms have one pipeline and say so
                             assert ("stages ignored" in t) == (stages != 2), (M, N, K, stages, t)
+                    assert m.stages_honoured(nn, (M, N, K), stages) == ("stages ignored" not in t), (M, N, K, stages, t)  # the status form of the same fact
                     t2 = m.describe(tn, (M, N, K), stages)
                     assert t2.replace(",TN>", ",NN>") == t and ",TN>" in t2, (t, t2)
     # the policy actually uses its repertoire on this grid
@@ -148,3 +149,18 @@ def test_flash_attn_planner_invariants_over_a_grid_of_shapes(built):
         m.describe(sq, (1, 32, 4096, 512), 2)
     with pytest.raises(ValueError):
         m.describe(tq, (1, 8, 100, 64), 2)
+
+
+def test_stages_honoured_status(built):
+    """cln_stages_honoured (VERDICT r4 #8): a `stages` value the plan cannot act on is reported as a status, not only as text."""
+    m = built.manifest
+    nn = "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem"
+    assert m.stages_honoured(nn, (4096, 4096, 4096), 2) and m.stages_honoured(nn, (4096, 4096, 4096), 3)  # 256 x 256: w4 / ring of slots
+    assert m.stages_honoured(nn, (5120, 5120, 5120), 2) and not m.stages_honoured(nn, (5120, 5120, 5120), 4)  # 160 x 160: one pipeline
+    assert not m.stages_honoured(nn, (1024, 1024, 16384), 2)  # split-K
+    fa = "flash_attn_mma_stages_split_q_tiling_qkv"
+    assert m.stages_honoured(fa, (1, 16, 4096, 768), 1) and m.stages_honoured(fa, (1, 16, 4096, 768), 2)
+    with pytest.raises(ValueError):
+        m.stages_honoured(nn, (100, 100, 100), 2)
+    with pytest.raises(LookupError):
+        m.stages_honoured("hgemm_naive_f16", (256, 256, 256), 2)
