@@ -54,6 +54,8 @@ struct GeoDW4 {
 // DW4_CARRY: the last MFMA group of a phase (operands already in registers) is issued AFTER the barrier, under the LDS round trips the next phase
 // starts with. DW4_M0WALK: the pieces of a tile request walk M0 (2 instructions per piece instead of 4). DW4_SPREAD: the softmax in four sections
 // behind four MFMA groups instead of two. (DW4_ABL_*: probe ablations, garbage results.)
+// DW4_ABL_NOWAIT (probe ablation, garbage results): the requests are issued but their landing is never waited for -- separates the cost of ISSUING the
+// LDS-DMA from the cost of WAITING for it (a two-slot ring gives a request one step, ~1 us, to land).
 // DW4_UNROLL2: two tiles per loop iteration, so that the ring-slot parity of every LDS address is a compile-time constant (fragment addresses become
 // register + immediate: no per-fragment address arithmetic) and the hazard pads in front of MFMA groups whose operands come straight from LDS go away --
 // the kernel is ISSUE-bound: one wave per SIMD issues ~1 instruction per 4-5 clocks and a 16-key step carried 213 instructions for 36 MFMAs at D = 768.
@@ -64,7 +66,7 @@ struct GeoDW4 {
 // of the loop, one per wave index, each placing its request behind MFMA w of a group -- was written too: hipcc then no longer keeps O^T in one AGPR
 // block (80 / 240 spilled registers at D = 768 / 1024), not measured.
 enum : int { DW4_1STAGE = 1, DW4_NO_DEFER = 2, DW4_ABL_DMA = 4, DW4_ABL_SOFTMAX = 8, DW4_CARRY = 16, DW4_M0WALK = 32, DW4_SPREAD = 64, DW4_UNROLL2 = 128,
-              DW4_SKEW4 = 256, DW4_SKEW8 = 512, DW4_DEFAULT = DW4_CARRY | DW4_M0WALK | DW4_SPREAD };
+              DW4_SKEW4 = 256, DW4_SKEW8 = 512, DW4_ABL_NOWAIT = 1024, DW4_DEFAULT = DW4_CARRY | DW4_M0WALK | DW4_SPREAD };
 
 template <int D, int OPT = 0, int KPF = 2, int VPF = 2>
 __global__ __launch_bounds__(256, 1) void fa2_fwd_dw4_kernel(const half_t* __restrict__ Q, const half_t* __restrict__ K,
@@ -393,7 +395,7 @@ __global__ __launch_bounds__(256, 1) void fa2_fwd_dw4_kernel(const half_t* __res
       });
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): P / alpha are in LDS, the K fragment reads are done
-    if constexpr ((OPT & (DW4_1STAGE | DW4_ABL_DMA)) == 0) hgemm::wait_vmcnt<2 * PPW>();  // V(j) has landed
+    if constexpr ((OPT & (DW4_1STAGE | DW4_ABL_DMA | DW4_ABL_NOWAIT)) == 0) hgemm::wait_vmcnt<2 * PPW>();  // V(j) has landed
     DW4_BARRIER();
     skew();
 
@@ -468,7 +470,7 @@ __global__ __launch_bounds__(256, 1) void fa2_fwd_dw4_kernel(const half_t* __res
       }
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the partials are in LDS, the V fragment reads are done
-    if constexpr ((OPT & (DW4_1STAGE | DW4_ABL_DMA)) == 0) hgemm::wait_vmcnt<2 * PPW>();  // K(j+2) has landed
+    if constexpr ((OPT & (DW4_1STAGE | DW4_ABL_DMA | DW4_ABL_NOWAIT)) == 0) hgemm::wait_vmcnt<2 * PPW>();  // K(j+2) has landed
     DW4_BARRIER();
     skew();
   };

@@ -56,6 +56,9 @@ int m16x_probe_run(int D, int code, const void* q, const void* k, const void* v,
   // copy an S^T register right behind the asm MFMA that writes it, and its hazard pass cannot see that MFMA -- the form is
   // correct only where the allocator happens not to; profiles/r03_fa_m16s_one_wave_per_simd_probe.log.)
   MS(64, 150, 64, 4, 1, false) MS(64, 151, 64, 4, 2, false) MS(64, 153, 64, 4, 2, true) MS(64, 155, 64, 8, 2, true)
+  // (round 5: the same form instantiated at D = 128 -- <128, 64, 4, 2, false / true>, <128, 64, 8, 2, true> -- spills 4-8 registers, returns wrong results (its
+  // hazard distances were only ever arranged for D = 64's two k-steps) and, timed as it is, runs 19-27 % BEHIND the 8-wave kernel: profiles/r05_fa_m16s_d128_probe.log,
+  // r05_fa_m16s_d128_probe_timing.log. Halving the fragment reads does not pay for losing the partner wave under whose MFMAs the softmax hides. Not kept instantiated.)
 #undef MS
   // 160 + id: the sum-checked two-group kernel on v_mfma_f32_32x32x16_f16 (flash_attn_m32x.cuh, D = 64, 128-key tiles): <BC, PD, OX>
   if (D == 64 && code == 160) return launch_m32x<128, 4, 1>(q, k, v, o, B, H, N, s);

@@ -179,6 +179,8 @@ CLN_API int cln_fa2_variant(int D, int nw, int vt, int opt, int abl, const void*
   DW4(640, 144) DW4(640, 145) DW4(640, 240) DW4(768, 240) DW4(768, 241) DW4(1024, 240) DW4(1024, 241) DW4(768, 176) DW4(1024, 176) DW4(640, 128) DW4(768, 128) DW4(1024, 128)
   // + 256 / 512 = wave w idles 16 w / 32 w clocks after every loop barrier (DW4_SKEW4 / DW4_SKEW8) on the production options
   DW4(640, 400) DW4(640, 656) DW4(768, 496) DW4(768, 752) DW4(1024, 496) DW4(1024, 752)
+  // + 1024 = requests issued, never waited for (garbage results); + 4 = not issued at all -- on the production options
+  DW4(640, 1168) DW4(768, 1264) DW4(1024, 1264) DW4(640, 148) DW4(768, 244) DW4(1024, 244)
   // + 1024 = one loop copy per wave index, the LDS-DMA request of a group behind MFMA w of the group (DW4_STAG)
   // D = 512 (config C5) on the same kernel with 128 rows per workgroup (GeoDW4<512, 2>)
   DW4(512, 0) DW4(512, 1) DW4(512, 2) DW4(512, 16) DW4(512, 48) DW4(512, 112) DW4(512, 113) DW4(512, 114) DW4(512, 4) DW4(512, 116)

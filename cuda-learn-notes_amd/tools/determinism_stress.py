@@ -44,12 +44,15 @@ for (B, H, N, D) in SHAPES:
     bad_total += bad
     print("DET fa %s err-vs-fp32 %.2e  mismatching launches %d / %d  worst |diff| %.3e  %s" % ((B, H, N, D), err, bad, REPS, worst,
                                                                                               pkg.manifest.describe(fn.__name__, (B, H, N, D), 2)[:40]), flush=True)
-for S in (4096, 2048, 3072, 2560):
+# squares, then (round 5) shapes that take the one-launch split-K (2 splits, fix-up by the last-arriving workgroup: the sum order must not depend on
+# which workgroup arrives last), the two-launch split-K and the tail split
+for S in (4096, 2048, 3072, 2560, (512, 8192, 8192), (640, 5120, 5120), (1024, 1024, 16384), (4864, 4864, 4864)):
+    M_, N_, K_ = S if isinstance(S, tuple) else (S, S, S)
     torch.manual_seed(3)
-    a = torch.randn(S, S, dtype=torch.half, device=dev)
-    b = torch.randn(S, S, dtype=torch.half, device=dev)
-    c = torch.zeros(S, S, dtype=torch.half, device=dev)
-    st = bu.make_block_swizzle_stride(S, S)
+    a = torch.randn(M_, K_, dtype=torch.half, device=dev)
+    b = torch.randn(K_, N_, dtype=torch.half, device=dev)
+    c = torch.zeros(M_, N_, dtype=torch.half, device=dev)
+    st = bu.make_block_swizzle_stride(N_, K_)
     for name in ("hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem",):
         fn = getattr(hg, name)
         fn(a, b, c, 2, True, st)
@@ -61,5 +64,6 @@ for S in (4096, 2048, 3072, 2560):
             fn(a, b, c, 2, True, st)
             bad += 0 if torch.equal(c, first) else 1
         bad_total += bad
-        print("DET hgemm %d %s mismatching launches %d / %d" % (S, name[-28:], bad, REPS), flush=True)
+        print("DET hgemm %s %s mismatching launches %d / %d  %s" % ("x".join(map(str, (M_, N_, K_))), name[-28:], bad, REPS,
+                                                                     pkg.manifest.describe(name, (M_, N_, K_), 2)[-70:]), flush=True)
 print("DET total mismatches", bad_total)

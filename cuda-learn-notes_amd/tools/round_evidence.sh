@@ -65,7 +65,8 @@ timeout 300 python $T/hg_rect_probe.py 2>&1 | grep "^RECT" > $OUT/${TAG}_hgemm_r
 timeout 300 python $T/fa_small_grid_probe.py 2>&1 | grep "^SMALLGRID" > $OUT/${TAG}_fa_small_grid_probe.log; echo "small grid probe rc=$?"
 timeout 300 python $T/fa_fscale_probe.py 2>&1 | grep "^FSCALE" > $OUT/${TAG}_fa_fscale_probe.log; echo "fscale probe rc=$?"
 ( NBUF=16 FORMS=stages=2,stages=1 timeout 300 python $T/fa_race_stress.py 1 32 4096 512 60; NBUF=16 FORMS=stages=2,stages=1 timeout 300 python $T/fa_race_stress.py 4 8 2048 64 100;
-  NBUF=16 FORMS=stages=2 timeout 300 python $T/fa_race_stress.py 2 32 4096 256 40 ) 2>&1 | grep "^RACE" > $OUT/${TAG}_fa_back_to_back_stress.log; echo "stress rc=$?"
+  NBUF=16 FORMS=stages=2 timeout 300 python $T/fa_race_stress.py 2 32 4096 256 40;
+  for D in 640 768 1024; do NBUF=16 FORMS=stages=2,stages=1 timeout 300 python $T/fa_race_stress.py 1 16 4096 $D 30; done ) 2>&1 | grep "^RACE" > $OUT/${TAG}_fa_back_to_back_stress.log; echo "stress rc=$?"
 fi
 cut -c1-1500 $OUT/${TAG}_bench_20steps.json; echo; cat $OUT/${TAG}_fa_kernel_trace.csv; cat $OUT/${TAG}_bw_rocprof.txt
 ls -la $OUT/${TAG}_* | head -40
