@@ -17,6 +17,7 @@
 #include "stream_scratch.h"
 #include <string.h>
 #include <math.h>
+#include <cstdint>
 #include <mutex>
 #include <vector>
 
@@ -146,7 +147,9 @@ SplitK splitk_plan(int M, int N, int K) {
 //     workspaces exist at a time (least recently used evicted first).
 //   * under stream capture the library never allocates, frees or records: a stream without a workspace takes the single-pass plan, and a
 //     captured graph holds the pointer of the workspace it was captured with -- replay it on the capture stream (or give each graph its own
-//     region through cln_hgemm_set_workspace), include/cln_amd.h says so.
+//     region through cln_hgemm_set_workspace), include/cln_amd.h says so. A library-owned workspace that a capture has used is PINNED: neither
+//     the LRU eviction nor growth frees it behind the graph's back (a larger shape on that stream runs single-pass); only
+//     cln_release_workspaces() -- the caller's statement that no such graph will be replayed -- does.
 struct SplitKWs {
   int dev = 0;
   hipStream_t stream = nullptr;
@@ -155,6 +158,7 @@ struct SplitKWs {
   bool user = false;          // caller-owned region (cln_hgemm_set_workspace)
   hipEvent_t ev = nullptr;    // completion of the last launch that used the region (library-owned only)
   unsigned long long used = 0;
+  bool pinned = false;        // a stream capture has used the region: a graph holds its address, so the library never frees it on its own
 };
 constexpr size_t SPLITK_OWNED_MAX = 8;
 std::mutex g_ws_mu;
@@ -184,19 +188,22 @@ SplitKWs* ws_acquire(hipStream_t stream, size_t bytes) {
   for (auto& w : g_ws)
     if (w.dev == dev && w.stream == stream) e = &w;
   if (e && e->user) return e->bytes >= bytes ? (e->used = ++g_ws_clock, e) : nullptr;
-  if (e && e->bytes >= bytes) return e->used = ++g_ws_clock, e;
-  if (bytes > SPLITK_WS_MAX + W4_TICKET_FLOATS * 4 || stream_capturing(stream)) return nullptr;
+  if (e && e->bytes >= bytes) {
+    if (!e->pinned && stream_capturing(stream)) e->pinned = true;
+    return e->used = ++g_ws_clock, e;
+  }
+  if (bytes > SPLITK_WS_MAX + W4_TICKET_FLOATS * 4 || (e && e->pinned) || stream_capturing(stream)) return nullptr;
   size_t want = 16u << 20;
   while (want < bytes) want <<= 1;
   if (e) {
     ws_free_entry(*e);  // grow: waits for the stream's earlier split-K launches (rare: sizes double)
   } else {
     size_t owned = 0;
-    for (auto& w : g_ws) owned += w.user ? 0 : 1;
-    while (owned >= SPLITK_OWNED_MAX) {  // evict the least recently used library-owned workspace
+    for (auto& w : g_ws) owned += (w.user || w.pinned) ? 0 : 1;
+    while (owned >= SPLITK_OWNED_MAX) {  // evict the least recently used library-owned workspace (never a pinned one: see above)
       size_t lru = g_ws.size();
       for (size_t i = 0; i < g_ws.size(); ++i)
-        if (!g_ws[i].user && (lru == g_ws.size() || g_ws[i].used < g_ws[lru].used)) lru = i;
+        if (!g_ws[i].user && !g_ws[i].pinned && (lru == g_ws.size() || g_ws[i].used < g_ws[lru].used)) lru = i;
       ws_free_entry(g_ws[lru]);
       g_ws.erase(g_ws.begin() + lru);
       --owned;
@@ -553,6 +560,12 @@ CLN_API int cln_hgemm_set_workspace(void* ptr, size_t bytes, void* stream) {
   std::lock_guard<std::mutex> lock(g_ws_mu);
   for (size_t i = 0; i < g_ws.size(); ++i)
     if (g_ws[i].dev == dev && g_ws[i].stream == st) {
+      if (!g_ws[i].user && g_ws[i].pinned) {
+        // a captured graph still holds this library-owned region: it stays allocated (and counted by cln_hgemm_workspace_held) under a key no stream
+        // has, until cln_release_workspaces()
+        g_ws[i].stream = reinterpret_cast<hipStream_t>(~(uintptr_t)0 - g_ws_clock++);
+        break;
+      }
       if (!g_ws[i].user) ws_free_entry(g_ws[i]);
       g_ws.erase(g_ws.begin() + i);
       break;

@@ -114,6 +114,7 @@ def main():
                " *                   The first 4 KiB are zeroed on `stream` by the call; keep the region alive and untouched while launches are queued.\n"
                " * Threads: calls are serialised per process while a workspace is in use (the lock covers the 1-2 launches of a split-K call), so two\n"
                " * host threads may call hgemm on one stream. Graphs: a captured launch holds the pointer of the workspace its capture stream had;\n"
+               " * a library-owned workspace that a capture has used is pinned (never evicted or regrown; freed by cln_release_workspaces() only);\n"
                " * replay the graph on the capture stream, or give every graph its own caller-owned region. A shape's result does not depend on\n"
                " * whose workspace is used, but it differs in the last bit from the single-pass plan (fp32 summation order), so eager and captured\n"
                " * runs of a split-K shape on a stream WITHOUT a workspace are not bit-identical ($CLN_AMD_NO_SPLITK=1 forces single-pass everywhere). */")

@@ -594,6 +594,47 @@ def test_split_k_under_stream_capture(hg, built, dev):
         check(c, a, b)
 
 
+def test_workspace_of_a_captured_graph_is_never_evicted(hg, built, dev):
+    """A graph captured on a stream that owns a library workspace holds that workspace's ADDRESS. Twelve other streams running split-K afterwards
+    would push it out of the 8-entry LRU: a workspace a capture has used is pinned (csrc/hgemm.hip SplitKWs::pinned), so the replayed graph still
+    writes into live memory and still returns the right product; cln_release_workspaces() frees it."""
+    from cuda_learn_notes_amd import host
+    fn = getattr(hg, "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem")
+    M, N, K = 512, 512, 8192
+    assert host.hgemm_workspace_bytes(M, N, K) > 0
+    a, b = seeded(41, M, K), seeded(42, K, N)
+    ad, bd = a.to(dev), b.to(dev)
+    host.release_workspaces()
+    st = torch.cuda.Stream()
+    c = torch.zeros(M, N, dtype=torch.half, device=dev)
+    with torch.cuda.stream(st):
+        fn(ad, bd, c, 2, False, 0)  # the stream's workspace now exists
+        st.synchronize()
+        ref = c.clone()
+        one = host.hgemm_workspace_held()  # one workspace of this shape (16 MiB doubled until the partials + tickets fit)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            fn(ad, bd, c, 2, False, 0)
+    check(ref, a, b)
+    assert one > 0
+    others = [torch.cuda.Stream() for _ in range(12)]
+    scratch = torch.zeros(M, N, dtype=torch.half, device=dev)
+    for o in others:
+        with torch.cuda.stream(o):
+            fn(ad, bd, scratch, 2, False, 0)
+        o.synchronize()
+    held = host.hgemm_workspace_held()
+    assert held == 9 * one, (held, one)  # the 8 evictable ones + the pinned one
+    with torch.cuda.stream(st):
+        for _ in range(3):
+            c.zero_()
+            g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(c, ref)
+    del g
+    assert host.release_workspaces() > 0 and host.hgemm_workspace_held() == 0
+
+
 @pytest.mark.parametrize("M,N,K", [(4352, 4352, 4352), (5888, 5888, 1792), (4096, 4352, 2048), (4864, 4864, 4864)])
 def test_tail_split_matches_the_fp32_product(hg, built, dev, M, N, K):
     """A count of 256 x 256 tiles just past whole rounds of 256 (csrc/hgemm.hip tail_plan): the rows that fill whole rounds run the single-pass
