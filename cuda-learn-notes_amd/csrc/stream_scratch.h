@@ -8,7 +8,8 @@
 //     recently used one re-assigned after a hipDeviceSynchronize() when a 65th stream shows up (a process that cycles streams never leaks);
 //   * nullptr when the slot cannot be had without touching the device (first use or eviction while the stream is being captured, allocation
 //     failure): the caller then zeroes y on the stream (a memset node under capture) and the kernel adds into y directly, as before;
-//   * a captured launch holds its capture stream's slot: replay graphs on the capture stream (include/cln_amd.h, workspace notes).
+//   * a captured launch holds its capture stream's slot: replay graphs on the capture stream (include/cln_amd.h, workspace notes); such a slot is
+//     pinned -- never re-assigned to another stream -- until cln_release_workspaces().
 #pragma once
 #include "common.h"
 

@@ -8,6 +8,7 @@ constexpr int SLOTS = 64, MAX_DEV = 64;
 struct Slot {
   hipStream_t stream = nullptr;
   bool live = false;
+  bool pinned = false;  // a stream capture has used the slot: a graph holds its address, it is never re-assigned (until cln_release_workspaces)
   unsigned long long used = 0;
 };
 struct DevSlab {
@@ -32,7 +33,10 @@ ClnScratch* cln_stream_scratch(hipStream_t stream) {
   DevSlab& d = g_slab[dev];
   if (d.p) {
     for (int i = 0; i < SLOTS; ++i)
-      if (d.slot[i].live && d.slot[i].stream == stream) return d.slot[i].used = ++g_clock, d.p + i;
+      if (d.slot[i].live && d.slot[i].stream == stream) {
+        if (!d.slot[i].pinned && capturing(stream)) d.slot[i].pinned = true;
+        return d.slot[i].used = ++g_clock, d.p + i;
+      }
   }
   if (capturing(stream)) return nullptr;  // nothing below may run during a capture
   if (!d.p) {
@@ -48,9 +52,9 @@ ClnScratch* cln_stream_scratch(hipStream_t stream) {
   for (int i = 0; i < SLOTS && pick < 0; ++i)
     if (!d.slot[i].live) pick = i;
   if (pick < 0) {  // all 64 in use: take the least recently used one once everything queued on the device is done (its last launch left it zeroed)
-    pick = 0;
-    for (int i = 1; i < SLOTS; ++i)
-      if (d.slot[i].used < d.slot[pick].used) pick = i;
+    for (int i = 0; i < SLOTS; ++i)
+      if (!d.slot[i].pinned && (pick < 0 || d.slot[i].used < d.slot[pick].used)) pick = i;
+    if (pick < 0) return nullptr;  // every slot belongs to a captured graph: the caller's zero-fill path
     if (hipDeviceSynchronize() != hipSuccess) return (void)hipGetLastError(), nullptr;
   }
   d.slot[pick].stream = stream, d.slot[pick].live = true, d.slot[pick].used = ++g_clock;
