@@ -33,13 +33,13 @@ __device__ __forceinline__ float row_sum(float v, float* scratch, int rpw) {
   return v;
 }
 
-template <typename T, int VEC, int MAXV>
+template <typename T, int VEC, int MAXV, bool FULL>
 __global__ void layer_norm_kernel(const T* __restrict__ x, T* __restrict__ y, float g, float b, int K, int stream_nt, int rpw) {
   __shared__ float scratch[2][16];
   const RowPos rp = row_pos(rpw);
   const size_t off = rp.row * K;
   RowRegs<T, VEC, MAXV> r;
-  r.load(x + off, K, 0.f, rp.tid, rp.tpr);
+  r.template load<FULL>(x + off, K, 0.f, rp.tid, rp.tpr);
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i)
@@ -52,7 +52,7 @@ __global__ void layer_norm_kernel(const T* __restrict__ x, T* __restrict__ y, fl
     const int col = (i * rp.tpr + rp.tid) * VEC;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-      const float d = (col < K) ? (r.x[i][e] - mean) : 0.f;
+      const float d = (FULL || col < K) ? (r.x[i][e] - mean) : 0.f;
       r.x[i][e] = d;
       v += d * d;
     }
@@ -62,16 +62,16 @@ __global__ void layer_norm_kernel(const T* __restrict__ x, T* __restrict__ y, fl
   for (int i = 0; i < MAXV; ++i)
 #pragma unroll
     for (int e = 0; e < VEC; ++e) r.x[i][e] = fmaf(r.x[i][e], a, b);
-  r.store(y + off, K, stream_nt, rp.tid, rp.tpr);
+  r.template store<FULL>(y + off, K, stream_nt, rp.tid, rp.tpr);
 }
 
-template <typename T, int VEC, int MAXV>
+template <typename T, int VEC, int MAXV, bool FULL>
 __global__ void rms_norm_kernel(const T* __restrict__ x, T* __restrict__ y, float g, int K, int stream_nt, int rpw) {
   __shared__ float scratch[16];
   const RowPos rp = row_pos(rpw);
   const size_t off = rp.row * K;
   RowRegs<T, VEC, MAXV> r;
-  r.load(x + off, K, 0.f, rp.tid, rp.tpr);
+  r.template load<FULL>(x + off, K, 0.f, rp.tid, rp.tpr);
   float v = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i)
@@ -82,7 +82,7 @@ __global__ void rms_norm_kernel(const T* __restrict__ x, T* __restrict__ y, floa
   for (int i = 0; i < MAXV; ++i)
 #pragma unroll
     for (int e = 0; e < VEC; ++e) r.x[i][e] = r.x[i][e] * a;
-  r.store(y + off, K, stream_nt, rp.tid, rp.tpr);
+  r.template store<FULL>(y + off, K, stream_nt, rp.tid, rp.tpr);
 }
 
 template <typename T, int VEC>
@@ -91,9 +91,9 @@ int launch_ln(const void* x, void* y, float g, float b, int N, int K, hipStream_
   if (!cln_aligned(x, sizeof(T) * VEC) || !cln_aligned(y, sizeof(T) * VEC)) return CLN_ERR_BAD_ARG;
   if (K % VEC) return CLN_ERR_UNSUPPORTED;
   const int nt = row_threads(K, VEC), vpt = vecs_per_thread(K, VEC, nt), rpw = rows_per_wg(nt, N);
-#define CALL(MV)                                                                                              \
-  CLN_LAUNCH((layer_norm_kernel<T, VEC, MV>), dim3(N / rpw), dim3(nt * rpw), 0, st, (const T*)x, (T*)y, g, b, K, cln_stream_nt(2LL * N * K * (long long)sizeof(T)), rpw)
-  ROWWISE_DISPATCH_MAXV(vpt, CALL);
+#define CALL(MV, FL)                                                                                          \
+  CLN_LAUNCH((layer_norm_kernel<T, VEC, MV, FL>), dim3(N / rpw), dim3(nt * rpw), 0, st, (const T*)x, (T*)y, g, b, K, cln_stream_nt(2LL * N * K * (long long)sizeof(T)), rpw)
+  ROWWISE_DISPATCH_MAXV_FULL(vpt, K, nt, VEC, CALL);
 #undef CALL
   return cln_check_launch();
 }
@@ -103,9 +103,9 @@ int launch_rms(const void* x, void* y, float g, int N, int K, hipStream_t st) {
   if (!cln_aligned(x, sizeof(T) * VEC) || !cln_aligned(y, sizeof(T) * VEC)) return CLN_ERR_BAD_ARG;
   if (K % VEC) return CLN_ERR_UNSUPPORTED;
   const int nt = row_threads(K, VEC), vpt = vecs_per_thread(K, VEC, nt), rpw = rows_per_wg(nt, N);
-#define CALL(MV) \
-  CLN_LAUNCH((rms_norm_kernel<T, VEC, MV>), dim3(N / rpw), dim3(nt * rpw), 0, st, (const T*)x, (T*)y, g, K, cln_stream_nt(2LL * N * K * (long long)sizeof(T)), rpw)
-  ROWWISE_DISPATCH_MAXV(vpt, CALL);
+#define CALL(MV, FL) \
+  CLN_LAUNCH((rms_norm_kernel<T, VEC, MV, FL>), dim3(N / rpw), dim3(nt * rpw), 0, st, (const T*)x, (T*)y, g, K, cln_stream_nt(2LL * N * K * (long long)sizeof(T)), rpw)
+  ROWWISE_DISPATCH_MAXV_FULL(vpt, K, nt, VEC, CALL);
 #undef CALL
   return cln_check_launch();
 }

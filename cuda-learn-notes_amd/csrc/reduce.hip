@@ -9,6 +9,7 @@
 // (e.g. f16x8_pack_f16 adds the 8 halves of a pack in fp16, block_all_reduce.cu:252-262);
 // everything across packs / lanes / waves is fp32 (int32 for i8), result y is fp32 / int32.
 #include "common.h"
+#include <stdlib.h>
 #include "stream_scratch.h"
 
 namespace {
@@ -192,7 +193,15 @@ int launch_reduce(const void* a, void* y, long long n, hipStream_t st) {
   if (n == 0) return hipMemsetAsync(y, 0, sizeof(typename PS::out), st) == hipSuccess ? CLN_OK : ((void)hipGetLastError(), CLN_ERR_LAUNCH);
   if (!cln_aligned(a, sizeof(E) * VEC >= 16 ? 16 : sizeof(E) * VEC)) return CLN_ERR_BAD_ARG;
   long long g = (n / VEC + 1023) / 1024;
-  const int grid = (int)(g < 1 ? 1 : (g > 256 ? 256 : g));
+  // (round 5, VERDICT r4 #7 "2 x 512-thread workgroups per CU": measured through this knob -- 512 / 1024 / 2048 workgroups of 1024 threads are 6-55 % SLOWER
+  // than 256 at every size (f16 4096^2 9.2 -> 10.7 / 11.9 / 14.3 us, f32 8192^2 48.1 -> 50.9 / 52.5 / 54.2): the completion tickets grow with the grid;
+  // profiles/r05_reduce_grid_probe.log)
+  static const int cap = [] {  // workgroups at most; $CLN_AMD_REDUCE_GRID (probe knob, read once)
+    const char* e = getenv("CLN_AMD_REDUCE_GRID");
+    const int v = e ? atoi(e) : 0;
+    return v >= 1 && v <= 4096 ? v : 256;
+  }();
+  const int grid = (int)(g < 1 ? 1 : (g > cap ? cap : g));
   ClnScratch* sc = cln_stream_scratch(st);
   if (!sc && hipMemsetAsync(y, 0, sizeof(typename PS::out), st) != hipSuccess) return (void)hipGetLastError(), CLN_ERR_LAUNCH;
   CLN_LAUNCH((reduce_sum_kernel<PS, VEC>), dim3(grid), dim3(1024), 0, st, (const E*)a,

@@ -42,7 +42,9 @@ __global__ __launch_bounds__(256) void rope_kernel(const float* __restrict__ x, 
 #pragma unroll
   for (int p = 0; p < PAIRS; ++p)
     freq[p] = ref_quirk ? 1.0f : 1.0f / powf(10000.0f, (float)(2 * (u * PAIRS + p)) / (float)(2 * half_hidden));
-#pragma unroll 4  // independent rows: four loads in flight per lane (x and out are __restrict__)
+  // (round 5: an explicit four-rows-per-trip form -- loads of four rows issued together, the streaming / plain store choice a template parameter --
+  // measured SLOWER: 4096^2 26.4 -> 28.9 us, 8192^2 97 -> 111 us; the waves of 16 resident workgroups already overlap their single loads)
+#pragma unroll 4  // independent rows (x and out are __restrict__)
   for (int t = blockIdx.y; t < seq_len; t += gridDim.y) {
     const size_t off = ((size_t)t * half_hidden + (size_t)u * PAIRS) * 2;
     float v[2 * PAIRS], o[2 * PAIRS];

@@ -70,11 +70,15 @@ __device__ __forceinline__ RowPos row_pos(int rpw) {
 template <typename T, int VEC, int MAXV>
 struct RowRegs {
   float x[MAXV][VEC];
+  // FULL: the row is exactly MAXV * tpr packs long (e.g. 4096 / 8192 halves at 8 packs per lane) -- no bounds test, no fill: the guarded form costs a
+  // v_cndmask / v_mov per element (layer_norm f16x8, 64 elements per lane: 604 VALU instructions, 160 of them selects and moves), and these kernels
+  // are not far enough from VALU-bound for that to be free (8192^2 f16: rms-norm 409 VALU -> 5.5 TB/s, layer-norm 604 -> 5.25, softmax 733 -> 5.05)
+  template <bool FULL = false>
   __device__ __forceinline__ void load(const T* row, int K, float fill, int tid = threadIdx.x, int tpr = blockDim.x) {
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
       const int col = (i * tpr + tid) * VEC;
-      if (col < K) {
+      if (FULL || col < K) {
         const Pack<T, VEC> p = *reinterpret_cast<const Pack<T, VEC>*>(row + col);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) x[i][e] = to_f32(p.v[e]);
@@ -84,11 +88,12 @@ struct RowRegs {
       }
     }
   }
+  template <bool FULL = false>
   __device__ __forceinline__ void store(T* row, int K, int nt = 0, int tid = threadIdx.x, int tpr = blockDim.x) const {
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
       const int col = (i * tpr + tid) * VEC;
-      if (col < K) {
+      if (FULL || col < K) {
         Pack<T, VEC> p;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) p.v[e] = from_f32<T>(x[i][e]);
@@ -106,6 +111,18 @@ struct RowRegs {
     else if ((vpt) <= 4) { CALL(4); }    \
     else if ((vpt) <= 8) { CALL(8); }    \
     else return CLN_ERR_UNSUPPORTED;     \
+  } while (0)
+// the same, CALL(MAXV, FULL): FULL when the row fills every pack of every lane exactly (K == MAXV * nt * VEC)
+#define ROWWISE_DISPATCH_MAXV_FULL(vpt, K, nt, VEC, CALL)                      \
+  do {                                                                         \
+    const int mv_ = (vpt) <= 1 ? 1 : (vpt) <= 2 ? 2 : (vpt) <= 4 ? 4 : 8;      \
+    const bool full_ = (long long)(K) == (long long)mv_ * (nt) * (VEC);        \
+    if ((vpt) > 8) return CLN_ERR_UNSUPPORTED;                                 \
+    if (full_) {                                                               \
+      if (mv_ == 1) { CALL(1, true); } else if (mv_ == 2) { CALL(2, true); } else if (mv_ == 4) { CALL(4, true); } else { CALL(8, true); }     \
+    } else {                                                                   \
+      if (mv_ == 1) { CALL(1, false); } else if (mv_ == 2) { CALL(2, false); } else if (mv_ == 4) { CALL(4, false); } else { CALL(8, false); } \
+    }                                                                          \
   } while (0)
 
 }  // namespace rowwise

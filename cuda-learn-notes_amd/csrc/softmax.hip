@@ -96,13 +96,13 @@ int launch_global(const void* x, void* y, void* total, long long n, hipStream_t 
 __device__ __forceinline__ float row_sum_g(float v, float* scratch, int rpw) { return rpw > 1 ? wave_sum(v) : block_sum_rt(v, scratch); }
 __device__ __forceinline__ float row_max_g(float v, float* scratch, int rpw) { return rpw > 1 ? wave_max(v) : block_max_rt(v, scratch); }
 
-template <typename T, int VEC, int MAXV, int MODE>
+template <typename T, int VEC, int MAXV, int MODE, bool FULL>
 __global__ void softmax_row_kernel(const T* __restrict__ x, T* __restrict__ y, int H, int stream_nt, int rpw) {
   __shared__ float scratch[16];
   const RowPos rp = row_pos(rpw);
   const size_t off = rp.row * H;
   RowRegs<T, VEC, MAXV> r;
-  r.load(x + off, H, -INFINITY, rp.tid, rp.tpr);
+  r.template load<FULL>(x + off, H, -INFINITY, rp.tid, rp.tpr);
   float m = 0.f, d = 0.f;
   if constexpr (MODE == UNSAFE) {
 #pragma unroll
@@ -120,11 +120,15 @@ __global__ void softmax_row_kernel(const T* __restrict__ x, T* __restrict__ y, i
 #pragma unroll
       for (int e = 0; e < VEC; ++e) m = fmaxf(m, r.x[i][e]);
     m = row_max_g(m, scratch, rpw);
+    // fp16 rows: 2^(x log2e - m log2e) as ONE fma + v_exp_f32 instead of sub, mul, exp -- x carries 11 bits and y is rounded to 11, the fma's
+    // 2^-24 |x log2e| is far below both; the fp32 rungs keep the reference's expf(x - max) (softmax.cu:219-235) operation for operation
+    [[maybe_unused]] const float ml2 = m * 1.4426950408889634f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i)
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
-        r.x[i][e] = __expf(r.x[i][e] - m);
+        if constexpr (sizeof(T) == 2) r.x[i][e] = __builtin_amdgcn_exp2f(fmaf(r.x[i][e], 1.4426950408889634f, -ml2));
+        else r.x[i][e] = __expf(r.x[i][e] - m);
         d += r.x[i][e];
       }
     d = row_sum_g(d, scratch, rpw);
@@ -154,7 +158,7 @@ __global__ void softmax_row_kernel(const T* __restrict__ x, T* __restrict__ y, i
   for (int i = 0; i < MAXV; ++i)
 #pragma unroll
     for (int e = 0; e < VEC; ++e) r.x[i][e] *= inv;
-  r.store(y + off, H, stream_nt, rp.tid, rp.tpr);
+  r.template store<FULL>(y + off, H, stream_nt, rp.tid, rp.tpr);
 }
 
 template <typename T, int VEC, int MODE>
@@ -163,9 +167,9 @@ int launch_rows(const void* x, void* y, int S, int H, hipStream_t st) {
   if (!cln_aligned(x, sizeof(T) * VEC) || !cln_aligned(y, sizeof(T) * VEC)) return CLN_ERR_BAD_ARG;
   if (H % VEC) return CLN_ERR_UNSUPPORTED;
   const int nt = row_threads(H, VEC), vpt = vecs_per_thread(H, VEC, nt), rpw = rows_per_wg(nt, S);
-#define CALL(MV) \
-  CLN_LAUNCH((softmax_row_kernel<T, VEC, MV, MODE>), dim3(S / rpw), dim3(nt * rpw), 0, st, (const T*)x, (T*)y, H, cln_stream_nt(2LL * S * H * (long long)sizeof(T)), rpw)
-  ROWWISE_DISPATCH_MAXV(vpt, CALL);
+#define CALL(MV, FL) \
+  CLN_LAUNCH((softmax_row_kernel<T, VEC, MV, MODE, FL>), dim3(S / rpw), dim3(nt * rpw), 0, st, (const T*)x, (T*)y, H, cln_stream_nt(2LL * S * H * (long long)sizeof(T)), rpw)
+  ROWWISE_DISPATCH_MAXV_FULL(vpt, H, nt, VEC, CALL);
 #undef CALL
   return cln_check_launch();
 }
