@@ -41,9 +41,12 @@ struct HardSwish {
   // the reference's piecewise form (hardswish.cu:37-45: x >= 3 -> x, x <= -3 -> 0, else x (x + 3) / 6) as two selects over the middle branch.
   // Round 4 shipped the branch-free x * med3(x + 3, 0, 6) / 6 (4 VALU): it returned NaN for x = -inf (-inf * 0), +inf instead of x above
   // FLT_MAX / 6 and was 1 ulp off x for x >= 3 -- the selects cost 3 more VALU per element and keep the reference's edges.
+  // Round 5: one select instead of two -- t = med3(x + 3, 0, 6) * (1/6) is EXACTLY 1.0f for x >= 3 (6 * fp32(1/6) = 1.0000000298 rounds to 1), so x * t
+  // returns x itself there (also above FLT_MAX / 6: the clamp comes before the product), and only x <= -3 needs the select (t = 0: -inf * 0 would be NaN).
+  // 6 VALU per element instead of 7; the middle branch is x * ((x + 3) / 6), within an fp32 rounding of the reference's x (x + 3) / 6.
   static __device__ __forceinline__ float f(float x) {
-    const float mid = x * (x + 3.f) * (1.0f / 6.0f);
-    return x >= 3.f ? x : (x <= -3.f ? 0.f : mid);
+    const float t = __builtin_amdgcn_fmed3f(x + 3.f, 0.f, 6.f) * (1.0f / 6.0f);
+    return x <= -3.f ? 0.f : x * t;
   }
 };
 struct HardShrink {
