@@ -51,7 +51,8 @@ GROUPS = [
                    " * Replaces reference kernels/flash-attn/pybind/flash_attn.cc:182-215\n"
                    " * (`void f(torch::Tensor Q, K, V, O, int stages)`)."),
     ("elementwise", "c = a + b. Replaces reference kernels/elementwise/elementwise.cu:163-177."),
-    ("reduce", "y[0] += sum(a); y is fp32 (int32 for i8) and must be zeroed by the caller.\n"
+    ("reduce", "y[0] = sum(a); y is fp32 (int32 for i8), 1 element, OVERWRITTEN by the launch (round 5: a self-resetting per-stream scratch word takes the\n"
+               " * block partials, the last block moves the total into y; the reference binding's zeroed y works unchanged -- block_all_reduce.cu:737-738).\n"
                " * Replaces reference kernels/reduce/block_all_reduce.cu:734-813 (`torch::Tensor f(torch::Tensor x)`)."),
     ("softmax", "Softmax. softmax_f32[x4]: one distribution over all n elements, total_ws = 1 zeroed float.\n"
                 " * *_per_token: x,y are [S,H]. Replaces reference kernels/softmax/softmax.cu:776-885."),
@@ -66,7 +67,7 @@ GROUPS = [
     ("sgemm", "SGEMM: C[M,N] = A[M,K] * B[K,N], fp32 row-major. Replaces reference kernels/sgemm/sgemm.cu:495-640,\n"
               " * sgemm_async.cu bindings, sgemm_wmma_tf32_stage.cu:575-700 (TF32 rungs -> exact-f32 MFMA)."),
     ("sgemm_vendor", "Vendor SGEMM rows (libcln_amd_vendor.so): reference kernels/sgemm/sgemm_cublas.cu:80-120."),
-    ("dot_product", "y[0] += sum(a*b), y fp32[1] zeroed by the caller. Replaces reference kernels/dot-product/dot_product.cu:232-276."),
+    ("dot_product", "y[0] = sum(a*b), y fp32[1], OVERWRITTEN by the launch (as the reduce family above; a zeroed y works unchanged). Replaces reference kernels/dot-product/dot_product.cu:232-276."),
     ("sgemv", "y[M] = a[M,K] * x[K], fp32. Replaces reference kernels/sgemv/sgemv.cu:138-190 (K % 32, K % 128, K == 16)."),
     ("hgemv", "y[M] = a[M,K] * x[K], fp16 in/out, fp32 accumulate. Replaces reference kernels/hgemv/hgemv.cu:140-196."),
     ("mat_transpose", "y[col,row] = x[row,col]^T, fp32, bit-exact. Replaces reference kernels/mat-transpose/mat_transpose.cu:270-360."),
