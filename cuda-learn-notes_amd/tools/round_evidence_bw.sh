@@ -1,3 +1,6 @@
+#!/bin/bash
+# The three evidence pieces of round_evidence.sh that depend on the bandwidth / row kernels only, for a refresh after those kernels change:
+# rocprofv3 kernel-trace of the bandwidth families (-> r05_bw_rocprof.json / .txt), every reference-style script on the GPU, every script against its torch row.
 TAG=r05; REPO=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$REPO/gpurun_out; T=$REPO/cuda-learn-notes_amd/tools
 mkdir -p $OUT; cd $REPO; export PYTHONUNBUFFERED=1
 rm -rf $OUT/bwprof
