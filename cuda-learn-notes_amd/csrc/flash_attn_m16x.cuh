@@ -66,6 +66,9 @@ enum : int {
   // 32-key step and query block with an all-ones A operand (every row of its 16x16 result is the row-sum vector, so no cross-lane reduction at the
   // end either); the 64 v_add_f32 per tile go, and the fp16-overflow check of the optimistic blocks becomes a running v_max3 of the exponents (<= 15).
   M16X_MFMA_SUM = 1 << 19,
+  // probe (round 5): the partial row sums by v_dot2_f32_f16 -- acc += p0 + p1 over the fp16-ROUNDED pair in ONE instruction instead of two v_add_f32 (64 -> 32
+  // row-sum instructions per wave and 128-key tile at D = 64); l becomes the sum of the same fp16 values the numerator uses, an fp16 overflow still fails the check (inf)
+  M16X_DOT2_SUM = 1 << 20,
   M16X_ONE_POS = 2           // the shipped position: top of phase B (the MFMA-only phase), 0.95-1.0x of stages = 2 (profiles/r04_fa_one_stage_probe.log)
 };
 
@@ -258,8 +261,9 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
       const float a1 = (OX & M16X_ABL_EXP) != 0 ? x1 : __builtin_amdgcn_exp2f(x1);
       if constexpr (MS) {
         if (track) acc[qb] = fmaxf(fmaxf(acc[qb], x0), x1);  // v_max3_f32
-      } else acc[qb] += a0 + a1;
+      } else if constexpr ((OX & M16X_DOT2_SUM) == 0) acc[qb] += a0 + a1;
       const h2 a = __builtin_convertvector(f2{a0, a1}, h2);
+      if constexpr (!MS && (OX & M16X_DOT2_SUM) != 0) acc[qb] = __builtin_amdgcn_fdot2(a, h2{(half_t)1.0f, (half_t)1.0f}, acc[qb], false);
       // an input-only empty asm is a chained node of the instruction selector: the item stays in the step it was
       // written in (without it hipcc sinks every exponential below the last MFMA of the phase)
       asm volatile("" ::"v"(a), "v"(acc[qb]));

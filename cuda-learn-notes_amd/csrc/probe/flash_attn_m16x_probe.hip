@@ -47,6 +47,8 @@ int m16x_probe_run(int D, int code, const void* q, const void* k, const void* v,
   MX(128, 197, 32, 128, 4, 5, 262149) MX(128, 198, 32, 128, 4, 6, 262149) MX(128, 199, 32, 128, 4, 3, 262149)
   // 194..: row sums on the matrix pipe (M16X_MFMA_SUM = 524288 on top of the shipped options 5); 195: + fp32-scaled scores
   MX(64, 194, 32, 128, 8, 4, 524293) MX(128, 194, 32, 128, 4, 4, 524293) MX(64, 196, 64, 64, 4, 1, 524293) MX(64, 195, 32, 128, 8, 4, 786437) MX(128, 195, 32, 128, 4, 4, 786437)
+  // 186 / 187: partial row sums by v_dot2_f32_f16 (M16X_DOT2_SUM = 1048576 on top of the shipped options 5); 187 = the 64-rows-per-wave form
+  MX(64, 186, 32, 128, 8, 4, 1048581) MX(128, 186, 32, 128, 4, 4, 1048581) MX(64, 187, 64, 64, 4, 1, 1048581)
 #undef MX
   // 150 + id: the one-wave-per-SIMD form (flash_attn_m16s.cuh: 4 waves x 64 rows), <D, BC, PD, NDEF>
 #define MS(DD, CODE, BCC, PDD, NDEFF, FINEE) \
