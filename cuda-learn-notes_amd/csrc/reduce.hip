@@ -127,7 +127,7 @@ struct alignas(sizeof(E) * VEC) Pack {
 // One workgroup of 1024 threads per CU at most (256 x 16 waves cover the chip's wave slots): the final
 // device-scope atomics on the single result word serialise at ~12 ns each (MI355X_MICROARCH "fanin"), so
 // the grid is capped at the CU count -- 4096 small workgroups spent 50 us in that tail alone.
-template <typename PS, int VEC>
+template <typename PS, int VEC, bool DEEP = false>
 __global__ __launch_bounds__(1024) void reduce_sum_kernel(const typename PS::elem* __restrict__ a,
                                                           typename PS::out* __restrict__ y, long long n, ClnScratch* sc) {
   using E = typename PS::elem;
@@ -140,6 +140,14 @@ __global__ __launch_bounds__(1024) void reduce_sum_kernel(const typename PS::ele
   // 8 independent loads in flight per lane (round 4; 4 before): at the reference scripts' own sizes a lane owns 8-16 packs in all
   // (4096^2 f16x8: 8), so the kernel is a few round trips to HBM long and each batch of loads that has to wait for the previous one is
   // ~1 us of a 6-8 us launch
+  if constexpr (DEEP)
+  for (; i + 15 * stride < nvec; i += 16 * stride) {  // (probe, $CLN_AMD_REDUCE_DEEP=1) sixteen loads in flight per lane
+    Pack<E, VEC> p[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) p[u] = *reinterpret_cast<const Pack<E, VEC>*>(a + (i + u * stride) * VEC);
+#pragma unroll
+    for (int u = 0; u < 16; u += 4) s0 += PS::sum(p[u].v), s1 += PS::sum(p[u + 1].v), s2 += PS::sum(p[u + 2].v), s3 += PS::sum(p[u + 3].v);
+  }
   for (; i + 7 * stride < nvec; i += 8 * stride) {
     Pack<E, VEC> p[8];
 #pragma unroll
@@ -204,8 +212,13 @@ int launch_reduce(const void* a, void* y, long long n, hipStream_t st) {
   const int grid = (int)(g < 1 ? 1 : (g > cap ? cap : g));
   ClnScratch* sc = cln_stream_scratch(st);
   if (!sc && hipMemsetAsync(y, 0, sizeof(typename PS::out), st) != hipSuccess) return (void)hipGetLastError(), CLN_ERR_LAUNCH;
-  CLN_LAUNCH((reduce_sum_kernel<PS, VEC>), dim3(grid), dim3(1024), 0, st, (const E*)a,
-             (typename PS::out*)y, n, sc);
+  static const bool deep = [] { const char* e = getenv("CLN_AMD_REDUCE_DEEP"); return e && atoi(e) != 0; }();
+  if (deep) {
+    CLN_LAUNCH((reduce_sum_kernel<PS, VEC, true>), dim3(grid), dim3(1024), 0, st, (const E*)a, (typename PS::out*)y, n, sc);
+  } else {
+    CLN_LAUNCH((reduce_sum_kernel<PS, VEC>), dim3(grid), dim3(1024), 0, st, (const E*)a,
+               (typename PS::out*)y, n, sc);
+  }
   return cln_check_launch();
 }
 
