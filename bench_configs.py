@@ -67,6 +67,46 @@ def _cpu_time(fn, budget_s=0.8, max_iters=50):
 
 
 # ----------------------------------------------------------------------------------------------------------------
+# vendor yardsticks of the bandwidth rows (round 6): what the ROCm stack reaches on the SAME buffers, rotation and timing protocol --
+# hipMemcpyDtoDAsync for the 1R + 1W rows, rocprim::reduce for the reductions (csrc/yardstick_vendor.hip), torch.add(out=) for the 2R + 1W rows
+def _yardsticks():
+    import ctypes as C
+    try:
+        lib = C.CDLL(_loader.so_path("libcln_amd_vendor.so"))
+        lib.cln_yardstick_copy.argtypes, lib.cln_yardstick_copy.restype = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p], C.c_int
+        for n in ("cln_yardstick_reduce_f32", "cln_yardstick_reduce_f16"):
+            f = getattr(lib, n)
+            f.argtypes, f.restype = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.POINTER(C.c_size_t), C.c_void_p], C.c_int
+        return lib
+    except (OSError, AttributeError):  # a build without the optional yardstick unit: the rows simply carry no yardstick
+        return None
+
+
+def _yardstick_calls(lib, kind, dtype, sets, z, dev):
+    """Zero-argument callables, one per rotating set (x, x2, y), of the vendor yardstick for a row of signature `kind`; (name, calls) or None."""
+    import ctypes as C
+    st = _stream()
+    if kind == "P3":
+        return "torch.add(out=) on the GPU", [(lambda a=x, b=x2, c=y: torch.add(a, b, out=c)) for (x, x2, y) in sets]
+    if lib is None:
+        return None
+    if kind == "R1":
+        fn = lib.cln_yardstick_reduce_f16 if dtype == torch.float16 else lib.cln_yardstick_reduce_f32
+        n = sets[0][0].numel()
+        need = C.c_size_t(0)
+        if fn(sets[0][0].data_ptr(), z.data_ptr(), n, None, C.byref(need), st) != 0:
+            return None
+        tmp = torch.empty(max(int(need.value), 16), dtype=torch.uint8, device=dev)
+        tb = C.c_size_t(int(need.value))
+        tp, zp = tmp.data_ptr(), z.data_ptr()
+        calls = [(lambda xp=x.data_ptr(): fn(xp, zp, n, tp, C.byref(tb), st)) for (x, _, _) in sets]
+        calls[0].keep = tmp
+        return "rocprim::reduce (fp32 accumulation)", calls
+    nbytes = sets[0][0].numel() * sets[0][0].element_size()
+    return "hipMemcpyDtoDAsync", [(lambda xp=x.data_ptr(), yp=y.data_ptr(): lib.cln_yardstick_copy(yp, xp, nbytes, st)) for (x, _, y) in sets]
+
+
+# ----------------------------------------------------------------------------------------------------------------
 # bandwidth kernels
 def _bw_specs(orc=None):
     """(kernel name, dtype, signature kind, algorithmic bytes per element, torch-CPU callable of the same op -- the reference
@@ -133,6 +173,8 @@ def bandwidth_rows(dev, orc, shapes=((4096, 4096), (8192, 8192)), cpu_shape=(409
     rows = []
     z = torch.zeros(4, dtype=torch.float32, device=dev)
     g = torch.Generator(device="cpu").manual_seed(11)
+    ylib = _yardsticks()
+    ycache = {}  # (kind, dtype, shape) -> yardstick result: rows that share a signature share the vendor measurement
     for name, dtype, kind, bpe, cpu_op in _bw_specs(orc):
         fn = _loader.symbol(name)
         for (S, K) in shapes:
@@ -147,12 +189,13 @@ def bandwidth_rows(dev, orc, shapes=((4096, 4096), (8192, 8192)), cpu_shape=(409
             except Exception as e:  # noqa: BLE001 -- out of memory on a small box: report, do not abort the bench
                 rows.append({"kernel": name, "shape": [S, K], "error": str(e)[:120]})
                 continue
-            calls = []
+            calls, sets = [], []
             for i in range(nsets):
                 base = i * (n_in + n_out)
                 x = pool[base]
                 x2 = pool[base + 1] if n_in == 2 else None
                 y = pool[base + n_in] if n_out else None
+                sets.append((x, x2, y))
                 calls.append(_bw_call(fn, kind, x, x2, y, z, S, K))
             rc = calls[0]()
             torch.cuda.synchronize()
@@ -176,6 +219,24 @@ def bandwidth_rows(dev, orc, shapes=((4096, 4096), (8192, 8192)), cpu_shape=(409
                    "gbps_same_buffers": round(nbytes / ms_same * 1e-6, 1),
                    "same_buffers_fit_infinity_cache": bool(set_bytes < MALL_BYTES),
                    "us_64_row_launch": None if ms_tiny is None else round(ms_tiny * 1e3, 3)}
+            # the vendor yardstick on the same rotating sets, same protocol (one per signature / dtype / shape; rope, softmax and the norms share the copy)
+            ykey = ("1R1W" if kind not in ("P3", "R1") else kind, esz, S, K)
+            if ykey not in ycache:
+                ycache[ykey] = None
+                yc = _yardstick_calls(ylib, kind, dtype, sets, z, dev)
+                if yc is not None:
+                    try:
+                        yms, _ = _region_ms(yc[1], 3 * nsets)
+                        yms_same, _ = _region_ms(yc[1][:1], 50)
+                        ycache[ykey] = {"what": yc[0], "us_per_launch": round(yms * 1e3, 3), "us_same_buffers": round(yms_same * 1e3, 3)}
+                    except Exception as e:  # noqa: BLE001
+                        ycache[ykey] = {"what": yc[0], "error": str(e)[:120]}
+            if ycache[ykey] and "us_per_launch" in ycache[ykey]:
+                yd = ycache[ykey]
+                # bytes the yardstick moves equal the row's algorithmic bytes (copy: 1R + 1W; reduce: 1R; add: 2R + 1W), so time ratios are rate ratios
+                row["yardstick"] = {"what": yd["what"], "us_per_launch": yd["us_per_launch"], "gbps": round(nbytes / yd["us_per_launch"] * 1e-3, 1),
+                                    "ours_over_yardstick": round(yd["us_per_launch"] / (ms * 1e3), 4),
+                                    "same_buffers_ours_over_yardstick": round(yd["us_same_buffers"] / (ms_same * 1e3), 4)}
             if (S, K) == tuple(cpu_shape):
                 xc = torch.randn(S, K, generator=g).to(dtype)
                 x2c = torch.randn(S, K, generator=g).to(dtype)
@@ -190,7 +251,7 @@ def bandwidth_rows(dev, orc, shapes=((4096, 4096), (8192, 8192)), cpu_shape=(409
                     row["cpu_baseline"] = {"error": str(e)[:120]}
                 del xc, x2c
             rows.append(row)
-            del pool, calls
+            del pool, calls, sets
             torch.cuda.empty_cache()
     return rows
 
@@ -213,6 +274,13 @@ def config_c1(dev, orc):
         out[name] = {"us_per_launch": round(ms * 1e3, 3), "gbps": round(nbytes / ms * 1e-6, 1),
                      "frac_of_8TBs": round(nbytes / ms * 1e-6 / bu.PEAK_HBM_GBPS, 4), "launches": launches,
                      "rotating_sets": int(nsets), "gbps_same_buffers": round(nbytes / ms_same * 1e-6, 1)}
+    # vendor yardstick: torch.add(out=) on the GPU over the same rotating sets, same timing protocol
+    ycalls = [(lambda a=pool[3 * i], b=pool[3 * i + 1], c=pool[3 * i + 2]: torch.add(a, b, out=c)) for i in range(nsets)]
+    yms, _ = _region_ms(ycalls, 3 * nsets)
+    yms_same, _ = _region_ms(ycalls[:1], 100)
+    out["yardstick"] = {"what": "torch.add(out=) on the GPU", "us_per_launch": round(yms * 1e3, 3), "gbps": round(nbytes / yms * 1e-6, 1),
+                        "gbps_same_buffers": round(nbytes / yms_same * 1e-6, 1),
+                        "ours_over_yardstick": {k: round(yms * 1e3 / out[k]["us_per_launch"], 4) for k in ("elementwise_add_f32", "elementwise_add_f32x4")}}
     # correctness of the row that was just timed, against the host result (bit-exact: fp32 add)
     a, b, c = pool[0], pool[1], pool[2]
     _loader.symbol("elementwise_add_f32")(a.data_ptr(), b.data_ptr(), c.data_ptr(), n, _stream())

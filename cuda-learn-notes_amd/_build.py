@@ -1,7 +1,8 @@
 """Build the gfx950 shared objects in-tree with hipcc (no torch headers, no pybind, no hipify).
 
   csrc/*.hip  --hipcc -c-->  build/*.o  --hipcc -shared-->  lib/libcln_amd.so         (the product: reference names only)
-  csrc/hgemm_vendor*.hip, fa2_vendor_ck.hip  ----------->  lib/libcln_amd_vendor.so  (comparison rows: rocBLAS, hipBLASLt, ck_tile FMHA)
+  csrc/hgemm_vendor*.hip, fa2_vendor_ck.hip, yardstick_vendor.hip  ->  lib/libcln_amd_vendor.so  (comparison rows: rocBLAS, hipBLASLt, ck_tile FMHA;
+                                                           bench yardsticks: hipMemcpyDtoD, rocprim::reduce)
   csrc/*_probe.hip  ------------------------------------>  lib/libcln_amd_probe.so   (TEST-ONLY: tuning hooks, ablation and
                                                            probe instantiations; nothing in the product path loads it)
   csrc/pyext/cln_fastcall.c  --gcc-->  lib/_cln_fastcall*.so  (CPython vectorcall entries in front of the C-ABI; optional)
@@ -27,10 +28,10 @@ KERNEL_SOURCES = [
     "elementwise.hip", "activation.hip", "blas1.hip", "indexing.hip", "reduce.hip", "softmax.hip", "norm.hip", "rope.hip",
     "sgemm.hip", "stream_scratch.hip", "hgemm.hip", "hgemm_ring_nn.hip", "hgemm_ring_tn.hip", "flash_attn.hip", "flash_attn_m16x.hip", "describe.hip",
 ]
-VENDOR_SOURCES = ["hgemm_vendor.hip", "hgemm_vendor_lt.hip", "fa2_vendor_ck.hip"]  # the last: ck_tile FMHA instances (~1 min of hipcc)
+VENDOR_SOURCES = ["hgemm_vendor.hip", "hgemm_vendor_lt.hip", "fa2_vendor_ck.hip", "yardstick_vendor.hip"]  # the last: ck_tile FMHA instances (~1 min of hipcc)
 # a comparison row whose sources are the ROCm image's ck_tile headers: if they are missing or do not compile, the vendor
 # library is linked without it (the callers treat the row as absent) instead of failing the whole build
-OPTIONAL_SOURCES = {"fa2_vendor_ck.hip", "hgemm_vendor_lt.hip"}  # (the hipBLASLt row too: an image without hipBLASLt still builds the product)
+OPTIONAL_SOURCES = {"fa2_vendor_ck.hip", "hgemm_vendor_lt.hip", "yardstick_vendor.hip"}  # (the hipBLASLt row too: an image without hipBLASLt still builds the product)
 # test-only library; it re-links the two ring compile units for the explicit (tile, BK, stages) hook
 # (csrc/probe/: the probe compile units and the kernels that only they instantiate -- nothing under it is linked into libcln_amd.so)
 PROBE_SOURCES = ["probe/hgemm_probe.hip", "probe/flash_attn_probe.hip", "probe/flash_attn_m16x_probe.hip"]

@@ -87,6 +87,7 @@ def load_so(so_name):
         lib.cln_hgemm_set_workspace.argtypes, lib.cln_hgemm_set_workspace.restype = [c_void_p, ctypes.c_size_t, c_void_p], c_int
         lib.cln_release_workspaces.argtypes, lib.cln_release_workspaces.restype = [], ctypes.c_size_t
         lib.cln_hgemm_workspace_held.argtypes, lib.cln_hgemm_workspace_held.restype = [], ctypes.c_size_t
+        lib.cln_hgemm_library_workspace.argtypes, lib.cln_hgemm_library_workspace.restype = [c_int], c_int
     _cache[so_name] = lib
     return lib
 

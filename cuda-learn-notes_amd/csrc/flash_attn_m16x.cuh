@@ -69,13 +69,31 @@ enum : int {
   // probe (round 5): the partial row sums by v_dot2_f32_f16 -- acc += p0 + p1 over the fp16-ROUNDED pair in ONE instruction instead of two v_add_f32 (64 -> 32
   // row-sum instructions per wave and 128-key tile at D = 64); l becomes the sum of the same fp16 values the numerator uses, an fp16 overflow still fails the check (inf)
   M16X_DOT2_SUM = 1 << 20,
+  // probe (round 6, VERDICT r5 #1b "C4's fixed cost"): every wave stamps s_memrealtime (100 MHz, chip-wide) and s_memtime (shader clock) at kernel entry,
+  // at the top of the KV loop (prologue done), behind the loop and behind its last O store (waited for), plus its HW_ID / XCC_ID -- 10 words per wave into
+  // g_m16x_stamps (probe library: cln_probe_set_stamps). tools/fa_c4_stamps.py turns them into the launch ramp, prologue, per-tile and tail times per CU.
+  M16X_STAMP = 1 << 21,
   M16X_ONE_POS = 2           // the shipped position: top of phase B (the MFMA-only phase), 0.95-1.0x of stages = 2 (profiles/r04_fa_one_stage_probe.log)
 };
+
+inline unsigned long long* g_m16x_stamps = nullptr;  // device buffer of the M16X_STAMP probe form (10 words per wave); never set in the product library
 
 template <int D_, int RPW_, int BC_, int PD = 4, int NDEF = 1, int OX = 0, bool VT = false>
 __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __restrict__ Q, const half_t* __restrict__ K,
                                                               const half_t* __restrict__ V, half_t* __restrict__ O,
-                                                              int N, int n_qblk, int n_heads, float scale_log2e) {
+                                                              int N, int n_qblk, int n_heads, float scale_log2e, unsigned long long* stamps) {
+  constexpr bool STAMP = (OX & M16X_STAMP) != 0;
+  unsigned long long st_rt[4] = {0, 0, 0, 0}, st_mt[4] = {0, 0, 0, 0};
+  auto stamp = [&](int i) __attribute__((always_inline)) {
+    if constexpr (STAMP) {
+      __builtin_amdgcn_sched_barrier(0);
+      st_rt[i] = __builtin_amdgcn_s_memrealtime();
+      st_mt[i] = __builtin_amdgcn_s_memtime();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  stamp(0);
   using G = GeoM16<D_, RPW_, BC_>;
   constexpr int D = G::D, NKB = G::NKB, NKS = G::NKS, NQB = G::NQB, NU = G::NU, NDB = G::NDB, NQK = G::NQK, NPV = G::NPV;
   constexpr int NOPT = NKB - NDEF;            // key blocks exponentiated in phase A
@@ -208,6 +226,7 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
     asm volatile("" ::: "memory");
   }
 
+  stamp(1);
   for (int j = 0; j < T; ++j) {
     const int jn = j + 1 < T ? j + 1 : T - 1;
     const int kb_j = kbase + (j & 1) * G::STAGE, vb_j = vbase + (j & 1) * G::STAGE + G::TILE;
@@ -483,6 +502,7 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
     if constexpr ((OX & M16X_ABL_BAR) == 0) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   }
+  stamp(2);
   if (grp == 0) {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -518,6 +538,17 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
     const int row = idx / LPR, c = idx % LPR;
     cln_store_stream(reinterpret_cast<u4*>(og + (size_t)row * D + c * 8), *reinterpret_cast<const u4*>(ob + row * G::OS + c * 16), (OX & M16X_NT_STORE) != 0 ? 1 : 0);
   }
+  if constexpr (STAMP) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the O rows have left
+    stamp(3);
+    if (stamps && lane_e == 0) {
+      unsigned long long* p = stamps + ((size_t)blockIdx.x * (G::NT / 64) + wave) * 10;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) p[2 * i] = st_rt[i], p[2 * i + 1] = st_mt[i];
+      p[8] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_REG_HW_ID: wave / SIMD / CU / SH / SE
+      p[9] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_REG_XCC_ID
+    }
+  }
 }
 
 template <int D_, int RPW_, int BC_, int PD = 4, int NDEF = 1, int OX = 0, bool VT = false>
@@ -529,7 +560,7 @@ int launch_m16x(const void* q, const void* k, const void* v, void* o, int B, int
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)G::D);
   const int n_qblk = N / G::BR;
   CLN_LAUNCH((fa2_fwd_m16x_kernel<D_, RPW_, BC_, PD, NDEF, OX, VT>), dim3(n_qblk * B * H), dim3(G::NT), G::LDS_BYTES, stream,
-             (const half_t*)q, (const half_t*)k, (const half_t*)v, (half_t*)o, N, n_qblk, B * H, scale_log2e);
+             (const half_t*)q, (const half_t*)k, (const half_t*)v, (half_t*)o, N, n_qblk, B * H, scale_log2e, (OX & M16X_STAMP) != 0 ? g_m16x_stamps : nullptr);
   return cln_check_launch();
 }
 

@@ -15,6 +15,7 @@
 #include "hgemm_splitk.cuh"
 #include "hgemm_valu.cuh"
 #include "stream_scratch.h"
+#include <stdlib.h>
 #include <string.h>
 #include <math.h>
 #include <cstdint>
@@ -136,9 +137,11 @@ SplitK splitk_plan(int M, int N, int K) {
 }
 
 // ---- split-K workspace (round 5: caller-visible, bounded, freeable) -------------------------------
-// One workspace per (device, stream): W4_TICKET_FLOATS zeroed arrival counters + the fp32 partials. Either the CALLER's
-// (cln_hgemm_set_workspace: the library never allocates for that stream; a shape whose workspace does not fit takes the single-pass plan) or
-// library-owned (allocated on first use, grown by doubling up to SPLITK_WS_MAX).
+// One workspace per (device, stream): W4_TICKET_FLOATS zeroed arrival counters + the fp32 partials. The CALLER's (cln_hgemm_set_workspace: the
+// library never allocates for that stream; a shape whose workspace does not fit takes the single-pass plan) -- and that is the ONLY kind by
+// default (round 6, SURVEY 8(b) "no hidden workspace"): a stream nobody gave a region runs every shape single-pass. host.py hands each stream a
+// tensor from torch's caching allocator; a C caller without an allocator of its own opts in to library-owned buffers with
+// cln_hgemm_library_workspace(1) (allocated on first use, partial area a power of two from 16 MiB up to SPLITK_WS_MAX).
 //   * g_ws_mu is held from the lookup to the END of the launch sequence that uses the workspace (1-2 launches): two host threads calling hgemm
 //     on one stream can no longer interleave their partial / reduce launches (ctypes drops the GIL around the C call). On one
 //     stream the launches of consecutive calls run in order, so one workspace per stream is enough.
@@ -161,6 +164,7 @@ struct SplitKWs {
   bool pinned = false;        // a stream capture has used the region: a graph holds its address, so the library never frees it on its own
 };
 constexpr size_t SPLITK_OWNED_MAX = 8;
+bool g_lib_ws = false;  // library-owned workspaces allowed (cln_hgemm_library_workspace); guarded by g_ws_mu
 std::mutex g_ws_mu;
 std::vector<SplitKWs> g_ws;
 unsigned long long g_ws_clock = 0;
@@ -188,13 +192,15 @@ SplitKWs* ws_acquire(hipStream_t stream, size_t bytes) {
   for (auto& w : g_ws)
     if (w.dev == dev && w.stream == stream) e = &w;
   if (e && e->user) return e->bytes >= bytes ? (e->used = ++g_ws_clock, e) : nullptr;
+  if (!g_lib_ws) return nullptr;  // no caller-owned region and the library may not allocate: single-pass plan
   if (e && e->bytes >= bytes) {
     if (!e->pinned && stream_capturing(stream)) e->pinned = true;
     return e->used = ++g_ws_clock, e;
   }
   if (bytes > SPLITK_WS_MAX + W4_TICKET_FLOATS * 4 || (e && e->pinned) || stream_capturing(stream)) return nullptr;
-  size_t want = 16u << 20;
-  while (want < bytes) want <<= 1;
+  size_t want = 16u << 20;  // the PARTIAL area is the power of two (header + 2^k bytes asked for 2^(k+1)); the ticket header rides on top
+  while (want < bytes - W4_TICKET_FLOATS * 4) want <<= 1;
+  want += W4_TICKET_FLOATS * 4;
   if (e) {
     ws_free_entry(*e);  // grow: waits for the stream's earlier split-K launches (rare: sizes double)
   } else {
@@ -231,20 +237,17 @@ void ws_mark_used(SplitKWs* e, hipStream_t stream) {  // g_ws_mu held, after the
 // every shape of the round-4 split-K / tail probes under 0 = never, the default, 64 = always): at 2 splits one launch is 1-4 % faster than partial +
 // reduce launch (512 x 8192^2 68.1 -> 67.3 us, 2048^2 x 8192 70.6 -> 70.1, 640 x 5120^2 43.4 -> 41.9); at 4 splits the tile's reduction on ONE CU
 // (1 MiB of partials at one CU's load rate) costs 3-5 us more than the reduce launch it saves (256 x 4096^2 23.4 -> 26.6 us, 4352^3 138.9 -> 149.6),
-// at 8 and more 5-6 us more. $CLN_AMD_SPLITK_FUSED_MAX_S overrides (0 = never).
-int splitk_fused_max_s() {
-  static const int v = [] {
-    const char* e = getenv("CLN_AMD_SPLITK_FUSED_MAX_S");
-    return e ? atoi(e) : 2;
-  }();
-  return v;
-}
+// at 8 and more 5-6 us more. (The probe library's kinds 17 / 18 launch either form at any S: tools/hg_splitk_fused_probe.py.)
+constexpr int splitk_fused_max_s() { return 2; }
+// A CAPTURED launch never takes the one-launch form (round 6): its arrival tickets are mutable state in the workspace header, a graph replays
+// on whatever stream is current, and a ticket lost or doubled by an overlapping launch never recovers. Partial + reduce launch keeps no state
+// between calls (same bits).
 template <int LAYOUT>
-int splitk_dispatch(const SplitK& sk, const void* a, const void* b, void* c, float* ws, int M, int N, int K, hipStream_t st) {
+int splitk_dispatch(const SplitK& sk, const void* a, const void* b, void* c, float* ws, int M, int N, int K, hipStream_t st, bool fused_ok) {
   // `ws` = tickets + partials; the two-launch form uses the partial area only
 #define CLN_SK(BMM, BNN)                                                                                                        \
   if (sk.bm == BMM && sk.bn == BNN)                                                                                             \
-    return sk.S <= splitk_fused_max_s() ? launch_w4_splitk_fused<LAYOUT, 26, BMM, BNN>(a, b, c, ws, M, N, K, sk.S, st)         \
+    return fused_ok && sk.S <= splitk_fused_max_s() ? launch_w4_splitk_fused<LAYOUT, 26, BMM, BNN>(a, b, c, ws, M, N, K, sk.S, st)         \
                                         : launch_w4_splitk<LAYOUT, 26, BMM, BNN>(a, b, c, ws + W4_TICKET_FLOATS, M, N, K, sk.S, st);
   CLN_SK(256, 256) CLN_SK(192, 256) CLN_SK(192, 192) CLN_SK(128, 256) CLN_SK(160, 160)
 #undef CLN_SK
@@ -330,7 +333,7 @@ int best_dispatch(const void* a, const void* b, void* c, int M, int N, int K, in
     std::lock_guard<std::mutex> lock(g_ws_mu);  // held across the launch(es): see the workspace notes above
     SplitKWs* w = ws_acquire(st, w4_splitk_ws_bytes(M, N, sk.S));
     if (w) {
-      const int rc = splitk_dispatch<LAYOUT>(sk, a, b, c, w->p, M, N, K, st);
+      const int rc = splitk_dispatch<LAYOUT>(sk, a, b, c, w->p, M, N, K, st, !stream_capturing(st));
       ws_mark_used(w, st);
       return rc;
     }
@@ -340,7 +343,7 @@ int best_dispatch(const void* a, const void* b, void* c, int M, int N, int K, in
     std::lock_guard<std::mutex> lock(g_ws_mu);
     SplitKWs* w = ws_acquire(st, w4_splitk_ws_bytes(M - ts.m_split, N, ts.S));
     if (w) {
-      const int rc = ts.S <= splitk_fused_max_s()
+      const int rc = ts.S <= splitk_fused_max_s() && !stream_capturing(st)
                          ? launch_w4_tail_split<LAYOUT, W4_EPILOGUE, W4_PRODUCTION, 256, 256, true>(a, b, c, w->p, M, N, K, ts.m_split, ts.S, swizzle, stride, st)
                          : launch_w4_tail_split<LAYOUT, W4_EPILOGUE, W4_PRODUCTION, 256, 256, false>(a, b, c, w->p + W4_TICKET_FLOATS, M, N, K, ts.m_split, ts.S, swizzle, stride, st);
       ws_mark_used(w, st);
@@ -539,7 +542,8 @@ CLN_G6(hgemm_mma_stages_block_swizzle_tn_cute,
                        : ring_dispatch_tn(T128, a, b, c, M, N, K, stages, swizzle, swizzle_stride, stream)))
 
 // ---- workspace entry points (include/cln_amd.h; not part of the reference surface: its bindings take only a, b, c --
-// kernels/hgemm/mma/basic/hgemm_mma_stage.cu:2380-2413 -- so the default stays library-owned, but it is bounded, visible and freeable)
+// kernels/hgemm/mma/basic/hgemm_mma_stage.cu:2380-2413 -- and never allocate, kernels/hgemm/pybind/hgemm.cc:58-107: neither does this library
+// unless asked to, cln_hgemm_library_workspace)
 // bytes the split-K / tail-split plan of the best-dispatch names needs for (M, N, K); 0 = the shape runs single-pass and never touches a workspace
 CLN_API size_t cln_hgemm_workspace_bytes(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
@@ -576,6 +580,16 @@ CLN_API int cln_hgemm_set_workspace(void* ptr, size_t bytes, void* stream) {
   w.dev = dev, w.stream = st, w.p = (float*)ptr, w.bytes = bytes, w.user = true, w.used = ++g_ws_clock;
   g_ws.push_back(w);
   return CLN_OK;
+}
+// Library-owned workspaces on (1) / off (0, the default): the opt-in of a C caller that has no allocator of its own. On: a stream without a caller-owned
+// region gets a library buffer on its first split-K shape (at most SPLITK_OWNED_MAX at a time, least recently used freed after its last launch's
+// event; never allocated or freed under stream capture; one a capture has used is pinned until cln_release_workspaces()). Off: such a stream runs
+// single-pass; buffers already held stay held until cln_release_workspaces(). Returns the previous setting.
+CLN_API int cln_hgemm_library_workspace(int enable) {
+  std::lock_guard<std::mutex> lock(g_ws_mu);
+  const int was = g_lib_ws ? 1 : 0;
+  g_lib_ws = enable != 0;
+  return was;
 }
 // Frees every library-owned workspace (after the launches that used it have completed) and forgets the caller-owned ones. Returns the bytes freed.
 CLN_API size_t cln_release_workspaces(void) {

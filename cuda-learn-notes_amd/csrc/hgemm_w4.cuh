@@ -26,7 +26,6 @@
 // Versus the 128x64 wave tile: 32 fragment reads per 128 MFMAs instead of 48 (LDS bytes per flop -33 %), 2 barriers per
 // 128 MFMAs instead of 4 per 64, no slot in which a SIMD's matrix pipe waits for the partner wave's rendezvous.
 #pragma once
-#include <stdlib.h>
 #include <type_traits>
 
 #include "hgemm_mfma.cuh"
@@ -526,13 +525,7 @@ inline int w4_nt_ok(int M, int N, int K) { return 2LL * ((long long)M * K + (lon
 // 10240^3 (420 MB of operands) -1.5 ... 0 %, 8192^3 0 % -- profiles/r04_hgemm_block_walk_probe.log. Bit-identical results.
 constexpr long long W4_INTERLEAVED_OPERANDS = 512LL << 20;
 inline int w4_interleaved_walk(int M, int N, int K, int swizzle, int tiles) {
-  // $CLN_AMD_W4_BLOCK_WALK = 0 / 1 forces the walk off / on (for A/B measurements; read once); unset: by operand size
-  static const int forced = [] {
-    const char* e = getenv("CLN_AMD_W4_BLOCK_WALK");
-    return e ? (e[0] == '1' ? 1 : 0) : -1;
-  }();
   if (!swizzle || tiles < 512) return 0;
-  if (forced >= 0) return forced;
   return (tiles >= 1024 && 2LL * ((long long)M * K + (long long)K * N) >= W4_INTERLEAVED_OPERANDS) ? 1 : 0;
 }
 // kernel argument `swizzle`: bit 0 block swizzle, bit 1 non-temporal C stores, bit 2 the interleaved-chunk walk

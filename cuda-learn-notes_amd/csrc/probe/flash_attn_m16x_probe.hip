@@ -48,6 +48,8 @@ int m16x_probe_run(int D, int code, const void* q, const void* k, const void* v,
   // 194..: row sums on the matrix pipe (M16X_MFMA_SUM = 524288 on top of the shipped options 5); 195: + fp32-scaled scores
   MX(64, 194, 32, 128, 8, 4, 524293) MX(128, 194, 32, 128, 4, 4, 524293) MX(64, 196, 64, 64, 4, 1, 524293) MX(64, 195, 32, 128, 8, 4, 786437) MX(128, 195, 32, 128, 4, 4, 786437)
   // 186 / 187: partial row sums by v_dot2_f32_f16 (M16X_DOT2_SUM = 1048576 on top of the shipped options 5); 187 = the 64-rows-per-wave form
+  // 188 / 189: the shipped kernels with per-wave time stamps (M16X_STAMP = 2097152 on top of the options 5; cln_probe_set_stamps first)
+  MX(64, 188, 32, 128, 8, 4, 2097157) MX(128, 188, 32, 128, 4, 4, 2097157) MX(64, 189, 64, 64, 4, 1, 2097157)
   MX(64, 186, 32, 128, 8, 4, 1048581) MX(128, 186, 32, 128, 4, 4, 1048581) MX(64, 187, 64, 64, 4, 1, 1048581)
 #undef MX
   // 150 + id: the one-wave-per-SIMD form (flash_attn_m16s.cuh: 4 waves x 64 rows), <D, BC, PD, NDEF>
@@ -70,3 +72,9 @@ int m16x_probe_run(int D, int code, const void* q, const void* k, const void* v,
 }
 
 }  // namespace fa2
+
+// device buffer (10 x 8 bytes per wave of the launch) the M16X_STAMP forms write into; NULL switches the stores off
+CLN_API int cln_probe_set_stamps(void* buf) {
+  fa2::g_m16x_stamps = reinterpret_cast<unsigned long long*>(buf);
+  return CLN_OK;
+}

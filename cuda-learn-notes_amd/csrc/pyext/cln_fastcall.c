@@ -76,6 +76,11 @@ static int tensor_info(PyObject* t, PyObject* want_dtype, long cur_dev, TInfo* o
   if (PyErr_Occurred()) goto fail;
   out->shape = PyObject_GetAttr(t, s_shape);
   if (!out->shape || !PyTuple_Check(out->shape)) { Py_CLEAR(out->shape); goto fail; }
+  /* every extent a plain int that fits a long long (symbolic sizes, overflow: slow path) -- dim() below can then never fail or leave an exception set */
+  for (Py_ssize_t i = 0; i < PyTuple_GET_SIZE(out->shape); ++i) {
+    PyObject* e = PyTuple_GET_ITEM(out->shape, i);
+    if (!PyLong_CheckExact(e) || (PyLong_AsLongLong(e) == -1 && PyErr_Occurred())) { Py_CLEAR(out->shape); goto fail; }
+  }
   return 0;
 fail:
   PyErr_Clear();
@@ -110,9 +115,14 @@ static int as_float(PyObject* o, float* out) {
 static int as_int(PyObject* o, int* out) { /* int(o): bools and ints */
   long v = PyLong_AsLong(o);
   if (v == -1 && PyErr_Occurred()) { PyErr_Clear(); return -1; }
+  if (v < INT32_MIN || v > INT32_MAX) return -1; /* the slow path's int() hands ctypes the same value and ctypes raises */
   *out = (int)v;
   return 0;
 }
+
+/* The C-ABI call runs WITHOUT the GIL: the callee may block -- workspace bookkeeping under its mutex, a hipDeviceSynchronize when a 65th
+ * stream asks for a scratch slot -- and ctypes, the path this entry replaces, released it too. */
+#define CLN_CALL(rc, expr) do { Py_BEGIN_ALLOW_THREADS (rc) = (expr); Py_END_ALLOW_THREADS } while (0) /* `expr` touches no Python object */
 
 static PyObject* fast_call(PyObject* self_, PyObject* const* args, size_t nargsf, PyObject* kwnames) {
   FastFn* self = (FastFn*)self_;
@@ -140,29 +150,35 @@ static PyObject* fast_call(PyObject* self_, PyObject* const* args, size_t nargsf
     void* stream = PyLong_AsVoidPtr(r);
     Py_DECREF(r);
     if (PyErr_Occurred()) { PyErr_Clear(); goto slow; }
+    /* extents read while the GIL is held (the calls below run without it) */
+    const long long n0 = nt > 0 ? numel_of(t[0].shape) : 0;
+    const int two_d = nt > 0 && PyTuple_GET_SIZE(t[0].shape) == 2;
+    const long long r0l = two_d ? dim(t[0].shape, 0) : 0, c0l = two_d ? dim(t[0].shape, 1) : 0;
+    if (r0l > INT32_MAX || c0l > INT32_MAX) goto slow;
+    const int r0 = (int)r0l, c0 = (int)c0l;
     switch (self->kind) {
       case K_P3:
         if (!same_shape(t[0].shape, t[1].shape) || !same_shape(t[0].shape, t[2].shape)) goto slow;
-        rc = ((fn_p3)self->fn)(t[0].ptr, t[1].ptr, t[2].ptr, numel_of(t[0].shape), stream);
+        CLN_CALL(rc, ((fn_p3)self->fn)(t[0].ptr, t[1].ptr, t[2].ptr, n0, stream));
         break;
       case K_UN:
         if (!same_shape(t[0].shape, t[1].shape)) goto slow;
-        rc = ((fn_un)self->fn)(t[0].ptr, t[1].ptr, numel_of(t[0].shape), stream);
+        CLN_CALL(rc, ((fn_un)self->fn)(t[0].ptr, t[1].ptr, n0, stream));
         break;
       case K_XY:
         if (PyTuple_GET_SIZE(t[0].shape) != 2 || !same_shape(t[0].shape, t[1].shape)) goto slow;
-        rc = ((fn_xy)self->fn)(t[0].ptr, t[1].ptr, (int)dim(t[0].shape, 0), (int)dim(t[0].shape, 1), stream);
+        CLN_CALL(rc, ((fn_xy)self->fn)(t[0].ptr, t[1].ptr, r0, c0, stream));
         break;
       case K_LN: {
         float g, b;
         if (PyTuple_GET_SIZE(t[0].shape) != 2 || !same_shape(t[0].shape, t[1].shape) || as_float(args[2], &g) || as_float(args[3], &b)) goto slow;
-        rc = ((fn_ln)self->fn)(t[0].ptr, t[1].ptr, g, b, (int)dim(t[0].shape, 0), (int)dim(t[0].shape, 1), stream);
+        CLN_CALL(rc, ((fn_ln)self->fn)(t[0].ptr, t[1].ptr, g, b, r0, c0, stream));
         break;
       }
       case K_RN: {
         float g;
         if (PyTuple_GET_SIZE(t[0].shape) != 2 || !same_shape(t[0].shape, t[1].shape) || as_float(args[2], &g)) goto slow;
-        rc = ((fn_rn)self->fn)(t[0].ptr, t[1].ptr, g, (int)dim(t[0].shape, 0), (int)dim(t[0].shape, 1), stream);
+        CLN_CALL(rc, ((fn_rn)self->fn)(t[0].ptr, t[1].ptr, g, r0, c0, stream));
         break;
       }
       case K_G3:
@@ -171,13 +187,13 @@ static PyObject* fast_call(PyObject* self_, PyObject* const* args, size_t nargsf
         const long long M = dim(t[0].shape, 0), K = dim(t[0].shape, 1), N = dim(t[1].shape, 1);
         if (M > INT32_MAX || N > INT32_MAX || K > INT32_MAX || !shape_is(t[1].shape, 2, K, N, 0, 0) || !shape_is(t[2].shape, 2, M, N, 0, 0)) goto slow;
         if (self->kind == K_G3) {
-          rc = ((fn_g3)self->fn)(t[0].ptr, t[1].ptr, t[2].ptr, (int)M, (int)N, (int)K, stream);
+          CLN_CALL(rc, ((fn_g3)self->fn)(t[0].ptr, t[1].ptr, t[2].ptr, (int)M, (int)N, (int)K, stream));
         } else {
           int stages, stride = 1, sw = 0;
           if (as_int(args[3], &stages)) goto slow;
           if (nargs > 4) { sw = PyObject_IsTrue(args[4]); if (sw < 0) { PyErr_Clear(); goto slow; } }
           if (nargs > 5 && as_int(args[5], &stride)) goto slow;
-          rc = ((fn_g6)self->fn)(t[0].ptr, t[1].ptr, t[2].ptr, (int)M, (int)N, (int)K, stages, sw, stride, stream);
+          CLN_CALL(rc, ((fn_g6)self->fn)(t[0].ptr, t[1].ptr, t[2].ptr, (int)M, (int)N, (int)K, stages, sw, stride, stream));
         }
         break;
       }
@@ -187,7 +203,7 @@ static PyObject* fast_call(PyObject* self_, PyObject* const* args, size_t nargsf
         const long long B = dim(t[0].shape, 0), H = dim(t[0].shape, 1), N = dim(t[0].shape, 2), D = dim(t[0].shape, 3);
         if (!same_shape(t[0].shape, t[1].shape) || !same_shape(t[0].shape, t[3].shape)) goto slow;
         if (!(self->vt ? shape_is(t[2].shape, 4, B, H, D, N) : same_shape(t[0].shape, t[2].shape))) goto slow;
-        rc = ((fn_fa)self->fn)(t[0].ptr, t[1].ptr, t[2].ptr, t[3].ptr, (int)B, (int)H, (int)N, (int)D, stages, stream);
+        CLN_CALL(rc, ((fn_fa)self->fn)(t[0].ptr, t[1].ptr, t[2].ptr, t[3].ptr, (int)B, (int)H, (int)N, (int)D, stages, stream));
         break;
       }
       case K_R1:
@@ -204,8 +220,8 @@ static PyObject* fast_call(PyObject* self_, PyObject* const* args, size_t nargsf
         void* yp = p ? PyLong_AsVoidPtr(p) : NULL;
         Py_XDECREF(p);
         if (!p || PyErr_Occurred()) { PyErr_Clear(); Py_CLEAR(result); goto slow; }
-        if (self->kind == K_R1) rc = ((fn_r1)self->fn)(t[0].ptr, yp, numel_of(t[0].shape), stream);
-        else rc = ((fn_p3)self->fn)(t[0].ptr, t[1].ptr, yp, numel_of(t[0].shape), stream);
+        if (self->kind == K_R1) CLN_CALL(rc, ((fn_r1)self->fn)(t[0].ptr, yp, n0, stream));
+        else CLN_CALL(rc, ((fn_p3)self->fn)(t[0].ptr, t[1].ptr, yp, n0, stream));
         break;
       }
       default: goto slow;

@@ -9,7 +9,6 @@
 // (e.g. f16x8_pack_f16 adds the 8 halves of a pack in fp16, block_all_reduce.cu:252-262);
 // everything across packs / lanes / waves is fp32 (int32 for i8), result y is fp32 / int32.
 #include "common.h"
-#include <stdlib.h>
 #include "stream_scratch.h"
 
 namespace {
@@ -127,7 +126,7 @@ struct alignas(sizeof(E) * VEC) Pack {
 // One workgroup of 1024 threads per CU at most (256 x 16 waves cover the chip's wave slots): the final
 // device-scope atomics on the single result word serialise at ~12 ns each (MI355X_MICROARCH "fanin"), so
 // the grid is capped at the CU count -- 4096 small workgroups spent 50 us in that tail alone.
-template <typename PS, int VEC, bool DEEP = false>
+template <typename PS, int VEC>
 __global__ __launch_bounds__(1024) void reduce_sum_kernel(const typename PS::elem* __restrict__ a,
                                                           typename PS::out* __restrict__ y, long long n, ClnScratch* sc) {
   using E = typename PS::elem;
@@ -139,15 +138,8 @@ __global__ __launch_bounds__(1024) void reduce_sum_kernel(const typename PS::ele
   long long i = (long long)blockIdx.x * 1024 + threadIdx.x;
   // 8 independent loads in flight per lane (round 4; 4 before): at the reference scripts' own sizes a lane owns 8-16 packs in all
   // (4096^2 f16x8: 8), so the kernel is a few round trips to HBM long and each batch of loads that has to wait for the previous one is
-  // ~1 us of a 6-8 us launch
-  if constexpr (DEEP)
-  for (; i + 15 * stride < nvec; i += 16 * stride) {  // (probe, $CLN_AMD_REDUCE_DEEP=1) sixteen loads in flight per lane
-    Pack<E, VEC> p[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) p[u] = *reinterpret_cast<const Pack<E, VEC>*>(a + (i + u * stride) * VEC);
-#pragma unroll
-    for (int u = 0; u < 16; u += 4) s0 += PS::sum(p[u].v), s1 += PS::sum(p[u + 1].v), s2 += PS::sum(p[u + 2].v), s3 += PS::sum(p[u + 3].v);
-  }
+  // ~1 us of a 6-8 us launch. Sixteen in flight was built and measured in round 5 (f32 +2-3 %, f16 -2 %, the fp8 x16
+  // instances spill 10 registers): not shipped, removed in round 6 (profiles/r05_reduce_grid_probe.log, last rows)
   for (; i + 7 * stride < nvec; i += 8 * stride) {
     Pack<E, VEC> p[8];
 #pragma unroll
@@ -201,24 +193,13 @@ int launch_reduce(const void* a, void* y, long long n, hipStream_t st) {
   if (n == 0) return hipMemsetAsync(y, 0, sizeof(typename PS::out), st) == hipSuccess ? CLN_OK : ((void)hipGetLastError(), CLN_ERR_LAUNCH);
   if (!cln_aligned(a, sizeof(E) * VEC >= 16 ? 16 : sizeof(E) * VEC)) return CLN_ERR_BAD_ARG;
   long long g = (n / VEC + 1023) / 1024;
-  // (round 5, VERDICT r4 #7 "2 x 512-thread workgroups per CU": measured through this knob -- 512 / 1024 / 2048 workgroups of 1024 threads are 6-55 % SLOWER
-  // than 256 at every size (f16 4096^2 9.2 -> 10.7 / 11.9 / 14.3 us, f32 8192^2 48.1 -> 50.9 / 52.5 / 54.2): the completion tickets grow with the grid;
-  // profiles/r05_reduce_grid_probe.log)
-  static const int cap = [] {  // workgroups at most; $CLN_AMD_REDUCE_GRID (probe knob, read once)
-    const char* e = getenv("CLN_AMD_REDUCE_GRID");
-    const int v = e ? atoi(e) : 0;
-    return v >= 1 && v <= 4096 ? v : 256;
-  }();
+  // 256 workgroups at most. 512 / 1024 / 2048 workgroups of 1024 threads measured 6-55 % SLOWER at every size (f16 4096^2 9.2 -> 10.7 / 11.9 / 14.3 us,
+  // f32 8192^2 48.1 -> 50.9 / 52.5 / 54.2): the completion tickets grow with the grid (profiles/r05_reduce_grid_probe.log)
+  constexpr int cap = 256;
   const int grid = (int)(g < 1 ? 1 : (g > cap ? cap : g));
   ClnScratch* sc = cln_stream_scratch(st);
   if (!sc && hipMemsetAsync(y, 0, sizeof(typename PS::out), st) != hipSuccess) return (void)hipGetLastError(), CLN_ERR_LAUNCH;
-  static const bool deep = [] { const char* e = getenv("CLN_AMD_REDUCE_DEEP"); return e && atoi(e) != 0; }();
-  if (deep) {
-    CLN_LAUNCH((reduce_sum_kernel<PS, VEC, true>), dim3(grid), dim3(1024), 0, st, (const E*)a, (typename PS::out*)y, n, sc);
-  } else {
-    CLN_LAUNCH((reduce_sum_kernel<PS, VEC>), dim3(grid), dim3(1024), 0, st, (const E*)a,
-               (typename PS::out*)y, n, sc);
-  }
+  CLN_LAUNCH((reduce_sum_kernel<PS, VEC>), dim3(grid), dim3(1024), 0, st, (const E*)a, (typename PS::out*)y, n, sc);
   return cln_check_launch();
 }
 

@@ -10,7 +10,6 @@
 // no table (two v_sin/v_cos per pair hide under the 8 B/pair of traffic at ~6 TB/s); the frequency (one pow per
 // column) is formed once per thread, which owns a column and walks the rows.
 #include "common.h"
-#include <stdlib.h>
 
 namespace {
 
@@ -73,9 +72,8 @@ int launch_rope(const void* x, void* out, int seq_len, int hidden, int ref_quirk
   const int gx = (half_hidden / PAIRS + 255) / 256;
   // round 5 (profiles/r05_rope_grid_probe.log): at most 16384 workgroups and at least 4 rows per thread instead of 4096 / 16 -- 8192^2 96.9 -> 90.4 us
   // (5.54 -> 5.94 TB/s), 4096 x 2048 16.6 -> 14.3 us, 64 rows 5.4 -> 3.7 us, 4096^2 26.4 -> 26.0: a thread has ONE 16-byte load in flight, so the bytes in
-  // flight are the resident waves; the pow per column unit stays cheap beside four rows of sin / cos. $CLN_AMD_ROPE_WGS / $CLN_AMD_ROPE_ROWS: probe knobs, read once.
-  static const int cap_wg = [] { const char* e = getenv("CLN_AMD_ROPE_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 16384; }();
-  static const int min_rows = [] { const char* e = getenv("CLN_AMD_ROPE_ROWS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 4; }();
+  // flight are the resident waves; the pow per column unit stays cheap beside four rows of sin / cos.
+  constexpr int cap_wg = 16384, min_rows = 4;
   int gy = cap_wg / gx;
   if (gy > (seq_len + min_rows - 1) / min_rows) gy = (seq_len + min_rows - 1) / min_rows;
   if (gy < 1) gy = 1;

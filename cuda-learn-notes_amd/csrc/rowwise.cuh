@@ -3,7 +3,6 @@
 // write per element), per-lane access width fixed by the rung name (VEC * sizeof(T) bytes).
 #pragma once
 #include "common.h"
-#include <stdlib.h>
 
 namespace rowwise {
 
@@ -39,17 +38,12 @@ constexpr int ROWS_PER_WG_DEFAULT = 1;  // measured: 1 / 2 / 4 rows per workgrou
 // needs no LDS and no barrier, so several such rows can share a workgroup: 4096 one-wave workgroups become 1024 of four waves. Built to test whether
 // the workgroup count is the 4-5 us fixed cost of the 10-15 us launches at 4096^2: it is NOT -- f16 softmax / layer-norm / rms-norm
 // 14.3 / 14.1 / 14.1 us at 1 row per workgroup, 14.6 / 13.8 / 13.9 at 4, 16.9 / 16.5 / 16.2 at 8 -- so the default stays one row per workgroup;
-// $CLN_AMD_ROWS_PER_WG = 2 / 4 / 8 / 16 selects the grouped form (read once).
-inline int rows_per_wg(int nt, int rows) {
-  static const int forced = [] {
-    const char* e = getenv("CLN_AMD_ROWS_PER_WG");
-    const int v = e ? atoi(e) : 0;
-    return (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) ? v : 0;
-  }();
+// the kernels keep `rpw` as a runtime argument (1 from every C-ABI entry point; the round-5 environment knob that set it is gone).
+inline int rows_per_wg(int nt, int rows, int want = ROWS_PER_WG_DEFAULT) {
   if (nt != 64) return 1;
-  int r = forced ? forced : ROWS_PER_WG_DEFAULT;
+  int r = want;
   while (r > 1 && rows % r) r >>= 1;  // whole workgroups only: no row guard in the kernels
-  return r;
+  return r < 1 ? 1 : r;
 }
 // position of this thread in its row group: TPR threads per row, row = first row of the workgroup + group index
 struct RowPos {

@@ -6,10 +6,9 @@
 // (overwriting it -- y no longer has to be zeroed) and leaves sum and ticket at zero for the next launch: one dispatch, no fill.
 //   * one 4-KiB slot per (device, stream): launches on one stream run in order, so they can share it; 64 slots per device, the least
 //     recently used one re-assigned after a hipDeviceSynchronize() when a 65th stream shows up (a process that cycles streams never leaks);
-//   * nullptr when the slot cannot be had without touching the device (first use or eviction while the stream is being captured, allocation
-//     failure): the caller then zeroes y on the stream (a memset node under capture) and the kernel adds into y directly, as before;
-//   * a captured launch holds its capture stream's slot: replay graphs on the capture stream (include/cln_amd.h, workspace notes); such a slot is
-//     pinned -- never re-assigned to another stream -- until cln_release_workspaces().
+//   * nullptr while the stream is being captured (ALWAYS, round 6: a graph must not carry mutable library state -- replays run on any stream, next
+//     to eager launches and to each other) and on allocation failure: the caller then zeroes y on the stream (a memset node under capture) and the
+//     kernel adds into y directly, as the reference does.
 #pragma once
 #include "common.h"
 

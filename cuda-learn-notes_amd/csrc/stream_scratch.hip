@@ -8,7 +8,6 @@ constexpr int SLOTS = 64, MAX_DEV = 64;
 struct Slot {
   hipStream_t stream = nullptr;
   bool live = false;
-  bool pinned = false;  // a stream capture has used the slot: a graph holds its address, it is never re-assigned (until cln_release_workspaces)
   unsigned long long used = 0;
 };
 struct DevSlab {
@@ -29,16 +28,16 @@ bool capturing(hipStream_t st) {
 ClnScratch* cln_stream_scratch(hipStream_t stream) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return (void)hipGetLastError(), nullptr;
+  // A captured launch NEVER gets a slot (round 6): a graph replays on whatever stream is current, so a slot baked into it could be hit by an
+  // eager launch of its capture stream -- or by a second replay -- at the same time, and a lost or doubled ticket never recovers. The caller's
+  // fallback (memset node + one atomicAdd per block into y) has no state outside the call.
+  if (capturing(stream)) return nullptr;
   std::lock_guard<std::mutex> lock(g_mu);
   DevSlab& d = g_slab[dev];
   if (d.p) {
     for (int i = 0; i < SLOTS; ++i)
-      if (d.slot[i].live && d.slot[i].stream == stream) {
-        if (!d.slot[i].pinned && capturing(stream)) d.slot[i].pinned = true;
-        return d.slot[i].used = ++g_clock, d.p + i;
-      }
+      if (d.slot[i].live && d.slot[i].stream == stream) return d.slot[i].used = ++g_clock, d.p + i;
   }
-  if (capturing(stream)) return nullptr;  // nothing below may run during a capture
   if (!d.p) {
     ClnScratch* fresh = nullptr;
     if (hipMalloc(&fresh, sizeof(ClnScratch) * SLOTS) != hipSuccess || hipMemset(fresh, 0, sizeof(ClnScratch) * SLOTS) != hipSuccess) {
@@ -53,8 +52,7 @@ ClnScratch* cln_stream_scratch(hipStream_t stream) {
     if (!d.slot[i].live) pick = i;
   if (pick < 0) {  // all 64 in use: take the least recently used one once everything queued on the device is done (its last launch left it zeroed)
     for (int i = 0; i < SLOTS; ++i)
-      if (!d.slot[i].pinned && (pick < 0 || d.slot[i].used < d.slot[pick].used)) pick = i;
-    if (pick < 0) return nullptr;  // every slot belongs to a captured graph: the caller's zero-fill path
+      if (pick < 0 || d.slot[i].used < d.slot[pick].used) pick = i;
     if (hipDeviceSynchronize() != hipSuccess) return (void)hipGetLastError(), nullptr;
   }
   d.slot[pick].stream = stream, d.slot[pick].live = true, d.slot[pick].used = ++g_clock;

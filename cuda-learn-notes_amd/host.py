@@ -11,6 +11,7 @@ Reference bindings mirrored (checks and messages):
   head-dim switch default  -> RuntimeError("headdim not support!")           flash_attn_mma_share_qkv.cu:860,:882
 """
 import os
+import threading
 import types
 
 import torch
@@ -155,7 +156,24 @@ def _make_g6(name, dtype=torch.float16):
                         int(swizzle_stride), _stream()),
                "%s: M/N/K must be multiples of the block tile" % name)
     f.__name__ = name
-    return _fast("G6", name, fn, f, dtype)
+    call = _fast("G6", name, fn, f, dtype)
+    if not manifest.BY_NAME[name].impl.startswith("best<"):
+        return call
+
+    # the run-time dispatched names may split K: the stream's workspace is a tensor of torch's caching allocator, handed to the library before
+    # the launch (the library itself never allocates: include/cln_amd.h, workspace block)
+    def g(a, b, c, stages, swizzle=False, swizzle_stride=1):
+        try:
+            need = _ws_need[(a.shape[0], b.shape[1], a.shape[1])]
+        except KeyError:
+            need = _ws_need_of(a.shape[0], b.shape[1], a.shape[1])
+        except Exception:  # noqa: BLE001 -- not tensors / wrong rank: the wrapper below raises the reference's error
+            need = 0
+        if need:
+            _ensure_workspace(need)
+        return call(a, b, c, stages, swizzle, swizzle_stride)
+    g.__name__ = name
+    return g
 
 
 def _make_h0(name):
@@ -433,7 +451,16 @@ def load_lib(*groups):
 
 
 # ---- split-K workspace of the best-dispatch HGEMM names (include/cln_amd.h; not part of the reference surface) -----------------------------
-_user_workspaces = {}  # (device, raw stream) -> the torch tensor handed to the library: kept alive here until it is withdrawn
+# Round 6 ("no hidden workspace"): the LIBRARY owns nothing. Every (device, stream) that runs a split-K shape through this module gets
+# ONE uint8 tensor from torch's caching allocator (allocated on that stream, so its lifetime follows torch's stream semantics), registered with
+# cln_hgemm_set_workspace and grown when a larger shape shows up. At most _WS_MAX of them are kept (least recently used withdrawn first); one that a
+# stream capture has used is pinned -- the graph holds its address -- until release_workspaces(). A tensor the CALLER registered
+# (hgemm_set_workspace) is never replaced or evicted.
+_WS_MAX = 8
+_ws_need = {}     # (M, N, K) -> bytes the plan of the shape uses (0: single-pass)
+_workspaces = {}  # (device, raw stream) -> [tensor, bytes, user, pinned, clock]
+_ws_clock = 0
+_ws_lock = threading.Lock()  # two host threads on one stream: one of them registers the tensor, the other finds it
 
 
 def hgemm_workspace_bytes(M, N, K):
@@ -441,31 +468,92 @@ def hgemm_workspace_bytes(M, N, K):
     return int(_loader.load_so("libcln_amd.so").cln_hgemm_workspace_bytes(int(M), int(N), int(K)))
 
 
+def _ws_need_of(M, N, K):
+    need = _ws_need[(M, N, K)] = hgemm_workspace_bytes(M, N, K)
+    if len(_ws_need) > 4096:
+        _ws_need.clear()
+    return need
+
+
+def _ws_withdraw(key):
+    lib = _loader.load_so("libcln_amd.so")
+    with torch.cuda.device(key[0]):
+        lib.cln_hgemm_set_workspace(None, 0, key[1])
+    _workspaces.pop(key, None)
+
+
+def _ensure_workspace(need):
+    """The current stream's workspace holds at least `need` bytes after this call -- or the launch runs single-pass (growth is not allowed while
+    the stream is being captured: an allocation made under capture belongs to the graph's private pool)."""
+    global _ws_clock
+    key = (_current_device(), _stream())
+    ent = _workspaces.get(key)
+    _ws_clock += 1
+    if ent is not None and (ent[1] >= need or ent[2]):
+        ent[4] = _ws_clock
+        if not ent[3] and torch.cuda.is_current_stream_capturing():
+            ent[3] = True
+        return
+    with _ws_lock:
+        _grow_workspace(key, need)
+
+
+def _grow_workspace(key, need):
+    ent = _workspaces.get(key)
+    if ent is not None and (ent[1] >= need or ent[2]):
+        return
+    if torch.cuda.is_current_stream_capturing() or (ent is not None and ent[3]):
+        return
+    if ent is None:
+        free = [k for k, e in _workspaces.items() if not e[2] and not e[3]]
+        while len(free) >= _WS_MAX:
+            lru = min(free, key=lambda k: _workspaces[k][4])
+            free.remove(lru)
+            _ws_withdraw(lru)
+    size = max(16 << 20, (need + (2 << 20) - 1) // (2 << 20) * (2 << 20))  # whole 2-MiB pages of the caching allocator, 16 MiB at least (few regrowths)
+    buf = torch.empty(size, dtype=torch.uint8, device="cuda:%d" % key[0])
+    lib = _loader.load_so("libcln_amd.so")
+    _raise("cln_hgemm_set_workspace", lib.cln_hgemm_set_workspace(buf.data_ptr(), size, key[1]))
+    _workspaces[key] = [buf, size, False, False, _ws_clock]  # the old tensor (if any) goes back to the allocator: launches queued on ITS stream run before any reuse
+
+
 def hgemm_set_workspace(buf):
     """Give the launches on torch's CURRENT stream a caller-owned workspace: `buf` is a contiguous GPU tensor (any dtype; e.g.
-    torch.empty(nbytes, dtype=torch.uint8, device="cuda") from torch's caching allocator, so its lifetime follows torch's stream semantics),
-    or None to go back to the library-owned one. The library zeroes the first 4 KiB on the stream; shapes that need more than the buffer
-    holds run single-pass."""
+    torch.empty(nbytes, dtype=torch.uint8, device="cuda")), or None to go back to the one this module keeps per stream. The library zeroes the
+    first 4 KiB on the stream; shapes that need more than the buffer holds run single-pass."""
     lib = _loader.load_so("libcln_amd.so")
     key = (_current_device(), _stream())
     if buf is None:
         _raise("cln_hgemm_set_workspace", lib.cln_hgemm_set_workspace(None, 0, key[1]))
-        _user_workspaces.pop(key, None)
+        _workspaces.pop(key, None)
         return
     _check_dev(buf)
-    _raise("cln_hgemm_set_workspace", lib.cln_hgemm_set_workspace(buf.data_ptr(), buf.numel() * buf.element_size(), key[1]))
-    _user_workspaces[key] = buf
+    nbytes = buf.numel() * buf.element_size()
+    _raise("cln_hgemm_set_workspace", lib.cln_hgemm_set_workspace(buf.data_ptr(), nbytes, key[1]))
+    _workspaces[key] = [buf, nbytes, True, False, _ws_clock]
 
 
 def release_workspaces():
-    """Free every library-owned workspace / scratch slab (after the launches that use them have completed); returns the bytes freed."""
-    _user_workspaces.clear()
+    """Withdraw every workspace this module registered (their tensors go back to torch's allocator), and free what the library itself holds: the
+    scalar-result kernels' ticket slabs and -- after cln_hgemm_library_workspace(1) only -- library-owned split-K buffers. Returns the bytes the
+    LIBRARY freed. Call it only when no graph that captured a split-K launch will be replayed again."""
+    _workspaces.clear()
     return int(_loader.load_so("libcln_amd.so").cln_release_workspaces())
 
 
 def hgemm_workspace_held():
-    """Bytes of library-owned split-K workspace this process currently holds."""
+    """Bytes of LIBRARY-owned split-K workspace this process currently holds (0 unless cln_hgemm_library_workspace(1) was called)."""
     return int(_loader.load_so("libcln_amd.so").cln_hgemm_workspace_held())
+
+
+def hgemm_workspace_tensors():
+    """(device, raw stream) -> bytes of the workspace tensors this module currently keeps registered (torch-owned)."""
+    return {k: e[1] for k, e in _workspaces.items()}
+
+
+def hgemm_library_workspace(enable):
+    """C callers' opt-in to library-owned (hipMalloc) workspaces; this module never needs it. Returns the previous setting."""
+    return bool(_loader.load_so("libcln_amd.so").cln_hgemm_library_workspace(int(bool(enable))))
 
 
 def hgemm_variant(kind, layout, tile, bk, stages, a, b, c, swizzle=0, swizzle_stride=1):

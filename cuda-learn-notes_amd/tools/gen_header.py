@@ -84,7 +84,11 @@ def main():
                " * Conventions: plain pointers to DEVICE memory, sizes as int / long long, `stream` is a hipStream_t\n"
                " * passed as void* (NULL = default stream). Every function returns 0 on success or\n"
                " *   -1 bad argument, -2 unsupported shape, -3 HIP launch error, -4 vendor-library error.\n"
-               " * Launches are asynchronous on `stream`; the callee never allocates or keeps pointers.\n"
+               " * Launches are asynchronous on `stream`. The callee allocates no device memory for the data path and keeps no pointer of the\n"
+               " * caller's, with two stated exceptions: (1) the split-K workspace a caller REGISTERS per stream (cln_hgemm_set_workspace, end of\n"
+               " * this file; library-owned buffers exist only after cln_hgemm_library_workspace(1)); (2) one 256-KiB slab per device of 4-KiB\n"
+               " * ticket slots for the scalar-result kernels (block_all_reduce_sum_*, dot_prod_*), hipMalloc'ed on their first eager call and\n"
+               " * freed by cln_release_workspaces(); captured launches never touch it.\n"
                " */\n#ifndef CLN_AMD_H\n#define CLN_AMD_H\n#ifdef __cplusplus\nextern \"C\" {\n#endif\n#include <stddef.h>\n")
     out.append("#define CLN_OK 0\n#define CLN_ERR_BAD_ARG (-1)\n#define CLN_ERR_UNSUPPORTED (-2)\n"
                "#define CLN_ERR_LAUNCH (-3)\n#define CLN_ERR_VENDOR (-4)\n")
@@ -107,22 +111,28 @@ def main():
                " * only a, b, c -- kernels/hgemm/mma/basic/hgemm_mma_stage.cu:2380-2413 -- and never need one). Shapes with few output tiles and a\n"
                " * long K (and the last tile rows of a tile count just past whole rounds of 256) are split over K; the fp32 partials live in ONE\n"
                " * workspace per (device, stream): 4 KiB of arrival counters + S*M*N floats.\n"
-               " *   default         library-owned: allocated on first use (never during stream capture: such a launch runs single-pass), grown by\n"
-               " *                   doubling up to 256 MiB, at most 8 held per process (least recently used freed first, after its last launch has\n"
-               " *                   completed), all freed by cln_release_workspaces().\n"
-               " *   caller-owned    cln_hgemm_set_workspace(ptr, bytes, stream): the library never allocates for that stream; size it with\n"
-               " *                   cln_hgemm_workspace_bytes(M, N, K) (0 = the shape runs single-pass); a shape that needs more runs single-pass.\n"
-               " *                   The first 4 KiB are zeroed on `stream` by the call; keep the region alive and untouched while launches are queued.\n"
+               " *   default         NONE: the library never allocates. A stream that was given no region runs every shape single-pass.\n"
+               " *   caller-owned    cln_hgemm_set_workspace(ptr, bytes, stream): size it with cln_hgemm_workspace_bytes(M, N, K) (0 = the shape runs\n"
+               " *                   single-pass anyway); a shape that needs more than `bytes` runs single-pass. The first 4 KiB are zeroed on `stream` by\n"
+               " *                   the call; keep the region alive and untouched while launches are queued; ptr = NULL withdraws it. (host.py does this\n"
+               " *                   for every stream with one tensor from torch's caching allocator.)\n"
+               " *   library-owned   opt-in, cln_hgemm_library_workspace(1), for callers without an allocator of their own: allocated with hipMalloc on a\n"
+               " *                   stream's first split-K shape (never during stream capture: such a launch runs single-pass), 4 KiB + a power of two\n"
+               " *                   from 16 to 256 MiB, at most 8 held per process (least recently used freed first, after its last launch has completed),\n"
+               " *                   all freed by cln_release_workspaces().\n"
                " * Threads: calls are serialised per process while a workspace is in use (the lock covers the 1-2 launches of a split-K call), so two\n"
-               " * host threads may call hgemm on one stream. Graphs: a captured launch holds the pointer of the workspace its capture stream had;\n"
-               " * a library-owned workspace that a capture has used is pinned (never evicted or regrown; freed by cln_release_workspaces() only);\n"
-               " * replay the graph on the capture stream, or give every graph its own caller-owned region. A shape's result does not depend on\n"
-               " * whose workspace is used, but it differs in the last bit from the single-pass plan (fp32 summation order), so eager and captured\n"
-               " * runs of a split-K shape on a stream WITHOUT a workspace are not bit-identical ($CLN_AMD_NO_SPLITK=1 forces single-pass everywhere). */")
+               " * host threads may call hgemm on one stream. Graphs: a captured launch holds the pointer of the workspace its capture stream had and\n"
+               " * always takes the partial + reduce form (no arrival counters: nothing in the region outlives the call). Do not replay such a graph\n"
+               " * CONCURRENTLY with other work that uses the same region (another replay, or eager split-K calls on the capture stream): the partials\n"
+               " * of the two would mix -- give every graph that must overlap its own caller-owned region. A library-owned workspace that a capture has\n"
+               " * used is pinned (never evicted or regrown; freed by cln_release_workspaces() only). A shape's result does not depend on whose\n"
+               " * workspace is used, but it differs in the last bit from the single-pass plan (fp32 summation order), so runs of a split-K shape with\n"
+               " * and WITHOUT a workspace are not bit-identical ($CLN_AMD_NO_SPLITK=1, the library's only environment variable, forces single-pass everywhere). */")
     out.append("size_t cln_hgemm_workspace_bytes(int M, int N, int K);")
     out.append("int cln_hgemm_set_workspace(void* ptr, size_t bytes, void* stream);")
     out.append("size_t cln_release_workspaces(void);   /* returns the bytes freed */")
     out.append("size_t cln_hgemm_workspace_held(void); /* library-owned bytes currently held */")
+    out.append("int cln_hgemm_library_workspace(int enable); /* returns the previous setting (default 0) */")
     out.append("\n#ifdef __cplusplus\n}\n#endif\n#endif /* CLN_AMD_H */\n")
     path = os.path.join(ROOT, "include", "cln_amd.h")
     os.makedirs(os.path.dirname(path), exist_ok=True)

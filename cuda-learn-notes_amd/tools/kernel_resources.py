@@ -176,6 +176,42 @@ def asm_mfma_operand_hazards(asm_text, mangled_name):
     return problems
 
 
+def asm_inflight_load_hazards(asm_text, mangled_name, load_re=r"global_load_dwordx4 .* sc1"):
+    """Loads issued from INLINE ASM with an "=v" output (csrc/hgemm_w4.cuh, the split-K fix-up's agent-scope loads): the compiler regards the output as
+    defined right behind the asm statement although the data lands only at the later `s_waitcnt vmcnt(0)` (a separate asm statement) -- a copy or a
+    spill of the destination placed between the two would read registers the load has not filled yet. Walks every kernel body: from each
+    matching load to the next `s_waitcnt` whose vmcnt is 0, no instruction other than another load may name one of its destination registers.
+    Returns the offending (load, instruction) pairs."""
+    m = re.search(r"^%s:" % re.escape(mangled_name), asm_text, re.M)
+    if not m:
+        return ["kernel not found: " + mangled_name]
+    body = asm_text[m.end():asm_text.index("s_endpgm", m.end())]
+    ins = [ln.split(";")[0].strip() for ln in body.split("\n")]
+    ins = [i for i in ins if i and not i.startswith(".")]
+    problems, seen = [], 0
+    for k, i in enumerate(ins):
+        if not re.match(load_re, i):
+            continue
+        seen += 1
+        dst = _vregs(i.split(None, 1)[1].split(",")[0])
+        for j in range(k + 1, len(ins)):
+            p = ins[j]
+            if p.startswith("s_waitcnt") and ("vmcnt(0)" in p or re.fullmatch(r"s_waitcnt 0x?0*", p) or p.strip() == "s_waitcnt lgkmcnt(0) vmcnt(0)"):
+                break
+            if p.endswith(":") or p.startswith("s_cbranch") or p.startswith("s_branch"):
+                problems.append((i, "control flow before the wait: " + p))
+                break
+            if re.match(load_re, p):
+                continue
+            toks = p.split(None, 1)
+            regs = set()
+            for t in (toks[1].split(", ") if len(toks) > 1 else []):
+                regs |= _vregs(t.split(" ")[0])
+            if regs & dst:
+                problems.append((i, p))
+    return problems if seen else ["no load matching %r in %s" % (load_re, mangled_name)]
+
+
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     keep = None

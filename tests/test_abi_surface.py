@@ -39,7 +39,7 @@ def test_header_declares_manifest_and_libs_export_it(built):
     hdr = open(os.path.join(ROOT, "include", "cln_amd.h")).read()
     declared = re.findall(r"^int (\w+)\(", hdr, flags=re.M)
     assert len(declared) == len(set(declared))
-    names = {e.name for e in built.manifest.ENTRIES} | {"cln_describe", "cln_stages_honoured", "cln_hgemm_set_workspace"}
+    names = {e.name for e in built.manifest.ENTRIES} | {"cln_describe", "cln_stages_honoured", "cln_hgemm_set_workspace", "cln_hgemm_library_workspace"}
     assert set(declared) == names
     from cuda_learn_notes_amd import _loader
     main = ctypes.CDLL(_loader.so_path("libcln_amd.so"))
@@ -50,7 +50,7 @@ def test_header_declares_manifest_and_libs_export_it(built):
     assert hasattr(main, "cln_describe") and hasattr(main, "cln_stages_honoured")
     # the split-K workspace entry points (round 5): declared in the header and exported
     ws_api = re.findall(r"^(?:size_t|int) (cln_\w*workspace\w*)\(", hdr, flags=re.M)
-    assert sorted(ws_api) == ["cln_hgemm_set_workspace", "cln_hgemm_workspace_bytes", "cln_hgemm_workspace_held", "cln_release_workspaces"]
+    assert sorted(ws_api) == ["cln_hgemm_library_workspace", "cln_hgemm_set_workspace", "cln_hgemm_workspace_bytes", "cln_hgemm_workspace_held", "cln_release_workspaces"]
     for n in ws_api:
         assert hasattr(main, n), n
     # tuning / ablation hooks (some produce garbage by design) must not be reachable from the product library
@@ -128,3 +128,23 @@ def test_optional_comparison_rows_may_be_absent_from_the_vendor_library(built, m
     assert hasattr(lib, "hgemm_cublas_tensor_op_nn") and hasattr(lib, "hgemm_mma_m16n8k16_naive")
     assert not hasattr(lib, "cln_hgemm_hipblaslt_nn")
     assert set(built.manifest.OPTIONAL_LIBS) == {"hgemm_vendor_lt", "fa2_vendor_ck"}
+
+
+def test_product_library_reads_one_documented_environment_variable(built):
+    """round 5 shipped eight getenv() tuning knobs in libcln_amd.so that changed the launched kernels behind the C-ABI with no test
+    on their non-default values. Round 6: the product library reads ONE variable, $CLN_AMD_NO_SPLITK (documented in include/cln_amd.h and
+    INTEGRATION.md); probe switches live in csrc/probe/ / libcln_amd_probe.so. Checked on the BUILT library (every CLN_AMD_* string in it) and on the
+    product sources (every getenv call)."""
+    import glob
+    from cuda_learn_notes_amd import _loader
+    allow = {b"CLN_AMD_NO_SPLITK"}
+    blob = open(_loader.so_path("libcln_amd.so"), "rb").read()
+    assert set(re.findall(rb"CLN_AMD_[A-Z0-9_]+", blob)) == allow
+    csrc = os.path.join(ROOT, "cuda-learn-notes_amd", "csrc")
+    calls = []
+    for path in glob.glob(os.path.join(csrc, "*")):
+        if os.path.isfile(path) and not os.path.basename(path).startswith(("hgemm_vendor", "fa2_vendor")):
+            calls += [(os.path.basename(path), m) for m in re.findall(r'getenv\("(\w+)"\)', open(path, errors="replace").read())]
+    assert calls == [("hgemm.hip", "CLN_AMD_NO_SPLITK")], calls
+    hdr = open(os.path.join(ROOT, "include", "cln_amd.h")).read()
+    assert "CLN_AMD_NO_SPLITK" in hdr and set(re.findall(r"CLN_AMD_[A-Z0-9_]+", hdr)) <= {"CLN_AMD_NO_SPLITK", "CLN_AMD_H"}

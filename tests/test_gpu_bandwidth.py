@@ -347,6 +347,39 @@ def test_reduce_and_dot_overwrite_their_result(lib, built, dev, oracle):
         assert abs(got.item() - want) <= 1e-3 * max(1.0, abs(want)) + 1e-2
 
 
+def test_captured_reduce_carries_no_library_state_replay_overlaps_eager_launches(lib, dev, oracle):
+    """a stream that ALREADY owns a scratch slot is captured. The graph must not bake that slot in -- torch replays on the
+    current stream, so a replay can overlap eager launches of the capture stream (or another replay), and a lost or doubled ticket in a shared slot
+    never recovers. Round 6: a captured launch always takes the memset + atomicAdd form. Warm up on s, capture on s, then replay on a SECOND stream
+    while eager launches run on s: every result right, and the eager path of s still right afterwards."""
+    g = torch.Generator().manual_seed(16)
+    xs = [torch.randn(1 << 20, generator=g) for _ in range(2)]
+    xd = [x.to(dev) for x in xs]
+    exact = [oracle.reduce_sum(x) for x in xs]
+    tol = [1e-3 * max(1.0, abs(e)) + 1e-2 for e in exact]
+    s, other = torch.cuda.Stream(), torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            assert abs(lib.block_all_reduce_sum_f32x4_f32(xd[0]).item() - exact[0]) <= tol[0]  # s owns a slot now
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            y = lib.block_all_reduce_sum_f32x4_f32(xd[1])
+    torch.cuda.synchronize()
+    eager = []
+    for rnd in range(50):
+        with torch.cuda.stream(other):
+            graph.replay()
+            got = y.clone()
+        with torch.cuda.stream(s):
+            eager.append(lib.block_all_reduce_sum_f32x4_f32(xd[0]))
+        other.synchronize()
+        assert abs(got.item() - exact[1]) <= tol[1], rnd
+    torch.cuda.synchronize()
+    assert all(abs(e.item() - exact[0]) <= tol[0] for e in eager)
+    with torch.cuda.stream(s):
+        assert abs(lib.block_all_reduce_sum_f32x4_f32(xd[0]).item() - exact[0]) <= tol[0]
+
+
 def test_reduce_under_stream_capture_takes_the_memset_path(lib, dev, oracle):
     """No scratch slot may be allocated while a stream is being captured: a stream without one zeroes y with a memset node and adds into it
     directly; replays give the same sum."""

@@ -1,8 +1,9 @@
 """GPU parity: every FlashAttention-2 forward entry point through the C-ABI vs the fp64 CPU oracle and
 the golden fixture produced by the reference's own unfused_standard_attn.
 Tolerance: the reference's `--check` uses allclose(atol=1e-2) and expects max diff < ~1e-3
-(flash_attn_mma.py:421, README.md:89); we assert max |O - O_fp64| <= 3e-3 on N(0,1) inputs
-(P is rounded to fp16 before the second GEMM, output rounded to fp16)."""
+(flash_attn_mma.py:421, README.md:89); round 6 ("3e-3 is ~7 % of a typical output at N = 2048"): the bound follows
+the output's scale -- fa_tol(ref) below, fitted with >= 1.3x margin on profiles/r06_fa_tol_calibration.log (head dims 32 ... 1024, N 64 ... 4096,
+N(0,1) inputs and keys amplified 4x; tools/fa_tol_calibrate.py): 1.2e-3 at config C4, 5e-4 at C5."""
 import os
 
 import numpy as np
@@ -10,7 +11,22 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
-TOL = 3e-3
+
+
+def fa_tol(ref):
+    """max |O - O_ref| allowed for the kernels behind the PLAIN names at D <= 128 (Q * log2(e)/sqrt(d) rounded to fp16 once; P and O rounded to fp16):
+    2^-9 max|O_ref| + 4e-4, never more than the old flat amplified-key bound 6e-3. Measured worst case / bound: 0.73 on N(0,1) inputs (1.26e-3 at
+    N = D = 128, where max|O| = 1.09), 0.80 on keys amplified 4x (4.8e-3 at max|O| = 5.1). The reference's own --check: atol 1e-2 (flash_attn_mma.py:421)."""
+    return min(2.0 ** -9 * float(ref.abs().max()) + 4e-4, TOL_AMPLIFIED_KEYS)
+
+
+def fa_tol_f32(ref):
+    """The same for the kernels that scale the scores in fp32 (the *_acc_f32 names, the split-KV rung, every name at D >= 256): 2^-10 max|O_ref| + 2e-4,
+    never more than 3e-3 (the flat bound of rounds 1-5). Measured worst case / bound: 0.56 (N(0,1): 7.2e-4 at D = 512; keys x4: 2.3e-3 at max|O| = 4)."""
+    return min(2.0 ** -10 * float(ref.abs().max()) + 2e-4, TOL)
+
+
+TOL = 3e-3  # the cap of fa_tol_f32; no test compares against it directly any more
 # Inputs with AMPLIFIED keys (|k| up to 4-6x a N(0,1) row: the rescale-regime tests) on kernels that run with the
 # pre-scaled Q (OPT_PRE, D <= 128): Q * log2(e)/sqrt(d) is rounded to fp16 once, so a score carries a relative error of
 # 2^-11 per term and |delta s| grows with |k| (measured 3.9e-3 max on O where the unscaled kernel has 2e-3). Still inside
@@ -48,7 +64,7 @@ def test_golden_fixture(fa, built, dev):
     for stages in (1, 2):
         o = run(fa, built, "flash_attn_mma_stages_split_q_shared_qkv", q, k, v, stages, dev)
         assert torch.allclose(o.float(), ref, atol=1e-2)
-        assert (o.float() - ref).abs().max() <= TOL
+        assert (o.float() - ref).abs().max() <= fa_tol(ref)
 
 
 def all_names(built):
@@ -63,7 +79,7 @@ def test_every_entry_point(fa, built, dev, oracle):
         for stages in (1, 2):
             o = run(fa, built, name, q, k, v, stages, dev)
             err = (o.double() - ref).abs().max().item()
-            assert err <= TOL, (name, stages, err)
+            assert err <= fa_tol(ref), (name, stages, err)
 
 
 @pytest.mark.parametrize("D", [32, 64, 96, 128, 256])
@@ -76,7 +92,7 @@ def test_head_dims(fa, built, dev, oracle, name, D):
     ref = oracle.attention_fp64(q, k, v)
     for stages in (1, 2):
         o = run(fa, built, name, q, k, v, stages, dev)
-        assert (o.double() - ref).abs().max().item() <= TOL
+        assert (o.double() - ref).abs().max().item() <= (fa_tol_f32(ref) if D >= 256 else fa_tol(ref))
 
 
 @pytest.mark.parametrize("D", [320, 384, 512, 640, 768, 1024])
@@ -86,7 +102,7 @@ def test_large_head_dims_tiling(fa, built, dev, oracle, D):
     ref = oracle.attention_fp64(q, k, v)
     for name in ("flash_attn_mma_stages_split_q_tiling_qk", "flash_attn_mma_stages_split_q_tiling_qkv_acc_f32"):
         o = run(fa, built, name, q, k, v, 1, dev)
-        assert (o.double() - ref).abs().max().item() <= TOL, name
+        assert (o.double() - ref).abs().max().item() <= fa_tol_f32(ref), name
 
 
 @pytest.mark.parametrize("D", [320, 384, 512, 640, 768, 1024])
@@ -103,7 +119,7 @@ def test_stages_one_above_d256_is_the_single_stage_form_of_the_same_kernel(fa, b
         ref = oracle.attention_fp64(q, k, v)
         o1 = run(fa, built, name, q, k, v, 1, dev)
         o2 = run(fa, built, name, q, k, v, 2, dev)
-        assert (o1.double() - ref).abs().max().item() <= TOL
+        assert (o1.double() - ref).abs().max().item() <= fa_tol_f32(ref)
         assert torch.equal(o1, o2)
 
 
@@ -115,7 +131,7 @@ def test_d512_dsplit_kernel_shapes(fa, built, dev, oracle, B, H, N):
     ref = oracle.attention_fp64(q, k, v)
     for name in ("flash_attn_mma_stages_split_q_tiling_qkv", "flash_attn_mma_stages_split_q_tiling_qk_swizzle_q"):
         o = run(fa, built, name, q, k, v, 2, dev)
-        assert (o.double() - ref).abs().max().item() <= TOL, name
+        assert (o.double() - ref).abs().max().item() <= fa_tol_f32(ref), name
 
 
 @pytest.mark.parametrize("B,H,N", [(2, 96, 256), (1, 24, 2048), (3, 8, 2048)])
@@ -127,7 +143,7 @@ def test_d256_pingpong_kernel_shapes(fa, built, dev, oracle, B, H, N):
     o = run(fa, built, "flash_attn_mma_stages_split_q_shared_qkv", q, k, v, 2, dev)
     for (b, h) in ((0, 0), (B - 1, H - 1), (B // 2, H // 3)):
         ref = oracle.attention_fp64(q[b:b + 1, h:h + 1], k[b:b + 1, h:h + 1], v[b:b + 1, h:h + 1])
-        assert (o[b:b + 1, h:h + 1].double() - ref).abs().max().item() <= TOL, (b, h)
+        assert (o[b:b + 1, h:h + 1].double() - ref).abs().max().item() <= fa_tol_f32(ref), (b, h)
 
 
 @pytest.mark.parametrize("B,H,N", [(2, 96, 256), (1, 24, 2048), (3, 8, 2048), (1, 7, 8192)])
@@ -137,7 +153,7 @@ def test_d128_pingpong_kernel_shapes(fa, built, dev, oracle, B, H, N):
     o = run(fa, built, "flash_attn_mma_stages_split_q_shared_qkv", q, k, v, 2, dev)
     for (b, h) in ((0, 0), (B - 1, H - 1), (B // 2, H // 3)):
         ref = oracle.attention_fp64(q[b:b + 1, h:h + 1], k[b:b + 1, h:h + 1], v[b:b + 1, h:h + 1])
-        assert (o[b:b + 1, h:h + 1].double() - ref).abs().max().item() <= TOL, (b, h)
+        assert (o[b:b + 1, h:h + 1].double() - ref).abs().max().item() <= fa_tol(ref), (b, h)
 
 
 @pytest.mark.parametrize("B,H,N", [(2, 96, 256), (4, 8, 2048), (1, 7, 8192)])
@@ -148,7 +164,7 @@ def test_d64_pingpong_kernel_shapes(fa, built, dev, oracle, B, H, N):
     o = run(fa, built, "flash_attn_mma_stages_split_q_shared_qkv", q, k, v, 2, dev)
     for (b, h) in ((0, 0), (B - 1, H - 1), (B // 2, H // 3)):
         ref = oracle.attention_fp64(q[b:b + 1, h:h + 1], k[b:b + 1, h:h + 1], v[b:b + 1, h:h + 1])
-        assert (o[b:b + 1, h:h + 1].double() - ref).abs().max().item() <= TOL, (b, h)
+        assert (o[b:b + 1, h:h + 1].double() - ref).abs().max().item() <= fa_tol(ref), (b, h)
 
 
 @pytest.mark.parametrize("D", [640, 768, 1024])
@@ -160,7 +176,7 @@ def test_d640_d768_d1024_ring_kernel_shapes(fa, built, dev, oracle, D, B, H, N):
     q, k, v = seeded(61, B, H, N, D), seeded(62, B, H, N, D), seeded(63, B, H, N, D)
     ref = oracle.attention_fp64(q, k, v)
     o = run(fa, built, "flash_attn_mma_stages_split_q_tiling_qkv", q, k, v, 2, dev)
-    assert (o.double() - ref).abs().max().item() <= TOL
+    assert (o.double() - ref).abs().max().item() <= fa_tol_f32(ref)
 
 
 @pytest.mark.parametrize("D,N", [(320, 128), (320, 640), (384, 384), (384, 1152), (640, 64), (640, 320)])
@@ -172,7 +188,7 @@ def test_padded_head_dims(fa, built, dev, oracle, D, N):
     q, k, v = seeded(71, B, H, N, D), seeded(72, B, H, N, D), seeded(73, B, H, N, D)
     ref = oracle.attention_fp64(q, k, v)
     o = run(fa, built, "flash_attn_mma_stages_split_q_tiling_qkv", q, k, v, 2, dev)
-    assert (o.double() - ref).abs().max().item() <= TOL
+    assert (o.double() - ref).abs().max().item() <= fa_tol_f32(ref)
 
 
 def test_d512_rejects_ragged_seqlen(fa, dev):
@@ -202,7 +218,7 @@ def test_workgroup_shapes_by_seqlen(fa, built, dev, oracle, N, D):
     ref = oracle.attention_fp64(q, k, v)
     for name in ("flash_attn_mma_stages_split_q", "flash_attn_mma_stages_split_q_shared_kv_swizzle_qkv"):
         o = run(fa, built, name, q, k, v, 2, dev)
-        assert (o.double() - ref).abs().max().item() <= TOL, (name, N, D)
+        assert (o.double() - ref).abs().max().item() <= fa_tol(ref), (name, N, D)
 
 
 @pytest.mark.parametrize("B,H,N,D", [(4, 8, 2048, 128), (2, 8, 2048, 64), (1, 8, 2048, 32), (2, 16, 1024, 96),
@@ -220,7 +236,7 @@ def test_workgroup_size_heuristic_covers_8_4_2_waves(fa, built, dev, oracle, B, 
         getattr(fa, name)(q, k, vv, o, 2)
         for (b, h) in ((0, 0), (B - 1, H - 1), (B // 2, H // 2)):
             ref = oracle.attention_fp64(q[b, h].cpu(), k[b, h].cpu(), v[b, h].cpu())
-            assert (o[b, h].cpu().double() - ref).abs().max().item() <= TOL, (name, b, h)
+            assert (o[b, h].cpu().double() - ref).abs().max().item() <= fa_tol(ref), (name, b, h)
 
 
 def test_deferred_max_paths(fa, built, dev, oracle):
@@ -238,14 +254,14 @@ def test_deferred_max_paths(fa, built, dev, oracle):
     for name in ("flash_attn_mma_stages_split_q_shared_qkv", "flash_attn_mma_stages_split_q_shared_qkv_swizzle_qkv"):
         o = run(fa, built, name, q, k, v, 2, dev)
         assert torch.isfinite(o).all()
-        assert (o.double() - ref).abs().max().item() <= TOL_AMPLIFIED_KEYS, name
+        assert (o.double() - ref).abs().max().item() <= fa_tol(ref), name
 
 
 @pytest.mark.parametrize("B,H,N,D", [(1, 48, 1024, 64), (1, 48, 1024, 128), (1, 128, 1024, 64), (2, 3, 1024, 64), (2, 3, 1024, 128), (2, 3, 384, 32), (2, 3, 384, 96)])
 def test_acc_f32_names_scale_the_scores_in_fp32(fa, built, dev, oracle, B, H, N, D):
     """The reference's *_acc_f32 names (fp32 accumulation of both GEMMs, flash_attn_mma_share_qkv_F32F16F16F32.cu:66 -- the precise rung)
     run the D <= 128 kernels with Q as loaded and the scores scaled in fp32: the rescale-regime inputs (keys amplified 3-5x, a
-    creeping maximum) stay inside TOL = 3e-3, where the plain names (fp16 pre-scaled Q) need 6e-3; large grids (fa2_fwd_m16x,
+    creeping maximum) stay inside fa_tol_f32 (2^-10 max|O| + 2e-4, at most 3e-3), where the plain names (fp16 pre-scaled Q) get fa_tol (2^-9 max|O| + 4e-4, at most 6e-3); large grids (fa2_fwd_m16x,
     fa2_fwd_m16x64r) and small ones (fa2_fwd_v2), both `stages` values, bit-identical to each other."""
     q, k, v = seeded(31, B, H, N, D), seeded(32, B, H, N, D), seeded(33, B, H, N, D)
     if N == 1024:
@@ -270,10 +286,10 @@ def test_acc_f32_names_scale_the_scores_in_fp32(fa, built, dev, oracle, B, H, N,
         err = (o2[:, heads].double() - ref).abs().max().item()
         assert torch.isfinite(o2).all()
         if "_acc_f32" in name:
-            assert err <= TOL, (name, err)
+            assert err <= fa_tol_f32(ref), (name, err)
         else:
             plain_err = err
-            assert err <= TOL_AMPLIFIED_KEYS, (name, err)
+            assert err <= fa_tol(ref), (name, err)
     assert plain_err is not None
 
 
@@ -297,7 +313,7 @@ def test_pingpong_kernels_deferred_max_and_rescale(fa, built, dev, oracle, D, H)
     assert torch.isfinite(o).all()
     for h in (0, 1, H - 1):
         ref = oracle.attention_fp64(q[:, h:h + 1], k[:, h:h + 1], v[:, h:h + 1])
-        assert (o[:, h:h + 1].double() - ref).abs().max().item() <= (TOL_AMPLIFIED_KEYS if D <= 128 else TOL), h
+        assert (o[:, h:h + 1].double() - ref).abs().max().item() <= (fa_tol(ref) if D <= 128 else fa_tol_f32(ref)), h
 
 
 @pytest.mark.parametrize("D,H", [(64, 48), (128, 48), (256, 48), (512, 2), (768, 2), (1024, 3), (320, 2), (384, 3), (640, 2)])
@@ -332,7 +348,7 @@ def test_online_softmax_rescale_is_exercised(fa, built, dev, oracle):
     ref = oracle.attention_fp64(q, k, v)
     for stages in (1, 2):
         o = run(fa, built, "flash_attn_mma_stages_split_q_shared_qkv", q, k, v, stages, dev)
-        assert (o.double() - ref).abs().max().item() <= TOL
+        assert (o.double() - ref).abs().max().item() <= fa_tol(ref)
 
 
 def test_config_c4_full_size(fa, built, dev, oracle):
@@ -348,13 +364,13 @@ def test_config_c4_full_size(fa, built, dev, oracle):
     fa.flash_attn_mma_stages_split_q_shared_qkv(q, k, v, o, 2)
     ref32 = gpu_attention_fp32(q, k, v)
     per_head = (o.float() - ref32).abs().amax(dim=(2, 3)).flatten()
-    assert per_head.numel() == 32 and per_head.max().item() <= TOL, per_head.tolist()
+    assert per_head.numel() == 32 and per_head.max().item() <= fa_tol(ref32), (per_head.tolist(), fa_tol(ref32))  # 2^-9 max|O| + 4e-4 = 1.2e-3 at this shape
     oc, qc, kc, vc, rc = o.cpu(), q.cpu(), k.cpu(), v.cpu(), ref32.cpu()
     for b in range(B):
         for h in range(b % 4, H, 4):
             ref = oracle.attention_fp64(qc[b, h], kc[b, h], vc[b, h])
             assert (rc[b, h].double() - ref).abs().max().item() <= 2e-5, (b, h)
-            assert (oc[b, h].double() - ref).abs().max().item() <= TOL, (b, h)
+            assert (oc[b, h].double() - ref).abs().max().item() <= fa_tol(ref), (b, h)
 
 
 def gpu_attention_fp32(q, k, v):
@@ -381,11 +397,11 @@ def test_config_c5_all_heads(fa, built, dev, oracle):
     fa.flash_attn_mma_stages_split_q_tiling_qkv(q, k, v, o, 2)
     ref32 = gpu_attention_fp32(q, k, v)
     per_head = (o.float() - ref32).abs().amax(dim=(0, 2, 3))
-    assert per_head.max().item() <= TOL, per_head.tolist()
+    assert per_head.max().item() <= fa_tol_f32(ref32), (per_head.tolist(), fa_tol_f32(ref32))  # 2^-10 max|O| + 2e-4 = 5e-4 at this shape
     for h in (0, 31):
         ref = oracle.attention_fp64(q[0, h].cpu(), k[0, h].cpu(), v[0, h].cpu())
         assert (ref32[0, h].cpu().double() - ref).abs().max().item() <= 2e-5
-        assert (o[0, h].cpu().double() - ref).abs().max().item() <= TOL
+        assert (o[0, h].cpu().double() - ref).abs().max().item() <= fa_tol_f32(ref)
 
 
 @pytest.mark.parametrize("D", [32, 64, 96, 128])
@@ -399,7 +415,7 @@ def test_split_kv_rung(fa, built, dev, oracle, D, B, H, N):
     outs = {}
     for stages in (1, 2):
         o = run(fa, built, "flash_attn_mma_stages_split_kv", q, k, v, stages, dev)
-        assert (o.double() - ref).abs().max().item() <= TOL, stages
+        assert (o.double() - ref).abs().max().item() <= fa_tol_f32(ref), stages
         outs[stages] = o
     # stages = 1 loads a tile and uses it, stages = 2 keeps the next tile in flight in registers: different kernels
     # (cln_describe says so), the same arithmetic in the same order
@@ -419,7 +435,7 @@ def test_split_kv_rung_rescale_and_uniform(fa, built, dev, oracle):
     k[0, 1, 10] = q[0, 1, 300] * 5.0
     ref = oracle.attention_fp64(q, k, v)
     o = run(fa, built, "flash_attn_mma_stages_split_kv", q, k, v, 2, dev)
-    assert torch.isfinite(o).all() and (o.double() - ref).abs().max().item() <= TOL
+    assert torch.isfinite(o).all() and (o.double() - ref).abs().max().item() <= fa_tol_f32(ref)
     ones = torch.ones(B, H, N, D).half()
     o = run(fa, built, "flash_attn_mma_stages_split_kv", ones, ones, v, 2, dev)
     assert (o.double() - v.double().mean(dim=2, keepdim=True).expand(B, H, N, D)).abs().max().item() <= 1e-3
@@ -447,7 +463,7 @@ def test_stages_one_is_the_single_stage_form_of_the_same_kernel(fa, built, dev, 
         assert one.replace("load-then-compute", "prefetch") == two + " [single stage: every tile fetch waited for where it is issued]", (one, two)
         o1 = run(fa, built, name, q, k, v, 1, dev)
         o2 = run(fa, built, name, q, k, v, 2, dev)
-        assert (o1[:, :2].double() - ref).abs().max().item() <= TOL_AMPLIFIED_KEYS, name
+        assert (o1[:, :2].double() - ref).abs().max().item() <= fa_tol(ref), name
         assert torch.equal(o1, o2), name
 
 
@@ -480,7 +496,7 @@ def test_pingpong_kernel_pre_scaled_variants(built, dev, oracle, D):
             host.fa2_variant((8, 0, 0, abl), q.to(dev), k.to(dev), v.to(dev), o)
             assert torch.isfinite(o).all(), (D, abl)
             err = (o.cpu().double() - ref).abs().max().item()
-            assert err <= (TOL_AMPLIFIED_KEYS if N == 1024 else TOL), (D, abl, (B, H, N), err)
+            assert err <= fa_tol(ref), (D, abl, (B, H, N), err)
             host.fa2_variant((8, 0, 0, abl), ones.to(dev), ones.to(dev), v.to(dev), o)
             assert (o.cpu().double() - mean_v).abs().max().item() <= 1e-3, (D, abl)
 
@@ -498,7 +514,7 @@ def test_register_blocked_kernel_variants(built, dev, oracle, D, B, H, N):
         o = torch.zeros(B, H, N, D, dtype=torch.half, device=dev)
         host.fa2_variant((4, 0, 0, abl), q.to(dev), k.to(dev), v.to(dev), o)
         err = (o.cpu().double() - ref).abs().max().item()
-        assert err <= TOL, (D, abl, err)
+        assert err <= fa_tol(ref), (D, abl, err)
 
 
 @pytest.mark.parametrize("D", [64, 128])
@@ -524,7 +540,7 @@ def test_register_blocked_kernel_rescale_regimes(built, dev, oracle, D):
         host.fa2_variant((4, 0, 0, abl), q.to(dev), k.to(dev), v.to(dev), o)
         assert torch.isfinite(o).all(), (D, abl)
         err = (o.cpu().double() - ref).abs().max().item()
-        assert err <= TOL, (D, abl, err)
+        assert err <= fa_tol(ref), (D, abl, err)
         host.fa2_variant((4, 0, 0, abl), ones.to(dev), ones.to(dev), v.to(dev), o)
         assert (o.cpu().double() - mean_v).abs().max().item() <= 1e-3, (D, abl)
 
@@ -543,7 +559,7 @@ def test_probe_variants_match_production(fa, built, dev, oracle):
         for var in variants:
             o = torch.zeros(B, H, N, D, dtype=torch.half, device=dev)
             host.fa2_variant(var, q.to(dev), k.to(dev), v.to(dev), o)
-            assert (o.cpu().double() - ref).abs().max().item() <= TOL, (D, var)
+            assert (o.cpu().double() - ref).abs().max().item() <= fa_tol(ref), (D, var)
 
 
 @pytest.mark.parametrize("D,abl", [(64, 600), (64, 608), (64, 601), (128, 600), (128, 602)])
@@ -564,7 +580,7 @@ def test_one_wave_per_simd_attention_probe(built, dev, oracle, D, abl):
         host.fa2_variant((4, 0, 0, abl), q.to(dev), k.to(dev), v.to(dev), o)
         assert torch.isfinite(o).all()
         ref = oracle.attention_fp64(q, k, v)
-        assert (o.cpu().double() - ref).abs().max().item() <= TOL_AMPLIFIED_KEYS, (B, H, N)
+        assert (o.cpu().double() - ref).abs().max().item() <= fa_tol(ref), (B, H, N)
 
 
 @pytest.mark.parametrize("D,abl,N", [(64, 540, 256), (64, 541, 512), (64, 545, 512), (64, 546, 1024), (128, 540, 256),
@@ -583,7 +599,7 @@ def test_attention_on_16x16x32_mfma_probe_forms(built, dev, oracle, D, abl, N):
         host.fa2_variant((8, 0, 0, abl), q.to(dev), k.to(dev), v.to(dev), o)
         assert torch.isfinite(o).all()
         ref = oracle.attention_fp64(q, k, v)
-        assert (o.cpu().double() - ref).abs().max().item() <= TOL_AMPLIFIED_KEYS, (B, H, N, D, abl)
+        assert (o.cpu().double() - ref).abs().max().item() <= fa_tol(ref), (B, H, N, D, abl)
 
 
 @pytest.mark.parametrize("abl", [950, 951, 953, 955])
@@ -606,7 +622,7 @@ def test_one_wave_per_simd_attention_on_16x16x32_probe(built, dev, oracle, abl):
         host.fa2_variant((8, 0, 0, abl), qd, kd, vd, o)
         assert torch.isfinite(o).all()
         ref = oracle.attention_fp64(q, k, v)
-        assert (o.cpu().double() - ref).abs().max().item() <= TOL_AMPLIFIED_KEYS, (B, H, N)
+        assert (o.cpu().double() - ref).abs().max().item() <= fa_tol(ref), (B, H, N)
         first = o.clone()
         for _ in range(200 if N == 1024 else 20):
             host.fa2_variant((8, 0, 0, abl), qd, kd, vd, o)
@@ -635,7 +651,7 @@ def test_sum_checked_attention_on_32x32x16_probe(built, dev, oracle, abl):
         host.fa2_variant((8, 0, 0, abl), qd, kd, vd, o)
         assert torch.isfinite(o).all()
         ref = oracle.attention_fp64(q, k, v)
-        assert (o.cpu().double() - ref).abs().max().item() <= TOL_AMPLIFIED_KEYS, (B, H, N)
+        assert (o.cpu().double() - ref).abs().max().item() <= fa_tol(ref), (B, H, N)
         first = o.clone()
         for _ in range(50 if N == 1024 else 10):
             host.fa2_variant((8, 0, 0, abl), qd, kd, vd, o)
@@ -659,7 +675,7 @@ def test_key_split_attention_probe(built, dev, oracle, abl):
         host.fa2_variant((8, 0, 0, abl), q.to(dev), k.to(dev), v.to(dev), o)
         assert torch.isfinite(o).all()
         ref = oracle.attention_fp64(q, k, v)
-        assert (o.cpu().double() - ref).abs().max().item() <= TOL_AMPLIFIED_KEYS, (B, H, N)
+        assert (o.cpu().double() - ref).abs().max().item() <= fa_tol(ref), (B, H, N)
 
 
 def test_pingpong_kernel_with_64_rows_per_wave(fa, built, dev, oracle):
@@ -683,7 +699,7 @@ def test_pingpong_kernel_with_64_rows_per_wave(fa, built, dev, oracle):
         assert torch.isfinite(o).all() and torch.equal(o, o2)
         for (b, h) in ((0, 0), (0, 1), (B - 1, H - 1), (0, H // 2)):
             ref = oracle.attention_fp64(q[b:b + 1, h:h + 1], k[b:b + 1, h:h + 1], v[b:b + 1, h:h + 1])
-            assert (o[b:b + 1, h:h + 1].double() - ref).abs().max().item() <= TOL_AMPLIFIED_KEYS, (B, H, N, b, h)
+            assert (o[b:b + 1, h:h + 1].double() - ref).abs().max().item() <= fa_tol(ref), (B, H, N, b, h)
     # a grid that does not fill whole rounds keeps the 32-row kernel
     assert built.manifest.describe(name, (2, 24, 4096, 64), 2).startswith("fa2_fwd_m16x<D=64")
 
@@ -701,7 +717,8 @@ def test_repeated_launches_are_bit_identical_and_right(fa, built, dev, B, H, N, 
     fn = fa.flash_attn_mma_stages_split_q_shared_qkv if D <= 256 else fa.flash_attn_mma_stages_split_q_tiling_qkv
     fn(q, k, v, o, 2)
     first = o.clone()
-    assert (first.float() - gpu_attention_fp32(q, k, v)).abs().max().item() <= TOL
+    ref = gpu_attention_fp32(q, k, v)
+    assert (first.float() - ref).abs().max().item() <= (fa_tol(ref) if D <= 128 else fa_tol_f32(ref))
     mismatching = 0
     for _ in range(300):
         o.zero_()
@@ -723,7 +740,7 @@ def test_ck_tile_fmha_comparator_row_is_a_correct_attention(built, dev, oracle, 
         for variant in ((0, 3) if D == 128 else (0,)):
             o = torch.zeros(B, H, N, D, dtype=torch.half, device=dev)
             ck(q.to(dev), k.to(dev), v.to(dev), o, variant)
-            assert (o.cpu().double() - ref).abs().max().item() <= TOL, (N, variant)
+            assert (o.cpu().double() - ref).abs().max().item() <= fa_tol(ref), (N, variant)
     bad = torch.zeros(1, 1, 256, 96, dtype=torch.half, device=dev)
     with pytest.raises(RuntimeError):
         ck(bad, bad, bad, torch.zeros_like(bad), 0)
@@ -750,7 +767,7 @@ def test_transposed_v_names_on_the_sum_checked_kernel(fa, built, dev, oracle, B,
     assert torch.equal(o_vt, o_pl)
     for (b, h) in ((0, 0), (0, H - 1), (B - 1, H // 2)):
         ref = oracle.attention_fp64(q[b:b + 1, h:h + 1], k[b:b + 1, h:h + 1], v[b:b + 1, h:h + 1])
-        assert (o_vt[b:b + 1, h:h + 1].double() - ref).abs().max().item() <= TOL_AMPLIFIED_KEYS, (b, h)
+        assert (o_vt[b:b + 1, h:h + 1].double() - ref).abs().max().item() <= fa_tol(ref), (b, h)
     for other in ("flash_attn_mma_stages_split_q_shared_kv_swizzle_qkv", "flash_attn_mma_stages_split_q_tiling_qk_swizzle_qkv"):
         assert torch.equal(run(fa, built, other, q, k, v, 2, dev), o_vt), other
 
@@ -758,7 +775,7 @@ def test_transposed_v_names_on_the_sum_checked_kernel(fa, built, dev, oracle, B,
 def test_seeded_fuzz_over_shapes_names_and_stages(fa, built, dev):
     """30 seeded random problems over the supported head dims, sequence lengths that are multiples of the kernels' row blocks, small and large
     grids, plain / acc_f32 / transposed-V / tiling names: the output matches an fp32 attention computed on the GPU (itself within 1e-4 of the
-    fp64 oracle on its first head) to TOL, and stages = 1 equals stages = 2 bit for bit; the failure message names the kernel."""
+    fp64 oracle on its first head) to fa_tol / fa_tol_f32, and stages = 1 equals stages = 2 bit for bit; the failure message names the kernel."""
     import random
     rng = random.Random(4)
     dims = [32, 64, 96, 128, 256, 320, 384, 512, 640, 768, 1024]
@@ -788,7 +805,8 @@ def test_seeded_fuzz_over_shapes_names_and_stages(fa, built, dev):
             o = torch.zeros_like(q)
             getattr(fa, name)(q, k, vv, o, stages)
             err = (o.float() - ref).abs().max().item()
-            assert err <= TOL, (case, name, (B, H, N, D), stages, what, err)
+            bound = fa_tol_f32(ref) if (D >= 256 or "_acc_f32" in name) else fa_tol(ref)
+            assert err <= bound, (case, name, (B, H, N, D), stages, what, err, bound)
             outs.append(o)
         assert torch.equal(outs[0], outs[1]), (case, name, (B, H, N, D), what)
     assert len(seen) >= 5, seen

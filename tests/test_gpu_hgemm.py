@@ -543,10 +543,13 @@ def test_split_k_full_matrix(hg, built, dev, M, N, K):
 
 
 def test_split_k_workspace_grows_and_is_per_stream(hg, built, dev):
-    """The fp32 workspace is owned by the library, one per stream, allocated on first use and grown on demand: a small problem, then a larger
-    one, then the small one again on the same stream, and two problems interleaved on two streams, all give the single-stream results."""
+    """One fp32 workspace per stream -- since round 6 a tensor of torch's caching allocator that host.py registers with the library (the library
+    itself allocates nothing), grown on demand: a small problem, then a larger one, then the small one again on the same stream, and two problems
+    interleaved on two streams, all give the single-stream results; the library holds no memory of its own at any point."""
+    from cuda_learn_notes_amd import host
     name = "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem"
     fn = getattr(hg, name)
+    host.release_workspaces()
     probs = []
     for (M, N, K) in ((256, 256, 8192), (1024, 1024, 16384), (256, 512, 4096)):
         a, b = seeded(M + 7, M, K).to(dev), seeded(N + 9, K, N).to(dev)
@@ -556,6 +559,8 @@ def test_split_k_workspace_grows_and_is_per_stream(hg, built, dev):
     torch.cuda.synchronize()
     for (a, b, c) in probs:
         check(c, a.cpu(), b.cpu())
+    (key, size), = host.hgemm_workspace_tensors().items()
+    assert size >= host.hgemm_workspace_bytes(1024, 1024, 16384) and host.hgemm_workspace_held() == 0
     s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
     outs = []
     for rnd in range(3):
@@ -567,23 +572,29 @@ def test_split_k_workspace_grows_and_is_per_stream(hg, built, dev):
     torch.cuda.synchronize()
     for o, c in outs:
         assert torch.equal(o, c)
+    assert len(host.hgemm_workspace_tensors()) == 3 and host.hgemm_workspace_held() == 0
 
 
-def test_split_k_under_stream_capture(hg, built, dev):
-    """A captured launch replays: the workspace the stream already owns is used inside a graph; a stream that owns none yet (allocation is not
-    allowed while capturing) takes the single-pass plan -- same result within the parity tolerance either way."""
+@pytest.mark.parametrize("M,N,K,eager_form", [(512, 512, 8192, "hgemm_splitk_reduce"), (2048, 2048, 8192, "in-kernel fix-up"), (640, 5120, 5120, "in-kernel fix-up")])
+def test_split_k_under_stream_capture(hg, built, dev, M, N, K, eager_form):
+    """A captured launch replays: the workspace the stream already has is used inside a graph (always as partial + reduce launch: no arrival
+    tickets in a graph, ADVICE r5 -- the same bits as the eager one-launch form); a stream that has none yet (nothing is allocated while
+    capturing) takes the single-pass plan -- same result within the parity tolerance either way."""
+    from cuda_learn_notes_amd import host
     name = "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem"
     fn = getattr(hg, name)
-    M, N, K = 512, 512, 8192
+    assert eager_form in built.manifest.describe(name, (M, N, K), 2)  # eager: more than 2 splits -> two launches, 2 splits -> one launch with tickets
     a, b = seeded(3, M, K), seeded(4, K, N)
     ad, bd = a.to(dev), b.to(dev)
     for warm in (True, False):
         st = torch.cuda.Stream()
         c = torch.zeros(M, N, dtype=torch.half, device=dev)
+        eager = None
         with torch.cuda.stream(st):
             if warm:
                 fn(ad, bd, c, 2, False, 0)  # the stream's workspace now exists
                 st.synchronize()
+                eager = c.clone()
                 c.zero_()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=st):
@@ -592,47 +603,78 @@ def test_split_k_under_stream_capture(hg, built, dev):
             g.replay()
         torch.cuda.synchronize()
         check(c, a, b)
+        if warm:
+            assert torch.equal(c, eager)
+            with torch.cuda.stream(st):  # the eager one-launch form still works on the stream the graph came from (its tickets were never in a graph)
+                for _ in range(3):
+                    c.zero_()
+                    g.replay()
+                    fn(ad, bd, c, 2, False, 0)
+            torch.cuda.synchronize()
+            assert torch.equal(c, eager)
+    assert host.hgemm_workspace_held() == 0
 
 
-def test_workspace_of_a_captured_graph_is_never_evicted(hg, built, dev):
-    """A graph captured on a stream that owns a library workspace holds that workspace's ADDRESS. Twelve other streams running split-K afterwards
-    would push it out of the 8-entry LRU: a workspace a capture has used is pinned (csrc/hgemm.hip SplitKWs::pinned), so the replayed graph still
-    writes into live memory and still returns the right product; cln_release_workspaces() frees it."""
-    from cuda_learn_notes_amd import host
-    fn = getattr(hg, "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem")
+@pytest.mark.parametrize("owner", ["torch", "library"])
+def test_workspace_of_a_captured_graph_is_never_evicted(hg, built, dev, owner):
+    """A graph captured on a stream that has a workspace holds that workspace's ADDRESS. Twelve other streams running split-K afterwards would push
+    it out of the 8-entry LRU: a workspace a capture has used is pinned, so the replayed graph still writes into live memory and still returns the
+    right product. owner = torch: the tensors host.py keeps per stream (the default: the library holds nothing). owner = library: the C caller's
+    opt-in, cln_hgemm_library_workspace(1), driven through the raw C-ABI (csrc/hgemm.hip SplitKWs::pinned); cln_release_workspaces() frees it."""
+    from cuda_learn_notes_amd import _loader, host
+    name = "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem"
     M, N, K = 512, 512, 8192
     assert host.hgemm_workspace_bytes(M, N, K) > 0
     a, b = seeded(41, M, K), seeded(42, K, N)
     ad, bd = a.to(dev), b.to(dev)
     host.release_workspaces()
-    st = torch.cuda.Stream()
-    c = torch.zeros(M, N, dtype=torch.half, device=dev)
-    with torch.cuda.stream(st):
-        fn(ad, bd, c, 2, False, 0)  # the stream's workspace now exists
-        st.synchronize()
-        ref = c.clone()
-        one = host.hgemm_workspace_held()  # one workspace of this shape (16 MiB doubled until the partials + tickets fit)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=st):
-            fn(ad, bd, c, 2, False, 0)
-    check(ref, a, b)
-    assert one > 0
-    others = [torch.cuda.Stream() for _ in range(12)]
-    scratch = torch.zeros(M, N, dtype=torch.half, device=dev)
-    for o in others:
-        with torch.cuda.stream(o):
-            fn(ad, bd, scratch, 2, False, 0)
-        o.synchronize()
-    held = host.hgemm_workspace_held()
-    assert held == 9 * one, (held, one)  # the 8 evictable ones + the pinned one
-    with torch.cuda.stream(st):
-        for _ in range(3):
-            c.zero_()
-            g.replay()
-    torch.cuda.synchronize()
-    assert torch.equal(c, ref)
-    del g
-    assert host.release_workspaces() > 0 and host.hgemm_workspace_held() == 0
+    if owner == "torch":
+        hfn = getattr(hg, name)
+
+        def fn(c):
+            hfn(ad, bd, c, 2, False, 0)
+    else:
+        raw = _loader.symbol(name)
+        assert host.hgemm_library_workspace(True) is False
+
+        def fn(c):
+            assert raw(ad.data_ptr(), bd.data_ptr(), c.data_ptr(), M, N, K, 2, 0, 0, torch.cuda.current_stream().cuda_stream) == 0
+    try:
+        st = torch.cuda.Stream()
+        c = torch.zeros(M, N, dtype=torch.half, device=dev)
+        with torch.cuda.stream(st):
+            fn(c)  # the stream's workspace now exists
+            st.synchronize()
+            ref = c.clone()
+            one = host.hgemm_workspace_held()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=st):
+                fn(c)
+        check(ref, a, b)
+        assert (one == 0) if owner == "torch" else (one == 4096 + (16 << 20)), one
+        others = [torch.cuda.Stream() for _ in range(12)]
+        scratch = torch.zeros(M, N, dtype=torch.half, device=dev)
+        for o in others:
+            with torch.cuda.stream(o):
+                fn(scratch)
+            o.synchronize()
+        if owner == "torch":
+            assert host.hgemm_workspace_held() == 0 and len(host.hgemm_workspace_tensors()) == 9  # the 8 evictable ones + the pinned one
+            assert (dev.index or 0, st.cuda_stream) in host.hgemm_workspace_tensors()
+        else:
+            assert host.hgemm_workspace_held() == 9 * one and not host.hgemm_workspace_tensors()
+        with torch.cuda.stream(st):
+            for _ in range(3):
+                c.zero_()
+                g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(c, ref)
+        del g
+        freed = host.release_workspaces()
+        assert (freed > 0) == (owner == "library") or owner == "torch"  # (torch: only scratch slabs, if any, are the library's to free)
+        assert host.hgemm_workspace_held() == 0 and not host.hgemm_workspace_tensors()
+    finally:
+        host.hgemm_library_workspace(False)
 
 
 @pytest.mark.parametrize("M,N,K", [(4352, 4352, 4352), (5888, 5888, 1792), (4096, 4352, 2048), (4864, 4864, 4864)])
@@ -673,12 +715,15 @@ def _hip_runtime():
 
 
 def test_workspace_entry_points_caller_owned_and_release(hg, built, dev):
-    """include/cln_amd.h workspace block: cln_hgemm_workspace_bytes says what a shape needs (0 for a single-pass shape), a caller-owned region
-    (a torch tensor from the caching allocator) gives the same bits as the library-owned one, a region that is too small makes the shape run
-    single-pass (still inside the parity tolerance), cln_release_workspaces frees what the library holds."""
-    from cuda_learn_notes_amd import host
+    """include/cln_amd.h workspace block: cln_hgemm_workspace_bytes says what a shape needs (0 for a single-pass shape); by default the LIBRARY
+    allocates nothing (round 6) -- host.py registers one torch tensor per stream; a region the caller registers itself gives the same bits, a region
+    that is too small makes the shape run single-pass (still inside the parity tolerance); through the raw C-ABI a stream without a region runs
+    single-pass until cln_hgemm_library_workspace(1) opts in to library-owned buffers (4 KiB + a power of two: ADVICE r5), which
+    cln_release_workspaces frees."""
+    from cuda_learn_notes_amd import _loader, host
     name = "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem"
     fn = getattr(hg, name)
+    raw = _loader.symbol(name)
     assert host.hgemm_workspace_bytes(4096, 4096, 4096) == 0  # 256 tiles, one round: single pass
     M, N, K = 1024, 1024, 16384
     need = host.hgemm_workspace_bytes(M, N, K)
@@ -688,44 +733,64 @@ def test_workspace_entry_points_caller_owned_and_release(hg, built, dev):
     a, b = seeded(21, M, K), seeded(22, K, N)
     ad, bd = a.to(dev), b.to(dev)
     st = torch.cuda.Stream()
+    key = (dev.index or 0, st.cuda_stream)
     with torch.cuda.stream(st):
         host.release_workspaces()
-        assert host.hgemm_workspace_held() == 0
-        c_lib = torch.zeros(M, N, dtype=torch.half, device=dev)
-        fn(ad, bd, c_lib, 2, False, 0)
+        assert host.hgemm_workspace_held() == 0 and not host.hgemm_workspace_tensors()
+        c_auto = torch.zeros(M, N, dtype=torch.half, device=dev)
+        fn(ad, bd, c_auto, 2, False, 0)
         st.synchronize()
-        held = host.hgemm_workspace_held()
-        assert held >= need and held <= 2 * max(need, 16 << 20)
+        assert host.hgemm_workspace_held() == 0  # nothing hidden
+        assert need <= host.hgemm_workspace_tensors()[key] <= max(16 << 20, need + (2 << 20))
         buf = torch.empty(need, dtype=torch.uint8, device=dev)
         buf.fill_(0xAB)  # garbage: the library zeroes the ticket header itself
         host.hgemm_set_workspace(buf)
-        assert host.hgemm_workspace_held() == 0  # the stream's library-owned buffer went away with the hand-over
+        assert host.hgemm_workspace_tensors()[key] == need
         c_usr = torch.zeros(M, N, dtype=torch.half, device=dev)
         for _ in range(3):  # self-resetting tickets: repeated launches on the same region
             c_usr.zero_()
             fn(ad, bd, c_usr, 2, False, 0)
         st.synchronize()
-        assert torch.equal(c_usr, c_lib)
-        assert host.hgemm_workspace_held() == 0  # the library did not allocate behind the caller's back
+        assert torch.equal(c_usr, c_auto)
         small = torch.empty(8192, dtype=torch.uint8, device=dev)
-        host.hgemm_set_workspace(small)  # too small for this shape: single-pass plan
+        host.hgemm_set_workspace(small)  # too small for this shape, and the caller's: never replaced -> single-pass plan
         c_sp = torch.zeros(M, N, dtype=torch.half, device=dev)
         fn(ad, bd, c_sp, 2, False, 0)
         st.synchronize()
-        assert host.hgemm_workspace_held() == 0
+        assert host.hgemm_workspace_tensors()[key] == 8192 and host.hgemm_workspace_held() == 0
         host.hgemm_set_workspace(None)
-        fn(ad, bd, c_usr, 2, False, 0)  # library-owned again
+        assert key not in host.hgemm_workspace_tensors()
+        # the raw C-ABI on a stream nobody gave a region: single-pass (the bits of c_sp), no allocation
+        c_raw = torch.zeros(M, N, dtype=torch.half, device=dev)
+        assert raw(ad.data_ptr(), bd.data_ptr(), c_raw.data_ptr(), M, N, K, 2, 0, 0, st.cuda_stream) == 0
         st.synchronize()
-        assert torch.equal(c_usr, c_lib) and host.hgemm_workspace_held() > 0
-    check(c_lib, a, b)
+        assert torch.equal(c_raw, c_sp) and host.hgemm_workspace_held() == 0
+        # ... until the C caller opts in
+        assert host.hgemm_library_workspace(True) is False
+        try:
+            c_lib = torch.zeros(M, N, dtype=torch.half, device=dev)
+            assert raw(ad.data_ptr(), bd.data_ptr(), c_lib.data_ptr(), M, N, K, 2, 0, 0, st.cuda_stream) == 0
+            st.synchronize()
+            p2 = 16 << 20
+            while p2 < need - 4096:
+                p2 <<= 1
+            assert torch.equal(c_lib, c_auto) and host.hgemm_workspace_held() == 4096 + p2
+            assert host.release_workspaces() >= 4096 + p2 and host.hgemm_workspace_held() == 0
+        finally:
+            assert host.hgemm_library_workspace(False) is True
+        fn(ad, bd, c_usr, 2, False, 0)  # host.py's own tensor again
+        st.synchronize()
+        assert torch.equal(c_usr, c_auto) and host.hgemm_workspace_held() == 0
+    check(c_auto, a, b)
     check(c_sp, a, b)
-    assert host.release_workspaces() > 0 and host.hgemm_workspace_held() == 0
+    host.release_workspaces()
 
 
 def test_workspace_does_not_leak_over_many_streams(hg, built, dev):
-    """a process that cycles streams must not pin a workspace per stream for ever. 300 raw HIP streams, each created,
-    used for one split-K launch and destroyed: the library never holds more than 8 workspaces (least recently used freed once its last launch has
-    completed -- the completion event outlives the stream), every result is right."""
+    """a process that cycles streams must not pin a workspace per stream for ever. (1) Library-owned buffers (the C caller's
+    opt-in): 300 raw HIP streams, each created, used for one split-K launch and destroyed -- the library never holds more than 8 workspaces (least
+    recently used freed once its last launch has completed: the completion event outlives the stream), every result is right. (2) host.py's torch
+    tensors: 40 torch streams, at most 8 tensors registered at a time."""
     import ctypes
     from cuda_learn_notes_amd import _loader, host
     hip = _hip_runtime()
@@ -733,31 +798,48 @@ def test_workspace_does_not_leak_over_many_streams(hg, built, dev):
     hip.hipStreamDestroy.argtypes, hip.hipStreamDestroy.restype = [ctypes.c_void_p], ctypes.c_int
     hip.hipStreamSynchronize.argtypes, hip.hipStreamSynchronize.restype = [ctypes.c_void_p], ctypes.c_int
     raw = _loader.symbol("hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem")
+    fn = getattr(hg, "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem")
     M, N, K = 256, 256, 8192
     assert host.hgemm_workspace_bytes(M, N, K) > 0
     a, b = seeded(31, M, K), seeded(32, K, N)
     ad, bd = a.to(dev), b.to(dev)
     ref = torch.zeros(M, N, dtype=torch.half, device=dev)
-    getattr(hg, "hgemm_mma_m16n8k16_mma2x4_warp4x4x2_stages_dsmem")(ad, bd, ref, 2, False, 0)
+    fn(ad, bd, ref, 2, False, 0)
     torch.cuda.synchronize()
     check(ref, a, b)
     host.release_workspaces()
+    one = 4096 + (16 << 20)
     peak = 0
     outs = [torch.zeros(M, N, dtype=torch.half, device=dev) for _ in range(4)]
-    for i in range(300):
-        s = ctypes.c_void_p()
-        assert hip.hipStreamCreate(ctypes.byref(s)) == 0
-        c = outs[i % 4]
-        assert raw(ad.data_ptr(), bd.data_ptr(), c.data_ptr(), M, N, K, 2, 0, 0, s) == 0
-        if i % 4 == 3:
-            assert hip.hipStreamSynchronize(s) == 0
-            assert torch.equal(c, ref), i
-        peak = max(peak, host.hgemm_workspace_held())
-        if i % 2 == 0:  # half of the streams are destroyed while their launch may still be queued
-            assert hip.hipStreamDestroy(s) == 0
+    assert host.hgemm_library_workspace(True) is False
+    try:
+        for i in range(300):
+            s = ctypes.c_void_p()
+            assert hip.hipStreamCreate(ctypes.byref(s)) == 0
+            c = outs[i % 4]
+            assert raw(ad.data_ptr(), bd.data_ptr(), c.data_ptr(), M, N, K, 2, 0, 0, s) == 0
+            if i % 4 == 3:
+                assert hip.hipStreamSynchronize(s) == 0
+                assert torch.equal(c, ref), i
+            peak = max(peak, host.hgemm_workspace_held())
+            if i % 2 == 0:  # half of the streams are destroyed while their launch may still be queued
+                assert hip.hipStreamDestroy(s) == 0
+        torch.cuda.synchronize()
+        assert 0 < peak <= 8 * one, peak
+        assert host.release_workspaces() <= 8 * one + (64 * 4096) * 2 and host.hgemm_workspace_held() == 0
+    finally:
+        host.hgemm_library_workspace(False)
+    streams = [torch.cuda.Stream() for _ in range(40)]
+    res = []
+    for i, st in enumerate(streams):
+        with torch.cuda.stream(st):
+            o = torch.zeros(M, N, dtype=torch.half, device=dev)
+            fn(ad, bd, o, 2, False, 0)
+            res.append(o)
+        assert len(host.hgemm_workspace_tensors()) <= 8 and host.hgemm_workspace_held() == 0
     torch.cuda.synchronize()
-    assert 0 < peak <= 8 * (16 << 20), peak
-    assert host.release_workspaces() <= 8 * (16 << 20) + (64 * 4096) * 2 and host.hgemm_workspace_held() == 0
+    assert all(torch.equal(o, ref) for o in res)
+    host.release_workspaces()
 
 
 def test_two_host_threads_on_one_stream_get_their_own_results(hg, built, dev):

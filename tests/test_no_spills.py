@@ -64,6 +64,10 @@ def test_inline_asm_mfma_stream_of_the_one_wave_per_simd_hgemm(tmp_path):
     for k in w4:
         assert k["agpr"] in (256, 192, 144, 128, 100) and k["spill"] == 0 and k["scratch"] == 0, k
         assert kr.asm_mfma_stream_check(text, k["name"]) == [], k["demangled"]
+        # the one-launch split-K fix-up reads the other splits' partials with agent-scope loads from inline asm; the wait is a separate asm statement:
+        # nothing may touch a destination register in between
+        if "hgemm_w4_kernel<0, 6," in k["demangled"] or "hgemm_w4_kernel<1, 6," in k["demangled"]:
+            assert kr.asm_inflight_load_hazards(text, k["name"]) == [], k["demangled"]
     # the ring-of-slots form (hgemm_w4s.cuh, stages 3 / 4 / 5 of the 256x256 names): same inline-asm MFMAs, same rules
     w4s = [k for k in kernels if "hgemm_w4s_kernel" in k["demangled"]]
     assert len(w4s) == 6, [k["demangled"] for k in w4s]  # ring depth 3 / 4 / 5 x NN / TN
