@@ -91,7 +91,7 @@ int launch_unary(const void* x, void* y, long long n, hipStream_t st_) {
   if (!x || !y || n < 0) return CLN_ERR_BAD_ARG;
   if (n == 0) return CLN_OK;
   if (sizeof(T) * CHUNK >= 16 && (!cln_aligned16(x) || !cln_aligned16(y))) return CLN_ERR_BAD_ARG;
-  const int grid = cln_stream_grid(n / VEC + 1, 256);
+  const int grid = cln_stream_grid(n / VEC + 1, 256, 2LL * n * (long long)sizeof(T));
   CLN_LAUNCH((unary_kernel<Op, T, VEC, CHUNK>), dim3(grid), dim3(256), 0, st_, (const T*)x, (T*)y, n, cln_stream_nt(2LL * n * (long long)sizeof(T)));
   return cln_check_launch();
 }

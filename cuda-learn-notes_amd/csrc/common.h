@@ -100,9 +100,12 @@ static inline int cln_stream_nt(long long footprint_bytes) { return footprint_by
 
 // Grid sizing for HBM-bound streaming kernels: enough workgroups to cover all
 // 256 CUs several times over, grid-stride for the rest (cdna guide G11).
-static inline int cln_stream_grid(long long work_items, int block) {
+// Round 6: a launch that moves >= 512 MB (`traffic_bytes`) is NOT capped -- one trip per thread, waves that retire are replaced instead of looping
+// in lockstep: y = 2x over f32x4 at 512 + 512 MB 96.8 -> 88.6 us (+9 %), c = a + b at 3 x 256 MB 155 -> 136 us (+14 %); below that the capped
+// grid-stride form is level or ahead (134 + 134 MB: 23.7 vs 24.1 us) -- tools/ubench/stream_forms.hip, profiles/r06_stream_forms_ubench.log.
+static inline int cln_stream_grid(long long work_items, int block, long long traffic_bytes = 0) {
   long long g = (work_items + block - 1) / block;
-  const long long cap = 256LL * CLN_STREAM_WGS_PER_CU;
+  const long long cap = traffic_bytes >= (512LL << 20) ? 0x7fffffffLL : 256LL * CLN_STREAM_WGS_PER_CU;
   if (g > cap) g = cap;
   if (g < 1) g = 1;
   return (int)g;

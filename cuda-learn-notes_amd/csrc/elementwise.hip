@@ -2,20 +2,35 @@
 //
 // Replaces the kernels + bindings of reference kernels/elementwise/elementwise.cu:24-108
 // (kernels) and :122-177 (TORCH_BINDING_ELEM_ADD launch-shape macro + PYBIND11_MODULE).
-// Design for gfx950: every rung is a grid-stride loop over a capped grid (256 CUs x 32
-// workgroups of 256 threads = every wave slot of the chip; outputs of launches that fill the MALL are written with
-// non-temporal stores, common.h cln_store_stream), the rung name fixes only the per-lane access width
-// (4 B, 16 B, 2 B, 4 B, 4x4 B, 16 B), exactly what the reference ladder teaches.
+// Design for gfx950: the rung name fixes only the per-lane access width (4 B, 16 B, 2 B, 4 B, 4x4 B, 16 B), exactly what the reference ladder
+// teaches. Walk (round 6): BLOCK-CONTIGUOUS, no loop -- workgroup b owns the 256 K consecutive packs from 256 K b on, every lane issues its K
+// load pairs, then its K stores; K = 4 below 512 MB of traffic, 1 above. Rounds 1-5 ran a grid-stride loop over a capped grid (256 CUs x 32
+// workgroups): with torch.add(out=) as the yardstick beside it that form was 9 % BEHIND at [8192,8192] f32 (148 vs 135 us); on the same box
+// (tools/ubench/stream_forms.hip, profiles/r06_stream_forms_ubench.log) grid-stride 155 us, one pack per thread 136, four per thread 138; at
+// [4096,4096] 36.6 / 36.1 / 35.2, at [2048,2048] 11.0 / 11.0 / 10.6. Every wave of a grid-stride launch alternates loads and stores in lockstep
+// with every other wave; waves that retire and are replaced do not. Non-temporal stores change none of these numbers (kept: outputs of launches
+// that fill the MALL do not displace their inputs, common.h cln_store_stream).
 #include "common.h"
 
 namespace {
 
-template <typename VT>
+template <typename VT, int K>
 __global__ __launch_bounds__(256) void add_vec_kernel(const VT* __restrict__ a, const VT* __restrict__ b,
                                                       VT* __restrict__ c, long long nvec, int stream_nt) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (; i < nvec; i += stride) cln_store_stream(c + i, (VT)(a[i] + b[i]), stream_nt);
+  const long long base = (long long)blockIdx.x * (256 * K) + threadIdx.x;
+  if (base + (K - 1) * 256 < nvec) {  // every pack of this lane exists (all workgroups but the last)
+    VT x[K], y[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) x[k] = a[base + k * 256];
+#pragma unroll
+    for (int k = 0; k < K; ++k) y[k] = b[base + k * 256];
+#pragma unroll
+    for (int k = 0; k < K; ++k) cln_store_stream(c + base + k * 256, (VT)(x[k] + y[k]), stream_nt);
+  } else {
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      if (base + k * 256 < nvec) c[base + k * 256] = a[base + k * 256] + b[base + k * 256];
+  }
 }
 
 // scalar tail (n not a multiple of the vector width)
@@ -29,9 +44,8 @@ __global__ void add_tail_kernel(const T* a, const T* b, T* c, long long start, l
 // (reference elementwise.cu:62-86); the "_pack" rung below moves them as one 16-byte access.
 __global__ __launch_bounds__(256) void add_f16x8_unpacked_kernel(const h2* __restrict__ a, const h2* __restrict__ b,
                                                                  h2* __restrict__ c, long long ngroups, int stream_nt) {
-  long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (; g < ngroups; g += stride) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // one group of eight halves per lane, no loop (see the walk note above)
+  if (g < ngroups) {
     const long long i = g * 4;
     h2 a0 = a[i + 0], a1 = a[i + 1], a2 = a[i + 2], a3 = a[i + 3];
     h2 b0 = b[i + 0], b1 = b[i + 1], b2 = b[i + 2], b3 = b[i + 3];
@@ -49,9 +63,12 @@ int launch_add(const void* a, const void* b, void* c, long long n, hipStream_t s
   if (VEC * sizeof(T) >= 16 && !(cln_aligned16(a) && cln_aligned16(b) && cln_aligned16(c))) return CLN_ERR_BAD_ARG;
   const long long nvec = n / VEC;
   if (nvec > 0) {
-    const int grid = cln_stream_grid(nvec, 256);
-    CLN_LAUNCH((add_vec_kernel<VT>), dim3(grid), dim3(256), 0, stream, (const VT*)a, (const VT*)b, (VT*)c,
-                       nvec, cln_stream_nt(3LL * n * (long long)sizeof(T)));
+    const long long traffic = 3LL * n * (long long)sizeof(T);
+    if (traffic >= (512LL << 20) || nvec < 4096) {
+      CLN_LAUNCH((add_vec_kernel<VT, 1>), dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, stream, (const VT*)a, (const VT*)b, (VT*)c, nvec, cln_stream_nt(traffic));
+    } else {
+      CLN_LAUNCH((add_vec_kernel<VT, 4>), dim3((unsigned)((nvec + 1023) / 1024)), dim3(256), 0, stream, (const VT*)a, (const VT*)b, (VT*)c, nvec, cln_stream_nt(traffic));
+    }
   }
   const long long done = nvec * VEC;
   if (done < n) {
@@ -81,8 +98,7 @@ CLN_API int elementwise_add_f16x8(const void* a, const void* b, void* c, long lo
   if (n == 0) return CLN_OK;
   const long long ngroups = n / 8;
   if (ngroups > 0) {
-    const int grid = cln_stream_grid(ngroups, 256);
-    CLN_LAUNCH(add_f16x8_unpacked_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const h2*)a,
+    CLN_LAUNCH(add_f16x8_unpacked_kernel, dim3((unsigned)((ngroups + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const h2*)a,
                        (const h2*)b, (h2*)c, ngroups, cln_stream_nt(6LL * n));
   }
   if (ngroups * 8 < n) {

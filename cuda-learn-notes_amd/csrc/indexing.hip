@@ -147,7 +147,7 @@ int launch_emb(const void* idx, const void* weight, void* out, long long n, int 
   if (PACKED && (!cln_aligned16(weight) || !cln_aligned16(out))) return CLN_ERR_BAD_ARG;
   if (n == 0) return CLN_OK;
   const long long total = n * (emb / VEC);
-  const int grid = cln_stream_grid(total, 256);
+  const int grid = cln_stream_grid(total, 256, 2LL * n * emb * (long long)sizeof(T));
   CLN_LAUNCH((embedding_kernel<T, VEC, PACKED>), dim3(grid), dim3(256), 0, st, (const int*)idx, (const T*)weight,
              (T*)out, n, emb, vocab, cln_stream_nt(2LL * n * emb * (long long)sizeof(T)));  // gathered rows + output
   return cln_check_launch();

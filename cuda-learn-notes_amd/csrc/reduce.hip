@@ -2,8 +2,8 @@
 // accumulator. Replaces reference kernels/reduce/block_all_reduce.cu:42-687 (kernels) and
 // :734-813 (bindings). HBM-bound: sizeof(T) bytes read per element.
 //
-// gfx950 design: capped grid-stride streaming (256 CUs x 16 workgroups), per-lane access width
-// fixed by the rung name, wave64 xor-butterfly -> one LDS hop -> ONE atomic per workgroup
+// gfx950 design: block-contiguous streaming on up to 1024 workgroups of 256 threads (the walk note above the kernel), per-lane access width
+// fixed by the rung name, wave64 xor-butterfly -> one LDS hop -> ONE atomic + ticket per workgroup
 // (the reference's structure, re-derived for 64 lanes: NUM_WARPS = NT/64).
 // "acc" in the rung name is the precision of the IN-PACK sum, as in the reference
 // (e.g. f16x8_pack_f16 adds the 8 halves of a pack in fp16, block_all_reduce.cu:252-262);
@@ -123,47 +123,40 @@ struct alignas(sizeof(E) * VEC) Pack {
   E v[VEC];
 };
 
-// One workgroup of 1024 threads per CU at most (256 x 16 waves cover the chip's wave slots): the final
-// device-scope atomics on the single result word serialise at ~12 ns each (MI355X_MICROARCH "fanin"), so
-// the grid is capped at the CU count -- 4096 small workgroups spent 50 us in that tail alone.
+// Walk (round 6): BLOCK-CONTIGUOUS chunks on small workgroups. Up to 1024 workgroups of 256 threads; a workgroup takes chunk c = blockIdx, blockIdx +
+// grid, ... of 256 K consecutive packs, every lane issues its K loads (lane + 256 k of the chunk) and then sums them: K = 4 for 16-byte packs, 8 below.
+// Rounds 1-5 ran ONE 1024-thread workgroup per CU over a strided walk (pack i + u * grid * 1024, 8 loads in flight). With rocprim::reduce as the
+// yardstick beside it (bench.py `yardstick`) that form was 2-6 % behind; the stream alone, partials stored without any atomic
+// (tools/ubench/stream_forms.hip, profiles/r06_stream_forms_ubench.log): f32 [4096,4096] strided 12.8 us, this walk 11.9; [8192,8192] 45.9 -> 44.6;
+// f16 7.5 -> 7.0 and 24.1 -> 22.4 us. The same ubench with 1024-thread workgroups over contiguous chunks gains 0-2 % only: it is the small workgroup
+// (a wave that retires is replaced without waiting for fifteen others) at least as much as the address pattern.
+// Finish: one RETURNING atomic + one ticket per workgroup on 32 sets of <= 32 workgroups (stream_scratch.h; the single-word fan-in serialises at
+// ~12 ns per atomic, which is why round 5 measured 512-2048 workgroups on EIGHT sets 6-55 % slower: profiles/r05_reduce_grid_probe.log).
+constexpr int RED_NT = 256, RED_MAX_WG = 1024, RED_SETS = 32;
 template <typename PS, int VEC>
-__global__ __launch_bounds__(1024) void reduce_sum_kernel(const typename PS::elem* __restrict__ a,
-                                                          typename PS::out* __restrict__ y, long long n, ClnScratch* sc) {
+__global__ __launch_bounds__(RED_NT) void reduce_sum_kernel(const typename PS::elem* __restrict__ a, typename PS::out* __restrict__ y, long long n, ClnScratch* sc) {
   using E = typename PS::elem;
   using O = typename PS::out;
-  __shared__ O scratch[16];
+  using P = Pack<E, VEC>;
+  constexpr int K = sizeof(P) >= 16 ? 4 : 8;
+  __shared__ O scratch[RED_NT / 64];
   O s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-  const long long nvec = n / VEC;
-  const long long stride = (long long)gridDim.x * 1024;
-  long long i = (long long)blockIdx.x * 1024 + threadIdx.x;
-  // 8 independent loads in flight per lane (round 4; 4 before): at the reference scripts' own sizes a lane owns 8-16 packs in all
-  // (4096^2 f16x8: 8), so the kernel is a few round trips to HBM long and each batch of loads that has to wait for the previous one is
-  // ~1 us of a 6-8 us launch. Sixteen in flight was built and measured in round 5 (f32 +2-3 %, f16 -2 %, the fp8 x16
-  // instances spill 10 registers): not shipped, removed in round 6 (profiles/r05_reduce_grid_probe.log, last rows)
-  for (; i + 7 * stride < nvec; i += 8 * stride) {
-    Pack<E, VEC> p[8];
+  const long long nvec = n / VEC, chunk = (long long)RED_NT * K, nfull = nvec / chunk;
+  const P* ap = reinterpret_cast<const P*>(a);
+  for (long long c = blockIdx.x; c < nfull; c += gridDim.x) {
+    const P* p0 = ap + c * chunk + threadIdx.x;
+    P p[K];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) p[u] = *reinterpret_cast<const Pack<E, VEC>*>(a + (i + u * stride) * VEC);
-    s0 += PS::sum(p[0].v), s1 += PS::sum(p[1].v), s2 += PS::sum(p[2].v), s3 += PS::sum(p[3].v);
-    s0 += PS::sum(p[4].v), s1 += PS::sum(p[5].v), s2 += PS::sum(p[6].v), s3 += PS::sum(p[7].v);
+    for (int k = 0; k < K; ++k) p[k] = p0[k * RED_NT];
+#pragma unroll
+    for (int k = 0; k < K; k += 4) s0 += PS::sum(p[k].v), s1 += PS::sum(p[k + 1].v), s2 += PS::sum(p[k + 2].v), s3 += PS::sum(p[k + 3].v);
   }
-  for (; i + 3 * stride < nvec; i += 4 * stride) {
-    const Pack<E, VEC> p0 = *reinterpret_cast<const Pack<E, VEC>*>(a + i * VEC);
-    const Pack<E, VEC> p1 = *reinterpret_cast<const Pack<E, VEC>*>(a + (i + stride) * VEC);
-    const Pack<E, VEC> p2 = *reinterpret_cast<const Pack<E, VEC>*>(a + (i + 2 * stride) * VEC);
-    const Pack<E, VEC> p3 = *reinterpret_cast<const Pack<E, VEC>*>(a + (i + 3 * stride) * VEC);
-    s0 += PS::sum(p0.v);
-    s1 += PS::sum(p1.v);
-    s2 += PS::sum(p2.v);
-    s3 += PS::sum(p3.v);
-  }
-  for (; i < nvec; i += stride) {
-    const Pack<E, VEC> p = *reinterpret_cast<const Pack<E, VEC>*>(a + i * VEC);
-    s0 += PS::sum(p.v);
+  if (blockIdx.x == (unsigned)(nfull % gridDim.x)) {  // the packs past the last whole chunk: the workgroup whose turn it would be
+    for (long long i = nfull * chunk + threadIdx.x; i < nvec; i += RED_NT) s0 += PS::sum(ap[i].v);
   }
   O s = (s0 + s1) + (s2 + s3);
   if (blockIdx.x == 0) {  // ragged tail, element-wise
-    for (long long t = nvec * VEC + threadIdx.x; t < n; t += 1024) {
+    for (long long t = nvec * VEC + threadIdx.x; t < n; t += RED_NT) {
       E one[VEC] = {};
       one[0] = a[t];
       // sum of a pack whose other slots are zero == decode of the single element
@@ -177,11 +170,11 @@ __global__ __launch_bounds__(1024) void reduce_sum_kernel(const typename PS::ele
   if (lane == 0) scratch[w] = s;
   __syncthreads();
   if (w == 0) {
-    O t = (lane < 16) ? scratch[lane] : (O)0;
+    O t = (lane < RED_NT / 64) ? scratch[lane] : (O)0;
 #pragma unroll
-    for (int m = 8; m >= 1; m >>= 1) t += __shfl_xor(t, m, 64);
-    if (sc) cln_scratch_finish<O>(sc, y, t, gridDim.x, lane);  // the block that completes the launch moves the total into y and re-zeroes the scratch (stream_scratch.h)
-    else if (lane == 0) atomicAdd(y, t);                       // no scratch slot (stream capture): y was zeroed on the stream by the launcher
+    for (int m = RED_NT / 128; m >= 1; m >>= 1) t += __shfl_xor(t, m, 64);
+    if (sc) cln_scratch_finish<O, RED_SETS>(sc, y, t, gridDim.x, lane);  // the block that completes the launch moves the total into y and re-zeroes the scratch (stream_scratch.h)
+    else if (lane == 0) atomicAdd(y, t);                                 // no scratch slot (stream capture): y was zeroed on the stream by the launcher
   }
 }
 
@@ -192,14 +185,12 @@ int launch_reduce(const void* a, void* y, long long n, hipStream_t st) {
   if (!a || !y || n < 0) return CLN_ERR_BAD_ARG;
   if (n == 0) return hipMemsetAsync(y, 0, sizeof(typename PS::out), st) == hipSuccess ? CLN_OK : ((void)hipGetLastError(), CLN_ERR_LAUNCH);
   if (!cln_aligned(a, sizeof(E) * VEC >= 16 ? 16 : sizeof(E) * VEC)) return CLN_ERR_BAD_ARG;
-  long long g = (n / VEC + 1023) / 1024;
-  // 256 workgroups at most. 512 / 1024 / 2048 workgroups of 1024 threads measured 6-55 % SLOWER at every size (f16 4096^2 9.2 -> 10.7 / 11.9 / 14.3 us,
-  // f32 8192^2 48.1 -> 50.9 / 52.5 / 54.2): the completion tickets grow with the grid (profiles/r05_reduce_grid_probe.log)
-  constexpr int cap = 256;
-  const int grid = (int)(g < 1 ? 1 : (g > cap ? cap : g));
+  constexpr int K = sizeof(E) * VEC >= 16 ? 4 : 8;
+  const long long chunks = (n / VEC + (long long)RED_NT * K - 1) / ((long long)RED_NT * K);
+  const int grid = (int)(chunks < 1 ? 1 : (chunks > RED_MAX_WG ? RED_MAX_WG : chunks));
   ClnScratch* sc = cln_stream_scratch(st);
   if (!sc && hipMemsetAsync(y, 0, sizeof(typename PS::out), st) != hipSuccess) return (void)hipGetLastError(), CLN_ERR_LAUNCH;
-  CLN_LAUNCH((reduce_sum_kernel<PS, VEC>), dim3(grid), dim3(1024), 0, st, (const E*)a, (typename PS::out*)y, n, sc);
+  CLN_LAUNCH((reduce_sum_kernel<PS, VEC>), dim3(grid), dim3(RED_NT), 0, st, (const E*)a, (typename PS::out*)y, n, sc);
   return cln_check_launch();
 }
 

@@ -4,7 +4,7 @@
 // kernels add one atomic per block into it: every call is TWO dispatches (fill + kernel), 8.4 us of host time against torch.sum's 4.
 // Here the blocks add into a library-owned, zero-initialised scratch word; the block that takes the LAST ticket moves the total into y
 // (overwriting it -- y no longer has to be zeroed) and leaves sum and ticket at zero for the next launch: one dispatch, no fill.
-//   * one 4-KiB slot per (device, stream): launches on one stream run in order, so they can share it; 64 slots per device, the least
+//   * one 16-KiB slot per (device, stream): launches on one stream run in order, so they can share it; 64 slots per device, the least
 //     recently used one re-assigned after a hipDeviceSynchronize() when a 65th stream shows up (a process that cycles streams never leaks);
 //   * nullptr while the stream is being captured (ALWAYS, round 6: a graph must not carry mutable library state -- replays run on any stream, next
 //     to eager launches and to each other) and on allocation failure: the caller then zeroes y on the stream (a memset node under capture) and the
@@ -12,15 +12,17 @@
 #pragma once
 #include "common.h"
 
-// One slot: EIGHT partial sums and tickets, each on its own 128-byte line (a block uses set blockIdx & 7 = its XCD), and one top ticket. All of a
-// launch's blocks hammering ONE word serialise at ~12 ns per atomic (MI355X_MICROARCH.md "fanin": 256 blocks = 3 us of tail); eight sets of 32 take 0.4 us.
+// One slot: up to THIRTY-TWO partial sums and tickets, each on its own 128-byte line (a block uses set blockIdx & (SETS - 1); with 8 sets that is its
+// XCD), and one top ticket. All of a launch's blocks hammering ONE word serialise at ~12 ns per atomic (MI355X_MICROARCH.md "fanin": 256 blocks =
+// 3 us of tail); eight sets of 32 take 0.4 us. Round 6: the reductions run 1024 small workgroups (block-contiguous walk, reduce.hip) on 32 sets of 32.
+constexpr int CLN_SCRATCH_MAX_SETS = 32;
 struct ClnScratch {
-  struct { float sum; unsigned pad[31]; } part[8];        // fp32 or int32 bits
-  struct { unsigned ticket; unsigned pad[31]; } arrive[8];  // blocks of the set that have added their partial
-  unsigned top;                                           // sets whose last block has arrived
-  unsigned pad[511];
+  struct { float sum; unsigned pad[31]; } part[CLN_SCRATCH_MAX_SETS];        // fp32 or int32 bits
+  struct { unsigned ticket; unsigned pad[31]; } arrive[CLN_SCRATCH_MAX_SETS];  // blocks of the set that have added their partial
+  unsigned top;                                                              // sets whose last block has arrived
+  unsigned pad[2047];
 };
-static_assert(sizeof(ClnScratch) == 4096, "one slot = 4 KiB");
+static_assert(sizeof(ClnScratch) == 16384, "one slot = 16 KiB");
 
 ClnScratch* cln_stream_scratch(hipStream_t stream);
 size_t cln_stream_scratch_release();  // frees every slab (cln_release_workspaces); returns the bytes freed
@@ -31,12 +33,13 @@ size_t cln_stream_scratch_release();  // frees every slab (cln_release_workspace
 //   lane 0: partial added to the set's sum with a RETURNING atomic -- the add has been performed at the point of coherence once its value is
 //           back, only then is the set's ticket taken (no release fence: a fence writes back and invalidates the XCD's L2, per block);
 //           the last block of a set takes the top ticket; the block that takes the last top ticket knows every set is complete
-//   lanes 0..7 of that block: one exchange each (all in flight together) collects and re-zeroes the eight sums
-template <typename O>
+//   lanes 0..SETS-1 of that block: one exchange each (all in flight together) collects and re-zeroes the sums
+template <typename O, int SETS = 8>
 __device__ __forceinline__ void cln_scratch_finish(ClnScratch* sc, O* y, O t, unsigned nblocks, int lane) {
+  static_assert(SETS >= 1 && SETS <= CLN_SCRATCH_MAX_SETS && (SETS & (SETS - 1)) == 0, "a power of two of sets, at most 32");
   int last = 0;
   if (lane == 0) {
-    const unsigned g = blockIdx.x & 7u, in_set = (nblocks - g + 7u) >> 3, sets = nblocks < 8u ? nblocks : 8u;
+    const unsigned g = blockIdx.x & (unsigned)(SETS - 1), in_set = (nblocks - g + (unsigned)(SETS - 1)) / (unsigned)SETS, sets = nblocks < (unsigned)SETS ? nblocks : (unsigned)SETS;
     O old = __hip_atomic_fetch_add(reinterpret_cast<O*>(&sc->part[g].sum), t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("" : "+v"(old)::"memory");
     unsigned tk = __hip_atomic_fetch_add(&sc->arrive[g].ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -53,9 +56,9 @@ __device__ __forceinline__ void cln_scratch_finish(ClnScratch* sc, O* y, O t, un
   last = __shfl(last, 0, 64);
   if (last) {  // wave-uniform
     O v = (O)0;
-    if (lane < 8) v = __hip_atomic_exchange(reinterpret_cast<O*>(&sc->part[lane].sum), (O)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane < SETS) v = __hip_atomic_exchange(reinterpret_cast<O*>(&sc->part[lane].sum), (O)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-    for (int m = 4; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    for (int m = SETS / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
     if (lane == 0) *y = v;
   }
 }

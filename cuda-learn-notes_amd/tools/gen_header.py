@@ -86,7 +86,7 @@ def main():
                " *   -1 bad argument, -2 unsupported shape, -3 HIP launch error, -4 vendor-library error.\n"
                " * Launches are asynchronous on `stream`. The callee allocates no device memory for the data path and keeps no pointer of the\n"
                " * caller's, with two stated exceptions: (1) the split-K workspace a caller REGISTERS per stream (cln_hgemm_set_workspace, end of\n"
-               " * this file; library-owned buffers exist only after cln_hgemm_library_workspace(1)); (2) one 256-KiB slab per device of 4-KiB\n"
+               " * this file; library-owned buffers exist only after cln_hgemm_library_workspace(1)); (2) one 1-MiB slab per device of 16-KiB\n"
                " * ticket slots for the scalar-result kernels (block_all_reduce_sum_*, dot_prod_*), hipMalloc'ed on their first eager call and\n"
                " * freed by cln_release_workspaces(); captured launches never touch it.\n"
                " */\n#ifndef CLN_AMD_H\n#define CLN_AMD_H\n#ifdef __cplusplus\nextern \"C\" {\n#endif\n#include <stddef.h>\n")

@@ -826,7 +826,7 @@ def test_workspace_does_not_leak_over_many_streams(hg, built, dev):
                 assert hip.hipStreamDestroy(s) == 0
         torch.cuda.synchronize()
         assert 0 < peak <= 8 * one, peak
-        assert host.release_workspaces() <= 8 * one + (64 * 4096) * 2 and host.hgemm_workspace_held() == 0
+        assert host.release_workspaces() <= 8 * one + (64 * 16384) * 2 and host.hgemm_workspace_held() == 0
     finally:
         host.hgemm_library_workspace(False)
     streams = [torch.cuda.Stream() for _ in range(40)]
