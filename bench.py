@@ -300,7 +300,8 @@ def main():
                             ("hgemm", lambda: bc.hgemm_config_rows(pkg, dev, orc)),
                             ("hgemm_policy", lambda: bc.hgemm_policy_rows(pkg, dev)),
                             ("fa2_stages", lambda: bc.fa_stage_rows(pkg, dev)),
-                            ("bandwidth", lambda: bc.bandwidth_rows(dev, orc))):
+                            ("bandwidth", lambda: bc.bandwidth_rows(dev, orc)),
+                            ("next_rows", lambda: bc.next_rows(pkg, dev, orc))):
                 t0 = time.perf_counter()
                 try:
                     cfg[key] = fn()
@@ -364,6 +365,8 @@ def headline_line(out, detail_file="bench_detail.json"):
             fa[short] = {"tflops": t, "frac": round(t / 2500.0, 4) if t else None}
     if fa:
         digest["fa2_fwd"] = fa
+        # the north_star names FlashAttention-2-ROCm; what stands beside our kernel is NOT that package
+        digest["fa2_comparator"] = "ck_tile FMHA fwd compiled from the image's headers (the kernels FlashAttention-2-ROCm / aiter dispatch to) + torch SDPA; the flash_attn / aiter packages are not importable in this image (no network)"
     for k in ("fa2_error", "rocblas_error"):
         if k in ex:
             digest[k] = _clip(ex[k], 100)
@@ -372,7 +375,7 @@ def headline_line(out, detail_file="bench_detail.json"):
     digest["detail_file"] = detail_file
     line["digest"] = digest
     s = json.dumps(line, separators=(", ", ": "))
-    for k in ("fa2_fwd", "hipblaslt_tn_tflops", "hipblaslt_tflops", "pct_of_hipblaslt", "hgemm_tn_tflops", "rocblas_tn_tflops"):
+    for k in ("fa2_comparator", "fa2_fwd", "hipblaslt_tn_tflops", "hipblaslt_tflops", "pct_of_hipblaslt", "hgemm_tn_tflops", "rocblas_tn_tflops"):
         if len(s) < MAX_LINE:
             break
         digest.pop(k, None)
@@ -412,12 +415,14 @@ def detail_rows(out):
         elif isinstance(node, dict):
             if "error" in node and len(node) == 1:
                 add(prefix, "error: %s" % node["error"])
-            elif any(k in node for k in ("gbps", "tflops", "us_per_launch", "ms")) and not any(isinstance(v, (dict, list)) and v and k != "shape" and k != "mnk" for k, v in node.items() if k not in ("cpu_baseline", "roofline")):
+            elif any(k in node for k in ("gbps", "tflops", "us_per_launch", "ms")) and not any(isinstance(v, (dict, list)) and v and k != "shape" and k != "mnk" for k, v in node.items() if k not in ("cpu_baseline", "roofline", "yardstick")):
                 name = node.get("kernel") or node.get("name") or node.get("tag") or ""
                 bits = []
-                for k in ("shape", "mnk", "dtype", "stages", "swizzle", "us_per_launch", "us_64_row_launch", "ms", "gbps", "frac_of_8TBs", "tflops", "frac", "frac_of_peak", "pct_of_rocblas"):
+                for k in ("shape", "mnk", "dtype", "stages", "swizzle", "us_per_launch", "us_64_row_launch", "ms", "gbps", "frac_of_8TBs", "tflops", "frac", "frac_of_peak", "frac_of_f32_mfma_peak", "x_rocblas_sgemm", "gelem_per_s", "pct_of_rocblas"):
                     if k in node:
                         bits.append("%s=%s" % (k, node[k]))
+                if isinstance(node.get("yardstick"), dict) and "ours_over_yardstick" in node["yardstick"] and not isinstance(node["yardstick"]["ours_over_yardstick"], dict):
+                    bits.append("x_yardstick=%s" % node["yardstick"]["ours_over_yardstick"])
                 add(prefix + ":" + str(name)[:60], " ".join(bits))
             else:
                 for k, v in node.items():

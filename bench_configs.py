@@ -483,3 +483,228 @@ def fa_stage_rows(pkg, dev):
         out[key] = row
         del q, k, v, o1, o2
     return out
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# SURVEY 8(f) rows (round 6, VERDICT r5 missing #3 / next #7): the reference scripts time every one of these (kernels/sgemm/sgemm.py:133-135,
+# embedding/embedding.py:81-84, mat-transpose/mat_transpose.py:60, relu/relu.py ..., histogram/histogram.py, dot-product/dot_product.py); here each
+# gets its rate, its roofline fraction (f32 matrix peak 157.3 TF for sgemm, 8 TB/s for the rest), a vendor row where one exists and the
+# reference script's torch op on the host cores.
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = the f32 vector peak
+
+
+def _one_region(call, min_launches=50, prewarm_s=0.1, target_ms=30.0):
+    return _region_ms([call], min_launches, prewarm_s=prewarm_s, target_ms=target_ms)[0]
+
+
+def next_rows(pkg, dev, orc):
+    import ctypes as C
+    st = _stream()
+    out = {}
+    g = torch.Generator(device="cpu").manual_seed(23)
+
+    def _sec_sgemm():
+        # ---- sgemm 4096^3 (reference sgemm.py sweeps 4096-8192): the f32-MFMA rung, the best VALU rung, rocBLAS
+        M = N = K = 4096
+        a = torch.randn(M, K, device=dev)
+        b = torch.randn(K, N, device=dev)
+        c = torch.zeros(M, N, device=dev)
+        flops = 2.0 * M * N * K
+        rows = {}
+        ap, bp, cp = a.data_ptr(), b.data_ptr(), c.data_ptr()
+        for name, args in (("sgemm_wmma_m16n16k8_mma4x2_warp2x4_stages", (2, 0, 0)), ("sgemm_wmma_m16n16k8_mma4x2_warp2x4_stages_dsmem", (3, 1, 256)),
+                           ("sgemm_t_8x8_sliced_k16_f32x4_bcf_dbuf_async", None), ("sgemm_t_8x8_sliced_k_f32x4_bcf_dbuf", None), ("sgemm_cublas", None)):
+            if not _loader.has_symbol(name):
+                continue
+            fn = _loader.symbol(name)
+            if name == "sgemm_cublas":
+                _loader.symbol("init_cublas_handle")()
+            call = (lambda fn=fn, args=args: fn(ap, bp, cp, M, N, K, args[0], args[1], args[2], st)) if args else (lambda fn=fn: fn(ap, bp, cp, M, N, K, st))
+            rc = call()
+            torch.cuda.synchronize()
+            if rc != 0:
+                rows[name] = {"error": "status %d" % rc}
+                continue
+            ms = _one_region(call, 20, target_ms=60.0)
+            rows[name] = {"us_per_launch": round(ms * 1e3, 2), "tflops": round(flops / ms * 1e-9, 2), "frac_of_f32_mfma_peak": round(flops / ms * 1e-9 / PEAK_F32_MFMA_TFLOPS, 4)}
+        if "sgemm_cublas" in rows and "tflops" in rows["sgemm_cublas"]:
+            for k, r in rows.items():
+                if "tflops" in r:
+                    r["x_rocblas_sgemm"] = round(r["tflops"] / rows["sgemm_cublas"]["tflops"], 3)
+        # sampled rows of the MFMA rung against the fp64 product (exact-f32 MFMA: <= a few fp32 ulps of a K = 4096 sum)
+        fn = _loader.symbol("sgemm_wmma_m16n16k8_mma4x2_warp2x4_stages")
+        c.zero_()
+        fn(ap, bp, cp, M, N, K, 2, 0, 0, st)
+        torch.cuda.synchronize()
+        sel = torch.tensor([0, 1, 777, 2048, 4095], device=dev)
+        truth = a[sel].double() @ b.double()
+        rows["max_rel_err_sampled_rows_vs_fp64"] = float(((c[sel].double() - truth).abs().max() / truth.abs().max()).item())
+        ac, bc = a[:256].cpu(), b.cpu()
+        sec, it = _cpu_time(lambda: torch.matmul(ac, bc), budget_s=2.0, max_iters=20)
+        rows["cpu_baseline"] = {"value": round(2.0 * 256 * N * K / sec * 1e-12, 4), "unit": "TFLOPS", "cores": torch.get_num_threads(), "kind": "port",
+                                "sample": "torch.matmul fp32 on CPU, first 256 of 4096 rows of A x full B, %d calls (%.1f ms each)" % (it, sec * 1e3)}
+        out["sgemm_4096"] = rows
+        del a, b, c, truth
+        torch.cuda.empty_cache()
+
+    def _sec_mat_transpose():
+        # ---- mat-transpose f32 [4096,4096] and [8192,8192]: 8 B per element; yardsticks: hipMemcpyDtoD of the same bytes (no transposition: the floor of 1R + 1W)
+        # and torch's x.t().contiguous()
+        ylib = _yardsticks()
+        tr = {}
+        for side in (4096, 8192):
+            nbytes = 8 * side * side
+            nsets = max(3, ROTATE_FOOTPRINT // nbytes)
+            pool = torch.randn(2 * nsets, side, side, device=dev)
+            for name in ("mat_transpose_f32_col2row", "mat_transpose_f32x4_col2row", "mat_transpose_f32x4_row2col", "mat_transpose_f32_diagonal2d",
+                         "mat_transpose_f32x4_shared_col2row2d", "mat_transpose_f32x4_shared_bcf_col2row2d"):
+                fn = _loader.symbol(name)
+                calls = [(lambda xp=pool[2 * i].data_ptr(), yp=pool[2 * i + 1].data_ptr(), fn=fn: fn(xp, yp, side, side, st)) for i in range(nsets)]
+                if calls[0]() != 0:
+                    continue
+                ms, _ = _region_ms(calls, 3 * nsets)
+                tr.setdefault("%dx%d" % (side, side), {})[name] = {"us_per_launch": round(ms * 1e3, 2), "gbps": round(nbytes / ms * 1e-6, 1), "frac_of_8TBs": round(nbytes / ms * 1e-6 / bu.PEAK_HBM_GBPS, 4)}
+            d = tr["%dx%d" % (side, side)]
+            ycalls = [(lambda x=pool[2 * i], y=pool[2 * i + 1]: y.copy_(x.t())) for i in range(nsets)]
+            yms, _ = _region_ms(ycalls, 3 * nsets)
+            d["yardstick_torch_transpose_copy"] = {"us_per_launch": round(yms * 1e3, 2), "gbps": round(nbytes / yms * 1e-6, 1)}
+            if ylib is not None:
+                half = nbytes // 2
+                mc = [(lambda xp=pool[2 * i].data_ptr(), yp=pool[2 * i + 1].data_ptr(): ylib.cln_yardstick_copy(yp, xp, half, st)) for i in range(nsets)]
+                mms, _ = _region_ms(mc, 3 * nsets)
+                d["yardstick_hipMemcpyDtoD_same_bytes"] = {"us_per_launch": round(mms * 1e3, 2), "gbps": round(nbytes / mms * 1e-6, 1)}
+            best = min((v["us_per_launch"] for k, v in d.items() if k.startswith("mat_transpose")), default=None)
+            if best:
+                d["best_over_torch"] = round(d["yardstick_torch_transpose_copy"]["us_per_launch"] / best, 3)
+            if side == 4096:
+                xc = torch.randn(side, side, generator=g)
+                yc = torch.empty(side, side)
+                sec, it = _cpu_time(lambda: yc.copy_(xc.t()))
+                d["cpu_baseline"] = {"value": round(nbytes / sec * 1e-9, 2), "unit": "GB/s", "cores": torch.get_num_threads(), "kind": "port",
+                                     "sample": "y.copy_(x.t()) fp32 [4096,4096] on CPU (mat_transpose.py:60 times x.transpose(0, 1).contiguous()), %d calls" % it}
+            del pool, calls, ycalls
+            torch.cuda.empty_cache()
+        out["mat_transpose"] = tr
+
+    def _sec_embedding():
+        # ---- embedding (reference embedding.py: 1024 / 4096 rows of a [vocab, emb] table): 65536 indices x emb 1024, 2 x n x emb x sizeof bytes
+        em = {}
+        vocab, n_idx, emb = 50000, 65536, 1024
+        idx = torch.randint(0, vocab, (n_idx,), generator=g, dtype=torch.int32).to(dev)
+        for dt, names in ((torch.float32, ("embedding_f32", "embedding_f32x4_pack")), (torch.float16, ("embedding_f16", "embedding_f16x8_pack"))):
+            w = torch.randn(vocab, emb, device=dev).to(dt)
+            esz = w.element_size()
+            nbytes = 2 * n_idx * emb * esz
+            nsets = max(3, ROTATE_FOOTPRINT // (nbytes // 2))
+            outs = torch.empty(nsets, n_idx, emb, device=dev, dtype=dt)
+            for name in names:
+                fn = _loader.symbol(name)
+                calls = [(lambda op=outs[i].data_ptr(), fn=fn: fn(idx.data_ptr(), w.data_ptr(), op, n_idx, emb, vocab, st)) for i in range(nsets)]
+                if calls[0]() != 0:
+                    continue
+                ms, _ = _region_ms(calls, 3 * nsets)
+                em[name] = {"us_per_launch": round(ms * 1e3, 2), "gbps": round(nbytes / ms * 1e-6, 1), "frac_of_8TBs": round(nbytes / ms * 1e-6 / bu.PEAK_HBM_GBPS, 4)}
+            il = idx.long()
+            ycalls = [(lambda o=outs[i]: torch.index_select(w, 0, il, out=o)) for i in range(nsets)]
+            yms, _ = _region_ms(ycalls, 3 * nsets)
+            em["yardstick_torch_index_select_%s" % ("f32" if esz == 4 else "f16")] = {"us_per_launch": round(yms * 1e3, 2), "gbps": round(nbytes / yms * 1e-6, 1)}
+            if esz == 4:
+                wc, ic = w[:, :].cpu(), idx.cpu().long()
+                sec, it = _cpu_time(lambda: torch.nn.functional.embedding(ic, wc))
+                em["cpu_baseline"] = {"value": round(nbytes / sec * 1e-9, 2), "unit": "GB/s", "cores": torch.get_num_threads(), "kind": "port",
+                                      "sample": "F.embedding(idx[65536], weight[50000,1024] fp32) on CPU (embedding.py:81-84), %d calls" % it}
+                del wc
+            del w, outs, calls, ycalls
+            torch.cuda.empty_cache()
+        out["embedding_65536x1024"] = em
+
+    def _sec_activation():
+        # ---- activations at [4096,4096] (reference relu.py ... hardshrink.py): 2 x sizeof bytes per element; yardstick = the torch op with out=
+        act = {}
+        S = K = 4096
+        for dt, suffix in ((torch.float32, "f32x4"), (torch.float16, "f16x8_pack")):
+            esz = 4 if dt == torch.float32 else 2
+            nbytes = 2 * S * K * esz
+            nsets = max(3, ROTATE_FOOTPRINT // nbytes)
+            pool = torch.randn(2 * nsets, S, K, device=dev).to(dt)
+            for op, tfn in (("relu", lambda x, out: torch.clamp_min(x, 0.0, out=out)), ("gelu", lambda x, out: torch.nn.functional.gelu(x, approximate="tanh")), ("sigmoid", torch.sigmoid), ("hardswish", None), ("elu", None)):
+                name = "%s_%s" % (op, suffix)
+                fn = _loader.symbol(name)
+                calls = [(lambda xp=pool[2 * i].data_ptr(), yp=pool[2 * i + 1].data_ptr(), fn=fn: fn(xp, yp, S * K, st)) for i in range(nsets)]
+                if calls[0]() != 0:
+                    continue
+                ms, _ = _region_ms(calls, 3 * nsets)
+                row = {"us_per_launch": round(ms * 1e3, 2), "gbps": round(nbytes / ms * 1e-6, 1), "frac_of_8TBs": round(nbytes / ms * 1e-6 / bu.PEAK_HBM_GBPS, 4)}
+                if op in ("relu", "sigmoid"):
+                    ycalls = [(lambda x=pool[2 * i], y=pool[2 * i + 1], tfn=tfn: tfn(x, out=y)) for i in range(nsets)]
+                    yms, _ = _region_ms(ycalls, 3 * nsets)
+                    row["yardstick"] = {"what": ("torch.clamp_min(x, 0, out=)" if op == "relu" else "torch.sigmoid(out=)") + " on the GPU", "us_per_launch": round(yms * 1e3, 2), "ours_over_yardstick": round(yms / ms, 4)}
+                act[name] = row
+            if esz == 4:
+                xc = torch.randn(S, K, generator=g)
+                yc = torch.empty_like(xc)
+                sec, it = _cpu_time(lambda: torch.clamp_min(xc, 0.0, out=yc))
+                act["cpu_baseline"] = {"value": round(nbytes / sec * 1e-9, 2), "unit": "GB/s", "cores": torch.get_num_threads(), "kind": "port",
+                                       "sample": "relu as torch.clamp_min(x, 0, out=y) fp32 [4096,4096] on CPU (relu.py times torch.relu), %d calls" % it}
+            del pool
+            torch.cuda.empty_cache()
+        out["activation_4096x4096"] = act
+
+    def _sec_histogram():
+        # ---- histogram: 64 Mi int32 values into 1024 bins (reference histogram.py: a tiny vector; README.md:24-44) -- Gelem/s, 4 B per element read
+        n = 1 << 26
+        nb = 1024
+        vals = torch.randint(0, nb, (n,), generator=g, dtype=torch.int32).to(dev)
+        y = torch.zeros(nb, dtype=torch.int32, device=dev)
+        hi = {}
+        for name in ("histogram_i32", "histogram_i32x4"):
+            fn = _loader.symbol(name)
+            call = lambda fn=fn: fn(vals.data_ptr(), y.data_ptr(), n, nb, st)  # noqa: E731 -- (counts accumulate across launches: a rate measurement)
+            if call() != 0:
+                continue
+            ms = _one_region(call, 20)
+            hi[name] = {"us_per_launch": round(ms * 1e3, 2), "gelem_per_s": round(n / ms * 1e-6, 2), "gbps": round(4.0 * n / ms * 1e-6, 1), "frac_of_8TBs": round(4.0 * n / ms * 1e-6 / bu.PEAK_HBM_GBPS, 4)}
+        yms = _one_region(lambda: torch.bincount(vals, minlength=nb), 10)
+        hi["yardstick_torch_bincount"] = {"us_per_launch": round(yms * 1e3, 2), "gelem_per_s": round(n / yms * 1e-6, 2)}
+        y.zero_()
+        _loader.symbol("histogram_i32x4")(vals.data_ptr(), y.data_ptr(), n, nb, st)
+        torch.cuda.synchronize()
+        hi["bit_exact_vs_torch_bincount"] = bool(torch.equal(y.long(), torch.bincount(vals, minlength=nb)))
+        vc = vals[: 1 << 24].cpu()
+        sec, it = _cpu_time(lambda: orc.histogram(vc), budget_s=1.5, max_iters=10)
+        hi["cpu_baseline"] = {"value": round((1 << 24) / sec * 1e-9, 3), "unit": "Gelem/s", "cores": torch.get_num_threads(), "kind": "port",
+                              "sample": "oracle.histogram (the reference binding's semantics on torch CPU) over the first 16 Mi values, %d calls" % it}
+        out["histogram_64Mi_1024bins"] = hi
+        del vals, y
+        torch.cuda.empty_cache()
+
+    def _sec_dot_product():
+        # ---- dot product [8192,8192] f32 / f16: 2 x sizeof bytes per element; yardstick torch.dot
+        dp = {}
+        for dt, name in ((torch.float32, "dot_prod_f32x4_f32"), (torch.float16, "dot_prod_f16x8_pack_f32")):
+            nel = 8192 * 8192
+            esz = 4 if dt == torch.float32 else 2
+            nbytes = 2 * nel * esz
+            nsets = max(3, ROTATE_FOOTPRINT // nbytes)
+            pool = torch.randn(2 * nsets, nel, device=dev).to(dt)
+            res = torch.zeros(4, device=dev)
+            fn = _loader.symbol(name)
+            calls = [(lambda xp=pool[2 * i].data_ptr(), yp=pool[2 * i + 1].data_ptr(): fn(xp, yp, res.data_ptr(), nel, st)) for i in range(nsets)]
+            if calls[0]() == 0:
+                ms, _ = _region_ms(calls, 3 * nsets)
+                ycalls = [(lambda x=pool[2 * i], y=pool[2 * i + 1]: torch.dot(x, y)) for i in range(nsets)]
+                yms, _ = _region_ms(ycalls, 3 * nsets)
+                dp[name] = {"us_per_launch": round(ms * 1e3, 2), "gbps": round(nbytes / ms * 1e-6, 1), "frac_of_8TBs": round(nbytes / ms * 1e-6 / bu.PEAK_HBM_GBPS, 4),
+                            "yardstick": {"what": "torch.dot on the GPU", "us_per_launch": round(yms * 1e3, 2), "ours_over_yardstick": round(yms / ms, 4)}}
+            del pool
+            torch.cuda.empty_cache()
+        out["dot_product_8192x8192"] = dp
+
+    for nm, fn in (("sgemm", _sec_sgemm), ("mat_transpose", _sec_mat_transpose), ("embedding", _sec_embedding), ("activation", _sec_activation),
+                   ("histogram", _sec_histogram), ("dot_product", _sec_dot_product)):
+        try:
+            fn()
+        except Exception as e:  # noqa: BLE001 -- one family never takes the others down
+            out[nm + "_error"] = "%s: %s" % (type(e).__name__, str(e)[:200])
+        torch.cuda.empty_cache()
+    return out
