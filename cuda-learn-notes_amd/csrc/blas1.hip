@@ -2,8 +2,8 @@
 //   reference kernels/dot-product/dot_product.cu:35-276, kernels/sgemv/sgemv.cu:29-190,
 //   kernels/hgemv/hgemv.cu:34-196, kernels/mat-transpose/mat_transpose.cu:29-360.
 // gfx950 design (all HBM/latency bound, nothing for the matrix cores):
-//  * dot_prod: the block_all_reduce structure with two input streams: one 1024-thread workgroup per CU,
-//    4 independent pack pairs in flight per lane, fp32 accumulate, DPP wave reduce, one atomic per workgroup.
+//  * dot_prod: the block_all_reduce structure with two input streams: up to 1024 workgroups of 256 threads over block-contiguous chunks,
+//    2-4 independent pack pairs in flight per lane, fp32 accumulate, DPP wave reduce, one atomic + ticket per workgroup.
 //  * gemv: y[m] = sum_k a[m,k] x[k]; G lanes per row (G = 16 / 32 / 64 by K), 64/G rows per wave, the rung's
 //    access width per lane, fp32 accumulate (the reference's hgemv adds in half), reduction inside the G-lane
 //    group on the VALU (DPP row ops; v_permlane16_swap / 32_swap across rows), 4 waves per workgroup.
@@ -11,6 +11,7 @@
 //    packing, 1-D vs 2-D grids, diagonal block order and a padded / unpadded shared tile; here:
 //      *_col2row*  -> read-coalesced streaming kernel (scattered 4-byte writes), 1 or 4 elements per lane
 //      *_row2col*  -> write-coalesced streaming kernel (scattered reads)
+//      f32x4_*2d   -> (round 6) 4 x 4 register blocks, 8 x 8 lanes per 32 x 32 block: 16-byte accesses and full lines on both sides, no LDS
 //      diagonal2d  -> write-coalesced kernel with the reference's diagonal block order
 //      *_shared_*  -> 64x64 tile through LDS, 16-byte accesses on BOTH sides; `bcf` pads the tile rows (+1)
 #include "common.h"
@@ -26,38 +27,46 @@ __device__ __forceinline__ float tof(float x) { return x; }
 __device__ __forceinline__ float tof(half_t x) { return (float)x; }
 
 // ---- dot product ---------------------------------------------------------------------------------
+// Round 6: the walk of block_all_reduce_sum (reduce.hip) -- up to 1024 workgroups of 256 threads over consecutive chunks of 256 K pack pairs, K = 2 for
+// 16-byte packs (4 loads in flight per lane, two streams), 4 below; one returning atomic + ticket per workgroup on 32 sets.
 template <typename T, int VEC>
-__global__ __launch_bounds__(1024) void dot_kernel(const T* __restrict__ a, const T* __restrict__ b,
-                                                   float* __restrict__ y, long long n, ClnScratch* sc) {
-  __shared__ float scratch[16];
+__global__ __launch_bounds__(256) void dot_kernel(const T* __restrict__ a, const T* __restrict__ b,
+                                                  float* __restrict__ y, long long n, ClnScratch* sc) {
+  using P = Pk<T, VEC>;
+  constexpr int K = sizeof(P) >= 16 ? 2 : 4;
+  __shared__ float scratch[4];
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  const long long nvec = n / VEC, stride = (long long)gridDim.x * 1024;
-  long long i = (long long)blockIdx.x * 1024 + threadIdx.x;
-  auto fma_pack = [&](long long j, float& acc) {
-    const Pk<T, VEC> pa = *reinterpret_cast<const Pk<T, VEC>*>(a + j * VEC);
-    const Pk<T, VEC> pb = *reinterpret_cast<const Pk<T, VEC>*>(b + j * VEC);
+  const long long nvec = n / VEC, chunk = 256LL * K, nfull = nvec / chunk;
+  const P* ap = reinterpret_cast<const P*>(a);
+  const P* bp = reinterpret_cast<const P*>(b);
+  auto fma_pack = [&](const P& pa, const P& pb, float& acc) {
 #pragma unroll
     for (int e = 0; e < VEC; ++e) acc = fmaf(tof(pa.v[e]), tof(pb.v[e]), acc);
   };
-  for (; i + 3 * stride < nvec; i += 4 * stride) {
-    fma_pack(i, s0);
-    fma_pack(i + stride, s1);
-    fma_pack(i + 2 * stride, s2);
-    fma_pack(i + 3 * stride, s3);
+  for (long long c = blockIdx.x; c < nfull; c += gridDim.x) {
+    const long long base = c * chunk + threadIdx.x;
+    P pa[K], pb[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) pa[k] = ap[base + k * 256];
+#pragma unroll
+    for (int k = 0; k < K; ++k) pb[k] = bp[base + k * 256];
+    fma_pack(pa[0], pb[0], s0);
+    fma_pack(pa[1], pb[1], s1);
+    if constexpr (K == 4) fma_pack(pa[2], pb[2], s2), fma_pack(pa[3], pb[3], s3);
   }
-  for (; i < nvec; i += stride) fma_pack(i, s0);
+  if (blockIdx.x == (unsigned)(nfull % gridDim.x))  // the packs past the last whole chunk
+    for (long long i = nfull * chunk + threadIdx.x; i < nvec; i += 256) fma_pack(ap[i], bp[i], s0);
   float s = (s0 + s1) + (s2 + s3);
   if (blockIdx.x == 0)
-    for (long long t = nvec * VEC + threadIdx.x; t < n; t += 1024) s = fmaf(tof(a[t]), tof(b[t]), s);
+    for (long long t = nvec * VEC + threadIdx.x; t < n; t += 256) s = fmaf(tof(a[t]), tof(b[t]), s);
   s = wave_sum(s);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (lane == 0) scratch[w] = s;
   __syncthreads();
   if (w == 0) {
     float t = 0.f;
-    if (lane == 0)
-      for (int k = 0; k < 16; ++k) t += scratch[k];
-    if (sc) cln_scratch_finish<float>(sc, y, t, gridDim.x, lane);  // the block that completes the launch moves the total into y (stream_scratch.h): y need not be zeroed
+    if (lane == 0) t = (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
+    if (sc) cln_scratch_finish<float, 32>(sc, y, t, gridDim.x, lane);  // the block that completes the launch moves the total into y (stream_scratch.h): y need not be zeroed
     else if (lane == 0) atomicAdd(y, t);
   }
 }
@@ -66,11 +75,12 @@ int launch_dot(const void* a, const void* b, void* y, long long n, hipStream_t s
   if (!a || !b || !y || n < 0) return CLN_ERR_BAD_ARG;
   if (n == 0) return hipMemsetAsync(y, 0, sizeof(float), st) == hipSuccess ? CLN_OK : ((void)hipGetLastError(), CLN_ERR_LAUNCH);
   if (sizeof(T) * VEC >= 16 && (!cln_aligned16(a) || !cln_aligned16(b))) return CLN_ERR_BAD_ARG;
-  long long g = (n / VEC + 1023) / 1024;
-  const int grid = (int)(g < 1 ? 1 : (g > 256 ? 256 : g));
+  constexpr int K = sizeof(T) * VEC >= 16 ? 2 : 4;
+  const long long chunks = (n / VEC + 256LL * K - 1) / (256LL * K);
+  const int grid = (int)(chunks < 1 ? 1 : (chunks > 1024 ? 1024 : chunks));
   ClnScratch* sc = cln_stream_scratch(st);
   if (!sc && hipMemsetAsync(y, 0, sizeof(float), st) != hipSuccess) return (void)hipGetLastError(), CLN_ERR_LAUNCH;
-  CLN_LAUNCH((dot_kernel<T, VEC>), dim3(grid), dim3(1024), 0, st, (const T*)a, (const T*)b, (float*)y, n, sc);
+  CLN_LAUNCH((dot_kernel<T, VEC>), dim3(grid), dim3(256), 0, st, (const T*)a, (const T*)b, (float*)y, n, sc);
   return cln_check_launch();
 }
 
@@ -180,12 +190,43 @@ __global__ __launch_bounds__(256) void tr_lds_tile(const float* __restrict__ x, 
   }
 }
 
-enum TrKind { TR_READ1, TR_READ4, TR_WRITE1, TR_WRITE4, TR_DIAG, TR_LDS, TR_LDS_BCF };
+// No LDS, no barrier (round 6): a wave owns a 32 x 32 block as 8 x 8 lanes of 4 x 4 REGISTER blocks. Lane (a, b) reads rows 4a .. 4a+3 at columns
+// 4b .. 4b+3 (four 16-byte loads: the 8 lanes of one a cover one 128-byte line per row), transposes by register renaming and writes rows 4b .. 4b+3 of y at
+// columns 4a .. 4a+3 (the 8 lanes of one b cover one 128-byte line per output row): full lines on both sides. Against the LDS tile on the same box
+// (tools/ubench/transpose_forms.hip, profiles/r06_transpose_forms_ubench.log): [8192,8192] 124.8 -> 108.0 us (4.30 -> 4.97 TB/s; hipMemcpyDtoD of the same
+// bytes 5.33), [4096,4096] 30.2 -> 29.2, [2048,2048] 7.5 -> 8.1 (the LDS tile stays ahead below ~32 MB). The two f32x4 *2d rungs run it when both extents
+// divide by 32; the `shared` rungs keep the LDS tile their name states.
+__global__ __launch_bounds__(256) void tr_reg4x4(const float* __restrict__ x, float* __restrict__ y, int row, int col) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int a = lane >> 3, b = lane & 7;
+  const int blocks_c = col / 32;
+  const long long w = (long long)blockIdx.x * 4 + wave;  // one 32 x 32 block per wave
+  const int br = (int)(w / blocks_c), bc = (int)(w - (long long)br * blocks_c);
+  if (br * 32 >= row) return;
+  float4 v[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const float4*>(x + (size_t)(br * 32 + 4 * a + i) * col + bc * 32 + 4 * b);
+  float* yo = y + (size_t)(bc * 32 + 4 * b) * row + br * 32 + 4 * a;
+  *reinterpret_cast<float4*>(yo) = float4{v[0].x, v[1].x, v[2].x, v[3].x};
+  *reinterpret_cast<float4*>(yo + (size_t)row) = float4{v[0].y, v[1].y, v[2].y, v[3].y};
+  *reinterpret_cast<float4*>(yo + 2 * (size_t)row) = float4{v[0].z, v[1].z, v[2].z, v[3].z};
+  *reinterpret_cast<float4*>(yo + 3 * (size_t)row) = float4{v[0].w, v[1].w, v[2].w, v[3].w};
+}
+
+enum TrKind { TR_READ1, TR_READ4, TR_WRITE1, TR_WRITE4, TR_DIAG, TR_LDS, TR_LDS_BCF, TR_READ4_2D, TR_WRITE4_2D };
 int launch_tr(int kind, const void* x, void* y, int row, int col, hipStream_t st) {
   if (!x || !y || row <= 0 || col <= 0) return CLN_ERR_BAD_ARG;
   const long long n = (long long)row * col;
   const float* xp = (const float*)x;
   float* yp = (float*)y;
+  if ((kind == TR_READ4_2D || kind == TR_WRITE4_2D)) {  // the f32x4 *2d rungs: the register-block kernel where the shape allows, else the 1-D rung of the same name
+    if (row % 32 == 0 && col % 32 == 0 && cln_aligned16(x) && cln_aligned16(y)) {
+      const long long waves = (long long)(row / 32) * (col / 32);
+      CLN_LAUNCH(tr_reg4x4, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, (const float*)x, (float*)y, row, col);
+      return cln_check_launch();
+    }
+    kind = kind == TR_READ4_2D ? TR_READ4 : TR_WRITE4;
+  }
   const bool v4 = (kind == TR_READ4 || kind == TR_WRITE4);
   if (v4 && ((kind == TR_READ4 ? col : row) % 4 || !cln_aligned16(x) || !cln_aligned16(y))) return CLN_ERR_UNSUPPORTED;
   if ((kind == TR_LDS || kind == TR_LDS_BCF) && (row % 64 || col % 64 || !cln_aligned16(x) || !cln_aligned16(y)))
@@ -241,9 +282,9 @@ CLN_TR(mat_transpose_f32x4_col2row, TR_READ4)
 CLN_TR(mat_transpose_f32_row2col, TR_WRITE1)
 CLN_TR(mat_transpose_f32x4_row2col, TR_WRITE4)
 CLN_TR(mat_transpose_f32_col2row2d, TR_READ1)
-CLN_TR(mat_transpose_f32x4_col2row2d, TR_READ4)
+CLN_TR(mat_transpose_f32x4_col2row2d, TR_READ4_2D)
 CLN_TR(mat_transpose_f32_row2col2d, TR_WRITE1)
-CLN_TR(mat_transpose_f32x4_row2col2d, TR_WRITE4)
+CLN_TR(mat_transpose_f32x4_row2col2d, TR_WRITE4_2D)
 CLN_TR(mat_transpose_f32_diagonal2d, TR_DIAG)
 CLN_TR(mat_transpose_f32x4_shared_col2row2d, TR_LDS)
 CLN_TR(mat_transpose_f32x4_shared_row2col2d, TR_LDS)

@@ -129,7 +129,10 @@ SplitK splitk_plan(int M, int N, int K) {
       const long long n = tiles * S, rounds = (n + 255) / 256;
       const double fill = n >= 256 ? 1.0 : (double)n / 256.0;
       const double tau = 2.0 * sh.bm * sh.bn * 64.0 / (5.86e6 * sh.eff) * (1.0 - 0.338 * (1.0 - fill));
-      const double t = rounds * ((double)(K / S / 64) * tau + 3.88 * sqrt(sh.bm * sh.bn / 65536.0)) + 5.18 + (4.0 * S * mn + 2.0 * mn) / 3.615e6;
+      double t = rounds * ((double)(K / S / 64) * tau + 3.88 * sqrt(sh.bm * sh.bn / 65536.0)) + 5.18 + (4.0 * S * mn + 2.0 * mn) / 3.615e6;
+      // the one-launch form (S <= splitk_fused_max_s: the tile's last workgroup reduces) measured 0.5-1.5 us under the two-launch cost the model was fitted on
+      // (512 x 8192^2 68.1 -> 67.3 us, 2048^2 x 8192 70.6 -> 70.1, 640 x 5120^2 43.4 -> 41.9: profiles/r05_hgemm_splitk_fused_probe.log) -- ADVICE r5
+      if (S <= 2) t -= 1.0;
       if (t < t_best) t_best = t, best.bm = sh.bm, best.bn = sh.bn, best.S = S;
     }
   }
@@ -237,7 +240,7 @@ void ws_mark_used(SplitKWs* e, hipStream_t stream) {  // g_ws_mu held, after the
 // every shape of the round-4 split-K / tail probes under 0 = never, the default, 64 = always): at 2 splits one launch is 1-4 % faster than partial +
 // reduce launch (512 x 8192^2 68.1 -> 67.3 us, 2048^2 x 8192 70.6 -> 70.1, 640 x 5120^2 43.4 -> 41.9); at 4 splits the tile's reduction on ONE CU
 // (1 MiB of partials at one CU's load rate) costs 3-5 us more than the reduce launch it saves (256 x 4096^2 23.4 -> 26.6 us, 4352^3 138.9 -> 149.6),
-// at 8 and more 5-6 us more. (The probe library's kinds 17 / 18 launch either form at any S: tools/hg_splitk_fused_probe.py.)
+// at 8 and more 5-6 us more. (The probe library launches either form at any S -- kind 17 two launches, kind 20 one: tools/hg_splitk_fused_probe.py.)
 constexpr int splitk_fused_max_s() { return 2; }
 // A CAPTURED launch never takes the one-launch form (round 6): its arrival tickets are mutable state in the workspace header, a graph replays
 // on whatever stream is current, and a ticket lost or doubled by an overlapping launch never recovers. Partial + reduce launch keeps no state

@@ -146,6 +146,22 @@ CLN_API int cln_hgemm_variant(int kind, int layout, int tile, int bk, int stages
 #undef SK_SHAPE
     return CLN_ERR_BAD_ARG;
   }
+  if (kind == 20) {  // (round 6) kind 17 as ONE launch: the last-arriving workgroup of a tile reduces (EPI 6) at ANY number of splits -- the product takes this form
+    // at 2 splits only (csrc/hgemm.hip splitk_fused_max_s); tools/hg_splitk_fused_probe.py times 17 against 20 on the planner's (tile, splits)
+    static float* ws = nullptr;  // probe-only workspace: tickets + 512 MiB of partials, allocated and zeroed once (the tickets reset themselves)
+    constexpr size_t WS_BYTES = 512u << 20;
+    if (!ws) {
+      if (hipMalloc(&ws, WS_BYTES + W4_TICKET_FLOATS * 4) != hipSuccess) return ws = nullptr, CLN_ERR_LAUNCH;
+      if (hipMemset(ws, 0, W4_TICKET_FLOATS * 4) != hipSuccess) return CLN_ERR_LAUNCH;
+    }
+    if ((size_t)stages * M * N * 4 > WS_BYTES) return CLN_ERR_UNSUPPORTED;
+#define SKF_SHAPE(TT, BMM, BNN)                                                                                                  \
+  if (tile == TT) return layout == TN ? launch_w4_splitk_fused<TN, 26, BMM, BNN>(a, b, c, ws, M, N, K, stages, stream)           \
+                                      : launch_w4_splitk_fused<NN, 26, BMM, BNN>(a, b, c, ws, M, N, K, stages, stream);
+    SKF_SHAPE(0, 256, 256) SKF_SHAPE(1, 128, 256) SKF_SHAPE(3, 192, 256) SKF_SHAPE(4, 192, 192) SKF_SHAPE(5, 160, 160)
+#undef SKF_SHAPE
+    return CLN_ERR_BAD_ARG;
+  }
   if (kind == 18) {  // tail split: `tile` = tile rows (of 256) given to split-K, `stages` = number of splits
     static float* ws = nullptr;
     constexpr size_t WS_BYTES = 512u << 20;

@@ -84,7 +84,7 @@ int launch_global(const void* x, void* y, void* total, long long n, hipStream_t 
     CLN_LAUNCH((softmax_one_block_kernel<VEC>), dim3(1), dim3(1024), 0, st, (const float*)x, (float*)y, (float*)total, n);
     return cln_check_launch();
   }
-  const int grid = cln_stream_grid(n / VEC + 1, 256);
+  const int grid = cln_stream_grid(n / VEC + 1, 256, 8LL * n);
   CLN_LAUNCH((exp_sum_kernel<VEC>), dim3(grid), dim3(256), 0, st, (const float*)x, (float*)total, n);
   if (cln_check_launch() != CLN_OK) return CLN_ERR_LAUNCH;  // a failed first pass would leave total = 0 -> inf
   CLN_LAUNCH((exp_div_kernel<VEC>), dim3(grid), dim3(256), 0, st, (const float*)x, (float*)y,

@@ -207,9 +207,11 @@ for _n, _impl in (("hgemv_k32_f16", "half,1,32 lanes/row"), ("hgemv_k128_f16x4",
                   ("hgemv_k16_f16", "half,1,16 lanes/row")):
     _add("hgemv", "GV", "gemv<%s> fp32 acc" % _impl, _n)
 _add("mat_transpose", "TR", "transpose read-coalesced<1>", "mat_transpose_f32_col2row", "mat_transpose_f32_col2row2d")
-_add("mat_transpose", "TR", "transpose read-coalesced<4>", "mat_transpose_f32x4_col2row", "mat_transpose_f32x4_col2row2d")
+_add("mat_transpose", "TR", "transpose read-coalesced<4>", "mat_transpose_f32x4_col2row")
+_add("mat_transpose", "TR", "transpose 4x4 register blocks, 8x8 lanes per 32x32 block, 16 B and full lines both sides, no LDS (extents % 32; else the 1-D f32x4 rung)",
+     "mat_transpose_f32x4_col2row2d", "mat_transpose_f32x4_row2col2d")
 _add("mat_transpose", "TR", "transpose write-coalesced<1>", "mat_transpose_f32_row2col", "mat_transpose_f32_row2col2d")
-_add("mat_transpose", "TR", "transpose write-coalesced<4>", "mat_transpose_f32x4_row2col", "mat_transpose_f32x4_row2col2d")
+_add("mat_transpose", "TR", "transpose write-coalesced<4>", "mat_transpose_f32x4_row2col")
 _add("mat_transpose", "TR", "transpose write-coalesced<1>, diagonal block order", "mat_transpose_f32_diagonal2d")
 _add("mat_transpose", "TR", "transpose 64x64 LDS tile, 16 B both sides", "mat_transpose_f32x4_shared_col2row2d",
      "mat_transpose_f32x4_shared_row2col2d")

@@ -78,6 +78,18 @@ def run(B, H, N, D, code, rows_per_wg, reps=5):
     print("STAMP   per tile (median loop / %d): %.1f ns;  shader clock inside the loop: %.3f GHz (s_memtime ticks per s_memrealtime ns: %.3f)" % (T, med(loop) / T, clk * 1.0, clk))
     print("STAMP   finish: first wave out %.0f, median %.0f, last %.0f ns  -> spread %.0f ns (%.1f %% of the span)" % (exit_.min().item(), med(exit_), exit_.max().item(),
           exit_.max().item() - exit_.min().item(), 100.0 * (exit_.max().item() - exit_.min().item()) / spans[-1]))
+    # per XCD: is the finish spread systematic (a slower die) or random?
+    for xi in sorted(set(xcc.tolist())):
+        sel = xcc == xi
+        print("STAMP   XCD %d: %4d waves  entry median %5.0f  loop median %7.0f (per tile %6.1f)  exit median %7.0f  max %7.0f ns   clock %.3f GHz"
+              % (xi, int(sel.sum()), med(entry_[sel]), med(loop[sel]), med(loop[sel]) / T, med(exit_[sel]), exit_[sel].max().item(),
+                 ((mt[sel, 2] - mt[sel, 1]) / (rt[sel, 2] - rt[sel, 1]).clamp(min=1)).median().item()))
+    # per workgroup: the slowest and the fastest
+    wg_exit = exit_.view(-1, 8).max(dim=1).values
+    wg_loop = loop.view(-1, 8).float().mean(dim=1)
+    order = wg_exit.argsort()
+    print("STAMP   workgroup exit: fastest 5 %s  slowest 5 %s ns; loop time of those: %s / %s" % (
+        [int(wg_exit[i]) for i in order[:5]], [int(wg_exit[i]) for i in order[-5:]], [int(wg_loop[i]) for i in order[:5]], [int(wg_loop[i]) for i in order[-5:]]))
     # group 0 / group 1 of a workgroup (waves 0-3 / 4-7): group 1 runs one phase behind
     g = torch.arange(nw) % 8 // 4
     for gi in (0, 1):
@@ -87,12 +99,14 @@ def run(B, H, N, D, code, rows_per_wg, reps=5):
 
 if __name__ == "__main__":
     args = [int(a) for a in sys.argv[1:5]] if len(sys.argv) >= 5 else None
-    shapes = [tuple(args)] if args else [(4, 8, 2048, 64), (4, 8, 4096, 64), (4, 8, 8192, 64), (4, 8, 2048, 128), (4, 8, 4096, 128)]
+    shapes = [tuple(args)] if args else [(4, 8, 2048, 64), (4, 8, 2048, 128), (4, 8, 4096, 128)]
     res = {}
     for (B, H, N, D) in shapes:
         res[(B, H, N, D)] = run(B, H, N, D, 988, 256)
     for D in (64, 128):
         a, b = res.get((4, 8, 2048, D)), res.get((4, 8, 4096, D))
+        if a and not b:
+            print("STAMP D=%d: C4-shaped launch span %.0f ns = %d tiles x %.1f ns + %.0f ns outside the KV loop" % (D, a[0], a[2], a[1] / a[2], a[0] - a[1]))
         if a and b:
             # same workgroup count per unit of N? no: 2N doubles the workgroups (2 rounds) AND the tiles; per-tile from the loop medians instead
             per_tile = b[1] / b[2]

@@ -33,10 +33,9 @@ python $T/bw_prof_summary.py $(ls $OUT/bwprof/*kernel_trace.csv $OUT/bwprof/*/*k
 timeout 900 bash $T/run_all_scripts.sh > $OUT/${TAG}_reference_style_scripts_on_gpu.log 2>&1; echo "scripts rc=$?"
 timeout 600 $REPO/cuda-learn-notes_amd/harness/hgemm_bench 200 > $OUT/${TAG}_hgemm_bench_cpp.log 2>&1; echo "harness rc=$?"
 # round 5: the one-wave-per-SIMD attention kernel for D = 640 / 768 / 1024 against the round-4 ring kernel (timing + LDS / fabric counters), the
-# one-launch split-K form under 0 / default / 64 splits, the host cost of a call through the CPython entry, every script against its torch row
+# one-launch against two-launch split-K through the probe hook on the planner's (tile, splits), the host cost of a call through the CPython entry, every script against its torch row
 timeout 400 python $T/fa_dw4_probe.py 2>&1 | grep "^CHK\|^BIT\|^FA" > $OUT/${TAG}_fa_dw4_probe_final.log; echo "dw4 probe rc=$?"
-rm -f $OUT/${TAG}_hgemm_splitk_fused_probe_evidence.log
-for s in 0 2 64; do CLN_AMD_SPLITK_FUSED_MAX_S=$s timeout 200 python $T/hg_splitk_fused_probe.py 2>&1 | grep "^SKF" >> $OUT/${TAG}_hgemm_splitk_fused_probe_evidence.log; done; echo "fused split-K probe rc=$?"
+timeout 300 python $T/hg_splitk_fused_probe.py 2>&1 | grep "^SKF" > $OUT/${TAG}_hgemm_splitk_fused_probe_evidence.log; echo "fused split-K probe rc=$?"
 timeout 120 python $T/host_overhead_probe.py 2>&1 | grep "^HOSTOV" > $OUT/${TAG}_host_call_overhead_final.log; echo "host overhead rc=$?"
 timeout 900 python $T/scripts_vs_torch.py 2>&1 | grep "^SVT" > $OUT/${TAG}_scripts_vs_torch.log; echo "scripts vs torch rc=$?"
 ( cd /tmp && export TMPDIR=/tmp

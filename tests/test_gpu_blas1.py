@@ -85,3 +85,10 @@ def test_transpose_ragged_shapes(lib, dev, oracle):
         assert torch.equal(y.cpu(), ref), name
     with pytest.raises(RuntimeError, match="multiples of"):
         lib.mat_transpose_f32x4_shared_col2row2d(x.to(dev), torch.zeros(53, 37, device=dev))
+    # the f32x4 *2d rungs: 4 x 4 register blocks when both extents divide by 32 (round 6), the 1-D f32x4 rung of the same name otherwise
+    for (M, N) in ((36, 100), (32, 96), (96, 32), (160, 224)):
+        x = torch.randn(M, N)
+        for name in ("mat_transpose_f32x4_col2row2d", "mat_transpose_f32x4_row2col2d"):
+            y = torch.full((N, M), -7.0, device=dev)
+            getattr(lib, name)(x.to(dev), y)
+            assert torch.equal(y.cpu(), oracle.mat_transpose(x)), (name, M, N)
