@@ -557,7 +557,7 @@ def next_rows(pkg, dev, orc):
             nsets = max(3, ROTATE_FOOTPRINT // nbytes)
             pool = torch.randn(2 * nsets, side, side, device=dev)
             for name in ("mat_transpose_f32_col2row", "mat_transpose_f32x4_col2row", "mat_transpose_f32x4_row2col", "mat_transpose_f32_diagonal2d",
-                         "mat_transpose_f32x4_shared_col2row2d", "mat_transpose_f32x4_shared_bcf_col2row2d"):
+                         "mat_transpose_f32x4_shared_col2row2d", "mat_transpose_f32x4_shared_bcf_col2row2d", "mat_transpose_f32x4_col2row2d"):
                 fn = _loader.symbol(name)
                 calls = [(lambda xp=pool[2 * i].data_ptr(), yp=pool[2 * i + 1].data_ptr(), fn=fn: fn(xp, yp, side, side, st)) for i in range(nsets)]
                 if calls[0]() != 0:

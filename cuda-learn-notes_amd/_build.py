@@ -122,6 +122,27 @@ def build_pyext(verbose=False, force=False):
     return out
 
 
+def build_harness(verbose=False):
+    """harness/hgemm_bench (the C++ caller of the C-ABI; tools/round_evidence.sh runs it): rebuilt when older than its source or the
+    libraries. Optional: a failure here never fails the library build."""
+    hdir = os.path.join(PKG_DIR, "harness")
+    src, out = os.path.join(hdir, "hgemm_bench.cpp"), os.path.join(hdir, "hgemm_bench")
+    deps = [src, os.path.join(LIBDIR, "libcln_amd.so"), os.path.join(LIBDIR, "libcln_amd_vendor.so")]
+    if not all(os.path.exists(d) for d in deps):
+        return None
+    if os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(d) for d in deps):
+        return out
+    cmd = [hipcc(), "-O2", "-std=c++17", src, "-I" + os.path.join(os.path.dirname(PKG_DIR), "include"), "-L" + LIBDIR, "-lcln_amd", "-lcln_amd_vendor",
+           "-Wl,-rpath,$ORIGIN/../lib", "-o", out]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        print("warning: harness/hgemm_bench did not build:\n%s" % r.stderr[-600:], file=sys.stderr)
+        return None
+    return out
+
+
 def build(verbose=False, force=False):
     os.makedirs(BUILD, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
@@ -144,6 +165,7 @@ def build(verbose=False, force=False):
     if force or not os.path.exists(probe_so) or any(objs[s][1] for s in PROBE_SOURCES + PROBE_SHARED):
         _link([objs[s][0] for s in PROBE_SOURCES + PROBE_SHARED], probe_so, [], verbose)
     build_pyext(verbose, force)
+    build_harness(verbose)
     return main_so, vend_so, probe_so
 
 
