@@ -105,6 +105,9 @@ void sweep(float* out, unsigned long long* clk) {
     printf("MP %-20s + k x %-17s %d wave/SIMD ns/unit:", FN[FORM], OPN[OP], w + 1);
     for (int i = 0; i < 8; ++i) printf(" k=%d %6.2f", KS[i], ns[i][w]);
     printf("\n");
+    printf("MP %-20s + k x %-17s %d wave/SIMD clk/unit:", FN[FORM], OPN[OP], w + 1);
+    for (int i = 0; i < 8; ++i) printf(" k=%d %6.2f", KS[i], ck[i][w]);
+    printf("\n");
   }
 }
 
