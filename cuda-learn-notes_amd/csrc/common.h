@@ -261,6 +261,25 @@ __device__ __forceinline__ h4 lds_read_tr16(const void* lds_addr) {
   return r;
 }
 
+// The same reads by LDS BYTE ADDRESS (an integer, as lds_addr_of() returns it) instead of a pointer derived from the `extern __shared__` symbol:
+// an address formed as `smem + offset` costs one v_add_u32 per access even when the symbol resolves to 0 (hipcc adds the relocated symbol to every
+// computed offset), and on gfx950 a plain VALU instruction is never free under MFMAs (matrix time and VALU time add). Callers fold the
+// symbol's address into their per-lane base ONCE, outside the loop.
+template <class T>
+__device__ __forceinline__ T lds_ld(unsigned lds_byte_addr) {
+  return *reinterpret_cast<const __attribute__((address_space(3))) T*>(lds_byte_addr);
+}
+template <class T>
+__device__ __forceinline__ void lds_st(unsigned lds_byte_addr, const T& v) {
+  *reinterpret_cast<__attribute__((address_space(3))) T*>(lds_byte_addr) = v;
+}
+__device__ __forceinline__ h4 lds_read_tr16_at(unsigned lds_byte_addr) {
+  fp16x4_tr t = __builtin_amdgcn_ds_read_tr16_b64_v4f16(reinterpret_cast<__attribute__((address_space(3))) fp16x4_tr*>(lds_byte_addr));
+  h4 r;
+  __builtin_memcpy(&r, &t, 8);
+  return r;
+}
+
 // Lane id recomputed at the point of use (two VALU instructions). The attention kernels run their KV loop with a full
 // register file; lane-derived epilogue addresses computed at kernel entry would be carried -- i.e. spilled -- across
 // it. Opaque to hipcc so it is neither hoisted nor merged with the entry-time lane id.

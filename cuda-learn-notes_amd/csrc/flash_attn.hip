@@ -16,6 +16,7 @@
 #include "flash_attn_splitkv.cuh"
 #include "flash_attn_v2.cuh"
 #include "flash_attn_m16.cuh"
+#include "flash_attn_pair2.cuh"
 #include "flash_attn_m16x_api.h"
 #include <string.h>
 
@@ -182,8 +183,9 @@ int fa2_run(const FaPlan& p, const void* q, const void* k, const void* v, void* 
         constexpr int ONE = 262144;  // flash_attn_m16.cuh: the tile requested in one burst at the top of phase A and waited for there
         if (D == 256) return p.one_stage ? fa2::launch_m16_pair<2, false, false, ONE>(q, k, v, o, B, H, N, s)
                                          : fa2::launch_m16_pair<2, false, false>(q, k, v, o, B, H, N, s);
-        if (D == 512) return p.one_stage ? fa2::launch_m16_pair<2, true, false, ONE>(q, k, v, o, B, H, N, s)
-                                         : fa2::launch_m16_pair<2, true, false>(q, k, v, o, B, H, N, s);
+        // D = 512 (config C5): pairs of waves split the ROWS for QK^T and the softmax (done once per row), d for PV (flash_attn_pair2.cuh, round 6)
+        if (D == 512) return p.one_stage ? fa2::launch_pair2<4, 4, fa2::PAIR2_ONE_STAGE>(q, k, v, o, B, H, N, s)
+                                         : fa2::launch_pair2<4, 4, 0>(q, k, v, o, B, H, N, s);
       }
       return CLN_ERR_UNSUPPORTED;
     case K_DSPLIT:
@@ -231,7 +233,7 @@ int fa2_describe(int family, bool vt, int B, int H, int N, int D, int stages, in
         return snprintf(buf, len, "fa2_fwd_m16x<D=%d,BC=%d,16x16x32 MFMA,%s,sum-checked softmax%s> 8 waves x 32 rows, two groups "
                                   "one phase apart%s", D, p.bc, qs, vts, st);
       if (D == 512)
-        return snprintf(buf, len, "fa2_fwd_m16<D=512,BC=32,16x16x32 MFMA,pairs of waves split d> 8 waves, 128 rows, two groups one phase apart%s", st);
+        return snprintf(buf, len, "fa2_fwd_pair2<D=512,BC=32,16x16x32 MFMA,pairs of waves: rows split for QK^T and the softmax, d for PV> 8 waves, 128 rows, two groups one phase apart%s", st);
       return snprintf(buf, len, "fa2_fwd_m16<D=%d,BC=%d,16x16x32 MFMA> 8 waves x 32 rows, two groups one phase apart%s", D, p.bc, st);
     case K_DSPLIT:
       if (p.d_inst != D)

@@ -338,7 +338,7 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16_pair_kernel(const half_t* 
                                                                   int N, int n_qblk, int n_heads, float scale_log2e) {
   using G = GeoM16Pair<PAIR>;
   constexpr int D = G::D, DH = G::DH, NKB = G::NKB, NKS = G::NKS, NQB = G::NQB, NDB = G::NDB, NQK = G::NQK, NPV = G::NPV;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  extern __shared__ __attribute__((aligned(1024))) char smem[];  // 1024: the fragment addresses below XOR bits 5 .. 8 into (LDS address of smem + offset)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i16 = lane & 15, g4 = lane >> 4;
@@ -417,11 +417,12 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16_pair_kernel(const half_t* 
 
   // K fragment (kb, ks): row 16*kb + i16, logical chunk part*32 + 4*ks + g4; V^T fragment (db): rows 4*g4 + (i16 >> 2)
   // and + 16, logical chunk part*32 + 2*db + ((i16 & 3) >> 1), 8-byte half i16 & 1
-  const int kbase = i16 * G::ROW + ((g4 ^ G::swz_k(i16)) << 4) + part * 512;
+  // (LDS byte addresses, the symbol's address folded in once: common.h lds_ld -- no per-access v_add_u32 of the symbol inside the loop)
+  const unsigned kbase = lds0 + i16 * G::ROW + ((g4 ^ G::swz_k(i16)) << 4) + part * 512;
   const int v_row = 4 * g4 + (i16 >> 2);
-  const int vbase = v_row * G::ROW + (((((i16 & 3) >> 1)) ^ G::swz_v(v_row)) << 4) + ((i16 & 1) << 3) + part * 512;
-  char* sx_mine = smem + G::RING + wave * 4096 + lane * 16;
-  const char* sx_peer = smem + G::RING + (wave ^ 1) * 4096 + lane * 16;
+  const unsigned vbase = lds0 + v_row * G::ROW + (((((i16 & 3) >> 1)) ^ G::swz_v(v_row)) << 4) + ((i16 & 1) << 3) + part * 512;
+  const unsigned sx_mine = lds0 + G::RING + wave * 4096 + lane * 16;
+  const unsigned sx_peer = lds0 + G::RING + (wave ^ 1) * 4096 + lane * 16;
   const bool lead = PRE && part == 0;  // this wave's partial starts at -m (PAIR = false: every wave)
 
   if (grp == 1) {
@@ -431,14 +432,14 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16_pair_kernel(const half_t* 
 
   for (int j = 0; j < T; ++j) {
     const int jn = j + 1 < T ? j + 1 : T - 1;
-    const int kb_j = kbase + (j & 1) * G::STAGE, vb_j = vbase + (j & 1) * G::STAGE + G::TILE;
+    const unsigned kb_j = kbase + (j & 1) * G::STAGE, vb_j = vbase + (j & 1) * G::STAGE + G::TILE;
     auto k_frag = [&](int t) __attribute__((always_inline)) {  // t = kb * NKS + ks
       const int kb = t / NKS, ks = t % NKS;
-      return *reinterpret_cast<const h8*>(smem + (kb_j ^ (ks << 6)) + kb * 16 * G::ROW);
+      return lds_ld<h8>((kb_j ^ (unsigned)(ks << 6)) + kb * 16 * G::ROW);
     };
     auto v_frag = [&](int db) __attribute__((always_inline)) {
-      const char* vp = smem + (vb_j ^ (db << 5));
-      return h8_cat(lds_read_tr16(vp), lds_read_tr16(vp + 16 * G::ROW));
+      const unsigned vp = vb_j ^ (unsigned)(db << 5);
+      return h8_cat(lds_read_tr16_at(vp), lds_read_tr16_at(vp + 16 * G::ROW));
     };
     // ================= phase A: partial S^T over this wave's half of d
     // DBG 262144 = the `stages = 1` form in ONE burst (round 4): the wave requests all its pieces of tile j + 1 here and waits for them
@@ -494,7 +495,7 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16_pair_kernel(const half_t* 
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-      for (int qb = 0; qb < NQB; ++qb) *reinterpret_cast<f4*>(sx_mine + (kb * NQB + qb) * 1024) = s[kb][qb];
+      for (int qb = 0; qb < NQB; ++qb) lds_st<f4>(sx_mine + (kb * NQB + qb) * 1024, s[kb][qb]);
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the partial is in LDS before the barrier
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -514,7 +515,7 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16_pair_kernel(const half_t* 
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
       for (int qb = 0; qb < NQB; ++qb) {
-        const f4 pp = *reinterpret_cast<const f4*>(sx_peer + (kb * NQB + qb) * 1024);
+        const f4 pp = lds_ld<f4>(sx_peer + (kb * NQB + qb) * 1024);
         if constexpr ((DBG & 512) != 0) {
           if (kb == 0 && qb == 0) pp_first[0] = pp;
           if (kb == 1 && qb == 0) pp_first[1] = pp;
@@ -610,7 +611,7 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16_pair_kernel(const half_t* 
     }
     if constexpr (PAIR && (DBG & 512) != 0) {  // bisect: was the partner's partial complete when it was read?
       asm volatile("s_sleep 8" ::: "memory");
-      const f4 a = *reinterpret_cast<const volatile f4*>(sx_peer), b = *reinterpret_cast<const volatile f4*>(sx_peer + 2048);
+      const f4 a = *reinterpret_cast<const volatile f4*>(smem + (sx_peer - lds0)), b = *reinterpret_cast<const volatile f4*>(smem + (sx_peer - lds0) + 2048);
       bool diff = false;
 #pragma unroll
       for (int r = 0; r < 4; ++r) diff |= (a[r] != pp_first[0][r]) | (b[r] != pp_first[1][r]);

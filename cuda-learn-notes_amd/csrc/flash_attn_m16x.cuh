@@ -105,7 +105,7 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
   static_assert((OX & M16X_FSCALE) == 0 || (OX & M16X_LATE_CHECK) == 0, "the fp32-scaled form has no late-check variant");
   static_assert((OX & M16X_MFMA_SUM) == 0 || (OX & M16X_LATE_CHECK) == 0, "row sums on the matrix pipe: no late-check variant");
   constexpr bool MS = (OX & M16X_MFMA_SUM) != 0;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  extern __shared__ __attribute__((aligned(1024))) char smem[];  // 1024: the fragment addresses XOR bits 4 .. 8 into (LDS address of smem + offset)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i16 = lane & 15, g4 = lane >> 4;
@@ -213,10 +213,11 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
     asm volatile("" ::: "memory");
   }
 
-  const int kbase = i16 * G::ROW + ((g4 ^ G::swz_k(i16)) << 4);
+  // LDS byte addresses with the symbol's address folded in ONCE (common.h lds_ld: `smem + offset` costs a v_add_u32 of the relocated symbol per access)
+  const unsigned kbase = lds0 + i16 * G::ROW + ((g4 ^ G::swz_k(i16)) << 4);
   const int v_row = 4 * g4 + (i16 >> 2);
-  const int vbase = VT ? i16 * RV + (((swz_vt(i16)) ^ (g4 >> 1)) << 4) + ((g4 & 1) << 3)  // V^T image: row = d, keys 4 g4 .. of a 32-key step
-                       : v_row * G::ROW + (((((i16 & 3) >> 1)) ^ G::swz_v(v_row)) << 4) + ((i16 & 1) << 3);
+  const unsigned vbase = lds0 + (VT ? i16 * RV + (((swz_vt(i16)) ^ (g4 >> 1)) << 4) + ((g4 & 1) << 3)  // V^T image: row = d, keys 4 g4 .. of a 32-key step
+                                    : v_row * G::ROW + (((((i16 & 3) >> 1)) ^ G::swz_v(v_row)) << 4) + ((i16 & 1) << 3));
 
   if constexpr ((OX & M16X_PRIO_STATIC) != 0) {
     if (grp == 1) __builtin_amdgcn_s_setprio(1);
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
   stamp(1);
   for (int j = 0; j < T; ++j) {
     const int jn = j + 1 < T ? j + 1 : T - 1;
-    const int kb_j = kbase + (j & 1) * G::STAGE, vb_j = vbase + (j & 1) * G::STAGE + G::TILE;
+    const unsigned kb_j = kbase + (j & 1) * G::STAGE, vb_j = vbase + (j & 1) * G::STAGE + G::TILE;
     constexpr bool PAIRED = (OX & M16X_PAIRED_QK) != 0 && NKS == 2 && NKB % 2 == 0 && NOPT % 2 == 0;
     auto kb_of = [](int t) { return PAIRED ? 2 * (t / 4) + (t & 1) : t / NKS; };
     auto ks_of = [](int t) { return PAIRED ? (t >> 1) & 1 : t % NKS; };
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
         h8 x = qf[kb % NQB][ks];
         asm volatile("" : "+v"(x));  // opaque: identical MFMAs of different key blocks must not be merged
         return x;
-      } else return *reinterpret_cast<const h8*>(smem + (kb_j ^ (ks << 6)) + kb * 16 * G::ROW);
+      } else return lds_ld<h8>((kb_j ^ (unsigned)(ks << 6)) + kb * 16 * G::ROW);
     };
     auto v_frag = [&](int idx) __attribute__((always_inline)) {
       const int u = idx / NDB, db = idx % NDB;
@@ -250,11 +251,10 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_m16x_kernel(const half_t* __re
       } else if constexpr (VT) {
         // A operand row = d = 16 db + i16; k-slots 8 g4 .. + 7 = keys 32u + 4 g4 .. + 3 and 32u + 16 + 4 g4 .. + 3 (the order the P
         // registers have): two plain 8-byte reads 32 bytes apart in the row (chunks 4u + g4/2 and + 2, swizzled by the row)
-        const char* vp = smem + (vb_j ^ ((4 * u) << 4)) + (16 * db) * RV;
-        return h8_cat(*reinterpret_cast<const h4*>(vp), *reinterpret_cast<const h4*>(smem + ((vb_j ^ ((4 * u + 2) << 4)) + (16 * db) * RV)));
+        return h8_cat(lds_ld<h4>((vb_j ^ (unsigned)((4 * u) << 4)) + (16 * db) * RV), lds_ld<h4>((vb_j ^ (unsigned)((4 * u + 2) << 4)) + (16 * db) * RV));
       } else {
-        const char* vp = smem + (vb_j ^ (db << 5)) + (32 * u) * G::ROW;
-        return h8_cat(lds_read_tr16(vp), lds_read_tr16(vp + 16 * G::ROW));
+        const unsigned vp = (vb_j ^ (unsigned)(db << 5)) + (32 * u) * G::ROW;
+        return h8_cat(lds_read_tr16_at(vp), lds_read_tr16_at(vp + 16 * G::ROW));
       }
     };
     f4 s[NKB][NQB];

@@ -46,8 +46,8 @@ def test_stages_knob_selects_a_different_flash_attn_kernel(built):
     tq = "flash_attn_mma_stages_split_q_tiling_qkv"
     one5, two5 = m.describe(tq, (1, 32, 4096, 512), 1), m.describe(tq, (1, 32, 4096, 512), 2)
     # above D = 256 stages = 1 is the SAME kernel family with every tile fetch waited for where it is issued
-    assert one5.startswith("fa2_fwd_m16<D=512") and "single stage" in one5
-    assert two5.startswith("fa2_fwd_m16<D=512") and "single stage" not in two5 and "stages ignored" not in two5
+    assert one5.startswith("fa2_fwd_pair2<D=512") and "single stage" in one5
+    assert two5.startswith("fa2_fwd_pair2<D=512") and "single stage" not in two5 and "stages ignored" not in two5
     for D in (320, 384, 640, 768, 1024):
         for N in (4096, 4160 if D >= 640 else 4224):  # sequence lengths the stage-2 kernel tiles are tiled by stage 1 too
             one, two = m.describe(tq, (1, 16, N, D), 1), m.describe(tq, (1, 16, N, D), 2)
@@ -113,7 +113,7 @@ def test_flash_attn_planner_invariants_over_a_grid_of_shapes(built):
     row / key granularity divides N (a launcher would otherwise refuse at run time what describe promised)."""
     m = built.manifest
     tq, sq = "flash_attn_mma_stages_split_q_tiling_qkv", "flash_attn_mma_stages_split_q_shared_qkv"
-    rows_per_wg = {"fa2_fwd_m16": 256, "fa2_fwd_m16x": 256, "fa2_fwd_m16x64r": 512, "fa2_fwd_dsplit": 128, "fa2_fwd_dw4": 64, "fa2_fwd_v2": 64}
+    rows_per_wg = {"fa2_fwd_m16": 256, "fa2_fwd_pair2": 128, "fa2_fwd_m16x": 256, "fa2_fwd_m16x64r": 512, "fa2_fwd_dsplit": 128, "fa2_fwd_dw4": 64, "fa2_fwd_v2": 64}
     fam_seen = set()
     for D in (32, 64, 96, 128, 256, 320, 384, 512, 640, 768, 1024):
         for (B, H) in ((1, 1), (1, 8), (4, 8), (1, 48), (2, 96), (1, 256)):
@@ -124,7 +124,7 @@ def test_flash_attn_planner_invariants_over_a_grid_of_shapes(built):
                     continue
                 fam = t.split("<")[0]
                 fam_seen.add((fam, D))
-                rows = 128 if (fam, D) == ("fa2_fwd_m16", 512) else rows_per_wg[fam]  # the D = 512 pair form: 4 pairs x 32 rows
+                rows = rows_per_wg[fam]  # (fa2_fwd_pair2, D = 512: 4 pairs of waves x 32 rows)
                 assert N % rows == 0 or fam == "fa2_fwd_v2", (B, H, N, D, t)
                 wgs256 = B * H * (N // 256) if N % 256 == 0 else 0
                 if D == 64 and N == 256:  # one row block per head, two key tiles: the 4-wave v2 kernel at every grid size
@@ -137,13 +137,13 @@ def test_flash_attn_planner_invariants_over_a_grid_of_shapes(built):
                 if D in (320, 384):
                     assert fam == "fa2_fwd_dsplit", t
                 if D == 512:
-                    assert fam == "fa2_fwd_m16" and "pairs of waves split d" in t, t
+                    assert fam == "fa2_fwd_pair2" and "rows split for QK^T and the softmax, d for PV" in t, t
                 if D in (640, 768, 1024):
                     assert fam == "fa2_fwd_dw4" and "one per SIMD" in t, t
                 if D <= 256:  # the shared-QKV name (max head dim 256) plans the same kernel
                     assert m.describe(sq, (B, H, N, D), 2) == t
     for want in (("fa2_fwd_m16x", 64), ("fa2_fwd_m16x", 128), ("fa2_fwd_m16", 256), ("fa2_fwd_m16x64r", 64), ("fa2_fwd_v2", 32),
-                 ("fa2_fwd_dsplit", 384), ("fa2_fwd_m16", 512), ("fa2_fwd_dw4", 1024), ("fa2_fwd_dw4", 640)):
+                 ("fa2_fwd_dsplit", 384), ("fa2_fwd_pair2", 512), ("fa2_fwd_dw4", 1024), ("fa2_fwd_dw4", 640)):
         assert want in fam_seen, (want, sorted(fam_seen))
     with pytest.raises(ValueError):  # "headdim not support!" of the shared-QKV rung (MAX_HEADDIM_CFG: 256)
         m.describe(sq, (1, 32, 4096, 512), 2)

@@ -45,8 +45,12 @@ def test_attention_kernels_in_the_product_library_are_exactly_the_plannable_ones
             linked.add(("fa2_fwd_dsplit", int(a[5]) or int(a[0])))
         elif f == "fa2_fwd_m16_pair_kernel":
             # fragment depth 2, scores scaled in fp32, no debug bits (262144 = the single-stage form `stages = 1` selects: one burst per tile)
-            assert a[:3] in (["2", "false", "false"], ["2", "true", "false"]) and a[3] in ("0", "262144"), a
-            linked.add(("fa2_fwd_m16", 512 if a[1] == "true" else 256, a[3] == "262144"))
+            # (PAIR = true, the round-3 .. 5 kernel of D = 512, is a probe-library kernel since round 6: fa2_fwd_pair2 runs that head dim)
+            assert a[:3] == ["2", "false", "false"] and a[3] in ("0", "262144"), a
+            linked.add(("fa2_fwd_m16", 256, a[3] == "262144"))
+        elif f == "fa2_fwd_pair2_kernel":  # <K fragments in flight, V fragments in flight, option bits (1 = the single-stage form)>: D = 512, round 6
+            assert a[:2] == ["4", "4"] and a[2] in ("0", "1"), a
+            linked.add(("fa2_fwd_pair2", 512, a[2] == "1"))
         elif f == "fa2_fwd_m16x_kernel":  # 6th argument: option bits (32768 = single-stage form); 7th: V given transposed ([B,H,D,N], the *_swizzle_qkv names)
             # the shipped options: phase-A priority + split prologue (1 << 18: fp32-scaled scores; 1 << 19: row sums on the matrix pipe, with them at 32 rows per wave)
             assert int(a[5]) & ~(32768 | (3 << 16) | (1 << 18) | (1 << 19)) == 5, a
@@ -87,7 +91,7 @@ def test_attention_kernels_in_the_product_library_are_exactly_the_plannable_ones
                         elif fam in ("fa2_fwd_m16x", "fa2_fwd_m16x64r"):
                             assert ("V^T" in t) == vt, t
                             plannable.add((fam, d, vt, one, f32s))
-                        elif fam in ("fa2_fwd_m16", "fa2_fwd_dw4"):
+                        elif fam in ("fa2_fwd_m16", "fa2_fwd_pair2", "fa2_fwd_dw4"):
                             assert not vt, t
                             plannable.add((fam, d, one))
                         else:
