@@ -184,8 +184,8 @@ int fa2_run(const FaPlan& p, const void* q, const void* k, const void* v, void* 
         if (D == 256) return p.one_stage ? fa2::launch_m16_pair<2, false, false, ONE>(q, k, v, o, B, H, N, s)
                                          : fa2::launch_m16_pair<2, false, false>(q, k, v, o, B, H, N, s);
         // D = 512 (config C5): pairs of waves split the ROWS for QK^T and the softmax (done once per row), d for PV (flash_attn_pair2.cuh, round 6)
-        if (D == 512) return p.one_stage ? fa2::launch_pair2<4, 4, fa2::PAIR2_ONE_STAGE>(q, k, v, o, B, H, N, s)
-                                         : fa2::launch_pair2<4, 4, 0>(q, k, v, o, B, H, N, s);
+        if (D == 512) return p.one_stage ? fa2::launch_pair2<4, 2, fa2::PAIR2_HOIST | fa2::PAIR2_ONE_STAGE>(q, k, v, o, B, H, N, s)
+                                         : fa2::launch_pair2<4, 2, fa2::PAIR2_HOIST>(q, k, v, o, B, H, N, s);
       }
       return CLN_ERR_UNSUPPORTED;
     case K_DSPLIT:

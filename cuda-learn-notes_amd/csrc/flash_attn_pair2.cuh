@@ -22,6 +22,8 @@
 // the same order within a lane), but the QK^T accumulation order over d differs (one chain of 16 k-steps instead of two chains of 8 added in
 // fp32): results agree to fp32 rounding, not bit for bit.
 #pragma once
+#include <type_traits>
+
 #include "flash_attn_m16.cuh"
 
 namespace fa2 {
@@ -43,6 +45,11 @@ struct GeoPair2 {
 
 enum : int {
   PAIR2_ONE_STAGE = 1,  // the `stages = 1` form: a wave requests all its pieces of tile j + 1 in one burst at the top of phase A and waits for them there
+  // fragment addresses WITHOUT VALU work inside the loop: the ring laid out [K slot 0 | K slot 1 | V slot 0 | V slot 1] (a slot is 32 KiB apart from its twin, so slot,
+  // key block and the 256-byte step all fit the 16-bit offset field of ds_read), two tiles per loop iteration (the slot is a compile-time constant), and the lane's
+  // swizzled bases (4 for K: base ^ (ks & 3) << 6; 16 for V^T: base ^ db << 5) computed once, in front of the loop, and pinned in registers. 18 XORs and the slot
+  // arithmetic leave every tile -- plain VALU time is never hidden under MFMAs on gfx950
+  PAIR2_HOIST = 2,
 };
 
 template <int PDK = 4, int PDV = 2, int OPT = 0>
@@ -82,7 +89,8 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_pair2_kernel(const half_t* __r
     const int piece = i * 4 + widx;
     const unsigned voff = src_lane ^ (unsigned)((grp == 0 ? G::swz_k(4 * i * G::RPP) : G::swz_v(4 * i * G::RPP)) << 4);
     const char* s = src_h + (size_t)jt * G::TILE + piece * 1024;
-    hgemm::glds16_asm(s, voff, lds0 + slot * G::STAGE + grp * G::TILE + piece * 1024);
+    if constexpr ((OPT & PAIR2_HOIST) != 0) hgemm::glds16_asm(s, voff, lds0 + grp * G::STAGE + slot * G::TILE + piece * 1024);
+    else hgemm::glds16_asm(s, voff, lds0 + slot * G::STAGE + grp * G::TILE + piece * 1024);
   };
 
   // ---- Q fragments: this wave's 16 rows over the whole head dim (B operand of S^T = K Q^T: query i16, d = 32 ks + 8 g4 .. + 7), as loaded
@@ -118,27 +126,50 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_pair2_kernel(const half_t* __r
   const unsigned p_w = px + part * 1024 + lane * 16, p_r = px + lane * 16;               // + 1024: the other half of the pair's rows
   const unsigned a_w = px + G::PX_A + part * 64 + i16 * 4, a_r = px + G::PX_A + i16 * 4;  // + 64
 
+  constexpr bool HOIST = (OPT & PAIR2_HOIST) != 0;
+  unsigned kx[4], vx[NDB];  // HOIST: the swizzled bases, pinned (an opaque asm: hipcc would otherwise re-derive them inside the loop to save registers)
+  if constexpr (HOIST) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      kx[c] = kbase ^ (unsigned)(c << 6);
+      asm volatile("" : "+v"(kx[c]));
+    }
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) {
+      vx[db] = (vbase + G::STAGE) ^ (unsigned)(db << 5);  // V slots behind the two K slots
+      asm volatile("" : "+v"(vx[db]));
+    }
+  }
+
   if (grp == 1) {  // group 1 runs one phase behind group 0
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   }
 
-  for (int j = 0; j < T; ++j) {
+  auto tile = [&](int j, auto slot_c) __attribute__((always_inline)) {
+    constexpr int SLOT = decltype(slot_c)::value;  // HOIST: the ring slot of tile j as a compile-time constant (-1: taken from j)
     const int jn = j + 1 < T ? j + 1 : T - 1;
+    const int nslot = HOIST ? 1 - SLOT : (j + 1) & 1;  // ring slot of tile j + 1
     const unsigned kb_j = kbase + (j & 1) * G::STAGE, vb_j = vbase + (j & 1) * G::STAGE + G::TILE;
     auto k_frag = [&](int t) __attribute__((always_inline)) {  // t = 2 ks + kb: the two key blocks alternate, a dependent MFMA sits two behind
       const int ks = t >> 1, kb = t & 1;
-      return lds_ld<h8>((kb_j ^ (unsigned)((ks & 3) << 6)) + (ks >> 2) * 256 + kb * 16 * G::ROW);
+      if constexpr (HOIST) return lds_ld<h8>(kx[ks & 3] + (unsigned)(SLOT * G::TILE + (ks >> 2) * 256 + kb * 16 * G::ROW));
+      else return lds_ld<h8>((kb_j ^ (unsigned)((ks & 3) << 6)) + (ks >> 2) * 256 + kb * 16 * G::ROW);
     };
     auto v_frag = [&](int db) __attribute__((always_inline)) {
-      const unsigned vp = vb_j ^ (unsigned)(db << 5);
-      return h8_cat(lds_read_tr16_at(vp), lds_read_tr16_at(vp + 16 * G::ROW));
+      if constexpr (HOIST) {
+        const unsigned vp = vx[db] + (unsigned)(SLOT * G::TILE);
+        return h8_cat(lds_read_tr16_at(vp), lds_read_tr16_at(vp + 16 * G::ROW));
+      } else {
+        const unsigned vp = vb_j ^ (unsigned)(db << 5);
+        return h8_cat(lds_read_tr16_at(vp), lds_read_tr16_at(vp + 16 * G::ROW));
+      }
     };
     // ================= phase A: S^T of this wave's 16 rows (complete), softmax, P and the rescale factors published
     if constexpr ((OPT & PAIR2_ONE_STAGE) != 0) {
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = 0; i < G::PPW; ++i) dma_piece(jn, (j + 1) & 1, i);
+      for (int i = 0; i < G::PPW; ++i) dma_piece(jn, nslot, i);
       hgemm::wait_vmcnt<0>();
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -155,7 +186,7 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_pair2_kernel(const half_t* __r
         else s[kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[t % PDK], qf[ks], s[kb], 0, 0, 0);
         cln_mfma_keep(s[kb], kf[t % PDK], qf[ks]);  // destination disjoint from the operands (common.h)
         if (t + PDK < NQK) kf[t % PDK] = k_frag(t + PDK);
-        if ((OPT & PAIR2_ONE_STAGE) == 0 && (t % DSTEP) == DSTEP - 1) dma_piece(jn, (j + 1) & 1, t / DSTEP);
+        if ((OPT & PAIR2_ONE_STAGE) == 0 && (t % DSTEP) == DSTEP - 1) dma_piece(jn, nslot, t / DSTEP);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -238,6 +269,14 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_pair2_kernel(const half_t* __r
     hgemm::wait_vmcnt<0>();  // own DMA pieces of tile j + 1 landed
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+  };
+  if constexpr (HOIST) {  // N is a multiple of 128: an even number of 32-key tiles
+    for (int j = 0; j < T; j += 2) {
+      tile(j, std::integral_constant<int, 0>{});
+      tile(j + 1, std::integral_constant<int, 1>{});
+    }
+  } else {
+    for (int j = 0; j < T; ++j) tile(j, std::integral_constant<int, -1>{});
   }
   if (grp == 0) {
     __builtin_amdgcn_s_barrier();
