@@ -20,6 +20,7 @@ def dynamic_lds(kernel_name):
     table = (("hgemm_pp_kernel", 2 * (256 + 256) * 64 * 2), ("hgemm_w4_kernel", 2 * (256 + 256) * 64 * 2), ("hgemm_pp32_kernel", 4 * (256 + 256) * 32 * 2),
              ("fa2_fwd_dsplit_kernelILi64E", 2 * 2 * 128 * 128), ("fa2_fwd_dsplit_kernelILi128E", 8 * 32 * (256 + 16)),
              ("fa2_fwd_m16_pair_kernelILi2ELb0E", 8 * 32 * (512 + 16)), ("fa2_fwd_m16_pair_kernelILi2ELb1E", 2 * 2 * 32 * 1024 + 8 * 4096),
+             ("fa2_fwd_pair2_kernel", 2 * 2 * 32 * 1024 + 4 * 4096 + 4 * 128),
              ("fa2_fwd_m16_kernelILi64E", 2 * 2 * 128 * 128), ("fa2_fwd_m16_kernelILi128E", 2 * 2 * 128 * 256),
              ("fa2_fwd_m16x_kernelILi64ELi32E", 2 * 2 * 128 * 128), ("fa2_fwd_m16x_kernelILi64ELi64E", 8 * 64 * (128 + 16)), ("fa2_fwd_m16x_kernelILi128E", 2 * 2 * 128 * 256),
              ("fa2_fwd_dring_kernelILi1024E", 4 * 16 * 2048 + 8 * 2048), ("fa2_fwd_dring_kernelILi768E", 4 * 16 * 1536 + 8 * 2048), ("fa2_fwd_dring_kernelILi640E", 4 * 16 * 1280 + 8 * 2048),
