@@ -124,9 +124,9 @@ FaPlan fa2_plan(int family, bool vt, int B, int H, int N, int D, int stages, int
       // over the 32x32x16 form at identical max-abs-error once its MFMA destinations were kept off the operand registers)
       if (N % 128 != 0) return p.rc = CLN_ERR_UNSUPPORTED, p;
       return p.kind = K_M16, p.d_inst = 512, p.nw = 8, p.bc = 32, p;
-    case 320: case 384:
+    case 320: case 384:  // round 6: the pair2 kernel on the D = 512 LDS geometry, every loop over the real head dim (rounds 2-5: the d-split kernel on that geometry)
       if (N % 128 != 0) return p.rc = CLN_ERR_UNSUPPORTED, p;
-      return p.kind = K_DSPLIT, p.d_inst = 512, p.nw = 8, p.bc = 32, p;
+      return p.kind = K_M16, p.d_inst = 512, p.nw = 8, p.bc = 32, p;
     case 640: case 768: case 1024:  // round 5: one wave per SIMD, 64 rows per workgroup (flash_attn_dw4.cuh)
       if (N % 64 != 0) return p.rc = CLN_ERR_UNSUPPORTED, p;
       return p.kind = K_DW4, p.d_inst = D, p.nw = 4, p.bc = 16, p;
@@ -186,14 +186,13 @@ int fa2_run(const FaPlan& p, const void* q, const void* k, const void* v, void* 
         // D = 512 (config C5): pairs of waves split the ROWS for QK^T and the softmax (done once per row), d for PV (flash_attn_pair2.cuh, round 6)
         if (D == 512) return p.one_stage ? fa2::launch_pair2<4, 2, fa2::PAIR2_HOIST | fa2::PAIR2_ONE_STAGE>(q, k, v, o, B, H, N, s)
                                          : fa2::launch_pair2<4, 2, fa2::PAIR2_HOIST>(q, k, v, o, B, H, N, s);
+        if (D == 384) return p.one_stage ? fa2::launch_pair2<4, 2, fa2::PAIR2_HOIST | fa2::PAIR2_ONE_STAGE, 384>(q, k, v, o, B, H, N, s)
+                                         : fa2::launch_pair2<4, 2, fa2::PAIR2_HOIST, 384>(q, k, v, o, B, H, N, s);
+        if (D == 320) return p.one_stage ? fa2::launch_pair2<4, 2, fa2::PAIR2_HOIST | fa2::PAIR2_ONE_STAGE, 320>(q, k, v, o, B, H, N, s)
+                                         : fa2::launch_pair2<4, 2, fa2::PAIR2_HOIST, 320>(q, k, v, o, B, H, N, s);
       }
       return CLN_ERR_UNSUPPORTED;
-    case K_DSPLIT:
-      if constexpr (!VT) {
-        // (the D = 64 / 128 forms of this kernel -- 32x32x16 MFMAs -- are in the probe library: variants 500 of kind 8)
-        // (D = 256 moved to the 16x16x32 kernel; its 32x32x16 form is probe variant 220 of kind 8)
-        return fa::launch_fa2_large_d(q, k, v, o, B, H, N, D, s, p.one_stage);
-      }
+    case K_DSPLIT:  // (no plan names it since round 6: every form of the 32x32x16 d-split kernel -- D = 64 / 128 / 256 / 512 and 320 / 384 on the 512 geometry -- is a probe variant of kind 8)
       return CLN_ERR_UNSUPPORTED;
     case K_DW4:
       if constexpr (!VT) return fa::launch_fa2_large_d(q, k, v, o, B, H, N, D, s, p.one_stage);
@@ -232,6 +231,8 @@ int fa2_describe(int family, bool vt, int B, int H, int N, int D, int stages, in
       if (D <= 128)
         return snprintf(buf, len, "fa2_fwd_m16x<D=%d,BC=%d,16x16x32 MFMA,%s,sum-checked softmax%s> 8 waves x 32 rows, two groups "
                                   "one phase apart%s", D, p.bc, qs, vts, st);
+      if (D == 320 || D == 384)
+        return snprintf(buf, len, "fa2_fwd_pair2<D=%d,BC=32,16x16x32 MFMA,LDS geometry of D=512,pairs of waves: rows split for QK^T and the softmax, d for PV> 8 waves, 128 rows, two groups one phase apart%s", D, st);
       if (D == 512)
         return snprintf(buf, len, "fa2_fwd_pair2<D=512,BC=32,16x16x32 MFMA,pairs of waves: rows split for QK^T and the softmax, d for PV> 8 waves, 128 rows, two groups one phase apart%s", st);
       return snprintf(buf, len, "fa2_fwd_m16<D=%d,BC=%d,16x16x32 MFMA> 8 waves x 32 rows, two groups one phase apart%s", D, p.bc, st);

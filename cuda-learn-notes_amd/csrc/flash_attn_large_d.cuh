@@ -8,7 +8,7 @@
 //              (flash_attn_dw4.cuh, round 5); before: quads of waves x 2 row groups, K / V through two-slot rings of 16-key tiles (flash_attn_dring.cuh,
 //              round 3, now probe-only); its predecessor probe/flash_attn_dwide.cuh -- one 32-key K tile and one V tile, no prefetch, D = 640 padded
 //              to 768 -- lives on in the probe library)
-//   320, 384   the D = 512 kernel's LDS geometry, every loop over the real head dim (DREAL; round 2)
+//   320, 384   (round 6: flash_attn_pair2.cuh with DREAL, planned in flash_attn.hip; the d-split form of rounds 2-5 is probe-only)
 #pragma once
 #include "flash_attn_dsplit.cuh"
 #include "flash_attn_dring.cuh"
@@ -20,8 +20,6 @@ inline int launch_fa2_large_d(const void* q, const void* k, const void* v, void*
   if (one_stage) {  // `stages = 1`: the same kernels with every tile request waited for where it is issued (no load under compute); d-split: one burst per tile
     constexpr int O1 = fa2::OPT_DEFAULT | fa2::OPT_1STAGE;
     switch (D) {
-      case 320: return fa2::launch_dsplit<512, 2, 1, fa2::OPT_DEFAULT, 512, 320>(q, k, v, o, B, H, N, s);
-      case 384: return fa2::launch_dsplit<512, 2, 1, fa2::OPT_DEFAULT, 512, 384>(q, k, v, o, B, H, N, s);
       case 640: return fa2::launch_dw4<640, fa2::DW4_CARRY | fa2::DW4_UNROLL2 | fa2::DW4_1STAGE>(q, k, v, o, B, H, N, s);
       case 768: return fa2::launch_dw4<768, fa2::DW4_DEFAULT | fa2::DW4_UNROLL2 | fa2::DW4_1STAGE>(q, k, v, o, B, H, N, s);
       case 1024: return fa2::launch_dw4<1024, fa2::DW4_DEFAULT | fa2::DW4_UNROLL2 | fa2::DW4_1STAGE>(q, k, v, o, B, H, N, s);
@@ -29,11 +27,9 @@ inline int launch_fa2_large_d(const void* q, const void* k, const void* v, void*
     }
   }
   switch (D) {
-    // D = 320 / 384: the D = 512 kernel's LDS geometry with the pair of waves splitting the REAL head dim evenly (no MFMA
-    // on padding): 745-817 / 793-876 TF at [1,16,4096,D] (profiles/r02_fa_native_320_384.log) vs 585 / 695 for the
-    // zero-padded round-1 form.
-    case 320: return fa2::launch_dsplit<512, 2, 1, fa2::OPT_DEFAULT, 0, 320>(q, k, v, o, B, H, N, s);
-    case 384: return fa2::launch_dsplit<512, 2, 1, fa2::OPT_DEFAULT, 0, 384>(q, k, v, o, B, H, N, s);
+    // (D = 320 / 384 ran the d-split kernel on the D = 512 LDS geometry in rounds 2-5 -- 745-817 / 793-876 TF at [1,16,4096,D], profiles/r02_fa_native_320_384.log;
+    // since round 6 they run fa2_fwd_pair2<DREAL> on the same geometry (flash_attn_pair2.cuh: +12-16 %, profiles/r06_pair2_d320_d384.log); the d-split form is probe
+    // variant 210 / 220 of kind 8)
     // (D = 512, config C5, is planned onto the 16x16x32 pair kernel of flash_attn_m16.cuh since round 3; this 32x32x16 form --
     // 990-1010 TF at [1,32,4096,512] -- stays as the geometry of 320 / 384 and as probe variant 210)
     // D = 640 / 768 / 1024 (flash_attn_dring.cuh): [1,16,4096,D] 604 -> 649 / 684 -> 703 / 691 -> 780 TF, [1,8,8192,1024] 657 -> 804

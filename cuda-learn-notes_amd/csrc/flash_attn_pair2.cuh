@@ -52,12 +52,18 @@ enum : int {
   PAIR2_HOIST = 2,
 };
 
-template <int PDK = 4, int PDV = 2, int OPT = 0>
+// DREAL != 0: the tensors have DREAL < 512 columns (320 / 384). The LDS geometry stays that of D = 512 (1024-byte rows; columns [p DREAL/2, (p + 1) DREAL/2) of a
+// row at the start of its 512-byte half p, the rest of a half never read -- the image of flash_attn_dsplit.cuh's PAD form); every loop runs over the REAL head dim:
+// DREAL / 32 k-steps for QK^T (10 / 12), DREAL / 32 output blocks per wave for PV (10 / 12): no MFMA multiplies padding.
+template <int PDK = 4, int PDV = 2, int OPT = 0, int DREAL = 0>
 __global__ __launch_bounds__(512, 2) void fa2_fwd_pair2_kernel(const half_t* __restrict__ Q, const half_t* __restrict__ K,
                                                                const half_t* __restrict__ V, half_t* __restrict__ O,
                                                                int N, int n_qblk, int n_heads, float scale_log2e) {
   using G = GeoPair2;
-  constexpr int D = G::D, DH = G::DH, NKS = G::NKS, NDB = G::NDB, NQK = G::NQK;
+  constexpr bool PAD = DREAL != 0;
+  static_assert(!PAD || (DREAL % 64 == 0 && DREAL > 256 && DREAL < 512), "head dims 320 / 384 ride on the D = 512 geometry");
+  constexpr int D = PAD ? DREAL : G::D, DH = D / 2;         // columns per row in memory; columns of a wave's PV half
+  constexpr int NKS = D / 32, KH = DH / 32, NDB = DH / 16, NQK = G::NKB * NKS;  // k-steps of QK^T (KH of them per 512-byte half of a row), output blocks per wave
   extern __shared__ __attribute__((aligned(1024))) char smem[];  // 1024: fragment addresses XOR bits 5 .. 8 into (LDS address of smem + offset)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -87,8 +93,15 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_pair2_kernel(const half_t* __r
   const unsigned src_lane = (unsigned)(lr * G::ROW) + (unsigned)((lc ^ (grp == 0 ? G::swz_k(rlow) : G::swz_v(rlow))) << 4);
   auto dma_piece = [&](int jt, int slot, int i) __attribute__((always_inline)) {
     const int piece = i * 4 + widx;
-    const unsigned voff = src_lane ^ (unsigned)((grp == 0 ? G::swz_k(4 * i * G::RPP) : G::swz_v(4 * i * G::RPP)) << 4);
-    const char* s = src_h + (size_t)jt * G::TILE + piece * 1024;
+    unsigned voff = src_lane ^ (unsigned)((grp == 0 ? G::swz_k(4 * i * G::RPP) : G::swz_v(4 * i * G::RPP)) << 4);
+    const char* s;
+    if constexpr (PAD) {  // voff >> 4 = the logical chunk X this lane's LDS position holds: half p = X >> 5, chunk cc = X & 31 of it; real if cc < DH / 8 (else never read)
+      const unsigned X = voff >> 4, pp = X >> 5, cc = X & 31;
+      voff = cc < (unsigned)(DH / 8) ? (pp * (unsigned)(DH / 8) + cc) << 4 : 0u;
+      s = src_h + (size_t)jt * (G::BC * D * 2) + piece * (D * 2);
+    } else {
+      s = src_h + (size_t)jt * G::TILE + piece * 1024;
+    }
     if constexpr ((OPT & PAIR2_HOIST) != 0) hgemm::glds16_asm(s, voff, lds0 + grp * G::STAGE + slot * G::TILE + piece * 1024);
     else hgemm::glds16_asm(s, voff, lds0 + slot * G::STAGE + grp * G::TILE + piece * 1024);
   };
@@ -152,7 +165,8 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_pair2_kernel(const half_t* __r
     const int nslot = HOIST ? 1 - SLOT : (j + 1) & 1;  // ring slot of tile j + 1
     const unsigned kb_j = kbase + (j & 1) * G::STAGE, vb_j = vbase + (j & 1) * G::STAGE + G::TILE;
     auto k_frag = [&](int t) __attribute__((always_inline)) {  // t = 2 ks + kb: the two key blocks alternate, a dependent MFMA sits two behind
-      const int ks = t >> 1, kb = t & 1;
+      const int kb = t & 1;
+      const int ks = (t >> 1) % KH + 8 * ((t >> 1) / KH);  // position in the LDS row, in 64-byte steps: KH real steps at the start of each 512-byte half
       if constexpr (HOIST) return lds_ld<h8>(kx[ks & 3] + (unsigned)(SLOT * G::TILE + (ks >> 2) * 256 + kb * 16 * G::ROW));
       else return lds_ld<h8>((kb_j ^ (unsigned)((ks & 3) << 6)) + (ks >> 2) * 256 + kb * 16 * G::ROW);
     };
@@ -178,7 +192,6 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_pair2_kernel(const half_t* __r
       h8 kf[PDK];
 #pragma unroll
       for (int i = 0; i < PDK; ++i) kf[i] = k_frag(i);
-      constexpr int DSTEP = NQK / G::PPW;
 #pragma unroll
       for (int t = 0; t < NQK; ++t) {
         const int ks = t >> 1, kb = t & 1;
@@ -186,7 +199,11 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_pair2_kernel(const half_t* __r
         else s[kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[t % PDK], qf[ks], s[kb], 0, 0, 0);
         cln_mfma_keep(s[kb], kf[t % PDK], qf[ks]);  // destination disjoint from the operands (common.h)
         if (t + PDK < NQK) kf[t % PDK] = k_frag(t + PDK);
-        if ((OPT & PAIR2_ONE_STAGE) == 0 && (t % DSTEP) == DSTEP - 1) dma_piece(jn, nslot, t / DSTEP);
+        if constexpr ((OPT & PAIR2_ONE_STAGE) == 0) {  // piece i behind step (i + 1) NQK / PPW - 1: spread evenly over the phase (NQK = 32 / 24 / 20)
+#pragma unroll
+          for (int i = 0; i < G::PPW; ++i)
+            if (t == ((i + 1) * NQK) / G::PPW - 1) dma_piece(jn, nslot, i);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -296,7 +313,8 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_pair2_kernel(const half_t* __r
   __builtin_amdgcn_s_waitcnt(0xC07F);
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  char* ob = smem + wave * (32 * G::OS);
+  constexpr int OS = DH * 2 + 16;
+  char* ob = smem + wave * (32 * OS);
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
     const float inv = lds_ld<float>(lds0 + G::LX + rg * 128 + qb * 64 + i16_e * 4);
@@ -305,7 +323,7 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_pair2_kernel(const half_t* __r
       h4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = (half_t)(ot[b][qb][e] * inv);
-      *reinterpret_cast<h4*>(ob + (qb * 16 + i16_e) * G::OS + (b * 16 + g4_e * 4) * 2) = o;
+      *reinterpret_cast<h4*>(ob + (qb * 16 + i16_e) * OS + (b * 16 + g4_e * 4) * 2) = o;
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -315,19 +333,19 @@ __global__ __launch_bounds__(512, 2) void fa2_fwd_pair2_kernel(const half_t* __r
   for (int it = 0; it < (32 * LPR) / 64; ++it) {
     const int idx = it * 64 + lane_e;
     const int row = idx / LPR, c = idx % LPR;
-    *reinterpret_cast<u4*>(og + (size_t)row * D + c * 8) = *reinterpret_cast<const u4*>(ob + row * G::OS + c * 16);
+    *reinterpret_cast<u4*>(og + (size_t)row * D + c * 8) = *reinterpret_cast<const u4*>(ob + row * OS + c * 16);
   }
 }
 
-template <int PDK = 4, int PDV = 2, int OPT = 0>
+template <int PDK = 4, int PDV = 2, int OPT = 0, int DREAL = 0>
 int launch_pair2(const void* q, const void* k, const void* v, void* o, int B, int H, int N, hipStream_t stream) {
   using G = GeoPair2;
   if (N % G::BR != 0) return CLN_ERR_UNSUPPORTED;
   static cln_lds_attr lds_attr;  // per device, thread-safe (common.h)
-  if (cln_ensure_lds(lds_attr, reinterpret_cast<const void*>(&fa2_fwd_pair2_kernel<PDK, PDV, OPT>), G::LDS_BYTES) != CLN_OK) return CLN_ERR_LAUNCH;
-  const float scale_log2e = 1.4426950408889634f / sqrtf((float)G::D);
+  if (cln_ensure_lds(lds_attr, reinterpret_cast<const void*>(&fa2_fwd_pair2_kernel<PDK, PDV, OPT, DREAL>), G::LDS_BYTES) != CLN_OK) return CLN_ERR_LAUNCH;
+  const float scale_log2e = 1.4426950408889634f / sqrtf((float)(DREAL ? DREAL : G::D));
   const int n_qblk = N / G::BR;
-  CLN_LAUNCH((fa2_fwd_pair2_kernel<PDK, PDV, OPT>), dim3(n_qblk * B * H), dim3(G::NT), G::LDS_BYTES, stream,
+  CLN_LAUNCH((fa2_fwd_pair2_kernel<PDK, PDV, OPT, DREAL>), dim3(n_qblk * B * H), dim3(G::NT), G::LDS_BYTES, stream,
              (const half_t*)q, (const half_t*)k, (const half_t*)v, (half_t*)o, N, n_qblk, B * H, scale_log2e);
   return cln_check_launch();
 }

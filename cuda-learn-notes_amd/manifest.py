@@ -107,8 +107,8 @@ _FA_VT = [
     "flash_attn_mma_stages_split_q_tiling_qk_swizzle_qkv",
 ]
 _FA_SPLIT_Q_IMPL = ("planner fa2_plan(shape, stages) [csrc/flash_attn.hip]: stages=1 -> the stage-2 kernel of the shape in its single-stage form (each tile requested in one burst and waited for where it is requested; bit-identical to stages=2); "
-                    "stages=2 -> fa2_fwd_m16x<D=128> / fa2_fwd_m16<D=256> (N a multiple of 256) | fa2_fwd_m16x<D=64> (> 128 workgroups of 256 rows) | fa2_fwd_pair2<D=512> (pairs of waves: rows split for QK^T and the softmax, d for PV) | fa2_fwd_m16x64r<D=64> (>=256 workgroups of 512 rows) | fa2_fwd_v2<D<=256, 4 waves when N allows, 8 at D=32|96 on large grids, 2 when N is an odd multiple of 64> | "
-                    "fa2_fwd_dsplit<320 / 384 on the D = 512 LDS geometry with the real d split evenly> | fa2_fwd_dw4<640 | 768 | 1024: one wave per SIMD, O^T in AGPRs, softmax once per row>; mfma_32x32x16 / 16x16x32, f32 acc; "
+                    "stages=2 -> fa2_fwd_m16x<D=128> / fa2_fwd_m16<D=256> (N a multiple of 256) | fa2_fwd_m16x<D=64> (> 128 workgroups of 256 rows) | fa2_fwd_pair2<D=512, and 320 / 384 on the D = 512 LDS geometry with every loop over the real head dim> (pairs of waves: rows split for QK^T and the softmax, d for PV) | fa2_fwd_m16x64r<D=64> (>=256 workgroups of 512 rows) | fa2_fwd_v2<D<=256, 4 waves when N allows, 8 at D=32|96 on large grids, 2 when N is an odd multiple of 64> | "
+                    "fa2_fwd_dw4<640 | 768 | 1024: one wave per SIMD, O^T in AGPRs, softmax once per row>; mfma_32x32x16 / 16x16x32, f32 acc; "
                     "the *_acc_f32 names at D <= 128: the same kernels with the scores scaled in fp32 instead of the fp16 pre-scaled Q "
                     "(see DISPATCH_EXAMPLES)")
 _add("flash_attn", "FA", "fa2_fwd_splitkv<D<=128>: 4 waves share 32 query rows, KV tile split over the waves, cross-wave "
@@ -368,8 +368,8 @@ DISPATCH_EXAMPLES = [
     (_SQKV + "_swizzle_qkv", (2, 8, 1920, 128), 2, "fa2_fwd_v2<D=128,NW=4,BC=64,prefetch,pre-scaled Q,V^T> 4 waves x 32 rows"),  # N a multiple of 128 only: the v2 kernel
     (_SQKV + "_swizzle_qkv", (4, 8, 2048, 128), 1, "fa2_fwd_m16x<D=128,BC=128,16x16x32 MFMA,pre-scaled Q,sum-checked softmax,V^T> 8 waves x 32 rows, two groups one phase apart" + _ONE),
     (_TQKV, (1, 32, 4096, 512), 2, "fa2_fwd_pair2<D=512,BC=32,16x16x32 MFMA,pairs of waves: rows split for QK^T and the softmax, d for PV> 8 waves, 128 rows, two groups one phase apart"),
-    (_TQKV, (1, 16, 4096, 384), 2, "fa2_fwd_dsplit<D=384,NSP=2,BC=32,LDS geometry of D=512> 8 waves, pairs split the real d evenly"),
-    (_TQKV, (1, 16, 4096, 320), 2, "fa2_fwd_dsplit<D=320,NSP=2,BC=32,LDS geometry of D=512> 8 waves, pairs split the real d evenly"),
+    (_TQKV, (1, 16, 4096, 384), 2, "fa2_fwd_pair2<D=384,BC=32,16x16x32 MFMA,LDS geometry of D=512,pairs of waves: rows split for QK^T and the softmax, d for PV> 8 waves, 128 rows, two groups one phase apart"),
+    (_TQKV, (1, 16, 4096, 320), 2, "fa2_fwd_pair2<D=320,BC=32,16x16x32 MFMA,LDS geometry of D=512,pairs of waves: rows split for QK^T and the softmax, d for PV> 8 waves, 128 rows, two groups one phase apart"),
     (_TQKV, (1, 16, 4096, 640), 2, "fa2_fwd_dw4<D=640,BC=16,2-slot K/V rings,O^T in AGPRs> 4 waves (one per SIMD) split d (160 columns each), 64 rows, softmax once per row by its owner wave"),
     (_TQKV, (1, 16, 4096, 1024), 2, "fa2_fwd_dw4<D=1024,BC=16,2-slot K/V rings,O^T in AGPRs> 4 waves (one per SIMD) split d (256 columns each), 64 rows, softmax once per row by its owner wave"),
     # stages = 1 above D = 256: the same kernel, single stage

@@ -135,7 +135,7 @@ def test_flash_attn_planner_invariants_over_a_grid_of_shapes(built):
                     nw = int(t.split("NW=")[1].split(",")[0])
                     assert nw == 4 or (nw == 8 and D in (32, 96) and wgs256 > (256 if D == 32 else 128)) or (nw == 2 and N % 128 != 0), (B, H, N, D, t)
                 if D in (320, 384):
-                    assert fam == "fa2_fwd_dsplit", t
+                    assert fam == "fa2_fwd_pair2" and "LDS geometry of D=512" in t, t
                 if D == 512:
                     assert fam == "fa2_fwd_pair2" and "rows split for QK^T and the softmax, d for PV" in t, t
                 if D in (640, 768, 1024):
@@ -143,7 +143,7 @@ def test_flash_attn_planner_invariants_over_a_grid_of_shapes(built):
                 if D <= 256:  # the shared-QKV name (max head dim 256) plans the same kernel
                     assert m.describe(sq, (B, H, N, D), 2) == t
     for want in (("fa2_fwd_m16x", 64), ("fa2_fwd_m16x", 128), ("fa2_fwd_m16", 256), ("fa2_fwd_m16x64r", 64), ("fa2_fwd_v2", 32),
-                 ("fa2_fwd_dsplit", 384), ("fa2_fwd_pair2", 512), ("fa2_fwd_dw4", 1024), ("fa2_fwd_dw4", 640)):
+                 ("fa2_fwd_pair2", 384), ("fa2_fwd_pair2", 512), ("fa2_fwd_dw4", 1024), ("fa2_fwd_dw4", 640)):
         assert want in fam_seen, (want, sorted(fam_seen))
     with pytest.raises(ValueError):  # "headdim not support!" of the shared-QKV rung (MAX_HEADDIM_CFG: 256)
         m.describe(sq, (1, 32, 4096, 512), 2)

@@ -50,8 +50,9 @@ def test_attention_kernels_in_the_product_library_are_exactly_the_plannable_ones
             linked.add(("fa2_fwd_m16", 256, a[3] == "262144"))
         elif f == "fa2_fwd_pair2_kernel":  # <K fragments in flight, V fragments in flight, option bits>: D = 512, round 6
             # option bits: 2 = swizzled fragment bases pinned in registers, two tiles per loop iteration (always); 1 = the single-stage form
-            assert a[:2] == ["4", "2"] and a[2] in ("2", "3"), a
-            linked.add(("fa2_fwd_pair2", 512, a[2] == "3"))
+            # 4th argument: the real head dim on the D = 512 LDS geometry (0 = 512)
+            assert a[:2] == ["4", "2"] and a[2] in ("2", "3") and a[3] in ("0", "320", "384"), a
+            linked.add(("fa2_fwd_pair2", int(a[3]) or 512, a[2] == "3"))
         elif f == "fa2_fwd_m16x_kernel":  # 6th argument: option bits (32768 = single-stage form); 7th: V given transposed ([B,H,D,N], the *_swizzle_qkv names)
             # the shipped options: phase-A priority + split prologue (1 << 18: fp32-scaled scores; 1 << 19: row sums on the matrix pipe, with them at 32 rows per wave)
             assert int(a[5]) & ~(32768 | (3 << 16) | (1 << 18) | (1 << 19)) == 5, a

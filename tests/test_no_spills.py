@@ -41,7 +41,7 @@ def test_production_attention_instantiations_are_in_the_report(tmp_path):
     # the product unit holds the three dispatched forms, each for V as [B,H,N,D] and as [B,H,D,N], each as the stage-2 pipeline and in its
     # single-stage form (`stages = 1`); the [B,H,N,D] ones also with the scores scaled in fp32 (the *_acc_f32 names)
     assert len(kernels_x) == 18, [k["demangled"] for k in kernels_x]
-    for want in ("fa2_fwd_dsplit_kernel<512, 2, 1,", "fa2_fwd_m16x_kernel<64, 32, 128, 8, 4, 5, false>", "fa2_fwd_m16x_kernel<128, 32, 128, 4, 4, 5, false>", "fa2_fwd_m16x_kernel<128, 32, 128, 4, 4, 5, true>", "fa2_fwd_m16_pair_kernel<2, false, false, 0>", "fa2_fwd_pair2_kernel<4, 2, 2>",
+    for want in ("fa2_fwd_pair2_kernel<4, 2, 2, 384>", "fa2_fwd_m16x_kernel<64, 32, 128, 8, 4, 5, false>", "fa2_fwd_m16x_kernel<128, 32, 128, 4, 4, 5, false>", "fa2_fwd_m16x_kernel<128, 32, 128, 4, 4, 5, true>", "fa2_fwd_m16_pair_kernel<2, false, false, 0>", "fa2_fwd_pair2_kernel<4, 2, 2, 0>",
                  "fa2_fwd_v2_kernel<128, 2, true", "fa2_fwd_splitkv_kernel<64, true>", "fa2_fwd_dw4_kernel<1024, 240, 2, 2>", "fa2_fwd_dw4_kernel<640, 145, 2, 2>", "fa2_fwd_m16x_kernel<64, 64, 64, 4, 1, 5, false>"):
         assert any(want in n for n in names), want
 
@@ -86,7 +86,7 @@ def test_production_attention_kernels_use_the_16x16x32_matrix_shape(tmp_path):
     kernels_x, sx = kr.report(os.path.join(ROOT, "cuda-learn-notes_amd", "csrc", "flash_attn_m16x.hip"), keep=str(tmp_path))
     text = open(s).read() + open(sx).read()
     for want in ("fa2_fwd_m16x_kernel<64, 32, 128, 8, 4, 5, false>", "fa2_fwd_m16x_kernel<128, 32, 128, 4, 4, 5, false>", "fa2_fwd_m16x_kernel<128, 32, 128, 4, 4, 5, true>", "fa2_fwd_m16_pair_kernel<2, false, false, 0>",
-                 "fa2_fwd_pair2_kernel<4, 2, 2>"):
+                 "fa2_fwd_pair2_kernel<4, 2, 2, 0>"):
         k = [k for k in kernels + kernels_x if want in k["demangled"]]
         assert len(k) == 1, want
         body = text[text.index("\n" + k[0]["name"] + ":"):]
