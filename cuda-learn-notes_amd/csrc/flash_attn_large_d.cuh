@@ -11,7 +11,6 @@
 //   320, 384   (round 6: flash_attn_pair2.cuh with DREAL, planned in flash_attn.hip; the d-split form of rounds 2-5 is probe-only)
 #pragma once
 #include "flash_attn_dsplit.cuh"
-#include "flash_attn_dring.cuh"
 #include "flash_attn_dw4.cuh"
 
 namespace fa {

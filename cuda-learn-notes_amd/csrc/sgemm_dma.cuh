@@ -1,0 +1,202 @@
+// SGEMM on the exact-f32 matrix instruction v_mfma_f32_32x32x2_f32, tiles fed by LDS-DMA (round 6).
+//
+// Reference rungs served: kernels/sgemm/sgemm_wmma_tf32_stage.cu (sgemm_wmma_m16n16k8_mma4x2_warp2x4_stages[_dsmem]; the reference
+// rounds to TF32 -- gfx950 has no TF32, the product here is exact f32 with f32 accumulation, i.e. strictly closer to the script's
+// torch.matmul row than the reference's own kernel).
+//
+// Why a second matrix-core kernel: the register-staged 128x128x16 kernel of rounds 2-5 (sgemm.hip sgemm_mfma_kernel) sits at 0.82 of
+// the 157 TF f32 matrix peak and 0.93x rocBLAS sgemm at 4096^3. It pays, per 128x128 tile and 16-deep step, 4 global loads + 10 LDS
+// stores per thread through VGPRs, a barrier every 32 MFMAs per wave, and moves 2x the L2 bytes of a 256x256 tile. This kernel:
+//   * block tile (WM*TM*32) x (WN*TN*32), 256x256 by default: 8 waves = two per SIMD, wave tile 128x64 (4 x 2 MFMA tiles, 128
+//     accumulator registers), one workgroup per CU;
+//   * K in BK-deep stages through a ring of S LDS slots filled by LDS-DMA (global_load_lds_dwordx4: no VGPR staging, no ds_write);
+//     ONE barrier per stage = per 128 MFMAs of a wave at BK = 32; the DMA of stage t+S-1 is issued right behind the barrier that frees
+//     its slot, so it has S-1 whole stages (>= 16k clocks) to land;
+//   * A image: rows of BK floats (128 B = one full line at BK = 32), 16-byte chunks XOR-swizzled on the SOURCE side so that the
+//     ds_read_b128 of 8 consecutive rows covers all 64 banks; k is permuted inside a group of 8 (lane half kh takes k = 8m + 4kh + s in
+//     step s) so ONE b128 read feeds four MFMA steps of an A tile -- the same permutation on B keeps the sum intact (f32 addition
+//     order inside a k8 group changes, nothing else);
+//   * B image: k-major rows of BN floats as they lie in memory; lanes 0..31 read 32 consecutive words of row k, lanes 32..63 of row
+//     k+4, whose chunks sit 128 B further (source-side XOR of chunk bit 3) so that the two halves use different banks.
+// Per wave and k8 group: TM b128 + 4 TN b32 LDS reads for 4 TM TN MFMAs of 64 clocks each -- the LDS and the vector ALU are idle
+// > 90 % of the time, which is the point: under the package power cap the clock is what the remaining energy buys.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+
+namespace sgemm_dma {
+
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+// LDS-DMA issued from asm (as hgemm_mfma.cuh glds16_asm): hipcc cannot prove that an in-flight DMA does not alias the fragment reads
+// of another ring slot and would drain vmcnt(0) before the first ds_read of every stage. Source = SGPR base + per-lane byte offset,
+// destination = M0 (wave-uniform) + lane * 16; ordered only by the counted waits below + the barrier.
+__device__ __forceinline__ void dma16(const void* sbase, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(sbase), "s"(lds_dst)
+               : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  static_assert(N >= 0 && N < 64, "vmcnt range");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int WM, int WN, int TM, int TN, int BK, int S>
+struct Geo {
+  static constexpr int NW = WM * WN, THREADS = NW * 64;
+  static constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  static constexpr int RB = BK * 4;            // bytes per A row in LDS
+  static constexpr int CPR = BK / 4;           // 16-byte chunks per A row
+  static constexpr int RPG = 256 / RB;         // A rows per 256-byte bank span
+  static constexpr int RPI = 64 / CPR;         // A rows per DMA instruction (1 KiB)
+  static constexpr int A_BYTES = BM * RB, B_BYTES = BK * BN * 4, STAGE = A_BYTES + B_BYTES;
+  static constexpr int A_I = A_BYTES / 1024 / NW, B_I = B_BYTES / 1024 / NW;  // DMA instructions per wave and stage
+  static constexpr int LDS = S * STAGE;
+  static_assert(A_BYTES % (1024 * NW) == 0 && B_BYTES % (1024 * NW) == 0, "whole DMA instructions per wave");
+  static_assert(BK % 8 == 0 && (BN * 4) % 512 == 0 && TN % 2 == 0, "k8 groups; B rows of whole 512-byte spans; column blocks in XOR pairs");
+};
+
+template <int WM, int WN, int TM, int TN, int BK, int S>
+__global__ __launch_bounds__(WM* WN * 64) void sgemm_dma_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                                float* __restrict__ C, int M, int N, int K, int tiles_n,
+                                                                int swizzle) {
+  using G = Geo<WM, WN, TM, TN, BK, S>;
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave-uniform: it addresses M0)
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int l31 = lane & 31, kh = lane >> 5;
+
+  int bid = blockIdx.x;
+  if (swizzle) {  // bijective XCD remap (workgroup b runs on XCD b % 8): each XCD gets a contiguous run of tiles
+    const int nblk = gridDim.x, xcd = bid & 7, local = bid >> 3, q = nblk >> 3, r = nblk & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+  }
+  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  const int m0 = tm * G::BM, n0 = tn * G::BN;
+
+  // ---- DMA sources: a scalar base that advances one stage at a time + per-lane byte offsets that never change; destinations wave-uniform
+  const char* abase = reinterpret_cast<const char*>(A + (size_t)m0 * K);
+  const char* bbase = reinterpret_cast<const char*>(B + n0);
+  const size_t astep = (size_t)BK * 4, bstep = (size_t)BK * N * 4;
+  unsigned avo[G::A_I], bvo[G::B_I];
+#pragma unroll
+  for (int q = 0; q < G::A_I; ++q) {
+    const int row = (wave * G::A_I + q) * G::RPI + lane / G::CPR;     // row of the tile this lane's chunk belongs to
+    const int pos = lane % G::CPR;                                    // chunk position in the LDS row
+    const int chunk = pos ^ ((row / G::RPG) % G::CPR);                // source chunk that lands there
+    avo[q] = ((unsigned)row * (unsigned)K + chunk * 4) * 4u;
+  }
+  constexpr int BCPR = G::BN / 4;  // chunks per B row
+#pragma unroll
+  for (int q = 0; q < G::B_I; ++q) {
+    const int unit = (wave * G::B_I + q) * 64 + lane;                 // chunk index in the stage's B image
+    const int krow = unit / BCPR, pos = unit % BCPR;
+    const int chunk = pos ^ (((krow >> 2) & 1) << 3);
+    bvo[q] = ((unsigned)krow * (unsigned)N + chunk * 4) * 4u;
+  }
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  auto issue = [&](int slot) {
+    const unsigned base = lds0 + slot * G::STAGE + wave * (G::A_I * 1024);
+#pragma unroll
+    for (int q = 0; q < G::A_I; ++q) dma16(abase, avo[q], base + q * 1024);
+    const unsigned bb = lds0 + slot * G::STAGE + G::A_BYTES + wave * (G::B_I * 1024);
+#pragma unroll
+    for (int q = 0; q < G::B_I; ++q) dma16(bbase, bvo[q], bb + q * 1024);
+  };
+
+  // ---- fragment read offsets (bytes inside a stage)
+  unsigned aoff[BK / 8];
+  {
+    const int sw = (l31 / G::RPG) % G::CPR;  // the 32-row tile offsets and the wave offset are multiples of RPG * CPR rows
+#pragma unroll
+    for (int m = 0; m < BK / 8; ++m) aoff[m] = (unsigned)((wm * TM * 32 + l31) * G::RB + (((2 * m + kh) ^ sw) << 4));
+  }
+  // B: row k = 8m + 4kh + s, column block j of this wave: lanes of the upper half read the block their XOR put them in
+  unsigned boff[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) boff[p] = (unsigned)(G::A_BYTES + (4 * kh) * G::BN * 4 + ((wn * TN * 32 + ((p ^ kh) << 5) + l31) << 2));
+
+  f16v acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nt = K / BK;
+  // prologue: stages 0 .. S-2 requested (a stage past the end of K re-reads the last one: the request count per iteration stays fixed)
+  int nxt = 0;  // stage the bases point at
+#pragma unroll
+  for (int s = 0; s < S - 1; ++s) {
+    issue(s);
+    if (nxt + 1 < nt) {
+      ++nxt;
+      abase += astep;
+      bbase += bstep;
+    }
+  }
+  int slot = 0, fill = S - 1;  // slot read in this iteration; slot filled in this iteration
+  for (int t = 0; t < nt; ++t) {
+    // this wave's requests for stage t have landed (the S-2 younger stages may still be in flight) ...
+    wait_vm<(S - 2) * (G::A_I + G::B_I)>();
+    __syncthreads();  // ... everyone's have, and everyone is done reading the slot that is filled next
+    issue(fill);
+    if (nxt + 1 < nt) {  // (past the end of K the bases stay on the last stage)
+      ++nxt;
+      abase += astep;
+      bbase += bstep;
+    }
+    const unsigned sb = lds0 + slot * G::STAGE;
+#pragma unroll
+    for (int m = 0; m < BK / 8; ++m) {
+      f4v a[TM];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = lds_ld<f4v>(sb + aoff[m] + i * 32 * G::RB);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        float b[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = lds_ld<float>(sb + boff[j & 1] + (8 * m + s) * G::BN * 4 + (j >> 1) * 256);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    slot = slot + 1 == S ? 0 : slot + 1;
+    fill = fill + 1 == S ? 0 : fill + 1;
+  }
+  wait_vm<0>();  // the re-read requests of the tail must not outlive the workgroup's LDS
+
+  // ---- C: result register r of a 32x32 tile is row (r & 3) + 8 (r >> 2) + 4 kh, column l31: 128-byte row segments per half wave
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        C[(size_t)row * N + n0 + (wn * TN + j) * 32 + l31] = acc[i][j][r];
+      }
+}
+
+template <int WM, int WN, int TM, int TN, int BK, int S>
+int launch(const void* a, const void* b, void* c, int M, int N, int K, int swizzle, hipStream_t st) {
+  using G = Geo<WM, WN, TM, TN, BK, S>;
+  if (M % G::BM || N % G::BN || K % BK) return CLN_ERR_UNSUPPORTED;
+  static cln_lds_attr attr;
+  auto kfn = sgemm_dma_kernel<WM, WN, TM, TN, BK, S>;
+  if (cln_ensure_lds(attr, reinterpret_cast<const void*>(kfn), G::LDS) != CLN_OK) return CLN_ERR_LAUNCH;
+  const int tiles_n = N / G::BN, grid = (M / G::BM) * tiles_n;
+  CLN_LAUNCH(kfn, dim3(grid), dim3(G::THREADS), G::LDS, st, (const float*)a, (const float*)b, (float*)c, M, N, K, tiles_n,
+             swizzle ? 1 : 0);
+  return cln_check_launch();
+}
+
+}  // namespace sgemm_dma
