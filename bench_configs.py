@@ -513,24 +513,33 @@ def next_rows(pkg, dev, orc):
         rows = {}
         ap, bp, cp = a.data_ptr(), b.data_ptr(), c.data_ptr()
         for name, args in (("sgemm_wmma_m16n16k8_mma4x2_warp2x4_stages", (2, 0, 0)), ("sgemm_wmma_m16n16k8_mma4x2_warp2x4_stages_dsmem", (3, 1, 256)),
-                           ("sgemm_t_8x8_sliced_k16_f32x4_bcf_dbuf_async", None), ("sgemm_t_8x8_sliced_k_f32x4_bcf_dbuf", None), ("sgemm_cublas", None)):
-            if not _loader.has_symbol(name):
-                continue
-            fn = _loader.symbol(name)
-            if name == "sgemm_cublas":
-                _loader.symbol("init_cublas_handle")()
-            call = (lambda fn=fn, args=args: fn(ap, bp, cp, M, N, K, args[0], args[1], args[2], st)) if args else (lambda fn=fn: fn(ap, bp, cp, M, N, K, st))
+                           ("sgemm_t_8x8_sliced_k16_f32x4_bcf_dbuf_async", None), ("sgemm_t_8x8_sliced_k_f32x4_bcf_dbuf", None), ("sgemm_cublas", None),
+                           ("torch_matmul_f32", None)):
+            if name == "torch_matmul_f32":  # (dispatches to a hipBLASLt stream-K kernel on this image: the faster of the two vendor rows)
+                prev = torch.backends.cuda.matmul.allow_tf32
+                torch.backends.cuda.matmul.allow_tf32 = False
+                call = lambda: torch.matmul(a, b, out=c)
+            else:
+                if not _loader.has_symbol(name):
+                    continue
+                fn = _loader.symbol(name)
+                if name == "sgemm_cublas":
+                    _loader.symbol("init_cublas_handle")()
+                call = (lambda fn=fn, args=args: fn(ap, bp, cp, M, N, K, args[0], args[1], args[2], st)) if args else (lambda fn=fn: fn(ap, bp, cp, M, N, K, st))
             rc = call()
             torch.cuda.synchronize()
-            if rc != 0:
+            if name != "torch_matmul_f32" and rc != 0:
                 rows[name] = {"error": "status %d" % rc}
                 continue
             ms = _one_region(call, 20, target_ms=60.0)
+            if name == "torch_matmul_f32":
+                torch.backends.cuda.matmul.allow_tf32 = prev
             rows[name] = {"us_per_launch": round(ms * 1e3, 2), "tflops": round(flops / ms * 1e-9, 2), "frac_of_f32_mfma_peak": round(flops / ms * 1e-9 / PEAK_F32_MFMA_TFLOPS, 4)}
         if "sgemm_cublas" in rows and "tflops" in rows["sgemm_cublas"]:
             for k, r in rows.items():
                 if "tflops" in r:
                     r["x_rocblas_sgemm"] = round(r["tflops"] / rows["sgemm_cublas"]["tflops"], 3)
+                    r["x_torch_matmul_hipblaslt"] = round(r["tflops"] / rows["torch_matmul_f32"]["tflops"], 3)
         # sampled rows of the MFMA rung against the fp64 product (exact-f32 MFMA: <= a few fp32 ulps of a K = 4096 sum)
         fn = _loader.symbol("sgemm_wmma_m16n16k8_mma4x2_warp2x4_stages")
         c.zero_()

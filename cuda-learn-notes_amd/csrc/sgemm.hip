@@ -5,14 +5,18 @@
 //
 // gfx950 design:
 //  * there is NO TF32 on CDNA4, but there IS an exact-f32 matrix instruction, v_mfma_f32_32x32x2_f32, at the f32
-//    vector rate (157 TF peak): the reference's TF32 rungs map onto it and return EXACT fp32 products (bitwise an
-//    fmaf chain) instead of 10-bit-mantissa ones. 128x128x16 tile, 4 waves (2x2), each 64x64 = 2x2 MFMA tiles;
-//    A staged into a padded m-major LDS image (stride 17 floats: conflict-free ds_read_b32 of 32 rows), B into a
-//    k-major image; `stages` LDS buffers with issue-early / write-late register staging; XCD-aware block order
-//    for `swizzle`.
+//    vector rate (157 TF peak): the reference's TF32 rungs map onto it and return EXACT fp32 products
+//    instead of 10-bit-mantissa ones. Round 6: sgemm_dma.cuh -- tiles fed by LDS-DMA through a 3-slot ring, ONE barrier
+//    per 16-deep stage placed in the stage's middle (in the shadow of an MFMA), no address arithmetic in the loop;
+//    tile 64x128 / 128x128 / 256x128 by a per-shape cost (sgemm_plan below). 4096^3: 149 TF = 0.95 of the peak
+//    (rounds 2-5, register-staged 128x128x16 with a barrier per stage: 130), rocBLAS sgemm 140, hipBLASLt 150.
+//    `stages` 2 and 3 run the same ring (read / landed / in flight is what keeps the barrier off the stage boundary);
+//    `swizzle` = XCD-aware block order. Every tile form adds the k products in the same order: the result does not
+//    depend on the tile the planner picks.
 //  * the CUDA-core ladder becomes a VALU thread-tile kernel: 128 x (16*TN) block, 8 x TN outputs per lane,
 //    v_fma_f32 from a transposed A image, optional double buffer and issue-early/write-late ("async").
 #include "common.h"
+#include "sgemm_dma.cuh"
 
 namespace {
 
@@ -154,92 +158,6 @@ __global__ __launch_bounds__(256) void sgemm_valu_tile_kernel(const float* __res
           f4{acc[i][j], acc[i][j + 1], acc[i][j + 2], acc[i][j + 3]};
 }
 
-// ---- exact-f32 matrix-core kernel ------------------------------------------------------------------
-// v_mfma_f32_32x32x2_f32: A operand lane l = A[i = l&31][k = l>>5], B operand lane l = B[k = l>>5][j = l&31];
-// result reg r: C[i = (r&3) + 8*(r>>2) + 4*(l>>5)][j = l&31].
-template <int STAGES>
-__global__ __launch_bounds__(256) void sgemm_mfma_kernel(const float* __restrict__ A, const float* __restrict__ B,
-                                                         float* __restrict__ C, int M, int N, int K, int tiles_n,
-                                                         int swizzle) {
-  constexpr int BM = 128, BN = 128, BK = 16, AS = BK + 1, BS = BN + 4;
-  __shared__ __attribute__((aligned(16))) float As[STAGES][BM][AS];  // m-major, padded: bank = (17 m + k) % 32
-  __shared__ __attribute__((aligned(16))) float Bs[STAGES][BK][BS];  // k-major
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  int bid = blockIdx.x;
-  if (swizzle) {  // bijective XCD remap (block b runs on XCD b % 8): contiguous runs of tiles per XCD
-    const int nblk = gridDim.x, xcd = bid & 7, local = bid >> 3, q = nblk >> 3, r = nblk & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
-  }
-  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
-
-  f4 ra[2], rb[2];  // 128x16 floats = 512 float4 / 256 threads
-  auto gload = [&](int k0) {
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int unit = tid + u * 256;
-      ra[u] = *reinterpret_cast<const f4*>(A + (size_t)(m0 + (unit >> 2)) * K + k0 + (unit & 3) * 4);
-      rb[u] = *reinterpret_cast<const f4*>(B + (size_t)(k0 + (unit >> 5)) * N + n0 + (unit & 31) * 4);
-    }
-  };
-  auto lstore = [&](int buf) {
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int unit = tid + u * 256;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) As[buf][unit >> 2][(unit & 3) * 4 + j] = ra[u][j];
-      *reinterpret_cast<f4*>(&Bs[buf][unit >> 5][(unit & 31) * 4]) = rb[u];
-    }
-  };
-  f16v acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int nt = K / BK;
-  const int l31 = lane & 31, kh = lane >> 5;
-  // prologue: STAGES-1 tiles resident, one more in registers
-#pragma unroll
-  for (int s = 0; s < STAGES - 1; ++s)
-    if (s < nt) {
-      gload(s * BK);
-      lstore(s);
-    }
-  __syncthreads();
-  for (int t = 0; t < nt; ++t) {
-    const int buf = t % STAGES;
-    const bool more = (t + STAGES - 1) < nt;
-    if (more) gload((t + STAGES - 1) * BK);  // lands during the MFMAs
-#pragma unroll
-    for (int kk = 0; kk < BK / 2; ++kk) {
-      float a[2], b[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = As[buf][wm * 64 + i * 32 + l31][kk * 2 + kh];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) b[j] = Bs[buf][kk * 2 + kh][wn * 64 + j * 32 + l31];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-    if (more) lstore((t + STAGES - 1) % STAGES);  // the buffer read in iteration t-1 (all waves passed its barrier)
-    __syncthreads();
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        C[(size_t)row * N + n0 + wn * 64 + j * 32 + l31] = acc[i][j][r];
-      }
-}
-
 template <int BK, int TN, bool DBUF, bool ASYNC>
 int launch_valu(const void* a, const void* b, void* c, int M, int N, int K, hipStream_t st) {
   int rc = check3(a, b, c, M, N, K);
@@ -249,19 +167,45 @@ int launch_valu(const void* a, const void* b, void* c, int M, int N, int K, hipS
              (const float*)a, (const float*)b, (float*)c, M, N, K);
   return cln_check_launch();
 }
+// ---- exact-f32 matrix-core rungs: tile choice. Cost of a tile form = (most tiles any CU gets) x (tile area) / (efficiency of the form on a full
+// chip, measured on the reference's sweep 4096..16384 x K 2048..8192, profiles/r06_sgemm_dma_sweep.log): the wide tile moves the fewest L2 bytes
+// and wins by 1-2 % once the output is >= 8192^2; 128x128 staggers its epilogues (four tiles per CU, three resident) and wins below; 64x128 only
+// pays where the larger tiles leave CUs idle (3072^3: 576 tiles of 128x128 are 2.25 per CU).
+struct SgemmPlan {
+  int bm, bn;
+};
+SgemmPlan sgemm_plan(int M, int N) {
+  const double area = (double)M * N;
+  const bool big = area >= 8192.0 * 8192.0, small = area < 4096.0 * 4096.0;
+  const long long t128 = (M % 128 || N % 128) ? 0 : (long long)(M / 128) * (N / 128);
+  struct Cand {
+    int bm, bn;
+    double eff;
+  } cands[3] = {{128, 128, t128 <= 256 ? 0.94 : big ? 0.975 : 1.005},  // (one 4-wave tile per CU leaves every SIMD a single wave)
+                {256, 128, big ? 1.0 : 0.995},
+                {64, 128, small ? 0.97 : 0.94}};
+  SgemmPlan best{64, 128};
+  double best_cost = 1e300;
+  for (const Cand& c : cands) {
+    if (M % c.bm || N % c.bn) continue;
+    const long long tiles = (long long)(M / c.bm) * (N / c.bn);
+    const double cost = (double)((tiles + 255) / 256) * c.bm * c.bn / c.eff;
+    if (cost < best_cost) {
+      best_cost = cost;
+      best = {c.bm, c.bn};
+    }
+  }
+  return best;
+}
 int launch_mfma(const void* a, const void* b, void* c, int M, int N, int K, int stages, int swizzle, hipStream_t st) {
+  (void)stages;
   int rc = check3(a, b, c, M, N, K);
   if (rc) return rc;
-  if (M % 128 || N % 128 || K % 16) return CLN_ERR_UNSUPPORTED;
-  const int tiles_n = N / 128, grid = (M / 128) * tiles_n;
-  if (stages >= 3) {
-    CLN_LAUNCH((sgemm_mfma_kernel<3>), dim3(grid), dim3(256), 0, st, (const float*)a, (const float*)b, (float*)c, M,
-               N, K, tiles_n, swizzle ? 1 : 0);
-  } else {
-    CLN_LAUNCH((sgemm_mfma_kernel<2>), dim3(grid), dim3(256), 0, st, (const float*)a, (const float*)b, (float*)c, M,
-               N, K, tiles_n, swizzle ? 1 : 0);
-  }
-  return cln_check_launch();
+  if (M % 64 || N % 128 || K % 16) return CLN_ERR_UNSUPPORTED;
+  const SgemmPlan p = sgemm_plan(M, N);
+  if (p.bm == 256) return sgemm_dma::launch<2, 2, 4, 2, 16, 3>(a, b, c, M, N, K, swizzle, st);
+  if (p.bm == 128) return sgemm_dma::launch<2, 2, 2, 2, 16, 3>(a, b, c, M, N, K, swizzle, st);
+  return sgemm_dma::launch<2, 2, 1, 2, 16, 3>(a, b, c, M, N, K, swizzle, st);
 }
 
 }  // namespace

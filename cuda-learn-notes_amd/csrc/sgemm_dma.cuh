@@ -23,6 +23,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace sgemm_dma {
@@ -58,14 +60,16 @@ struct Geo {
   static constexpr int A_I = A_BYTES / 1024 / NW, B_I = B_BYTES / 1024 / NW;  // DMA instructions per wave and stage
   static constexpr int LDS = S * STAGE;
   static_assert(A_BYTES % (1024 * NW) == 0 && B_BYTES % (1024 * NW) == 0, "whole DMA instructions per wave");
+  static_assert((A_I + B_I) <= (BK / 4) * TM * TN, "one DMA piece per MFMA of the second half stage");
   static_assert(BK % 8 == 0 && (BN * 4) % 512 == 0 && TN % 2 == 0, "k8 groups; B rows of whole 512-byte spans; column blocks in XOR pairs");
 };
 
 template <int WM, int WN, int TM, int TN, int BK, int S>
-__global__ __launch_bounds__(WM* WN * 64) void sgemm_dma_kernel(const float* __restrict__ A, const float* __restrict__ B,
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && TM * TN <= 8) ? 2 : 1) void sgemm_dma_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                                 float* __restrict__ C, int M, int N, int K, int tiles_n,
                                                                 int swizzle) {
   using G = Geo<WM, WN, TM, TN, BK, S>;
+  static_assert(S == 3 && BK >= 16, "three slots: read t, landed t+1, in flight t+2; fragment double buffers need >= 2 k8 groups");
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave-uniform: it addresses M0)
   const int wm = wave / WN, wn = wave - wm * WN;
@@ -100,26 +104,48 @@ __global__ __launch_bounds__(WM* WN * 64) void sgemm_dma_kernel(const float* __r
     bvo[q] = ((unsigned)krow * (unsigned)N + chunk * 4) * 4u;
   }
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const int nt = K / BK;
+  int nxt = 0;  // stage the bases point at
+  // one 1-KiB piece of a stage's A / B image (pieces 0 .. A_I-1: A; then B); behind the last one the bases move on to the next stage
+  // (a stage past the end of K re-reads the last one: the request count per stage stays fixed)
+  constexpr int NDMA = G::A_I + G::B_I;
+  auto issue_piece = [&](int slot, int d) {
+    if (d < G::A_I)
+      dma16(abase, avo[d], lds0 + slot * G::STAGE + (wave * G::A_I + d) * 1024);
+    else
+      dma16(bbase, bvo[d - G::A_I], lds0 + slot * G::STAGE + G::A_BYTES + (wave * G::B_I + d - G::A_I) * 1024);
+    if (d == NDMA - 1 && nxt + 1 < nt) {
+      ++nxt;
+      abase += astep;
+      bbase += bstep;
+    }
+  };
   auto issue = [&](int slot) {
-    const unsigned base = lds0 + slot * G::STAGE + wave * (G::A_I * 1024);
 #pragma unroll
-    for (int q = 0; q < G::A_I; ++q) dma16(abase, avo[q], base + q * 1024);
-    const unsigned bb = lds0 + slot * G::STAGE + G::A_BYTES + wave * (G::B_I * 1024);
-#pragma unroll
-    for (int q = 0; q < G::B_I; ++q) dma16(bbase, bvo[q], bb + q * 1024);
+    for (int d = 0; d < NDMA; ++d) issue_piece(slot, d);
   };
 
-  // ---- fragment read offsets (bytes inside a stage)
-  unsigned aoff[BK / 8];
+  // ---- fragment read addresses: one register per (slot, k8 group) for A and per (slot, column-block parity) for B, pinned (an address
+  // recomputed in the loop is a VALU instruction, and on gfx950 a VALU instruction is matrix-pipe time); everything else is an offset field
+  constexpr int MG = BK / 8, NSTEP = BK / 2;
+  unsigned ab[3][MG], bb_[3][2];
   {
     const int sw = (l31 / G::RPG) % G::CPR;  // the 32-row tile offsets and the wave offset are multiples of RPG * CPR rows
 #pragma unroll
-    for (int m = 0; m < BK / 8; ++m) aoff[m] = (unsigned)((wm * TM * 32 + l31) * G::RB + (((2 * m + kh) ^ sw) << 4));
-  }
-  // B: row k = 8m + 4kh + s, column block j of this wave: lanes of the upper half read the block their XOR put them in
-  unsigned boff[2];
+    for (int sl = 0; sl < 3; ++sl) {
 #pragma unroll
-  for (int p = 0; p < 2; ++p) boff[p] = (unsigned)(G::A_BYTES + (4 * kh) * G::BN * 4 + ((wn * TN * 32 + ((p ^ kh) << 5) + l31) << 2));
+      for (int m = 0; m < MG; ++m) {
+        ab[sl][m] = lds0 + sl * G::STAGE + (unsigned)((wm * TM * 32 + l31) * G::RB + (((2 * m + kh) ^ sw) << 4));
+        asm volatile("" : "+v"(ab[sl][m]));
+      }
+      // B: row k = 8m + 4kh + s, column block j of this wave: lanes of the upper half read the block their XOR put them in
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        bb_[sl][p] = lds0 + sl * G::STAGE + (unsigned)(G::A_BYTES + (4 * kh) * G::BN * 4 + ((wn * TN * 32 + ((p ^ kh) << 5) + l31) << 2));
+        asm volatile("" : "+v"(bb_[sl][p]));
+      }
+    }
+  }
 
   f16v acc[TM][TN];
 #pragma unroll
@@ -129,49 +155,64 @@ __global__ __launch_bounds__(WM* WN * 64) void sgemm_dma_kernel(const float* __r
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nt = K / BK;
-  // prologue: stages 0 .. S-2 requested (a stage past the end of K re-reads the last one: the request count per iteration stays fixed)
-  int nxt = 0;  // stage the bases point at
+  f4v a[2][TM];   // [k8 group parity]
+  float b[2][TN];  // [step parity]
+  auto load_a = [&](int par, unsigned base) {
 #pragma unroll
-  for (int s = 0; s < S - 1; ++s) {
-    issue(s);
-    if (nxt + 1 < nt) {
-      ++nxt;
-      abase += astep;
-      bbase += bstep;
-    }
-  }
-  int slot = 0, fill = S - 1;  // slot read in this iteration; slot filled in this iteration
-  for (int t = 0; t < nt; ++t) {
-    // this wave's requests for stage t have landed (the S-2 younger stages may still be in flight) ...
-    wait_vm<(S - 2) * (G::A_I + G::B_I)>();
-    __syncthreads();  // ... everyone's have, and everyone is done reading the slot that is filled next
-    issue(fill);
-    if (nxt + 1 < nt) {  // (past the end of K the bases stay on the last stage)
-      ++nxt;
-      abase += astep;
-      bbase += bstep;
-    }
-    const unsigned sb = lds0 + slot * G::STAGE;
+    for (int i = 0; i < TM; ++i) a[par][i] = lds_ld<f4v>(base + i * 32 * G::RB);
+  };
+  auto load_b = [&](int par, const unsigned* base2, int krow) {
 #pragma unroll
-    for (int m = 0; m < BK / 8; ++m) {
-      f4v a[TM];
+    for (int j = 0; j < TN; ++j) b[par][j] = lds_ld<float>(base2[j & 1] + krow * G::BN * 4 + (j >> 1) * 256);
+  };
+
+  // One stage out of slot SL. Fragments of step q+1 are requested in front of the MFMAs of step q (the first step of the NEXT stage in front
+  // of this stage's last step: no barrier sits between two stages). The stage's ONE barrier is in its middle, in the shadow of an MFMA:
+  // behind it stage t+1 has landed for every wave and every wave is past stage t-1, whose slot the requests for stage t+2 may now fill.
+  auto stage = [&](auto slc) {
+    constexpr int SL = decltype(slc)::value, NS = (SL + 1) % 3, FILL = (SL + 2) % 3;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = lds_ld<f4v>(sb + aoff[m] + i * 32 * G::RB);
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        float b[TN];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) b[j] = lds_ld<float>(sb + boff[j & 1] + (8 * m + s) * G::BN * 4 + (j >> 1) * 256);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j], acc[i][j], 0, 0, 0);
+    for (int q = 0; q < NSTEP; ++q) {
+      const int m = q >> 2, s = q & 3;
+      if (q + 1 < NSTEP) {
+        const int m1 = (q + 1) >> 2, s1 = (q + 1) & 3;
+        if (s1 == 0) load_a(m1 & 1, ab[SL][m1]);
+        load_b((q + 1) & 1, bb_[SL], 8 * m1 + s1);
+      } else {
+        load_a(0, ab[NS][0]);
+        load_b(0, bb_[NS], 0);
       }
+      if (q == NSTEP / 2) {
+        wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          // the requests for stage t+2, one piece in front of each MFMA from the barrier on (a burst of them is ~5 scalar instructions per
+          // piece during which this wave issues no MFMA)
+          const int g = (q - NSTEP / 2) * TM * TN + i * TN + j;
+          if (g >= 0 && g < NDMA) issue_piece(FILL, g);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m & 1][i][s], b[q & 1][j], acc[i][j], 0, 0, 0);
+        }
     }
-    slot = slot + 1 == S ? 0 : slot + 1;
-    fill = fill + 1 == S ? 0 : fill + 1;
+  };
+
+  issue(0);
+  issue(1);
+  wait_vm<G::A_I + G::B_I>();  // stage 0 has landed (stage 1 is waited for at the first mid-stage barrier)
+  __builtin_amdgcn_s_barrier();
+  load_a(0, ab[0][0]);
+  load_b(0, bb_[0], 0);
+  int t = 0;
+  for (; t + 3 <= nt; t += 3) {
+    stage(std::integral_constant<int, 0>{});
+    stage(std::integral_constant<int, 1>{});
+    stage(std::integral_constant<int, 2>{});
   }
+  if (t < nt) stage(std::integral_constant<int, 0>{});
+  if (t + 1 < nt) stage(std::integral_constant<int, 1>{});
   wait_vm<0>();  // the re-read requests of the tail must not outlive the workgroup's LDS
 
   // ---- C: result register r of a 32x32 tile is row (r & 3) + 8 (r >> 2) + 4 kh, column l31: 128-byte row segments per half wave

@@ -230,7 +230,7 @@ for _tn in (4, 8, 16):
     _add("sgemm", "S3", "sgemm_valu_tile<BK=16,8x%d,dbuf>" % _tn, "sgemm_t_8x%d_sliced_k16_f32x4_bcf_dbuf" % _tn)
     _add("sgemm", "S3", "sgemm_valu_tile<BK=16,8x%d,dbuf,issue-early/write-late>" % _tn,
          "sgemm_t_8x%d_sliced_k16_f32x4_bcf_dbuf_async" % _tn)
-_add("sgemm", "S6", "sgemm_mfma<128x128x16, v_mfma_f32_32x32x2_f32 (exact f32; no TF32 on gfx950), stages 2|3>",
+_add("sgemm", "S6", "sgemm_dma<64x128 | 128x128 | 256x128 by shape, 16-deep stages through a 3-slot LDS-DMA ring, v_mfma_f32_32x32x2_f32 (exact f32; no TF32 on gfx950)>",
      "sgemm_wmma_m16n16k8_mma4x2_warp2x4_stages", "sgemm_wmma_m16n16k8_mma4x2_warp2x4_stages_dsmem")
 _add("sgemm_vendor", "S3", "rocblas_sgemm (exact f32)", "sgemm_cublas", "sgemm_cublas_tf32")
 

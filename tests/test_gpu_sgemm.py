@@ -48,6 +48,37 @@ def test_sgemm_all_rungs(lib, dev, oracle, M, N, K):
                     assert torch.equal(c, first)  # schedule knobs never change the k-ordered fp32 result
 
 
+@pytest.mark.parametrize("M,N,K", [(64, 128, 16), (192, 384, 48), (3072, 3072, 32), (4096, 4096, 64), (8192, 8192, 48), (16384, 4096, 16)])
+def test_sgemm_matrix_core_tile_forms(lib, dev, oracle, M, N, K):
+    """The LDS-DMA f32-MFMA kernel (csrc/sgemm_dma.cuh) on shapes that the planner sends to each of its tile forms -- 64x128 (few tiles, or
+    3072^2: 576 tiles of 128x128 would be 2.25 per CU), 128x128 (4096^2), 256x128 (>= 8192^2) -- with K of one, two, three and four 16-deep
+    stages (prologue only / tail branches / one trip of the three-slot loop): fp64 oracle, and the same bits from every knob value."""
+    a, b = seeded(3 * M + K, M, K), seeded(5 * N + K, K, N)
+    ref = oracle.sgemm(a, b)
+    tol = 2e-5 * K ** 0.5
+    ad, bd = a.to(dev), b.to(dev)
+    first = None
+    for stages, swz in ((2, False), (3, True)):
+        c = torch.full((M, N), float("nan"), device=dev)
+        lib.sgemm_wmma_m16n16k8_mma4x2_warp2x4_stages(ad, bd, c, stages, swz, 256)
+        assert (c.cpu().double() - ref).abs().max().item() <= tol, (stages, swz)
+        first = c if first is None else first
+        assert torch.equal(c, first)
+
+
+def test_sgemm_matrix_core_result_does_not_depend_on_the_tile_form(lib, dev):
+    """Every tile form adds the k products of an output element in the same order, so a sub-block of a large product (256x128 tiles) equals the
+    small product of the same rows and columns (64x128 / 128x128 tiles) bit for bit."""
+    K = 208
+    a, b = seeded(11, 8192, K).to(dev), seeded(12, K, 8192).to(dev)
+    c = torch.zeros(8192, 8192, device=dev)
+    lib.sgemm_wmma_m16n16k8_mma4x2_warp2x4_stages(a, b, c, 2, True, 256)
+    for (r0, rows, c0, cols) in ((0, 64, 0, 128), (4096, 512, 2048, 1024), (1024, 4096, 2048, 4096)):
+        sub = torch.zeros(rows, cols, device=dev)
+        lib.sgemm_wmma_m16n16k8_mma4x2_warp2x4_stages(a[r0:r0 + rows].contiguous(), b[:, c0:c0 + cols].contiguous(), sub, 3, False, 256)
+        assert torch.equal(sub, c[r0:r0 + rows, c0:c0 + cols]), (rows, cols)
+
+
 def test_sgemm_identity_asymmetric_exact(lib, dev):
     n = 256
     a = torch.eye(n)
