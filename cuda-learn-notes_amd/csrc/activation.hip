@@ -59,25 +59,47 @@ template <typename T> __device__ __forceinline__ T st(float v);
 template <> __device__ __forceinline__ float st<float>(float v) { return v; }
 template <> __device__ __forceinline__ half_t st<half_t>(float v) { return (half_t)v; }
 
-// VEC elements per lane; PACKED: one VEC*sizeof(T)-byte access, else VEC accesses of CHUNK elements
+// VEC elements per lane; one VEC*sizeof(T)-byte access when CHUNK == VEC, else VEC / CHUNK accesses of CHUNK elements
 // (f16x8 = four half2 accesses in the reference, f32x4 = one float4).
-template <typename Op, typename T, int VEC, int CHUNK>
+// Walk (round 6, as elementwise.hip): BLOCK-CONTIGUOUS, no loop -- workgroup b owns the 256 K consecutive packs from 256 K b on, every lane
+// issues its K loads, then its K stores (K = 4 below 512 MB of traffic, 1 above). Rounds 1-5 ran a grid-stride loop over a capped grid, which
+// makes every wave alternate loads and stores in lockstep (profiles/r06_stream_forms_ubench.log: y = 2x 3-9 % slower in that form; the f32x4
+// rungs read 0.965-0.97x torch at [4096,4096] in profiles/r06_bench_detail_20steps.json).
+template <typename Op, typename T, int VEC, int CHUNK, int K>
 __global__ __launch_bounds__(256) void unary_kernel(const T* __restrict__ x, T* __restrict__ y, long long n, int stream_nt) {
   typedef T chunk_t __attribute__((ext_vector_type(CHUNK)));
+  constexpr int NC = VEC / CHUNK;
   const long long nvec = n / VEC;
-  const long long stride = (long long)gridDim.x * 256;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride) {
+  const long long base = (long long)blockIdx.x * (256 * K) + threadIdx.x;
+  if (base + (K - 1) * 256 < nvec) {  // every pack of this lane exists (all workgroups but the last)
     if constexpr (VEC == 1) {
-      cln_store_stream(y + i, st<T>(Op::f(ld(x[i]))), stream_nt);
+      T v[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) v[k] = x[base + k * 256];
+#pragma unroll
+      for (int k = 0; k < K; ++k) cln_store_stream(y + base + k * 256, st<T>(Op::f(ld(v[k]))), stream_nt);
     } else {
-      chunk_t v[VEC / CHUNK];
+      chunk_t v[K][NC];
 #pragma unroll
-      for (int c = 0; c < VEC / CHUNK; ++c) v[c] = *reinterpret_cast<const chunk_t*>(x + i * VEC + c * CHUNK);
+      for (int k = 0; k < K; ++k)
 #pragma unroll
-      for (int c = 0; c < VEC / CHUNK; ++c) {
+        for (int c = 0; c < NC; ++c) v[k][c] = *reinterpret_cast<const chunk_t*>(x + (base + k * 256) * VEC + c * CHUNK);
 #pragma unroll
-        for (int e = 0; e < CHUNK; ++e) v[c][e] = st<T>(Op::f(ld(v[c][e])));
-        cln_store_stream(reinterpret_cast<chunk_t*>(y + i * VEC + c * CHUNK), v[c], stream_nt);
+      for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+#pragma unroll
+          for (int e = 0; e < CHUNK; ++e) v[k][c][e] = st<T>(Op::f(ld(v[k][c][e])));
+          cln_store_stream(reinterpret_cast<chunk_t*>(y + (base + k * 256) * VEC + c * CHUNK), v[k][c], stream_nt);
+        }
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const long long i = base + k * 256;
+      if (i < nvec) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) y[i * VEC + e] = st<T>(Op::f(ld(x[i * VEC + e])));
       }
     }
   }
@@ -91,8 +113,12 @@ int launch_unary(const void* x, void* y, long long n, hipStream_t st_) {
   if (!x || !y || n < 0) return CLN_ERR_BAD_ARG;
   if (n == 0) return CLN_OK;
   if (sizeof(T) * CHUNK >= 16 && (!cln_aligned16(x) || !cln_aligned16(y))) return CLN_ERR_BAD_ARG;
-  const int grid = cln_stream_grid(n / VEC + 1, 256, 2LL * n * (long long)sizeof(T));
-  CLN_LAUNCH((unary_kernel<Op, T, VEC, CHUNK>), dim3(grid), dim3(256), 0, st_, (const T*)x, (T*)y, n, cln_stream_nt(2LL * n * (long long)sizeof(T)));
+  const long long nvec = n / VEC, traffic = 2LL * n * (long long)sizeof(T);
+  if (traffic >= (512LL << 20) || nvec < 4096) {
+    CLN_LAUNCH((unary_kernel<Op, T, VEC, CHUNK, 1>), dim3((unsigned)((nvec + 255) / 256 + (nvec == 0))), dim3(256), 0, st_, (const T*)x, (T*)y, n, cln_stream_nt(traffic));
+  } else {
+    CLN_LAUNCH((unary_kernel<Op, T, VEC, CHUNK, 4>), dim3((unsigned)((nvec + 1023) / 1024)), dim3(256), 0, st_, (const T*)x, (T*)y, n, cln_stream_nt(traffic));
+  }
   return cln_check_launch();
 }
 
