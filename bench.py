@@ -370,12 +370,18 @@ def headline_line(out, detail_file="bench_detail.json"):
     for k in ("fa2_error", "rocblas_error"):
         if k in ex:
             digest[k] = _clip(ex[k], 100)
+    try:  # the f32 matrix-core sgemm rung beside its two vendor rows (configs.next_rows.sgemm_4096 in the detail file)
+        sg = out["configs"]["next_rows"]["sgemm_4096"]["sgemm_wmma_m16n16k8_mma4x2_warp2x4_stages"]
+        digest["sgemm_4096"] = {"tflops": sg["tflops"], "frac_of_157_tf": sg["frac_of_f32_mfma_peak"], "x_rocblas": sg.get("x_rocblas_sgemm"),
+                                "x_hipblaslt": sg.get("x_torch_matmul_hipblaslt")}
+    except (KeyError, TypeError):
+        pass
     if "pmc" in out:
         digest["pmc"] = _pick(out["pmc"], ("status", "seconds"), 100)
     digest["detail_file"] = detail_file
     line["digest"] = digest
     s = json.dumps(line, separators=(", ", ": "))
-    for k in ("fa2_comparator", "fa2_fwd", "hipblaslt_tn_tflops", "hipblaslt_tflops", "pct_of_hipblaslt", "hgemm_tn_tflops", "rocblas_tn_tflops"):
+    for k in ("sgemm_4096", "fa2_comparator", "fa2_fwd", "hipblaslt_tn_tflops", "hipblaslt_tflops", "pct_of_hipblaslt", "hgemm_tn_tflops", "rocblas_tn_tflops"):
         if len(s) < MAX_LINE:
             break
         digest.pop(k, None)

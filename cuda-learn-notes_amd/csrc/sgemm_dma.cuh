@@ -231,6 +231,9 @@ template <int WM, int WN, int TM, int TN, int BK, int S>
 int launch(const void* a, const void* b, void* c, int M, int N, int K, int swizzle, hipStream_t st) {
   using G = Geo<WM, WN, TM, TN, BK, S>;
   if (M % G::BM || N % G::BN || K % BK) return CLN_ERR_UNSUPPORTED;
+  // the DMA's per-lane source offset is an unsigned 32-bit byte count inside the tile's A rows / the stage's B rows
+  if ((unsigned long long)G::BM * (unsigned long long)K * 4ull > 0xFFFFFFFFull || (unsigned long long)BK * (unsigned long long)N * 4ull > 0xFFFFFFFFull)
+    return CLN_ERR_UNSUPPORTED;
   static cln_lds_attr attr;
   auto kfn = sgemm_dma_kernel<WM, WN, TM, TN, BK, S>;
   if (cln_ensure_lds(attr, reinterpret_cast<const void*>(kfn), G::LDS) != CLN_OK) return CLN_ERR_LAUNCH;
