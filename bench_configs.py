@@ -709,8 +709,34 @@ def next_rows(pkg, dev, orc):
             torch.cuda.empty_cache()
         out["dot_product_8192x8192"] = dp
 
+    def _sec_gemv():
+        # ---- sgemv / hgemv: the reference scripts' own shape (sgemv.py:61: M = 1024, K = 128 -- a 0.5 MB launch, host-enqueue-bound) and a bandwidth shape
+        # [65536, 1024] (A read once: M K sizeof bytes); yardstick torch.mv (rocBLAS gemv)
+        gv = {}
+        for dt, name in ((torch.float32, "sgemv_k128_f32x4"), (torch.float32, "sgemv_k32_f32"), (torch.float16, "hgemv_k128_f16x4"), (torch.float16, "hgemv_k32_f16")):
+            fn = _loader.symbol(name)
+            esz = 4 if dt == torch.float32 else 2
+            for (M, K) in ((1024, 128), (65536, 1024)):
+                nbytes = M * K * esz
+                nsets = max(3, min(64, ROTATE_FOOTPRINT // nbytes))
+                pool = torch.randn(nsets, M, K, device=dev).to(dt)
+                x = torch.randn(K, 1, device=dev).to(dt)
+                y = torch.zeros(M, 1, device=dev, dtype=dt)
+                calls = [(lambda ap=pool[i].data_ptr(): fn(ap, x.data_ptr(), y.data_ptr(), M, K, st)) for i in range(nsets)]
+                if calls[0]() != 0:
+                    continue
+                ms, _ = _region_ms(calls, 3 * nsets)
+                xv, yv = x.view(K), y.view(M)
+                ycalls = [(lambda a=pool[i]: torch.mv(a, xv, out=yv)) for i in range(nsets)]
+                yms, _ = _region_ms(ycalls, 3 * nsets)
+                gv["%s@%dx%d" % (name, M, K)] = {"us_per_launch": round(ms * 1e3, 2), "gbps": round(nbytes / ms * 1e-6, 1), "frac_of_8TBs": round(nbytes / ms * 1e-6 / bu.PEAK_HBM_GBPS, 4),
+                                                  "yardstick": {"what": "torch.mv(out=) on the GPU", "us_per_launch": round(yms * 1e3, 2), "ours_over_yardstick": round(yms / ms, 4)}}
+                del pool
+                torch.cuda.empty_cache()
+        out["gemv"] = gv
+
     for nm, fn in (("sgemm", _sec_sgemm), ("mat_transpose", _sec_mat_transpose), ("embedding", _sec_embedding), ("activation", _sec_activation),
-                   ("histogram", _sec_histogram), ("dot_product", _sec_dot_product)):
+                   ("histogram", _sec_histogram), ("dot_product", _sec_dot_product), ("gemv", _sec_gemv)):
         try:
             fn()
         except Exception as e:  # noqa: BLE001 -- one family never takes the others down

@@ -66,4 +66,26 @@ for S in (4096, 2048, 3072, 2560, (512, 8192, 8192), (640, 5120, 5120), (1024, 1
         bad_total += bad
         print("DET hgemm %s %s mismatching launches %d / %d  %s" % ("x".join(map(str, (M_, N_, K_))), name[-28:], bad, REPS,
                                                                      pkg.manifest.describe(name, (M_, N_, K_), 2)[-70:]), flush=True)
+# round 6: the LDS-DMA f32-MFMA sgemm in its three tile forms (64x128, 128x128, 256x128): ring slots re-used three stages later, the barrier in
+# the middle of a stage -- a request that overtook a reader would show here
+sg = pkg.load("sgemm")
+for (M_, N_, K_) in ((3072, 3072, 2048), (4096, 4096, 4096), (8192, 8192, 1024), (1024, 1024, 8192)):
+    torch.manual_seed(5)
+    a = torch.randn(M_, K_, device=dev)
+    b = torch.randn(K_, N_, device=dev)
+    c = torch.zeros(M_, N_, device=dev)
+    fn = sg.sgemm_wmma_m16n16k8_mma4x2_warp2x4_stages
+    fn(a, b, c, 2, True, 256)
+    torch.cuda.synchronize()
+    first = c.clone()
+    sel = torch.tensor([0, M_ // 2 + 1, M_ - 1], device=dev)
+    truth = a[sel].double() @ b.double()
+    err = ((first[sel].double() - truth).abs().max() / truth.abs().max()).item()
+    bad = 0
+    for r in range(min(REPS, 100)):
+        c.fill_(float("nan"))
+        fn(a, b, c, 3 if r & 1 else 2, bool(r & 2), 256)
+        bad += 0 if torch.equal(c, first) else 1
+    bad_total += bad
+    print("DET sgemm %s sampled rel err vs fp64 %.2e  mismatching launches %d / %d (stages / swizzle knobs alternating)" % ("x".join(map(str, (M_, N_, K_))), err, bad, min(REPS, 100)), flush=True)
 print("DET total mismatches", bad_total)
