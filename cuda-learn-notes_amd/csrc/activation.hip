@@ -113,11 +113,18 @@ int launch_unary(const void* x, void* y, long long n, hipStream_t st_) {
   if (!x || !y || n < 0) return CLN_ERR_BAD_ARG;
   if (n == 0) return CLN_OK;
   if (sizeof(T) * CHUNK >= 16 && (!cln_aligned16(x) || !cln_aligned16(y))) return CLN_ERR_BAD_ARG;
-  const long long nvec = n / VEC, traffic = 2LL * n * (long long)sizeof(T);
-  if (traffic >= (512LL << 20) || nvec < 4096) {
-    CLN_LAUNCH((unary_kernel<Op, T, VEC, CHUNK, 1>), dim3((unsigned)((nvec + 255) / 256 + (nvec == 0))), dim3(256), 0, st_, (const T*)x, (T*)y, n, cln_stream_nt(traffic));
+  // An "unpacked" rung (f16x8: eight halves per lane moved as four half2 accesses) runs the kernel of its ACCESS width: access c of a lane is the
+  // lane's pack in the c-th 256-pack row of the workgroup's block, so every access instruction of a wave covers 256 contiguous bytes. (Rounds 1-5 gave a lane eight CONSECUTIVE halves, as the reference kernel does: four instructions that each touch
+  // 4 of every 16 bytes -- relu_f16x8 18.3 us against 14.2 for relu_f16x2 at [4096,4096], tools/rung_survey.py.)
+  // Packs per lane: 64 bytes of loads in flight per lane (4 packs of 16 bytes ... 16 packs of 4 or 2 bytes; the survey's relu_f16x2 ran 14.4 us with
+  // 4 packs per lane and 12.9 with 16); ONE pack for the 16-byte rungs above 512 MB of traffic (elementwise.hip's rule).
+  constexpr int AB = (int)sizeof(T) * CHUNK;                      // bytes per access
+  constexpr int KB = AB >= 16 ? 4 : (64 / AB > 16 ? 16 : 64 / AB);
+  const long long nvec = n / CHUNK, traffic = 2LL * n * (long long)sizeof(T);
+  if ((AB >= 16 && traffic >= (512LL << 20)) || nvec < 1024 * KB) {
+    CLN_LAUNCH((unary_kernel<Op, T, CHUNK, CHUNK, 1>), dim3((unsigned)((nvec + 255) / 256 + (nvec == 0))), dim3(256), 0, st_, (const T*)x, (T*)y, n, cln_stream_nt(traffic));
   } else {
-    CLN_LAUNCH((unary_kernel<Op, T, VEC, CHUNK, 4>), dim3((unsigned)((nvec + 1023) / 1024)), dim3(256), 0, st_, (const T*)x, (T*)y, n, cln_stream_nt(traffic));
+    CLN_LAUNCH((unary_kernel<Op, T, CHUNK, CHUNK, KB>), dim3((unsigned)((nvec + 256 * KB - 1) / (256 * KB))), dim3(256), 0, st_, (const T*)x, (T*)y, n, cln_stream_nt(traffic));
   }
   return cln_check_launch();
 }

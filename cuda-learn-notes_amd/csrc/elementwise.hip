@@ -40,22 +40,10 @@ __global__ void add_tail_kernel(const T* a, const T* b, T* c, long long start, l
   if (i < n) c[i] = a[i] + b[i];
 }
 
-// "f16x8" rung: eight halves per thread moved as four separate 4-byte half2 accesses
-// (reference elementwise.cu:62-86); the "_pack" rung below moves them as one 16-byte access.
-__global__ __launch_bounds__(256) void add_f16x8_unpacked_kernel(const h2* __restrict__ a, const h2* __restrict__ b,
-                                                                 h2* __restrict__ c, long long ngroups, int stream_nt) {
-  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // one group of eight halves per lane, no loop (see the walk note above)
-  if (g < ngroups) {
-    const long long i = g * 4;
-    h2 a0 = a[i + 0], a1 = a[i + 1], a2 = a[i + 2], a3 = a[i + 3];
-    h2 b0 = b[i + 0], b1 = b[i + 1], b2 = b[i + 2], b3 = b[i + 3];
-    cln_store_stream(c + i + 0, (h2)(a0 + b0), stream_nt);
-    cln_store_stream(c + i + 1, (h2)(a1 + b1), stream_nt);
-    cln_store_stream(c + i + 2, (h2)(a2 + b2), stream_nt);
-    cln_store_stream(c + i + 3, (h2)(a3 + b3), stream_nt);
-  }
-}
-
+// "f16x8" rung (eight halves per thread moved as four separate 4-byte half2 accesses, reference elementwise.cu:62-86; the "_pack" rung moves them as
+// one 16-byte access): the half2 kernel (sixteen packs per lane) -- access c of a lane is its pack in the c-th 256-pack row of the
+// workgroup's block, so every access instruction of a wave covers 256 contiguous bytes. Rounds 1-5 gave a lane eight CONSECUTIVE halves as the reference
+// does: four instructions that each touch 4 of every 16 bytes (22.3 us against 20.1 for the f16x2 rung at [4096,4096], tools/rung_survey.py).
 template <typename T, typename VT, int VEC>
 int launch_add(const void* a, const void* b, void* c, long long n, hipStream_t stream) {
   if (!a || !b || !c || n < 0) return CLN_ERR_BAD_ARG;
@@ -64,10 +52,13 @@ int launch_add(const void* a, const void* b, void* c, long long n, hipStream_t s
   const long long nvec = n / VEC;
   if (nvec > 0) {
     const long long traffic = 3LL * n * (long long)sizeof(T);
-    if (traffic >= (512LL << 20) || nvec < 4096) {
+    // packs per lane: 64 bytes per operand in flight per lane (4 packs of 16 bytes ... 16 of 4 or 2 bytes), ONE for the 16-byte rungs above 512 MB
+    constexpr int AB = (int)sizeof(VT);
+    constexpr int KB = AB >= 16 ? 4 : (64 / AB > 16 ? 16 : 64 / AB);
+    if ((AB >= 16 && traffic >= (512LL << 20)) || nvec < 1024 * KB) {
       CLN_LAUNCH((add_vec_kernel<VT, 1>), dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, stream, (const VT*)a, (const VT*)b, (VT*)c, nvec, cln_stream_nt(traffic));
     } else {
-      CLN_LAUNCH((add_vec_kernel<VT, 4>), dim3((unsigned)((nvec + 1023) / 1024)), dim3(256), 0, stream, (const VT*)a, (const VT*)b, (VT*)c, nvec, cln_stream_nt(traffic));
+      CLN_LAUNCH((add_vec_kernel<VT, KB>), dim3((unsigned)((nvec + 256 * KB - 1) / (256 * KB))), dim3(256), 0, stream, (const VT*)a, (const VT*)b, (VT*)c, nvec, cln_stream_nt(traffic));
     }
   }
   const long long done = nvec * VEC;
@@ -94,18 +85,7 @@ CLN_API int elementwise_add_f16x2(const void* a, const void* b, void* c, long lo
   return launch_add<half_t, h2, 2>(a, b, c, n, (hipStream_t)stream);
 }
 CLN_API int elementwise_add_f16x8(const void* a, const void* b, void* c, long long n, void* stream) {
-  if (!a || !b || !c || n < 0) return CLN_ERR_BAD_ARG;
-  if (n == 0) return CLN_OK;
-  const long long ngroups = n / 8;
-  if (ngroups > 0) {
-    CLN_LAUNCH(add_f16x8_unpacked_kernel, dim3((unsigned)((ngroups + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const h2*)a,
-                       (const h2*)b, (h2*)c, ngroups, cln_stream_nt(6LL * n));
-  }
-  if (ngroups * 8 < n) {
-    CLN_LAUNCH((add_tail_kernel<half_t>), dim3(1), dim3(64), 0, (hipStream_t)stream, (const half_t*)a,
-                       (const half_t*)b, (half_t*)c, ngroups * 8, n);
-  }
-  return cln_check_launch();
+  return launch_add<half_t, h2, 2>(a, b, c, n, (hipStream_t)stream);
 }
 CLN_API int elementwise_add_f16x8_pack(const void* a, const void* b, void* c, long long n, void* stream) {
   return launch_add<half_t, h8, 8>(a, b, c, n, (hipStream_t)stream);

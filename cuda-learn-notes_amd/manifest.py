@@ -131,7 +131,7 @@ _add("elementwise", "P3", "add_vec<float,4B>", "elementwise_add_f32")
 _add("elementwise", "P3", "add_vec<float4,16B>", "elementwise_add_f32x4")
 _add("elementwise", "P3", "add_vec<half,2B>", "elementwise_add_f16")
 _add("elementwise", "P3", "add_vec<half2,4B>", "elementwise_add_f16x2")
-_add("elementwise", "P3", "add_f16x8_unpacked(4x4B)", "elementwise_add_f16x8")
+_add("elementwise", "P3", "add_vec<half2,4B> with four times the packs per lane (eight halves as four coalesced 4-byte accesses)", "elementwise_add_f16x8")
 _add("elementwise", "P3", "add_vec<half8,16B>", "elementwise_add_f16x8_pack")
 
 for _n, _impl in [
