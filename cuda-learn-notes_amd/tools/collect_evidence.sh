@@ -9,7 +9,7 @@ for f in pytest_gpu.log bench_20steps.json bench_20steps.log bench_default.json 
          fa_kernel_trace.csv bw_rocprof.json bw_rocprof.txt reference_style_scripts_on_gpu.log hgemm_bench_cpp.log fa_dw4_probe_final.log hgemm_splitk_fused_probe_evidence.log \
          host_call_overhead_final.log scripts_vs_torch.log profile_round.log fa_c4_stamps.log fa_tol_calibration.log stream_forms_ubench.log transpose_forms_ubench.log \
          fa_stage1_vs_stage2.log hipblaslt_probe.log determinism_stress.log fa_ck_tile_comparator.log fa_one_stage_probe.log hgemm_w4s_probe.log hgemm_reference_sweep.log \
-         hgemm_tail_probe_after.log hgemm_rect_probe.log fa_small_grid_probe.log fa_fscale_probe.log fa_back_to_back_stress.log smoke.log; do
+         hgemm_tail_probe_after.log hgemm_rect_probe.log fa_small_grid_probe.log fa_fscale_probe.log fa_back_to_back_stress.log smoke.log rung_survey.log sgemm_reference_sweep.log; do
   [ -s $OUT/${TAG}_$f ] && cp $OUT/${TAG}_$f $P/${TAG}_$f
 done
 if [ "$2" != "--no-cpu" ]; then

@@ -63,6 +63,9 @@ timeout 400 python $T/hg_tail_probe.py 4352 4864 5888 6400 7168 7424 8448 9216 9
 timeout 300 python $T/hg_rect_probe.py 2>&1 | grep "^RECT" > $OUT/${TAG}_hgemm_rect_probe.log; echo "rect probe rc=$?"
 timeout 300 python $T/fa_small_grid_probe.py 2>&1 | grep "^SMALLGRID" > $OUT/${TAG}_fa_small_grid_probe.log; echo "small grid probe rc=$?"
 timeout 300 python $T/fa_fscale_probe.py 2>&1 | grep "^FSCALE" > $OUT/${TAG}_fa_fscale_probe.log; echo "fscale probe rc=$?"
+# round 6: every bandwidth-family name at one bandwidth shape; the reference's sgemm sweep through the LDS-DMA matrix-core kernel
+timeout 400 python $T/rung_survey.py 2>&1 | grep "^SURVEY" > $OUT/${TAG}_rung_survey.log; echo "rung survey rc=$?"
+timeout 400 python $T/sgemm_sweep.py 2>&1 | grep "^SGSWEEP" > $OUT/${TAG}_sgemm_reference_sweep.log; echo "sgemm sweep rc=$?"
 ( NBUF=16 FORMS=stages=2,stages=1 timeout 300 python $T/fa_race_stress.py 1 32 4096 512 60; NBUF=16 FORMS=stages=2,stages=1 timeout 300 python $T/fa_race_stress.py 4 8 2048 64 100;
   NBUF=16 FORMS=stages=2 timeout 300 python $T/fa_race_stress.py 2 32 4096 256 40;
   for D in 640 768 1024; do NBUF=16 FORMS=stages=2,stages=1 timeout 300 python $T/fa_race_stress.py 1 16 4096 $D 30; done ) 2>&1 | grep "^RACE" > $OUT/${TAG}_fa_back_to_back_stress.log; echo "stress rc=$?"
