@@ -61,10 +61,9 @@ template <> __device__ __forceinline__ half_t st<half_t>(float v) { return (half
 
 // VEC elements per lane; one VEC*sizeof(T)-byte access when CHUNK == VEC, else VEC / CHUNK accesses of CHUNK elements
 // (f16x8 = four half2 accesses in the reference, f32x4 = one float4).
-// Walk (round 6, as elementwise.hip): BLOCK-CONTIGUOUS, no loop -- workgroup b owns the 256 K consecutive packs from 256 K b on, every lane
-// issues its K loads, then its K stores (K = 4 below 512 MB of traffic, 1 above). Rounds 1-5 ran a grid-stride loop over a capped grid, which
-// makes every wave alternate loads and stores in lockstep (profiles/r06_stream_forms_ubench.log: y = 2x 3-9 % slower in that form; the f32x4
-// rungs read 0.965-0.97x torch at [4096,4096] in profiles/r06_bench_detail_20steps.json).
+// Walk of the NARROW rungs (2- / 4-byte accesses; round 6, as elementwise.hip): block-contiguous, no loop -- workgroup b owns the 256 K consecutive packs
+// from 256 K b on, every lane issues its K loads, then its K stores, K = 16: 64 bytes in flight per lane. (In rounds 1-5 these rungs walked the capped
+// grid-stride loop with ONE pack in flight per lane: relu_f16 16.7 us, relu_f16x8 -- four half2 accesses -- 18.3 us at [4096,4096]; now 13.7 / 12.8.)
 template <typename Op, typename T, int VEC, int CHUNK, int K>
 __global__ __launch_bounds__(256) void unary_kernel(const T* __restrict__ x, T* __restrict__ y, long long n, int stream_nt) {
   typedef T chunk_t __attribute__((ext_vector_type(CHUNK)));
@@ -108,6 +107,25 @@ __global__ __launch_bounds__(256) void unary_kernel(const T* __restrict__ x, T* 
   }
 }
 
+// The 16-byte rungs keep the capped grid-stride walk of rounds 1-5 (cln_stream_grid: 256 CUs x 32 workgroups, one trip per thread above 512 MB of traffic): on
+// tensors that sit in L2 / the Infinity Cache -- the reference scripts' shapes, one buffer set re-used -- it is 1-10 % AHEAD of the block-contiguous form
+// (profiles/r06_scripts_vs_torch.log of the two forms: [4096,2048] f16 4.7-6.4 us against 4.9-6.9), on rotating HBM sets 1-3 % behind it: the scripts decide.
+template <typename Op, typename T, int VEC>
+__global__ __launch_bounds__(256) void unary_stride_kernel(const T* __restrict__ x, T* __restrict__ y, long long n, int stream_nt) {
+  typedef T vec_t __attribute__((ext_vector_type(VEC)));
+  const long long nvec = n / VEC;
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride) {
+    vec_t v = *reinterpret_cast<const vec_t*>(x + i * VEC);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) v[e] = st<T>(Op::f(ld(v[e])));
+    cln_store_stream(reinterpret_cast<vec_t*>(y + i * VEC), v, stream_nt);
+  }
+  if (blockIdx.x == 0) {  // ragged tail (the reference requires N % VEC == 0)
+    for (long long i = nvec * VEC + threadIdx.x; i < n; i += 256) y[i] = st<T>(Op::f(ld(x[i])));
+  }
+}
+
 template <typename Op, typename T, int VEC, int CHUNK>
 int launch_unary(const void* x, void* y, long long n, hipStream_t st_) {
   if (!x || !y || n < 0) return CLN_ERR_BAD_ARG;
@@ -116,12 +134,15 @@ int launch_unary(const void* x, void* y, long long n, hipStream_t st_) {
   // An "unpacked" rung (f16x8: eight halves per lane moved as four half2 accesses) runs the kernel of its ACCESS width: access c of a lane is the
   // lane's pack in the c-th 256-pack row of the workgroup's block, so every access instruction of a wave covers 256 contiguous bytes. (Rounds 1-5 gave a lane eight CONSECUTIVE halves, as the reference kernel does: four instructions that each touch
   // 4 of every 16 bytes -- relu_f16x8 18.3 us against 14.2 for relu_f16x2 at [4096,4096], tools/rung_survey.py.)
-  // Packs per lane: 64 bytes of loads in flight per lane (4 packs of 16 bytes ... 16 packs of 4 or 2 bytes; the survey's relu_f16x2 ran 14.4 us with
-  // 4 packs per lane and 12.9 with 16); ONE pack for the 16-byte rungs above 512 MB of traffic (elementwise.hip's rule).
+  // Narrow rungs (2- / 4-byte accesses): 64 bytes of loads in flight per lane = 16 packs per lane (the survey's relu_f16x2 ran 14.4 us with 4 packs
+  // per lane and 12.9 with 16). The 16-byte rungs: unary_stride_kernel above.
   constexpr int AB = (int)sizeof(T) * CHUNK;                      // bytes per access
   constexpr int KB = AB >= 16 ? 4 : (64 / AB > 16 ? 16 : 64 / AB);
   const long long nvec = n / CHUNK, traffic = 2LL * n * (long long)sizeof(T);
-  if ((AB >= 16 && traffic >= (512LL << 20)) || nvec < 1024 * KB) {
+  if constexpr (AB >= 16) {
+    const int grid = cln_stream_grid(n / VEC + 1, 256, traffic);
+    CLN_LAUNCH((unary_stride_kernel<Op, T, VEC>), dim3(grid), dim3(256), 0, st_, (const T*)x, (T*)y, n, cln_stream_nt(traffic));
+  } else if (nvec < 1024 * KB) {
     CLN_LAUNCH((unary_kernel<Op, T, CHUNK, CHUNK, 1>), dim3((unsigned)((nvec + 255) / 256 + (nvec == 0))), dim3(256), 0, st_, (const T*)x, (T*)y, n, cln_stream_nt(traffic));
   } else {
     CLN_LAUNCH((unary_kernel<Op, T, CHUNK, CHUNK, KB>), dim3((unsigned)((nvec + 256 * KB - 1) / (256 * KB))), dim3(256), 0, st_, (const T*)x, (T*)y, n, cln_stream_nt(traffic));
