@@ -275,9 +275,13 @@ CLN_DOT(dot_prod_f16x8_pack_f32, half_t, 8)
 
 // (a [M,K], x [K], y [M], M, K, stream) -- reference `void sgemv_*(Tensor a, Tensor x, Tensor y)`; K constraints
 // as in the reference bindings (sgemv.cu:138-190: K % 32, K % 128, K == 16).
+// The one-element rungs on long rows (K a multiple of 64, >= 512) give the whole wave to ONE row: a load instruction then covers one contiguous run of 64
+// elements instead of two 32-element runs of two rows ([65536,1024]: hgemv_k32_f16 28.1 -> 26.6 us, sgemv_k32_f32 44.6 -> 42.7; the x4 rungs lose --
+// 26.4 -> 31.0 / 42.9 -> 48.2 -- with half the pieces of a row in flight per lane, and keep 32 lanes per row).
 #define CLN_GEMV(name, T, VEC, G, COND)                                                              \
   CLN_API int name(const void* a, const void* x, void* y, int M, int K, void* stream) {              \
     if (!(COND)) return CLN_ERR_UNSUPPORTED;                                                          \
+    if (G == 32 && VEC == 1 && K % 64 == 0 && K >= 512) return launch_gemv<T, VEC, 64>(a, x, y, M, K, (hipStream_t)stream); \
     return launch_gemv<T, VEC, G>(a, x, y, M, K, (hipStream_t)stream);                                \
   }
 CLN_GEMV(sgemv_k32_f32, float, 1, 32, K % 32 == 0)
