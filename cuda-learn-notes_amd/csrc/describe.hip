@@ -1,7 +1,7 @@
 // cln_describe: which gfx950 kernel a run-time dispatched C-ABI name runs for a given shape, as text.
 //
 //   int cln_describe(const char* name, int d0, int d1, int d2, int d3, int stages, char* buf, int buflen)
-//     HGEMM names (G6 signature):  d0 = M, d1 = N, d2 = K, d3 unused
+//     HGEMM names (G6 signature) and the two sgemm matrix-core names (S6):  d0 = M, d1 = N, d2 = K, d3 unused
 //     flash-attn names:            d0 = B, d1 = H, d2 = N, d3 = D
 //   returns the length of the text written to buf (NUL-terminated), or
 //     CLN_ERR_UNSUPPORTED (-2)  the name exists but the shape is outside its supported set (the launch would fail too)
@@ -14,10 +14,13 @@
 
 int cln_hgemm_describe(const char* name, int M, int N, int K, int stages, char* buf, int len);
 int cln_fa_describe(const char* name, int B, int H, int N, int D, int stages, char* buf, int len);
+int cln_sgemm_describe(const char* name, int M, int N, int K, int stages, char* buf, int len);
 
 CLN_API int cln_describe(const char* name, int d0, int d1, int d2, int d3, int stages, char* buf, int buflen) {
   if (!name || !buf || buflen <= 0) return CLN_ERR_BAD_ARG;
   int rc = cln_fa_describe(name, d0, d1, d2, d3, stages, buf, buflen);
+  if (rc != CLN_ERR_BAD_ARG) return rc;
+  rc = cln_sgemm_describe(name, d0, d1, d2, stages, buf, buflen);
   if (rc != CLN_ERR_BAD_ARG) return rc;
   return cln_hgemm_describe(name, d0, d1, d2, stages, buf, buflen);
 }

@@ -15,6 +15,8 @@
 //    depend on the tile the planner picks.
 //  * the CUDA-core ladder becomes a VALU thread-tile kernel: 128 x (16*TN) block, 8 x TN outputs per lane,
 //    v_fma_f32 from a transposed A image, optional double buffer and issue-early/write-late ("async").
+#include <string.h>
+
 #include "common.h"
 #include "sgemm_dma.cuh"
 
@@ -209,6 +211,18 @@ int launch_mfma(const void* a, const void* b, void* c, int M, int N, int K, int 
 }
 
 }  // namespace
+
+// cln_describe for the two matrix-core names (describe.hip): the tile form sgemm_plan picks for the shape, no launch
+int cln_sgemm_describe(const char* name, int M, int N, int K, int stages, char* buf, int len) {
+  (void)stages;
+  if (strcmp(name, "sgemm_wmma_m16n16k8_mma4x2_warp2x4_stages") != 0 && strcmp(name, "sgemm_wmma_m16n16k8_mma4x2_warp2x4_stages_dsmem") != 0)
+    return CLN_ERR_BAD_ARG;
+  if (M <= 0 || N <= 0 || K <= 0 || M % 64 || N % 128 || K % 16) return CLN_ERR_UNSUPPORTED;
+  const SgemmPlan p = sgemm_plan(M, N);
+  const int n = snprintf(buf, (size_t)len, "sgemm_dma<%dx%dx16,4 waves,%dx%d wave tiles,3-slot LDS-DMA ring,mid-stage barrier,v_mfma_f32_32x32x2_f32> [stages ignored: one ring]",
+                         p.bm, p.bn, p.bm == 256 ? 128 : p.bm / 2, 64);
+  return n < len ? n : len - 1;
+}
 
 #define CLN_S3(name, expr)                                                                         \
   CLN_API int name(const void* a, const void* b, void* c, int M, int N, int K, void* stream_) {   \

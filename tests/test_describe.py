@@ -26,6 +26,11 @@ def test_every_run_time_dispatched_name_describes_itself(built):
         elif e.sig == "G6" and e.lib == "hgemm":
             txt = m.describe(e.name, (4096, 4096, 4096), 2)
             assert txt.startswith(("hgemm_w4", "hgemm_pp", "mfma_ring")), (e.name, txt)
+        elif e.sig == "S6":
+            txt = m.describe(e.name, (4096, 4096, 4096), 2)
+            assert txt.startswith("sgemm_dma<128x128x16"), (e.name, txt)
+            with pytest.raises(ValueError):
+                m.describe(e.name, (4096, 4096 + 64, 4096), 2)
         elif e.sig == "G3" and e.lib == "hgemm":
             with pytest.raises(LookupError):
                 m.describe(e.name, (1024, 1024, 1024), 2)

@@ -82,3 +82,27 @@ def test_attention_small_grid_plan_against_the_committed_probe(built):
         assert what.startswith(m.group(9) + "<") and ("%s waves" % m.group(10)) in what, (line, what)
         n += 1
     assert n == 120
+
+
+def test_sgemm_tile_plan_is_near_the_measured_best_form(built):
+    """csrc/sgemm.hip sgemm_plan (through cln_describe, host only) against the committed sweep of the three tile forms of the LDS-DMA f32-MFMA kernel
+    (profiles/r06_sgemm_dma_sweep.log: the reference's sgemm sweep + ten off-sweep shapes, each form measured on one box): the planned form is within
+    2.5 % of the best measured form at every shape, within 1.2 % on the reference's own sweep."""
+    m = built.manifest
+    log = os.path.join(ROOT, "profiles", "r06_sgemm_dma_sweep.log")
+    rows = 0
+    for ln in open(log):
+        if not ln.startswith("SWEEP"):
+            continue
+        t = ln.split()
+        M, N, K = int(t[1]), int(t[2]), int(t[3])
+        forms = {t[i]: float(t[i + 1]) for i in range(9, len(t) - 3, 2) if t[i] != "|" and t[i + 1] != "n/a"}
+        txt = m.describe("sgemm_wmma_m16n16k8_mma4x2_warp2x4_stages", (M, N, K), 2)
+        form = re.search(r"sgemm_dma<(\d+x\d+)x16", txt).group(1)
+        assert form in forms, (form, forms)
+        best = max(forms.values())
+        in_sweep = M >= 4096 and N >= 4096 and K >= 2048
+        assert forms[form] >= (0.988 if in_sweep else 0.975) * best, (M, N, K, form, forms)
+        rows += 1
+    assert rows >= 30
+    assert not m.stages_honoured("sgemm_wmma_m16n16k8_mma4x2_warp2x4_stages_dsmem", (4096, 4096, 4096), 3)
