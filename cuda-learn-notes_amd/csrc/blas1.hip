@@ -137,6 +137,59 @@ __global__ __launch_bounds__(256) void gemv_kernel(const T* __restrict__ a, cons
   s = group_sum<G>(s);
   if (m < M && g == 0) y[m] = (T)s;
 }
+// Long rows, the two f16 rungs (hgemv_k128_f16x4: U = 4 pieces of 4 halves; hgemv_k32_f16: U = 8 pieces of one half -- 26.6 -> 22.2 us on [65536,1024]): a wave owns R consecutive rows with all 64 lanes on each; one x piece feeds R rows (x is read R times less often), a load
+// instruction covers 64 * VEC contiguous elements of ONE row, R * U row pieces are in flight per lane. Same-box A/B against the 32-lanes-per-row kernel and
+// torch.mv (scratch harness, rotating sets): [65536,1024] 26.4 -> 22.3 us (torch.mv 24.8), [16384,4096] 25.1 (24.8), [8192,8192] 25.9 at R = 2 (26.2);
+// R = 4 from 16384 rows on, 2 below (8192 rows leave R = 4 two waves per SIMD: 31.6 us). The f32x4 rung measured level or slower in this form and keeps 32 lanes per row.
+template <typename T, int VEC, int R, int U>
+__global__ __launch_bounds__(256) void gemv_rows_kernel(const T* __restrict__ a, const T* __restrict__ x, T* __restrict__ y, int M, int K) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m0 = (blockIdx.x * 4 + wave) * R;
+  if (m0 >= M) return;
+  float s[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) s[r] = 0.f;
+  const T* row[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) row[r] = a + (size_t)(m0 + r < M ? m0 + r : M - 1) * K;
+  int k = lane * VEC;
+  for (; k + (U - 1) * 64 * VEC < K; k += U * 64 * VEC) {
+    Pk<T, VEC> pa[R][U], px[U];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int u = 0; u < U; ++u) pa[r][u] = *reinterpret_cast<const Pk<T, VEC>*>(row[r] + k + u * 64 * VEC);
+#pragma unroll
+    for (int u = 0; u < U; ++u) px[u] = *reinterpret_cast<const Pk<T, VEC>*>(x + k + u * 64 * VEC);
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) s[r] = fmaf(tof(pa[r][u].v[e]), tof(px[u].v[e]), s[r]);
+  }
+  for (; k < K; k += 64 * VEC) {
+    const Pk<T, VEC> px = *reinterpret_cast<const Pk<T, VEC>*>(x + k);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const Pk<T, VEC> pa = *reinterpret_cast<const Pk<T, VEC>*>(row[r] + k);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) s[r] = fmaf(tof(pa.v[e]), tof(px.v[e]), s[r]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const float t = group_sum<64>(s[r]);
+    if (lane == 0 && m0 + r < M) y[m0 + r] = (T)t;
+  }
+}
+template <typename T, int VEC, int R, int U>
+int launch_gemv_rows(const void* a, const void* x, void* y, int M, int K, hipStream_t st) {
+  if (!a || !x || !y || M <= 0 || K <= 0) return CLN_ERR_BAD_ARG;
+  constexpr int RPB = 4 * R;
+  CLN_LAUNCH((gemv_rows_kernel<T, VEC, R, U>), dim3((M + RPB - 1) / RPB), dim3(256), 0, st, (const T*)a, (const T*)x, (T*)y, M, K);
+  return cln_check_launch();
+}
 template <typename T, int VEC, int G>
 int launch_gemv(const void* a, const void* x, void* y, int M, int K, hipStream_t st) {
   if (!a || !x || !y || M <= 0 || K <= 0) return CLN_ERR_BAD_ARG;
@@ -281,7 +334,13 @@ CLN_DOT(dot_prod_f16x8_pack_f32, half_t, 8)
 #define CLN_GEMV(name, T, VEC, G, COND)                                                              \
   CLN_API int name(const void* a, const void* x, void* y, int M, int K, void* stream) {              \
     if (!(COND)) return CLN_ERR_UNSUPPORTED;                                                          \
+    if (G == 32 && VEC == 1 && sizeof(T) == 2 && K % 64 == 0 && K >= 512 && M >= 4096)                                                  \
+      return M >= 16384 ? launch_gemv_rows<T, VEC, 4, 8>(a, x, y, M, K, (hipStream_t)stream)                                            \
+                        : launch_gemv_rows<T, VEC, 2, 8>(a, x, y, M, K, (hipStream_t)stream);                                           \
     if (G == 32 && VEC == 1 && K % 64 == 0 && K >= 512) return launch_gemv<T, VEC, 64>(a, x, y, M, K, (hipStream_t)stream); \
+    if (G == 32 && VEC > 1 && sizeof(T) == 2 && K % (64 * VEC) == 0 && K >= 4 * 64 * VEC && M >= 4096)                                   \
+      return M >= 16384 ? launch_gemv_rows<T, VEC, 4, 4>(a, x, y, M, K, (hipStream_t)stream)                                            \
+                        : launch_gemv_rows<T, VEC, 2, 4>(a, x, y, M, K, (hipStream_t)stream);                                           \
     return launch_gemv<T, VEC, G>(a, x, y, M, K, (hipStream_t)stream);                                \
   }
 CLN_GEMV(sgemv_k32_f32, float, 1, 32, K % 32 == 0)

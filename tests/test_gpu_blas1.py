@@ -31,8 +31,11 @@ def test_dot_product(lib, dev, oracle, shape):
         assert abs(got - ref) <= 1e-4 * (n ** 0.5) + 1e-5 * abs(ref), (name, got, ref)
 
 
+# (the last three: the rows-per-wave kernels of the f16 rungs -- four rows per wave from 16384 rows on, two below; row counts that leave a wave's last
+# rows empty, K with a remainder behind the unrolled pieces)
 @pytest.mark.parametrize("M,K,names", [(1024, 128, ("k32", "k128")), (1000, 32, ("k32",)), (4096, 4096, ("k32", "k128")),
-                                       (1024, 16, ("k16",)), (37, 16, ("k16",))])
+                                       (1024, 16, ("k16",)), (37, 16, ("k16",)), (20001, 1280, ("k32", "k128")), (5001, 768, ("k32", "k128")),
+                                       (4099, 2048, ("k32", "k128"))])
 def test_gemv(lib, dev, oracle, M, K, names):
     g = torch.Generator().manual_seed(M + K)
     a, x = torch.randn(M, K, generator=g), torch.randn(K, 1, generator=g)
