@@ -47,7 +47,7 @@ for e in manifest.ENTRIES:
             calls = [(lambda x=x, y=y: fn(x, y)) for x, y in bufs]
             nbytes = 2 * n * bufs[0][0].element_size()
         elif e.sig in ("LN", "RN"):
-            dt = torch.float32 if "_f32" in e.name.split("norm_")[1][:4] else torch.float16
+            dt = torch.float32 if e.name.split("norm_")[1].startswith("f32") else torch.float16
             bufs = [(torch.randn(S, H, device=dev).to(dt), torch.empty(S, H, device=dev, dtype=dt)) for _ in range(NSETS)]
             calls = [(lambda x=x, y=y: fn(x, y, 1.0, 0.0) if e.sig == "LN" else fn(x, y, 1.0)) for x, y in bufs]
             nbytes = 2 * n * bufs[0][0].element_size()
