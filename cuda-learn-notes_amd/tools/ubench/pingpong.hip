@@ -12,6 +12,7 @@
 //   MODE 3  pure ping-pong: group 0 runs X while group 1 runs Y, barrier, swap, barrier
 //   MODE 4  as 3, s_setprio 1 in Y / 0 in X       MODE 5  as 3, s_setprio 1 in X / 0 in Y
 //   MODE 6  as 4 without the workgroup barriers (free-running)
+//   MODE 7  as 2, but the block's 8 exponentials issued ONE behind each of the 8 MFMAs of the wave's own stream (round 6, late)
 // Prints shader clocks per period per SIMD (two wave-tiles) and ns. The shipped kernel: 4320 clocks per tile pair.
 //   hipcc --offload-arch=gfx950 -O3 pingpong.hip -o pingpong && ./pingpong
 #include <hip/hip_runtime.h>
@@ -113,6 +114,63 @@ __device__ __forceinline__ void y_block(St& st, int kb) {  // one 16-key block: 
     st.minit[qb][kb & 3] = __builtin_fmaf(st.minit[qb][kb & 3], 0.999f, mx * 1e-9f);
   }
 }
+// MODE 7: the 8 MFMAs of key block kbx with the 8 exponentials of key block kby ONE behind each MFMA (tools/ubench/mfma_port.hip: a single v_exp_f32 behind
+// an MFMA of the same wave costs 0.3 of its price, a second one nearly all of it), the block's other softmax items (adds, conversions, max3, fma) behind them.
+template <bool LDS>
+__device__ __forceinline__ void xy_block_interleaved(St& st, const char* smem, int lane, int kbx, int kby) {
+  h8 kf, vf;
+  float e[2][4];
+  int n = 0;
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    if constexpr (LDS) kf = *reinterpret_cast<const h8*>(smem + ((kbx * 2 + ks) * 1024 + lane * 16));
+    else { asm volatile("" : "+v"(st.kf)); kf = st.kf; }
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      st.s[kbx][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, st.q[qb][ks], ks == 0 ? st.minit[qb] : st.s[kbx][qb], 0, 0, 0);
+      asm volatile("" : "+v"(st.s[kbx][qb]) : "v"(kf), "v"(st.q[qb][ks]));
+      SB;
+      e[n >> 2][n & 3] = __builtin_amdgcn_exp2f(st.s[kby][n >> 2][n & 3]);
+      asm volatile("" : "+v"(e[n >> 2][n & 3]));
+      SB;
+      ++n;
+    }
+  }
+  const int u = kbx >> 1;
+#pragma unroll
+  for (int b = (kbx & 1) * 2; b < (kbx & 1) * 2 + 2; ++b) {
+    if constexpr (LDS) vf = *reinterpret_cast<const h8*>(smem + 16384 + ((u * 4 + b) * 1024 + lane * 16));
+    else { asm volatile("" : "+v"(st.vf)); vf = st.vf; }
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      st.o[b][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, st.p[u][qb], st.o[b][qb], 0, 0, 0);
+      asm volatile("" : "+v"(st.o[b][qb]) : "v"(vf), "v"(st.p[u][qb]));
+      SB;
+      e[n >> 2][n & 3] = __builtin_amdgcn_exp2f(st.s[kby][n >> 2][n & 3]);
+      asm volatile("" : "+v"(e[n >> 2][n & 3]));
+      SB;
+      ++n;
+    }
+  }
+  // the rest of y_block(kby) on the exponentials taken above
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    float mx = st.s[kby][qb][0];
+    mx = fmaxf(fmaxf(mx, st.s[kby][qb][1]), st.s[kby][qb][2]);
+    if (qb == 0) mx = fmaxf(fmaxf(mx, st.s[kby][qb][3]), st.s[kby][1][0]);
+    asm volatile("" ::"v"(mx));
+#pragma unroll
+    for (int r = 0; r < 4; r += 2) {
+      const float a0 = e[qb][r], a1 = e[qb][r + 1];
+      st.psum[qb] += a0 + a1;
+      const h2 a = __builtin_convertvector(f2{a0, a1}, h2);
+      asm volatile("" ::"v"(a), "v"(st.psum[qb]));
+      const int uu = kby >> 1, ee = (kby & 1) * 4 + r;
+      st.p[uu][qb][ee] = a[0], st.p[uu][qb][ee + 1] = a[1];
+    }
+    st.minit[qb][kby & 3] = __builtin_fmaf(st.minit[qb][kby & 3], 0.999f, mx * 1e-9f);
+  }
+}
 __device__ __forceinline__ void phase_y(St& st, int half, int nhalf) {
 #pragma unroll
   for (int kb = half * (8 / nhalf); kb < (half + 1) * (8 / nhalf); ++kb) y_block(st, kb);
@@ -151,7 +209,7 @@ __global__ __launch_bounds__(512, 2) void k(float* out, unsigned long long* clk,
   asm volatile("" : "+v"(st.minit[0]), "+v"(st.minit[1]));
   __syncthreads();
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-  if constexpr (MODE >= 3) {
+  if constexpr (MODE >= 3 && MODE != 7) {
     if (grp == 1) {
       if constexpr (MODE == 6) phase_y(st, 0, 1);
       else __builtin_amdgcn_s_barrier();
@@ -183,6 +241,16 @@ __global__ __launch_bounds__(512, 2) void k(float* out, unsigned long long* clk,
         }
         __builtin_amdgcn_s_barrier();
       }
+    } else if constexpr (MODE == 7) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int kb = h * 4; kb < h * 4 + 4; ++kb) {
+          xy_block_interleaved<LDS>(st, smem, lane, kb, (kb + 7) & 7);
+          SB;
+        }
+        __builtin_amdgcn_s_barrier();
+      }
     } else {
       // every wave runs [X, barrier, Y, barrier]; group 1 entered the loop one barrier late, so its X meets group 0's Y
       if constexpr (MODE == 4 || MODE == 6) __builtin_amdgcn_s_setprio(0);
@@ -199,7 +267,7 @@ __global__ __launch_bounds__(512, 2) void k(float* out, unsigned long long* clk,
       if constexpr (MODE != 6) __builtin_amdgcn_s_barrier();
     }
   }
-  if constexpr (MODE >= 3 && MODE != 6) {
+  if constexpr (MODE >= 3 && MODE != 6 && MODE != 7) {
     if (grp == 0) __builtin_amdgcn_s_barrier();
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -244,12 +312,14 @@ int main() {
     run<0, false>("X only: 64 MFMAs per wave and period", out, clk);
     run<1, false>("Y only: the softmax slice", out, clk);
     run<2, false>("mixed halves (the shipped shape), barrier per half", out, clk);
+    run<7, false>("mixed halves, ONE exponential behind each MFMA (1 : 1), rest of the slice per block", out, clk);
     run<3, false>("pure ping-pong: X in one group while Y in the other, 2 barriers", out, clk);
     run<4, false>("pure ping-pong, priority 1 in Y", out, clk);
     run<5, false>("pure ping-pong, priority 1 in X", out, clk);
     run<6, false>("pure ping-pong, priority 1 in Y, no barriers", out, clk);
     run<0, true>("X only: 64 MFMAs per wave and period", out, clk);
     run<2, true>("mixed halves (the shipped shape), barrier per half", out, clk);
+    run<7, true>("mixed halves, ONE exponential behind each MFMA (1 : 1), rest of the slice per block", out, clk);
     run<3, true>("pure ping-pong: X in one group while Y in the other, 2 barriers", out, clk);
     run<4, true>("pure ping-pong, priority 1 in Y", out, clk);
     run<6, true>("pure ping-pong, priority 1 in Y, no barriers", out, clk);
