@@ -12,7 +12,7 @@
 //    (rounds 2-5, register-staged 128x128x16 with a barrier per stage: 130), rocBLAS sgemm 140, hipBLASLt 150.
 //    `stages` 2 and 3 run the same ring (read / landed / in flight is what keeps the barrier off the stage boundary);
 //    `swizzle` = XCD-aware block order. Every tile form adds the k products in the same order: the result does not
-//    depend on the tile the planner picks.
+//    depend on the tile the planner picks (except where K is split in two for grids of <= 128 tiles: sgemm_plan).
 //  * the CUDA-core ladder becomes a VALU thread-tile kernel: 128 x (16*TN) block, 8 x TN outputs per lane,
 //    v_fma_f32 from a transposed A image, optional double buffer and issue-early/write-late ("async").
 #include <string.h>
@@ -175,8 +175,9 @@ int launch_valu(const void* a, const void* b, void* c, int M, int N, int K, hipS
 // pays where the larger tiles leave CUs idle (3072^3: 576 tiles of 128x128 are 2.25 per CU).
 struct SgemmPlan {
   int bm, bn;
+  bool ksplit;  // few tiles, long K: two workgroups per tile, each half of K (sgemm_dma.cuh KSPLIT)
 };
-SgemmPlan sgemm_plan(int M, int N) {
+SgemmPlan sgemm_plan(int M, int N, int K = 0) {
   const double area = (double)M * N;
   const bool big = area >= 8192.0 * 8192.0, small = area < 4096.0 * 4096.0;
   const long long t128 = (M % 128 || N % 128) ? 0 : (long long)(M / 128) * (N / 128);
@@ -186,7 +187,7 @@ SgemmPlan sgemm_plan(int M, int N) {
   } cands[3] = {{128, 128, t128 <= 256 ? 0.94 : big ? 0.975 : 1.005},  // (one 4-wave tile per CU leaves every SIMD a single wave)
                 {256, 128, big ? 1.0 : 0.995},
                 {64, 128, small ? 0.97 : 0.94}};
-  SgemmPlan best{64, 128};
+  SgemmPlan best{64, 128, false};
   double best_cost = 1e300;
   for (const Cand& c : cands) {
     if (M % c.bm || N % c.bn) continue;
@@ -194,9 +195,13 @@ SgemmPlan sgemm_plan(int M, int N) {
     const double cost = (double)((tiles + 255) / 256) * c.bm * c.bn / c.eff;
     if (cost < best_cost) {
       best_cost = cost;
-      best = {c.bm, c.bn};
+      best = {c.bm, c.bn, false};
     }
   }
+  // at most 128 tiles of 64x128 leave half of the CUs idle (1024^3: 66 TF against the vendors' 119): from K = 512 on the K range is split in two
+  // (1024^3 -> 256 workgroups; the two partial products meet in C by one fp32 atomic add each onto zeros -- commutative, so still bit-repeatable,
+  // but NOT the k order of the unsplit forms)
+  if (best.bm == 64 && (long long)(M / 64) * (N / 128) <= 128 && K >= 512) best.ksplit = true;
   return best;
 }
 int launch_mfma(const void* a, const void* b, void* c, int M, int N, int K, int stages, int swizzle, hipStream_t st) {
@@ -204,7 +209,8 @@ int launch_mfma(const void* a, const void* b, void* c, int M, int N, int K, int 
   int rc = check3(a, b, c, M, N, K);
   if (rc) return rc;
   if (M % 64 || N % 128 || K % 16) return CLN_ERR_UNSUPPORTED;
-  const SgemmPlan p = sgemm_plan(M, N);
+  const SgemmPlan p = sgemm_plan(M, N, K);
+  if (p.ksplit) return sgemm_dma::launch<2, 2, 1, 2, 16, 3, true>(a, b, c, M, N, K, swizzle, st);
   if (p.bm == 256) return sgemm_dma::launch<2, 2, 4, 2, 16, 3>(a, b, c, M, N, K, swizzle, st);
   if (p.bm == 128) return sgemm_dma::launch<2, 2, 2, 2, 16, 3>(a, b, c, M, N, K, swizzle, st);
   return sgemm_dma::launch<2, 2, 1, 2, 16, 3>(a, b, c, M, N, K, swizzle, st);
@@ -218,9 +224,9 @@ int cln_sgemm_describe(const char* name, int M, int N, int K, int stages, char* 
   if (strcmp(name, "sgemm_wmma_m16n16k8_mma4x2_warp2x4_stages") != 0 && strcmp(name, "sgemm_wmma_m16n16k8_mma4x2_warp2x4_stages_dsmem") != 0)
     return CLN_ERR_BAD_ARG;
   if (M <= 0 || N <= 0 || K <= 0 || M % 64 || N % 128 || K % 16) return CLN_ERR_UNSUPPORTED;
-  const SgemmPlan p = sgemm_plan(M, N);
-  const int n = snprintf(buf, (size_t)len, "sgemm_dma<%dx%dx16,4 waves,%dx%d wave tiles,3-slot LDS-DMA ring,mid-stage barrier,v_mfma_f32_32x32x2_f32> [stages ignored: one ring]",
-                         p.bm, p.bn, p.bm == 256 ? 128 : p.bm / 2, 64);
+  const SgemmPlan p = sgemm_plan(M, N, K);
+  const int n = snprintf(buf, (size_t)len, "sgemm_dma<%dx%dx16,4 waves,%dx%d wave tiles,3-slot LDS-DMA ring,mid-stage barrier,v_mfma_f32_32x32x2_f32>%s [stages ignored: one ring]",
+                         p.bm, p.bn, p.bm == 256 ? 128 : p.bm / 2, 64, p.ksplit ? " x 2 halves of K (memset + one fp32 atomic add per element and half)" : "");
   return n < len ? n : len - 1;
 }
 

@@ -64,7 +64,7 @@ struct Geo {
   static_assert(BK % 8 == 0 && (BN * 4) % 512 == 0 && TN % 2 == 0, "k8 groups; B rows of whole 512-byte spans; column blocks in XOR pairs");
 };
 
-template <int WM, int WN, int TM, int TN, int BK, int S>
+template <int WM, int WN, int TM, int TN, int BK, int S, bool KSPLIT = false>
 __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && TM * TN <= 8) ? 2 : 1) void sgemm_dma_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                                 float* __restrict__ C, int M, int N, int K, int tiles_n,
                                                                 int swizzle) {
@@ -104,7 +104,19 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && TM * TN <= 8) ? 2 : 1
     bvo[q] = ((unsigned)krow * (unsigned)N + chunk * 4) * 4u;
   }
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-  const int nt = K / BK;
+  // KSPLIT (few tiles, long K): blockIdx.y = 0 / 1 takes the first / second half of the stages and ADDS its product to a C the launcher zeroed --
+  // two commutative fp32 additions per element (0 + p + q = 0 + q + p): the result does not depend on which half arrives first
+  int nt = K / BK;
+  if constexpr (KSPLIT) {
+    const int first = (nt + 1) / 2;
+    if (blockIdx.y == 0) {
+      nt = first;
+    } else {
+      abase += (size_t)first * astep;
+      bbase += (size_t)first * bstep;
+      nt -= first;
+    }
+  }
   int nxt = 0;  // stage the bases point at
   // one 1-KiB piece of a stage's A / B image (pieces 0 .. A_I-1: A; then B); behind the last one the bases move on to the next stage
   // (a stage past the end of K re-reads the last one: the request count per stage stays fixed)
@@ -223,22 +235,36 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && TM * TN <= 8) ? 2 : 1
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        C[(size_t)row * N + n0 + (wn * TN + j) * 32 + l31] = acc[i][j][r];
+        float* dst = C + (size_t)row * N + n0 + (wn * TN + j) * 32 + l31;
+        if constexpr (KSPLIT) unsafeAtomicAdd(dst, acc[i][j][r]);  // global_atomic_add_f32, no return
+        else *dst = acc[i][j][r];
       }
 }
 
-template <int WM, int WN, int TM, int TN, int BK, int S>
+__global__ __launch_bounds__(256) void zero_f4_kernel(f4v* __restrict__ p, long long n4) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n4) p[i] = f4v{0.f, 0.f, 0.f, 0.f};
+}
+
+template <int WM, int WN, int TM, int TN, int BK, int S, bool KSPLIT = false>
 int launch(const void* a, const void* b, void* c, int M, int N, int K, int swizzle, hipStream_t st) {
   using G = Geo<WM, WN, TM, TN, BK, S>;
   if (M % G::BM || N % G::BN || K % BK) return CLN_ERR_UNSUPPORTED;
+  if (KSPLIT && K < 2 * BK) return CLN_ERR_UNSUPPORTED;
   // the DMA's per-lane source offset is an unsigned 32-bit byte count inside the tile's A rows / the stage's B rows
   if ((unsigned long long)G::BM * (unsigned long long)K * 4ull > 0xFFFFFFFFull || (unsigned long long)BK * (unsigned long long)N * 4ull > 0xFFFFFFFFull)
     return CLN_ERR_UNSUPPORTED;
   static cln_lds_attr attr;
-  auto kfn = sgemm_dma_kernel<WM, WN, TM, TN, BK, S>;
+  auto kfn = sgemm_dma_kernel<WM, WN, TM, TN, BK, S, KSPLIT>;
   if (cln_ensure_lds(attr, reinterpret_cast<const void*>(kfn), G::LDS) != CLN_OK) return CLN_ERR_LAUNCH;
   const int tiles_n = N / G::BN, grid = (M / G::BM) * tiles_n;
-  CLN_LAUNCH(kfn, dim3(grid), dim3(G::THREADS), G::LDS, st, (const float*)a, (const float*)b, (float*)c, M, N, K, tiles_n,
+  if (KSPLIT) {
+    // C zeroed by a kernel of ours, not hipMemsetAsync: replayed from a captured graph the runtime's memset node left stale patterns in a quarter
+    // of a 4 MB buffer from the second replay on (ROCm 7.2, profiles/r06_sgemm_ksplit.log); M * N is a multiple of 64 * 128 here
+    const long long n4 = (long long)M * N / 4;
+    CLN_LAUNCH(zero_f4_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (f4v*)c, n4);
+  }
+  CLN_LAUNCH(kfn, dim3(grid, KSPLIT ? 2 : 1), dim3(G::THREADS), G::LDS, st, (const float*)a, (const float*)b, (float*)c, M, N, K, tiles_n,
              swizzle ? 1 : 0);
   return cln_check_launch();
 }

@@ -98,3 +98,43 @@ def test_sgemm_unsupported_shape(lib, dev):
         lib.sgemm_t_8x8_sliced_k_f32x4(a, b, c)
     with pytest.raises(RuntimeError, match="values must be torch::kFloat32"):
         lib.sgemm_naive_f32(a.half(), b.half(), c.half())
+
+
+@pytest.mark.parametrize("M,N,K", [(1024, 1024, 1024), (512, 2048, 544), (64, 128, 528), (1024, 512, 4096)])
+def test_sgemm_matrix_core_k_split_for_few_tiles(lib, dev, oracle, M, N, K):
+    """At most 128 tiles of 64x128 and K >= 512: two workgroups per tile, each half of the stages (an odd stage count: 17 + 16), their products added
+    onto a zeroed C by one fp32 atomic each -- fp64 oracle, the output buffer's previous content must not matter, and 20 launches give the same
+    bits (two commutative additions per element)."""
+    a, b = seeded(7 * M + K, M, K), seeded(9 * N + K, K, N)
+    ref = oracle.sgemm(a, b)
+    tol = 2e-5 * K ** 0.5
+    ad, bd = a.to(dev), b.to(dev)
+    first = None
+    for r in range(20):
+        c = torch.full((M, N), float("nan") if r % 2 else 123.0, device=dev)
+        lib.sgemm_wmma_m16n16k8_mma4x2_warp2x4_stages(ad, bd, c, 2 + (r & 1), bool(r & 2), 256)
+        if first is None:
+            assert (c.cpu().double() - ref).abs().max().item() <= tol
+            first = c
+        assert torch.equal(c, first), r
+
+
+def test_sgemm_k_split_under_stream_capture(lib, dev):
+    """The split form is a memset node + a kernel node: a captured launch replays into a buffer that something else overwrote in between."""
+    M = N = K = 1024
+    a, b = seeded(1, M, K).to(dev), seeded(2, K, N).to(dev)
+    c = torch.zeros(M, N, device=dev)
+    lib.sgemm_wmma_m16n16k8_mma4x2_warp2x4_stages(a, b, c, 2, True, 256)
+    want = c.clone()
+    s = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        lib.sgemm_wmma_m16n16k8_mma4x2_warp2x4_stages(a, b, c, 2, True, 256)  # warm-up on the capture stream
+        torch.cuda.current_stream().synchronize()
+        with torch.cuda.graph(g, stream=s):
+            lib.sgemm_wmma_m16n16k8_mma4x2_warp2x4_stages(a, b, c, 2, True, 256)
+    for _ in range(3):
+        c.fill_(5.0)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(c, want)
