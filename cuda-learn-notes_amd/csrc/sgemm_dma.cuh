@@ -263,6 +263,7 @@ int launch(const void* a, const void* b, void* c, int M, int N, int K, int swizz
     // of a 4 MB buffer from the second replay on (ROCm 7.2, profiles/r06_sgemm_ksplit.log); M * N is a multiple of 64 * 128 here
     const long long n4 = (long long)M * N / 4;
     CLN_LAUNCH(zero_f4_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (f4v*)c, n4);
+    if (cln_check_launch() != CLN_OK) return CLN_ERR_LAUNCH;  // (the next CLN_LAUNCH clears the error slot)
   }
   CLN_LAUNCH(kfn, dim3(grid, KSPLIT ? 2 : 1), dim3(G::THREADS), G::LDS, st, (const float*)a, (const float*)b, (float*)c, M, N, K, tiles_n,
              swizzle ? 1 : 0);
