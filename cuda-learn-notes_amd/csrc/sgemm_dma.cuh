@@ -9,7 +9,8 @@
 // stores per thread through VGPRs, a barrier every 32 MFMAs per wave, and moves 2x the L2 bytes of a 256x256 tile. This kernel:
 //   * block tile (WM*TM*32) x (WN*TN*32), 256x256 by default: 8 waves = two per SIMD, wave tile 128x64 (4 x 2 MFMA tiles, 128
 //     accumulator registers), one workgroup per CU;
-//   * K in BK-deep stages through a ring of S LDS slots filled by LDS-DMA (global_load_lds_dwordx4: no VGPR staging, no ds_write);
+//   * K in BK-deep stages through a ring of S >= 3 LDS slots (3 for the large tiles; 8 for the 64x128 tile on grids of one workgroup per CU, where a stage
+//     lasts 0.4 us -- less than one trip to memory) filled by LDS-DMA (global_load_lds_dwordx4: no VGPR staging, no ds_write);
 //     ONE barrier per stage = per 128 MFMAs of a wave at BK = 32; the DMA of stage t+S-1 is issued right behind the barrier that frees
 //     its slot, so it has S-1 whole stages (>= 16k clocks) to land;
 //   * A image: rows of BK floats (128 B = one full line at BK = 32), 16-byte chunks XOR-swizzled on the SOURCE side so that the
@@ -48,6 +49,14 @@ __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
 template <int WM, int WN, int TM, int TN, int BK, int S>
 struct Geo {
   static constexpr int NW = WM * WN, THREADS = NW * 64;
@@ -69,7 +78,8 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && TM * TN <= 8) ? 2 : 1
                                                                 float* __restrict__ C, int M, int N, int K, int tiles_n,
                                                                 int swizzle) {
   using G = Geo<WM, WN, TM, TN, BK, S>;
-  static_assert(S == 3 && BK >= 16, "three slots: read t, landed t+1, in flight t+2; fragment double buffers need >= 2 k8 groups");
+  static_assert(S >= 3 && BK >= 16, "at least three slots: read t, landed t+1, in flight t+2 .. t+S-1; fragment double buffers need >= 2 k8 groups");
+  static_assert((S - 2) * (G::A_I + G::B_I) < 64, "vmcnt field");
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave-uniform: it addresses M0)
   const int wm = wave / WN, wn = wave - wm * WN;
@@ -121,7 +131,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && TM * TN <= 8) ? 2 : 1
   // one 1-KiB piece of a stage's A / B image (pieces 0 .. A_I-1: A; then B); behind the last one the bases move on to the next stage
   // (a stage past the end of K re-reads the last one: the request count per stage stays fixed)
   constexpr int NDMA = G::A_I + G::B_I;
-  auto issue_piece = [&](int slot, int d) {
+  auto issue_piece = [&](int slot, int d) __attribute__((always_inline)) {
     if (d < G::A_I)
       dma16(abase, avo[d], lds0 + slot * G::STAGE + (wave * G::A_I + d) * 1024);
     else
@@ -132,7 +142,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && TM * TN <= 8) ? 2 : 1
       bbase += bstep;
     }
   };
-  auto issue = [&](int slot) {
+  auto issue = [&](int slot) __attribute__((always_inline)) {
 #pragma unroll
     for (int d = 0; d < NDMA; ++d) issue_piece(slot, d);
   };
@@ -140,11 +150,11 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && TM * TN <= 8) ? 2 : 1
   // ---- fragment read addresses: one register per (slot, k8 group) for A and per (slot, column-block parity) for B, pinned (an address
   // recomputed in the loop is a VALU instruction, and on gfx950 a VALU instruction is matrix-pipe time); everything else is an offset field
   constexpr int MG = BK / 8, NSTEP = BK / 2;
-  unsigned ab[3][MG], bb_[3][2];
+  unsigned ab[S][MG], bb_[S][2];
   {
     const int sw = (l31 / G::RPG) % G::CPR;  // the 32-row tile offsets and the wave offset are multiples of RPG * CPR rows
 #pragma unroll
-    for (int sl = 0; sl < 3; ++sl) {
+    for (int sl = 0; sl < S; ++sl) {
 #pragma unroll
       for (int m = 0; m < MG; ++m) {
         ab[sl][m] = lds0 + sl * G::STAGE + (unsigned)((wm * TM * 32 + l31) * G::RB + (((2 * m + kh) ^ sw) << 4));
@@ -169,11 +179,11 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && TM * TN <= 8) ? 2 : 1
 
   f4v a[2][TM];   // [k8 group parity]
   float b[2][TN];  // [step parity]
-  auto load_a = [&](int par, unsigned base) {
+  auto load_a = [&](int par, unsigned base) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) a[par][i] = lds_ld<f4v>(base + i * 32 * G::RB);
   };
-  auto load_b = [&](int par, const unsigned* base2, int krow) {
+  auto load_b = [&](int par, const unsigned* base2, int krow) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) b[par][j] = lds_ld<float>(base2[j & 1] + krow * G::BN * 4 + (j >> 1) * 256);
   };
@@ -181,8 +191,8 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && TM * TN <= 8) ? 2 : 1
   // One stage out of slot SL. Fragments of step q+1 are requested in front of the MFMAs of step q (the first step of the NEXT stage in front
   // of this stage's last step: no barrier sits between two stages). The stage's ONE barrier is in its middle, in the shadow of an MFMA:
   // behind it stage t+1 has landed for every wave and every wave is past stage t-1, whose slot the requests for stage t+2 may now fill.
-  auto stage = [&](auto slc) {
-    constexpr int SL = decltype(slc)::value, NS = (SL + 1) % 3, FILL = (SL + 2) % 3;
+  auto stage = [&](auto slc) __attribute__((always_inline)) {
+    constexpr int SL = decltype(slc)::value, NS = (SL + 1) % S, FILL = (SL + S - 1) % S;
 #pragma unroll
     for (int q = 0; q < NSTEP; ++q) {
       const int m = q >> 2, s = q & 3;
@@ -195,7 +205,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && TM * TN <= 8) ? 2 : 1
         load_b(0, bb_[NS], 0);
       }
       if (q == NSTEP / 2) {
-        wait_vm<0>();
+        wait_vm<(S - 3) * NDMA>();  // stage t+1 has landed; t+2 .. t+S-2 may still be in flight
         __builtin_amdgcn_s_barrier();
       }
 #pragma unroll
@@ -211,20 +221,18 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && TM * TN <= 8) ? 2 : 1
     }
   };
 
-  issue(0);
-  issue(1);
-  wait_vm<G::A_I + G::B_I>();  // stage 0 has landed (stage 1 is waited for at the first mid-stage barrier)
+#pragma unroll
+  for (int sl = 0; sl < S - 1; ++sl) issue(sl);
+  wait_vm<(S - 2) * NDMA>();  // stage 0 has landed (stage 1 is waited for at the first mid-stage barrier)
   __builtin_amdgcn_s_barrier();
   load_a(0, ab[0][0]);
   load_b(0, bb_[0], 0);
   int t = 0;
-  for (; t + 3 <= nt; t += 3) {
-    stage(std::integral_constant<int, 0>{});
-    stage(std::integral_constant<int, 1>{});
-    stage(std::integral_constant<int, 2>{});
-  }
-  if (t < nt) stage(std::integral_constant<int, 0>{});
-  if (t + 1 < nt) stage(std::integral_constant<int, 1>{});
+  for (; t + S <= nt; t += S) static_for<0, S>([&](auto i) __attribute__((always_inline)) { stage(i); });
+  const int rest = nt - t;  // < S
+  static_for<0, S - 1>([&](auto i) __attribute__((always_inline)) {
+    if (decltype(i)::value < rest) stage(i);
+  });
   wait_vm<0>();  // the re-read requests of the tail must not outlive the workgroup's LDS
 
   // ---- C: result register r of a 32x32 tile is row (r & 3) + 8 (r >> 2) + 4 kh, column l31: 128-byte row segments per half wave
